@@ -1,0 +1,225 @@
+/*
+ * bpvo_hip — C ABI of the MI355X-native dense photometric alignment path.
+ *
+ * This is the drop-in boundary.  bpvo has no FFI
+ * layer of its own; the seams this ABI replaces are cited per entry point as
+ * `reference: <file>:<line>` (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = error (never throws).
+ *     bpvo_hip_last_error() gives the message; the C++ facade (vo.hpp) maps a
+ *     non-zero status to bpvo::Error like THROW_ERROR does (bpvo/utils.h:211-220).
+ *   - matrices are ROW-MAJOR float arrays (K[9], T[16], H[36]).
+ *   - host pointers unless a function name ends in `_device`.
+ *   - images are contiguous row-major rows x cols, u8 image + f32 disparity, as
+ *     VisualOdometry::addFrame takes them (bpvo/vo.h:71).  The caller keeps
+ *     ownership; data is copied before the call returns (bpvo/vo_frame.cc:50-51).
+ *   - per-point arrays handed back to the host use the REFERENCE layouts:
+ *     channel-major `a[c*N + i]` (bpvo/template_data.cc:96-97,108,133),
+ *     Jacobians `[C*N][6]`, valid flags uint16_t (bpvo/types.h:69-73).
+ *   - one ctx per (host thread, device); calls on one ctx are serialised by the
+ *     caller (the reference objects are not re-entrant either,
+ *     bpvo/template_data.h:80,86).
+ */
+#ifndef BPVO_HIP_C_API_H
+#define BPVO_HIP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: numeric values equal to the reference's (bpvo/types.h:127-169,418-441) */
+enum { BPVO_LOSS_HUBER = 0x10, BPVO_LOSS_TUKEY = 0x11, BPVO_LOSS_L2 = 0x12 };
+enum { BPVO_VERB_ITERATION = 0x20, BPVO_VERB_FINAL = 0x21, BPVO_VERB_SILENT = 0x22, BPVO_VERB_DEBUG = 0x23 };
+enum { BPVO_DESC_INTENSITY = 0x30, BPVO_DESC_BITPLANES = 0x37 };
+enum { BPVO_GRAD_CD3 = 0, BPVO_GRAD_CD5 = 1 };
+enum { BPVO_INTERP_LINEAR = 0, BPVO_INTERP_COSINE = 1, BPVO_INTERP_CUBIC = 2, BPVO_INTERP_CUBIC_HERMITE = 3 };
+enum { BPVO_STATUS_PARAMETER_TOL = 0x30, BPVO_STATUS_FUNCTION_TOL = 0x31, BPVO_STATUS_GRADIENT_TOL = 0x32,
+       BPVO_STATUS_MAX_ITERATIONS = 0x33, BPVO_STATUS_SOLVER_ERROR = 0x34 };
+enum { BPVO_KF_LARGE_TRANSLATION = 0x40, BPVO_KF_LARGE_ROTATION = 0x41, BPVO_KF_SMALL_FRAC_GOOD = 0x42,
+       BPVO_KF_NO_KEYFRAMING = 0x43, BPVO_KF_FIRST_FRAME = 0x44 };
+
+/* ---- error codes */
+enum { BPVO_OK = 0, BPVO_ERR_INVALID_ARG = -1, BPVO_ERR_UNSUPPORTED = -2, BPVO_ERR_NO_DATA = -3,
+       BPVO_ERR_NO_TEMPLATE = -4, BPVO_ERR_DEVICE = -5, BPVO_ERR_NO_DEVICE = -6 };
+
+/* POD mirror of bpvo::AlgorithmParameters, same 35 fields in the same order
+ * (reference: bpvo/types.h:171-413; defaults bpvo/types.cc:31-66). bool -> int. */
+typedef struct bpvo_hip_params {
+  int   numPyramidLevels;
+  int   minImageDimensionForPyramid;
+  float sigmaPriorToCensusTransform;
+  float sigmaBitPlanes;
+  float dfSigma1;
+  float dfSigma2;
+  int   latchNumBytes;
+  int   latchRotationInvariance;
+  int   latchHalfSsdSize;
+  int   centralDifferenceRadius;
+  float centralDifferenceSigmaBefore;
+  float centralDifferenceSigmaAfter;
+  int   laplacianKernelSize;
+  int   maxIterations;
+  float parameterTolerance;
+  float functionTolerance;
+  float gradientTolerance;
+  int   relaxTolerancesForCoarseLevels;
+  int   gradientEstimation;
+  int   interp;
+  int   lossFunction;
+  int   descriptor;
+  int   verbosity;
+  float minTranslationMagToKeyFrame;
+  float minRotationMagToKeyFrame;
+  float maxFractionOfGoodPointsToKeyFrame;
+  float goodPointThreshold;
+  int   minNumPixelsForNonMaximaSuppression;
+  int   nonMaxSuppRadius;
+  int   minNumPixelsToWork;
+  float minSaliency;
+  float minValidDisparity;
+  float maxValidDisparity;
+  int   maxTestLevel;
+  int   withNormalization;
+} bpvo_hip_params;
+
+/* reference: bpvo::OptimizerStatistics (bpvo/types.h:444-482; ctor bpvo/types.cc:306-310) */
+typedef struct bpvo_hip_stats {
+  int   numIterations;
+  float finalError;
+  float firstOrderOptimality;
+  int   status;
+} bpvo_hip_stats;
+
+#define BPVO_HIP_MAX_LEVELS 8
+
+/* reference: bpvo::Result (bpvo/types.h:489-563) minus the point cloud, which is
+ * fetched separately with bpvo_hip_get_point_cloud when isKeyFrame && hasPointCloud */
+typedef struct bpvo_hip_result {
+  float pose[16];
+  float covariance[36];                   /* never written by the reference: Identity (Q16) */
+  bpvo_hip_stats optimizerStatistics[BPVO_HIP_MAX_LEVELS];
+  int   numLevels;
+  int   isKeyFrame;
+  int   keyFramingReason;
+  int   hasPointCloud;
+} bpvo_hip_result;
+
+/* reference: bpvo::PointWithInfo, 32-byte record (bpvo/point_cloud.h:30-62) */
+typedef struct bpvo_hip_point_with_info {
+  float   xyzw[4];
+  uint8_t rgba[4];
+  float   weight;
+  char    pad[8];
+} bpvo_hip_point_with_info;
+
+typedef struct bpvo_hip_ctx bpvo_hip_ctx;
+
+/* Fill `p` with AlgorithmParameters() defaults (reference: bpvo/types.cc:31-66). */
+void bpvo_hip_default_params(bpvo_hip_params* p);
+
+/*
+ * Create a context: the device-resident equivalent of
+ * VisualOdometry::Impl's three VisualOdometryFrame objects + pose estimator
+ * (reference: bpvo/vo.cc:97-115, bpvo/vo_frame.cc:13-29).
+ *   n_frames   frame slots (each = image pyramid + disparity + descriptor pyramid + template pyramid)
+ *   n_pairs    estimation workspaces (residuals, valid, weights, GN state); 1 for sequential VO,
+ *              B for batches of independent frame pairs
+ *   device     HIP device ordinal
+ * numPyramidLevels <= 0 is resolved like bpvo/vo.cc:103-107.
+ */
+int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int rows, int cols,
+                    const bpvo_hip_params* p, int device, int n_frames, int n_pairs);
+void bpvo_hip_destroy(bpvo_hip_ctx* ctx);
+const char* bpvo_hip_last_error(const bpvo_hip_ctx* ctx);   /* ctx may be NULL: last create error */
+int bpvo_hip_num_levels(const bpvo_hip_ctx* ctx);
+int bpvo_hip_num_channels(const bpvo_hip_ctx* ctx);
+int bpvo_hip_level_size(const bpvo_hip_ctx* ctx, int level, int* rows, int* cols);
+
+/* ---- VisualOdometryFrame (reference: bpvo/vo_frame.h:21-90) ------------------------------- */
+/* setData: copy image+disparity, build image pyramid + descriptor pyramid
+ * (reference: bpvo/vo_frame.cc:48-55 -> dense_descriptor_pyramid.cc:67-78, image_pyramid.cc:43-50). */
+int bpvo_hip_frame_set_data(bpvo_hip_ctx* ctx, int slot, const uint8_t* image, const float* disparity);
+int bpvo_hip_frame_set_data_device(bpvo_hip_ctx* ctx, int slot, const uint8_t* d_image, const float* d_disparity);
+/* setTemplate: pixel selection, 3-D points, normalisation, pixels+gradients+Jacobians for levels
+ * L-1..maxTestLevel (reference: bpvo/vo_frame.cc:61-93 -> bpvo/template_data.cc:37-142). */
+int bpvo_hip_frame_set_template(bpvo_hip_ctx* ctx, int slot);
+int bpvo_hip_frame_clear(bpvo_hip_ctx* ctx, int slot);                /* vo_frame.h:47 */
+int bpvo_hip_frame_state(const bpvo_hip_ctx* ctx, int slot, int* has_data, int* has_template);
+
+/* batched forms: `count` slots first_slot, first_slot+stride, ... ; inputs are `count` images /
+ * disparities back to back.  One launch per stage covers all of them. */
+int bpvo_hip_frames_set_data(bpvo_hip_ctx* ctx, int first_slot, int slot_stride, int count,
+                             const uint8_t* images, const float* disparities, int on_device);
+int bpvo_hip_frames_set_template(bpvo_hip_ctx* ctx, int first_slot, int slot_stride, int count);
+
+/* accessors (parity surface) */
+int bpvo_hip_get_image(bpvo_hip_ctx* ctx, int slot, int level, uint8_t* out);               /* image_pyramid.cc:43-50 */
+int bpvo_hip_get_descriptor_channel(bpvo_hip_ctx* ctx, int slot, int level, int channel,
+                                    float* out);                                         /* dense_descriptor.h getChannel */
+int bpvo_hip_get_saliency(bpvo_hip_ctx* ctx, int slot, int level, float* out);               /* dense_descriptor.cc:92-100 */
+int bpvo_hip_num_points(bpvo_hip_ctx* ctx, int slot, int level, int* n);                      /* template_data.h numPoints */
+int bpvo_hip_get_points(bpvo_hip_ctx* ctx, int slot, int level, float* xyzw /*[N][4]*/);      /* template_data.h points */
+int bpvo_hip_get_point_indices(bpvo_hip_ctx* ctx, int slot, int level, int* inds /*[N], y*W+x*/);
+int bpvo_hip_get_pixels(bpvo_hip_ctx* ctx, int slot, int level, float* pixels /*[C*N]*/);     /* template_data.h pixels */
+int bpvo_hip_get_jacobians(bpvo_hip_ctx* ctx, int slot, int level, float* J /*[C*N][6]*/);    /* template_data.h jacobians */
+int bpvo_hip_get_normalization(bpvo_hip_ctx* ctx, int slot, int level, float T[16], float T_inv[16]); /* rigid_body_warp.h:62-71 */
+
+/* ---- operator-level seam used by PoseEstimatorGN::linearize (reference: bpvo/pose_estimator_gn.h:70-81):
+ * computeResiduals + estimateScale + ComputeWeights + LinearSystemBuilder::Run at pose T.
+ * reset_scale != 0 resets the AutoScaleEstimator first (pose_estimator_base.h:287-293).
+ * Outputs: H (6x6 row-major, symmetric), G, f_norm = sqrt(sum w v r^2), sigma, number of valid points. */
+int bpvo_hip_linearize(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, int level, const float T[16],
+                       int reset_scale, float H[36], float G[6], float* f_norm, float* sigma, int* num_valid);
+int bpvo_hip_get_residuals(bpvo_hip_ctx* ctx, int ws, float* r /*[C*N]*/, size_t* n);
+int bpvo_hip_get_valid(bpvo_hip_ctx* ctx, int ws, uint16_t* v /*[N]*/, size_t* n);
+int bpvo_hip_get_weights(bpvo_hip_ctx* ctx, int ws, float* w /*[C*N]*/, size_t* n);          /* vo_pose_estimator.cc:95-99 */
+int bpvo_hip_fraction_good(bpvo_hip_ctx* ctx, int ws, float threshold, float* frac);         /* vo_pose_estimator.cc:101-107 */
+
+/* ---- VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93):
+ * coarse-to-fine PoseEstimatorGN::run (pose_estimator_base.h:324-407). stats[numLevels]. */
+int bpvo_hip_estimate_pose(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, const float T_init[16],
+                           float T_est[16], bpvo_hip_stats* stats);
+
+/* ---- VisualOdometry (reference: bpvo/vo.h:42-100, bpvo/vo.cc:125-224). Uses frame slots 0..2 and
+ * workspace 0 of the ctx (needs n_frames >= 3). */
+int bpvo_hip_add_frame(bpvo_hip_ctx* ctx, const uint8_t* image, const float* disparity, bpvo_hip_result* result);
+int bpvo_hip_vo_num_points_at_level(bpvo_hip_ctx* ctx, int level, int* n);                    /* vo.cc:226-238 */
+int bpvo_hip_vo_points_at_level(bpvo_hip_ctx* ctx, int level, float* xyzw);                   /* vo.cc:240-248 */
+int bpvo_hip_get_point_cloud(bpvo_hip_ctx* ctx, bpvo_hip_point_with_info* pts, size_t* n, float pose[16]); /* vo.cc:260-281 */
+int bpvo_hip_trajectory_size(bpvo_hip_ctx* ctx, int* n);                                      /* trajectory.cc:42-50 */
+int bpvo_hip_get_trajectory(bpvo_hip_ctx* ctx, float* poses /*[n][16]*/);
+
+/* ---- batches of independent frame pairs (BASELINE.json config 5).
+ * Pair p uses frame slots 2p (reference/template frame A) and 2p+1 (current frame B) and workspace p.
+ * For each pair: A.setData, A.setTemplate, B.setData, estimatePose(A, B, Identity) -> poses[p].
+ * images = [A0,B0,A1,B1,...] (2*n_pairs images), disparities likewise (B's disparity is stored but unused).
+ * stats = [n_pairs][numLevels]. */
+int bpvo_hip_batch_run(bpvo_hip_ctx* ctx, int n_pairs, const uint8_t* images, const float* disparities,
+                       int on_device, float* poses /*[n_pairs][16]*/, bpvo_hip_stats* stats);
+/* same, but only the estimatePose stage on already prepared slots */
+int bpvo_hip_batch_estimate(bpvo_hip_ctx* ctx, int n_pairs, const float* T_init /*[n_pairs][16] or NULL=Identity*/,
+                            float* poses, bpvo_hip_stats* stats);
+/* device address of the packed result records of the last batch (32 floats per pair:
+ * pose 3x4 row-major (12), twist-free pad, per-level numIterations (4..), status ...) for an RCCL gather. */
+int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* ctx, const float** d_records, int* floats_per_pair);
+
+/* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx's own stream */
+typedef struct bpvo_hip_kernel_stat {
+  char     name[48];
+  uint64_t launches;
+  double   total_ms;          /* sum of HIP-event durations */
+  double   units;             /* units processed (points or pixels), summed over launches */
+  double   bytes_per_unit;    /* algorithmic bytes per unit */
+} bpvo_hip_kernel_stat;
+int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);        /* enable/disable + reset counters */
+int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int max_out, int* n_out);
+int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPVO_HIP_C_API_H */

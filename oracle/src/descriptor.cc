@@ -1,0 +1,91 @@
+// ORACLE — test infrastructure only (see orc.h).  Dense descriptors.
+#include "orc.h"
+
+#include <stdexcept>
+
+namespace orc {
+
+// bpvo/types.cc:31-66 (AlgorithmParameters() constructor defaults)
+void defaultParams(Params& p)
+{
+  p.numPyramidLevels = -1;
+  p.minImageDimensionForPyramid = 40;
+  p.sigmaPriorToCensusTransform = -1.0f;
+  p.sigmaBitPlanes = 0.5f;
+  p.dfSigma1 = 0.75f;
+  p.dfSigma2 = 1.75f;
+  p.latchNumBytes = 1;
+  p.latchRotationInvariance = 0;
+  p.latchHalfSsdSize = 1;
+  p.centralDifferenceRadius = 3;
+  p.centralDifferenceSigmaBefore = 0.75f;
+  p.centralDifferenceSigmaAfter = 1.75f;
+  p.laplacianKernelSize = 1;
+  p.maxIterations = 50;
+  p.parameterTolerance = 1e-7f;
+  p.functionTolerance = 1e-6f;
+  p.gradientTolerance = 1e-8f;
+  p.relaxTolerancesForCoarseLevels = 1;
+  p.gradientEstimation = kCD3;
+  p.interp = kLinear;
+  p.lossFunction = kTukey;
+  p.descriptor = kIntensity;
+  p.verbosity = 0x20;  // kIteration
+  p.minTranslationMagToKeyFrame = 0.15f;
+  p.minRotationMagToKeyFrame = 5.0f;
+  p.maxFractionOfGoodPointsToKeyFrame = 0.6f;
+  p.goodPointThreshold = 0.85f;
+  p.minNumPixelsForNonMaximaSuppression = 320 * 240;
+  p.nonMaxSuppRadius = 1;
+  p.minNumPixelsToWork = 256;
+  p.minSaliency = 0.1f;
+  p.minValidDisparity = 0.001f;
+  p.maxValidDisparity = 512.0f;
+  p.maxTestLevel = 0;
+  p.withNormalization = 1;
+}
+
+// DenseDescriptor::Create + compute (bpvo/dense_descriptor.cc:38-90):
+//   kIntensity -> IntensityDescriptor::compute (bpvo/intensity_descriptor.cc:31-43): u8 -> f32, exact (Mat::convertTo).
+//   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
+//                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
+//                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
+void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, Descriptor& d, int nthreads)
+{
+  d.rows = rows;
+  d.cols = cols;
+  const size_t n = (size_t) rows * cols;
+  if(p.descriptor == kIntensity) {
+    d.ch.resize(1);
+    d.ch[0].resize(n);
+    for(size_t i = 0; i < n; ++i) d.ch[0][i] = (float) img[i];
+    return;
+  }
+  if(p.descriptor != kBitPlanes) throw std::runtime_error("oracle: unsupported descriptor");
+
+  std::vector<uint8_t> C(n);
+  census(img, rows, cols, p.sigmaPriorToCensusTransform, C.data());
+  d.ch.resize(8);
+  (void) nthreads;
+#pragma omp parallel for num_threads(nthreads) if(nthreads > 1)
+  for(int b = 0; b < 8; ++b) {
+    std::vector<float> tmp(n);
+    for(size_t i = 0; i < n; ++i) tmp[i] = 1.0f * (float) ((C[i] & (1 << b)) >> b) - 0.0f;
+    d.ch[b].resize(n);
+    if(p.sigmaBitPlanes > 0.0f)
+      gaussianBlurF32_5x5(tmp.data(), rows, cols, p.sigmaBitPlanes, d.ch[b].data());
+    else
+      d.ch[b] = tmp;
+  }
+}
+
+// DenseDescriptor::computeSaliencyMap (bpvo/dense_descriptor.cc:92-100); IntensityDescriptor's override
+// (bpvo/intensity_descriptor.cc:45-53) is the C == 1 case of the same code.
+void computeSaliencyMap(const Descriptor& d, std::vector<float>& S)
+{
+  S.assign((size_t) d.rows * d.cols, 0.0f);
+  gradientAbsoluteMagnitude(d.ch[0].data(), d.rows, d.cols, S.data());
+  for(int i = 1; i < d.numChannels(); ++i) gradientAbsoluteMagnitudeAcc(d.ch[i].data(), d.rows, d.cols, S.data());
+}
+
+}  // namespace orc
