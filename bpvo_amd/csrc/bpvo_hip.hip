@@ -1,0 +1,1228 @@
+// libbpvo_hip: host driver + C ABI (include/bpvo_hip/c_api.h) of the MI355X-native dense alignment path.
+//
+// The host keeps bpvo's object model (frames with a descriptor pyramid and a template pyramid, a pose estimator with
+// per-level Gauss-Newton runs, the VisualOdometry keyframe state machine) but every O(pixels) / O(points) array lives
+// in HBM; per GN iteration the host sees one 4-byte "pairs still active" counter.  See DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace bpvo_hip;
+
+namespace {
+
+std::string g_create_error;
+
+struct LevelGeom {
+  int rows, cols;
+  size_t npix;
+  int nblk;        // 256-pixel chunks of the row-major scan
+  int cap;         // capacity of the template arrays
+  int nms_radius;  // <= 0: off
+  float K[9];
+  float b;
+};
+
+struct FrameSlot {
+  bool has_data = false, has_template = false;
+  void* data_slab = nullptr;
+  void* tmpl_slab = nullptr;
+  uint8_t* img[kMaxLevels] = {};
+  uint8_t* cen[kMaxLevels] = {};
+  float* desc[kMaxLevels] = {};
+  float* disp = nullptr;
+  float* sal[kMaxLevels] = {};
+  uint8_t* flag[kMaxLevels] = {};
+  int* blk_count[kMaxLevels] = {};
+  float4* pts[kMaxLevels] = {};
+  int* inds[kMaxLevels] = {};
+  float* pix[kMaxLevels] = {};
+  float* jac[kMaxLevels] = {};
+  float* nrm = nullptr;    // [L][4]
+  int* n_dev = nullptr;    // [L]
+  int n_host[kMaxLevels] = {};
+};
+
+struct Workspace {
+  float* r = nullptr;
+  uint8_t* valid = nullptr;
+  float* partials = nullptr;
+  int last_ref = -1, last_cur = -1, last_level = -1;
+};
+
+enum KernelClass { KC_PYRAMID = 0, KC_DESCRIPTOR, KC_SALIENCY_SELECT, KC_TEMPLATE, KC_WARP_RESIDUAL, KC_MEDIAN, KC_IRLS_REDUCE,
+                   KC_GN_STEP, KC_COUNT };
+const char* kKernelNames[KC_COUNT] = {"pyramid", "descriptor", "saliency_select", "template_build", "warp_residual", "median",
+                                      "irls_reduce", "gn_step"};
+
+struct EventPair { hipEvent_t a, b; int kc; double units; };
+
+}  // namespace
+
+struct bpvo_hip_ctx {
+  bpvo_hip_params params;
+  float K[9];
+  float baseline;
+  int rows, cols, L, C, device;
+  int n_frames, n_pairs;
+  LevelGeom geom[kMaxLevels];
+  float gauss_k[3];
+  hipStream_t stream = nullptr;
+  std::vector<FrameSlot> frames;
+  std::vector<Workspace> ws;
+  GNState* d_states = nullptr;
+  FrameJob* d_fjobs = nullptr;     // [L][n_frames]
+  PairJob* d_pjobs = nullptr;      // [L][n_pairs]
+  PairJob* d_job1 = nullptr;       // scratch single job (linearize / weights)
+  float* d_Tinit = nullptr;        // [n_pairs][16]
+  float* d_records = nullptr;      // [n_pairs][kRecordFloats]
+  float* d_wtmp = nullptr;         // [cap_max * C] weights scratch
+  int* d_active = nullptr;         // [2]
+  unsigned int* d_count = nullptr;
+  unsigned long long* d_counters = nullptr;   // [2] points, linearisations
+  // pinned staging
+  FrameJob* h_fjobs = nullptr;
+  PairJob* h_pjobs = nullptr;
+  GNState* h_states = nullptr;
+  int* h_ints = nullptr;           // [max(n_frames*L, 16)]
+  float* h_T = nullptr;            // [n_pairs*16]
+  int cap_max = 0;
+  // VisualOdometry state (bpvo/vo.cc:45-52)
+  int vo_ref = 0, vo_cur = 1, vo_prev = 2;
+  M44 T_kf;
+  std::vector<M44> trajectory;
+  std::vector<bpvo_hip_point_with_info> cloud;
+  M44 cloud_pose;
+  // measurement
+  bool profiling = false;
+  std::vector<EventPair> ev_pending;
+  std::vector<hipEvent_t> ev_pool;
+  double kc_ms[KC_COUNT] = {};
+  double kc_units[KC_COUNT] = {};
+  uint64_t kc_launches[KC_COUNT] = {};
+  uint64_t total_lin = 0;
+  std::string err;
+};
+
+namespace {
+
+#define HIP_CK(ctx_, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if(e_ != hipSuccess) {                                                                  \
+      (ctx_)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+      return BPVO_ERR_DEVICE;                                                               \
+    }                                                                                       \
+  } while(0)
+
+int fail(bpvo_hip_ctx* c, int code, const char* msg)
+{
+  c->err = msg;
+  return code;
+}
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  unsigned char* base;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count)
+  {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += align_up(count * sizeof(T));
+    return p;
+  }
+};
+
+// cv::getGaussianKernel(5, sigma, CV_32F) (OpenCV 2.4 smooth.cpp; reference call site bpvo/bitplanes_descriptor.cc:56):
+// exp in double, stored as float, normalised by the double sum of the floats.
+void gaussian_kernel5(double sigma, float k[3])
+{
+  float kk[5];
+  const double sigmaX = sigma > 0 ? sigma : ((5 - 1) * 0.5 - 1) * 0.3 + 0.8;
+  const double scale2X = -0.5 / (sigmaX * sigmaX);
+  double sum = 0;
+  for(int i = 0; i < 5; ++i) {
+    const double x = i - 2.0;
+    kk[i] = (float) std::exp(scale2X * x * x);
+    sum += kk[i];
+  }
+  sum = 1. / sum;
+  for(int i = 0; i < 5; ++i) kk[i] = (float) (kk[i] * sum);
+  k[0] = kk[2]; k[1] = kk[3]; k[2] = kk[4];
+}
+
+void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t* total)
+{
+  Carver cv{base};
+  for(int l = 0; l < c->L; ++l) f.img[l] = cv.take<uint8_t>(c->geom[l].npix);
+  f.disp = cv.take<float>(c->geom[0].npix);
+  for(int l = 0; l < c->L; ++l) f.desc[l] = cv.take<float>(c->geom[l].npix * c->C);
+  for(int l = 0; l < c->L; ++l) f.cen[l] = (c->C == 8) ? cv.take<uint8_t>(c->geom[l].npix) : nullptr;
+  if(total) *total = cv.off;
+}
+
+void carve_frame_tmpl(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t* total)
+{
+  Carver cv{base};
+  for(int l = 0; l < c->L; ++l) {
+    const LevelGeom& g = c->geom[l];
+    f.sal[l] = cv.take<float>(g.npix);
+    f.flag[l] = cv.take<uint8_t>(g.npix);
+    f.blk_count[l] = cv.take<int>(g.nblk);
+    f.pts[l] = cv.take<float4>(g.cap);
+    f.inds[l] = cv.take<int>(g.cap);
+    f.pix[l] = cv.take<float>((size_t) g.cap * c->C);
+    f.jac[l] = cv.take<float>((size_t) g.cap * c->C * 6);
+  }
+  f.nrm = cv.take<float>(4 * kMaxLevels);
+  f.n_dev = cv.take<int>(kMaxLevels);
+  if(total) *total = cv.off;
+}
+
+int ensure_template_storage(bpvo_hip_ctx* c, FrameSlot& f)
+{
+  if(f.tmpl_slab) return BPVO_OK;
+  size_t total = 0;
+  FrameSlot tmp;
+  carve_frame_tmpl(c, tmp, nullptr, &total);
+  HIP_CK(c, hipMalloc(&f.tmpl_slab, total));
+  HIP_CK(c, hipMemsetAsync(f.tmpl_slab, 0, total, c->stream));
+  carve_frame_tmpl(c, f, (unsigned char*) f.tmpl_slab, nullptr);
+  return BPVO_OK;
+}
+
+FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
+{
+  const LevelGeom& g = c->geom[l];
+  FrameJob j;
+  std::memset(&j, 0, sizeof(j));
+  j.img = f.img[l];
+  j.cen = f.cen[l];
+  j.desc = f.desc[l];
+  j.sal = f.sal[l];
+  j.flag = f.flag[l];
+  j.blk_count = f.blk_count[l];
+  j.n_out = f.n_dev ? f.n_dev + l : nullptr;
+  j.disp = f.disp;
+  j.pts = f.pts[l];
+  j.inds = f.inds[l];
+  j.pix = f.pix[l];
+  j.jac = f.jac[l];
+  j.nrm = f.nrm ? f.nrm + 4 * l : nullptr;
+  j.rows = g.rows; j.cols = g.cols; j.level = l; j.disp_cols = c->cols;
+  j.cap = g.cap;
+  j.nms_radius = g.nms_radius;
+  std::memcpy(j.K, g.K, sizeof(j.K));
+  j.b = g.b;
+  return j;
+}
+
+PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
+{
+  FrameSlot& fr = c->frames[ref];
+  FrameSlot& fc = c->frames[cur];
+  const LevelGeom& g = c->geom[l];
+  PairJob j;
+  std::memset(&j, 0, sizeof(j));
+  j.pts = fr.pts[l];
+  j.pix = fr.pix[l];
+  j.jac = fr.jac[l];
+  j.nrm = fr.nrm + 4 * l;
+  j.n = fr.n_host[l];
+  j.desc = fc.desc[l];
+  j.rows = g.rows; j.cols = g.cols;
+  std::memcpy(j.K, g.K, sizeof(j.K));
+  j.r = c->ws[ws].r;
+  j.valid = c->ws[ws].valid;
+  j.partials = c->ws[ws].partials;
+  j.st = c->d_states + ws;
+  return j;
+}
+
+// ---- measurement: HIP events on the ctx stream around kernel classes ------------------------------------------------
+hipEvent_t take_event(bpvo_hip_ctx* c)
+{
+  if(!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void) hipEventCreate(&e);
+  return e;
+}
+struct ScopedTimer {
+  bpvo_hip_ctx* c;
+  EventPair ep;
+  bool on;
+  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units) : c(c_), on(c_->profiling)
+  {
+    if(!on) return;
+    ep.kc = kc; ep.units = units;
+    ep.a = take_event(c); ep.b = take_event(c);
+    (void) hipEventRecord(ep.a, c->stream);
+  }
+  ~ScopedTimer()
+  {
+    if(!on) return;
+    (void) hipEventRecord(ep.b, c->stream);
+    c->ev_pending.push_back(ep);
+  }
+};
+void resolve_events(bpvo_hip_ctx* c)   // call after a stream sync
+{
+  for(auto& ep : c->ev_pending) {
+    float ms = 0.0f;
+    if(hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+      c->kc_ms[ep.kc] += ms;
+      c->kc_units[ep.kc] += ep.units;
+      c->kc_launches[ep.kc] += 1;
+    }
+    c->ev_pool.push_back(ep.a);
+    c->ev_pool.push_back(ep.b);
+  }
+  c->ev_pending.clear();
+}
+
+// ---- frame stages ---------------------------------------------------------------------------------------------------
+// slots: first, first+stride, ...; uploads the FrameJob table [L][count] and returns its device base
+int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count)
+{
+  for(int l = 0; l < c->L; ++l)
+    for(int i = 0; i < count; ++i) c->h_fjobs[(size_t) l * c->n_frames + i] = make_frame_job(c, c->frames[first + i * stride], l);
+  HIP_CK(c, hipMemcpyAsync(c->d_fjobs, c->h_fjobs, sizeof(FrameJob) * (size_t) c->L * c->n_frames, hipMemcpyHostToDevice, c->stream));
+  return BPVO_OK;
+}
+
+// VisualOdometryFrame::setData (reference: bpvo/vo_frame.cc:48-55) for `count` frames at once
+int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device)
+{
+  if(count <= 0) return BPVO_OK;
+  if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
+  if(!images || !disps) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
+  const size_t npix = c->geom[0].npix;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    HIP_CK(c, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, kind, c->stream));
+    HIP_CK(c, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), kind, c->stream));
+  }
+  int rc = upload_frame_jobs(c, first, stride, count);
+  if(rc) return rc;
+  const int NF = c->n_frames;
+  {
+    double px = 0;
+    for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_PYRAMID, px);
+    for(int l = 1; l < c->L; ++l)   // ImagePyramid::compute (bpvo/image_pyramid.cc:43-50)
+      launch_pyrdown(c->stream, c->d_fjobs + (size_t) (l - 1) * NF, c->d_fjobs + (size_t) l * NF, c->geom[l].cols, c->geom[l].rows, count);
+  }
+  {
+    double px = 0;
+    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_DESCRIPTOR, px);
+    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
+      const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
+      const LevelGeom& g = c->geom[l];
+      if(c->C == 1) {
+        launch_intensity(c->stream, jobs, g.cols, g.rows, count);
+      } else {
+        launch_census(c->stream, jobs, g.cols, g.rows, count);
+        launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k);
+      }
+    }
+  }
+  HIP_CK(c, hipGetLastError());
+  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_data = true;
+  return BPVO_OK;
+}
+
+// VisualOdometryFrame::setTemplate (reference: bpvo/vo_frame.cc:61-93 -> bpvo/template_data.cc:37-142) for `count` frames
+int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
+{
+  if(count <= 0) return BPVO_OK;
+  if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    if(!f.has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");   // vo_frame.cc:63
+    int rc = ensure_template_storage(c, f);
+    if(rc) return rc;
+  }
+  int rc = upload_frame_jobs(c, first, stride, count);
+  if(rc) return rc;
+  const int NF = c->n_frames;
+  const bpvo_hip_params& p = c->params;
+  const int border = std::max(p.nonMaxSuppRadius, 3);   // template_data.cc:51
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
+    const LevelGeom& g = c->geom[l];
+    {
+      ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count);
+      launch_saliency(c->stream, jobs, c->C, g.cols, g.rows, count);
+      launch_select(c->stream, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
+      launch_normalization(c->stream, jobs, count, p.withNormalization);
+    }
+    {
+      ScopedTimer t(c, KC_TEMPLATE, 0.0);
+      launch_template_build(c->stream, jobs, c->C, g.cap, count, p.gradientEstimation == BPVO_GRAD_CD5);
+    }
+  }
+  // one read-back of the point counts (host needs them to size the GN grids)
+  for(int i = 0; i < count; ++i)
+    HIP_CK(c, hipMemcpyAsync(c->h_ints + (size_t) i * kMaxLevels, c->frames[first + i * stride].n_dev, sizeof(int) * kMaxLevels,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  HIP_CK(c, hipGetLastError());
+  resolve_events(c);
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    double pts = 0;
+    for(int l = 0; l < c->L; ++l) {
+      f.n_host[l] = (l >= p.maxTestLevel) ? c->h_ints[(size_t) i * kMaxLevels + l] : 0;
+      pts += f.n_host[l];
+    }
+    c->kc_units[KC_TEMPLATE] += c->profiling ? pts : 0.0;
+    f.has_template = true;
+  }
+  return BPVO_OK;
+}
+
+// ---- estimatePose ---------------------------------------------------------------------------------------------------
+// VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93) for `n` workspaces at once.
+// refs[i], curs[i]: frame slots; workspace i.  T_init host [n][16] or null (Identity).
+int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
+                   bpvo_hip_stats* stats)
+{
+  if(n <= 0) return BPVO_OK;
+  if(n > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "more pairs than workspaces");
+  for(int i = 0; i < n; ++i)
+    if(wss[i] < 0 || wss[i] >= c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "bad workspace");
+  const bpvo_hip_params& p = c->params;
+  for(int i = 0; i < n; ++i) {
+    if(refs[i] < 0 || refs[i] >= c->n_frames || curs[i] < 0 || curs[i] >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot");
+    if(!c->frames[refs[i]].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
+    if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  }
+  const int NP = c->n_pairs;
+  std::vector<int> max_pts(c->L, 0);
+  for(int l = 0; l < c->L; ++l)
+    for(int i = 0; i < n; ++i) {
+      c->h_pjobs[(size_t) l * NP + i] = make_pair_job(c, wss[i], refs[i], curs[i], l);
+      max_pts[l] = std::max(max_pts[l], c->h_pjobs[(size_t) l * NP + i].n);
+    }
+  HIP_CK(c, hipMemcpyAsync(c->d_pjobs, c->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, c->stream));
+  const float* dT = nullptr;
+  if(T_init) {
+    std::memcpy(c->h_T, T_init, sizeof(float) * 16 * n);
+    HIP_CK(c, hipMemcpyAsync(c->d_Tinit, c->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, c->stream));
+    dT = c->d_Tinit;
+  }
+  launch_set_pose(c->stream, c->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
+
+  // PoseEstimatorParameters(AlgorithmParameters) (bpvo/pose_estimator_params.cc:27-33): maxFuncEvals stays 6*200 (Q4);
+  // the low-res parameter set equals the full-res one (Q3).
+  const int max_fun_evals = 6 * 200;
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    GNLaunch g;
+    g.jobs = c->d_pjobs + (size_t) l * NP;
+    g.npairs = n;
+    g.max_points = max_pts[l];
+    g.C = c->C;
+    g.loss = p.lossFunction;
+    launch_level_begin(c->stream, g.jobs, n, l);
+    if(g.max_points <= 0) continue;
+    HIP_CK(c, hipMemsetAsync(c->d_active, 0, 2 * sizeof(int), c->stream));
+    const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
+    for(int it = 0; it < max_lin; ++it) {
+      const int parity = it & 1;
+      { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
+      { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+      { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+      { ScopedTimer t(c, KC_GN_STEP, 0.0);
+        launch_gn_step(c->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                       p.gradientTolerance, c->d_active, parity, c->d_counters); }
+      HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_CK(c, hipStreamSynchronize(c->stream));
+      if(c->h_ints[0] == 0) break;
+    }
+  }
+  launch_pack_records(c->stream, c->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, c->d_records);
+  HIP_CK(c, hipMemcpyAsync(c->h_states, c->d_states, sizeof(GNState) * c->n_pairs, hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  HIP_CK(c, hipGetLastError());
+  resolve_events(c);
+  for(int i = 0; i < n; ++i) {
+    const GNState& st = c->h_states[wss[i]];
+    if(poses) std::memcpy(poses + 16 * (size_t) i, st.T_out, 16 * sizeof(float));
+    if(stats)
+      for(int l = 0; l < c->L; ++l) stats[(size_t) i * c->L + l] = st.stats[l];
+    Workspace& w = c->ws[wss[i]];
+    w.last_ref = refs[i];
+    w.last_cur = curs[i];
+    w.last_level = p.maxTestLevel;
+  }
+  return BPVO_OK;
+}
+
+int refresh_counters(bpvo_hip_ctx* c)
+{
+  unsigned long long h[2] = {0, 0};
+  HIP_CK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  c->total_lin = h[1];
+  // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
+  c->kc_units[KC_WARP_RESIDUAL] = (double) h[0];
+  c->kc_units[KC_IRLS_REDUCE] = (double) h[0];
+  c->kc_units[KC_MEDIAN] = (double) h[0];
+  c->kc_units[KC_GN_STEP] = (double) h[1];
+  return BPVO_OK;
+}
+
+int upload_single_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int level)
+{
+  c->h_pjobs[0] = make_pair_job(c, ws, ref, cur, level);
+  HIP_CK(c, hipMemcpyAsync(c->d_job1, c->h_pjobs, sizeof(PairJob), hipMemcpyHostToDevice, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));   // h_pjobs is reused by the next call
+  return BPVO_OK;
+}
+
+void trajectory_push(bpvo_hip_ctx* c, const M44& T)   // Trajectory::push_back + InvertPose (bpvo/trajectory.cc:30-50)
+{
+  M44 Ti = m44_identity();
+  for(int i = 0; i < 3; ++i)
+    for(int j = 0; j < 3; ++j) Ti.m[i * 4 + j] = T.m[j * 4 + i];
+  for(int i = 0; i < 3; ++i) {
+    float s = Ti.m[0 * 4 + i] * T.m[3];
+    s += Ti.m[1 * 4 + i] * T.m[7];
+    s += Ti.m[2 * 4 + i] * T.m[11];
+    Ti.m[i * 4 + 3] = -s;
+  }
+  if(!c->trajectory.empty()) c->trajectory.push_back(m44_mul(c->trajectory.back(), Ti));
+  else c->trajectory.push_back(Ti);
+}
+
+int fraction_good(bpvo_hip_ctx* c, int ws, float thr, float* frac)
+{
+  Workspace& w = c->ws[ws];
+  if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  const int n = c->frames[w.last_ref].n_host[w.last_level];
+  int rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
+  if(rc) return rc;
+  HIP_CK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), c->stream));
+  launch_count_good(c->stream, c->d_job1, n, c->C, c->params.lossFunction, thr, c->d_count);
+  unsigned int cnt = 0;
+  HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  cnt = (unsigned int) c->h_ints[0];
+  *frac = cnt / static_cast<float>((size_t) n * c->C);   // vo_pose_estimator.cc:105-106
+  return BPVO_OK;
+}
+
+int get_weights_host(bpvo_hip_ctx* c, int ws, std::vector<float>& w_cm, int* n_out)
+{
+  Workspace& w = c->ws[ws];
+  if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  const int n = c->frames[w.last_ref].n_host[w.last_level];
+  const int C = c->C;
+  int rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
+  if(rc) return rc;
+  launch_weights(c->stream, c->d_job1, n, C, c->params.lossFunction, c->d_wtmp);
+  std::vector<float> pm((size_t) n * C);
+  HIP_CK(c, hipMemcpyAsync(pm.data(), c->d_wtmp, pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  w_cm.resize(pm.size());
+  for(int i = 0; i < n; ++i)
+    for(int ch = 0; ch < C; ++ch) w_cm[(size_t) ch * n + i] = pm[(size_t) i * C + ch];
+  *n_out = n;
+  return BPVO_OK;
+}
+
+}  // namespace
+
+#define CHECK_CTX(c) if(!(c)) return BPVO_ERR_INVALID_ARG
+#define CHECK_SLOT(c, s) if((s) < 0 || (s) >= (c)->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot")
+#define CHECK_WS(c, w) if((w) < 0 || (w) >= (c)->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "bad workspace")
+#define CHECK_LEVEL(c, l) if((l) < (c)->params.maxTestLevel || (l) >= (c)->L) return fail(c, BPVO_ERR_INVALID_ARG, "bad level")
+
+extern "C" {
+
+void bpvo_hip_default_params(bpvo_hip_params* p)   // AlgorithmParameters() (reference: bpvo/types.cc:31-66)
+{
+  p->numPyramidLevels = -1;
+  p->minImageDimensionForPyramid = 40;
+  p->sigmaPriorToCensusTransform = -1.0f;
+  p->sigmaBitPlanes = 0.5f;
+  p->dfSigma1 = 0.75f;
+  p->dfSigma2 = 1.75f;
+  p->latchNumBytes = 1;
+  p->latchRotationInvariance = 0;
+  p->latchHalfSsdSize = 1;
+  p->centralDifferenceRadius = 3;
+  p->centralDifferenceSigmaBefore = 0.75f;
+  p->centralDifferenceSigmaAfter = 1.75f;
+  p->laplacianKernelSize = 1;
+  p->maxIterations = 50;
+  p->parameterTolerance = 1e-7f;
+  p->functionTolerance = 1e-6f;
+  p->gradientTolerance = 1e-8f;
+  p->relaxTolerancesForCoarseLevels = 1;
+  p->gradientEstimation = BPVO_GRAD_CD3;
+  p->interp = BPVO_INTERP_LINEAR;
+  p->lossFunction = BPVO_LOSS_TUKEY;
+  p->descriptor = BPVO_DESC_INTENSITY;
+  p->verbosity = BPVO_VERB_ITERATION;
+  p->minTranslationMagToKeyFrame = 0.15f;
+  p->minRotationMagToKeyFrame = 5.0f;
+  p->maxFractionOfGoodPointsToKeyFrame = 0.6f;
+  p->goodPointThreshold = 0.85f;
+  p->minNumPixelsForNonMaximaSuppression = 320 * 240;
+  p->nonMaxSuppRadius = 1;
+  p->minNumPixelsToWork = 256;
+  p->minSaliency = 0.1f;
+  p->minValidDisparity = 0.001f;
+  p->maxValidDisparity = 512.0f;
+  p->maxTestLevel = 0;
+  p->withNormalization = 1;
+}
+
+int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int rows, int cols, const bpvo_hip_params* p,
+                    int device, int n_frames, int n_pairs)
+{
+  if(!out || !K || !p || rows < 8 || cols < 8 || n_frames < 1 || n_pairs < 1) {
+    g_create_error = "invalid argument";
+    return BPVO_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device: libbpvo_hip has no CPU fallback";
+    return BPVO_ERR_NO_DEVICE;
+  }
+  if(device < 0 || device >= ndev) {
+    g_create_error = "bad device ordinal";
+    return BPVO_ERR_INVALID_ARG;
+  }
+  std::unique_ptr<bpvo_hip_ctx> c(new bpvo_hip_ctx);
+  c->params = *p;
+  std::memcpy(c->K, K, sizeof(c->K));
+  c->baseline = baseline;
+  c->rows = rows; c->cols = cols; c->device = device;
+  c->n_frames = n_frames; c->n_pairs = n_pairs;
+  if(c->params.numPyramidLevels <= 0)   // bpvo/vo.cc:101-105
+    c->params.numPyramidLevels = 1 + (int) std::round(std::log2(std::min(rows, cols) / (double) p->minImageDimensionForPyramid));
+  c->L = c->params.numPyramidLevels;
+  auto unsupported = [&](const char* m) { g_create_error = m; return BPVO_ERR_UNSUPPORTED; };
+  if(c->L < 1 || c->L > kMaxLevels) return unsupported("numPyramidLevels out of range (1..8)");
+  if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
+  if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES)
+    return unsupported("descriptor: only Intensity and BitPlanes are on the device path");
+  if(c->params.interp != BPVO_INTERP_LINEAR) return unsupported("interp: only kLinear is on the device path");
+  if(c->params.descriptor == BPVO_DESC_BITPLANES && c->params.sigmaPriorToCensusTransform > 0.0f)
+    return unsupported("sigmaPriorToCensusTransform > 0 (OpenCV-version-dependent u8 blur) is not on the device path");
+  if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
+    return unsupported("unknown lossFunction");
+  if(c->params.gradientEstimation != BPVO_GRAD_CD3 && c->params.gradientEstimation != BPVO_GRAD_CD5) return unsupported("unknown gradientEstimation");
+  c->C = (c->params.descriptor == BPVO_DESC_BITPLANES) ? 8 : 1;
+  gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
+
+  // level geometry (bpvo/vo_frame.cc:21-28: K *= 0.5, K(2,2) = 1, b *= 2; pyrDown sizes)
+  {
+    int r = rows, w = cols;
+    float Kp[9];
+    std::memcpy(Kp, K, sizeof(Kp));
+    float bp = baseline;
+    for(int l = 0; l < c->L; ++l) {
+      if(l > 0) {
+        r = (r + 1) / 2; w = (w + 1) / 2;
+        for(int k = 0; k < 9; ++k) Kp[k] *= 0.5f;
+        Kp[8] = 1.0f;
+        bp *= 2.0f;
+      }
+      LevelGeom& g = c->geom[l];
+      g.rows = r; g.cols = w; g.npix = (size_t) r * w;
+      g.nblk = (int) ((g.npix + 255) / 256);
+      const bool nms = (r * w >= c->params.minNumPixelsForNonMaximaSuppression) && c->params.nonMaxSuppRadius > 0;   // template_data.cc:43-49
+      g.nms_radius = nms ? c->params.nonMaxSuppRadius : -1;
+      // strict local maxima: at most one per 2x2 block (two adjacent pixels cannot both be strict maxima)
+      const size_t cap = nms ? (size_t) ((r + 1) / 2) * ((w + 1) / 2) : g.npix;
+      g.cap = (int) ((cap + 15) / 16 * 16);
+      std::memcpy(g.K, Kp, sizeof(Kp));
+      g.b = bp;
+      c->cap_max = std::max(c->cap_max, g.cap);
+      if(r < 8 || w < 8) return unsupported("pyramid level smaller than 8 pixels");
+    }
+  }
+
+  bpvo_hip_ctx* cp = c.get();
+  auto dev_fail = [&](hipError_t e, const char* what) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+    return BPVO_ERR_DEVICE;
+  };
+#define CREATE_CK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return dev_fail(e_, #expr); } while(0)
+  CREATE_CK(hipSetDevice(device));
+  CREATE_CK(hipStreamCreateWithFlags(&cp->stream, hipStreamNonBlocking));
+  cp->frames.resize(n_frames);
+  size_t data_total = 0;
+  { FrameSlot tmp; carve_frame_data(cp, tmp, nullptr, &data_total); }
+  for(auto& f : cp->frames) {
+    CREATE_CK(hipMalloc(&f.data_slab, data_total));
+    carve_frame_data(cp, f, (unsigned char*) f.data_slab, nullptr);
+  }
+  cp->ws.resize(n_pairs);
+  const size_t nblk_max = (size_t) gn_num_blocks(cp->cap_max);
+  for(auto& w : cp->ws) {
+    CREATE_CK(hipMalloc((void**) &w.r, sizeof(float) * (size_t) cp->cap_max * cp->C));
+    CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
+    CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
+  }
+  CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
+  CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
+  CREATE_CK(hipMalloc((void**) &cp->d_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
+  CREATE_CK(hipMalloc((void**) &cp->d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
+  CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
+  CREATE_CK(hipMalloc((void**) &cp->d_Tinit, sizeof(float) * 16 * n_pairs));
+  CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
+  CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
+  CREATE_CK(hipMalloc((void**) &cp->d_active, 2 * sizeof(int)));
+  CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
+  CREATE_CK(hipMalloc((void**) &cp->d_counters, 2 * sizeof(unsigned long long)));
+  CREATE_CK(hipMemset(cp->d_counters, 0, 2 * sizeof(unsigned long long)));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_states, sizeof(GNState) * n_pairs));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_T, sizeof(float) * 16 * n_pairs));
+#undef CREATE_CK
+  cp->T_kf = m44_identity();
+  cp->cloud_pose = m44_identity();
+  *out = c.release();
+  return BPVO_OK;
+}
+
+void bpvo_hip_destroy(bpvo_hip_ctx* c)
+{
+  if(!c) return;
+  (void) hipSetDevice(c->device);
+  if(c->stream) (void) hipStreamSynchronize(c->stream);
+  for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
+  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.partials); }
+  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_pjobs); (void) hipFree(c->d_job1);
+  (void) hipFree(c->d_Tinit); (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp); (void) hipFree(c->d_active);
+  (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
+  (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_pjobs); (void) hipHostFree(c->h_states); (void) hipHostFree(c->h_ints);
+  (void) hipHostFree(c->h_T);
+  for(auto& ep : c->ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
+  for(auto e : c->ev_pool) (void) hipEventDestroy(e);
+  if(c->stream) (void) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* bpvo_hip_last_error(const bpvo_hip_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+int bpvo_hip_num_levels(const bpvo_hip_ctx* c) { return c ? c->L : 0; }
+int bpvo_hip_num_channels(const bpvo_hip_ctx* c) { return c ? c->C : 0; }
+int bpvo_hip_level_size(const bpvo_hip_ctx* c, int level, int* rows, int* cols)
+{
+  if(!c || level < 0 || level >= c->L) return BPVO_ERR_INVALID_ARG;
+  *rows = c->geom[level].rows; *cols = c->geom[level].cols;
+  return BPVO_OK;
+}
+
+int bpvo_hip_frame_set_data(bpvo_hip_ctx* c, int slot, const uint8_t* image, const float* disparity)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot);
+  (void) hipSetDevice(c->device);
+  int rc = frames_set_data(c, slot, 1, 1, image, disparity, false);
+  if(rc) return rc;
+  HIP_CK(c, hipStreamSynchronize(c->stream));   // the caller may reuse its buffers on return (vo_frame.cc:50-51)
+  resolve_events(c);
+  return BPVO_OK;
+}
+int bpvo_hip_frame_set_data_device(bpvo_hip_ctx* c, int slot, const uint8_t* d_image, const float* d_disparity)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot);
+  (void) hipSetDevice(c->device);
+  int rc = frames_set_data(c, slot, 1, 1, d_image, d_disparity, true);
+  if(rc) return rc;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  resolve_events(c);
+  return BPVO_OK;
+}
+int bpvo_hip_frames_set_data(bpvo_hip_ctx* c, int first_slot, int slot_stride, int count, const uint8_t* images,
+                             const float* disparities, int on_device)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  int rc = frames_set_data(c, first_slot, slot_stride, count, images, disparities, on_device != 0);
+  if(rc) return rc;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  resolve_events(c);
+  return BPVO_OK;
+}
+int bpvo_hip_frame_set_template(bpvo_hip_ctx* c, int slot)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot);
+  (void) hipSetDevice(c->device);
+  return frames_set_template(c, slot, 1, 1);
+}
+int bpvo_hip_frames_set_template(bpvo_hip_ctx* c, int first_slot, int slot_stride, int count)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  return frames_set_template(c, first_slot, slot_stride, count);
+}
+int bpvo_hip_frame_clear(bpvo_hip_ctx* c, int slot)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot);
+  c->frames[slot].has_data = false;
+  c->frames[slot].has_template = false;
+  return BPVO_OK;
+}
+int bpvo_hip_frame_state(const bpvo_hip_ctx* c, int slot, int* has_data, int* has_template)
+{
+  if(!c || slot < 0 || slot >= c->n_frames) return BPVO_ERR_INVALID_ARG;
+  *has_data = c->frames[slot].has_data;
+  *has_template = c->frames[slot].has_template;
+  return BPVO_OK;
+}
+
+// ---- accessors ------------------------------------------------------------------------------------------------------
+int bpvo_hip_get_image(bpvo_hip_ctx* c, int slot, int level, uint8_t* out)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot);
+  if(level < 0 || level >= c->L) return fail(c, BPVO_ERR_INVALID_ARG, "bad level");
+  if(!c->frames[slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipMemcpyAsync(out, c->frames[slot].img[level], c->geom[level].npix, hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+int bpvo_hip_get_descriptor_channel(bpvo_hip_ctx* c, int slot, int level, int channel, float* out)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot); CHECK_LEVEL(c, level);
+  if(channel < 0 || channel >= c->C) return fail(c, BPVO_ERR_INVALID_ARG, "bad channel");
+  if(!c->frames[slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  (void) hipSetDevice(c->device);
+  const size_t npix = c->geom[level].npix;
+  // de-interleave one channel: 2-D copy with a source pitch of C floats
+  HIP_CK(c, hipMemcpy2DAsync(out, sizeof(float), c->frames[slot].desc[level] + channel, sizeof(float) * c->C, sizeof(float), npix,
+                             hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+int bpvo_hip_get_saliency(bpvo_hip_ctx* c, int slot, int level, float* out)
+{
+  CHECK_CTX(c); CHECK_SLOT(c, slot); CHECK_LEVEL(c, level);
+  if(!c->frames[slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "no template");
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipMemcpyAsync(out, c->frames[slot].sal[level], c->geom[level].npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+#define TMPL(c, slot, level)                                                                    \
+  CHECK_CTX(c); CHECK_SLOT(c, slot); CHECK_LEVEL(c, level);                                     \
+  if(!(c)->frames[slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "no template");      \
+  (void) hipSetDevice((c)->device);                                                             \
+  FrameSlot& f = (c)->frames[slot];                                                             \
+  const int n = f.n_host[level]
+
+int bpvo_hip_num_points(bpvo_hip_ctx* c, int slot, int level, int* n_out) { TMPL(c, slot, level); *n_out = n; return BPVO_OK; }
+int bpvo_hip_get_points(bpvo_hip_ctx* c, int slot, int level, float* xyzw)
+{
+  TMPL(c, slot, level);
+  if(n) HIP_CK(c, hipMemcpyAsync(xyzw, f.pts[level], sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+int bpvo_hip_get_point_indices(bpvo_hip_ctx* c, int slot, int level, int* inds)
+{
+  TMPL(c, slot, level);
+  if(n) HIP_CK(c, hipMemcpyAsync(inds, f.inds[level], sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+int bpvo_hip_get_pixels(bpvo_hip_ctx* c, int slot, int level, float* pixels)
+{
+  TMPL(c, slot, level);
+  const int C = c->C;
+  std::vector<float> pm((size_t) n * C);
+  if(n) HIP_CK(c, hipMemcpyAsync(pm.data(), f.pix[level], pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  for(int i = 0; i < n; ++i)
+    for(int ch = 0; ch < C; ++ch) pixels[(size_t) ch * n + i] = pm[(size_t) i * C + ch];   // -> channel-major
+  return BPVO_OK;
+}
+int bpvo_hip_get_jacobians(bpvo_hip_ctx* c, int slot, int level, float* J)
+{
+  TMPL(c, slot, level);
+  const int C = c->C;
+  std::vector<float> pm((size_t) n * C * 6);
+  if(n) HIP_CK(c, hipMemcpyAsync(pm.data(), f.jac[level], pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  for(int i = 0; i < n; ++i)
+    for(int ch = 0; ch < C; ++ch) std::memcpy(J + ((size_t) ch * n + i) * 6, pm.data() + ((size_t) i * C + ch) * 6, 6 * sizeof(float));
+  return BPVO_OK;
+}
+int bpvo_hip_get_normalization(bpvo_hip_ctx* c, int slot, int level, float T[16], float T_inv[16])
+{
+  TMPL(c, slot, level);
+  (void) n;
+  float nrm[4];
+  HIP_CK(c, hipMemcpyAsync(nrm, f.nrm + 4 * level, sizeof(nrm), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  M44 t = m44_identity(), ti = m44_identity();
+  t.m[0] = t.m[5] = t.m[10] = nrm[0];
+  t.m[3] = -nrm[0] * nrm[1]; t.m[7] = -nrm[0] * nrm[2]; t.m[11] = -nrm[0] * nrm[3];
+  ti.m[0] = ti.m[5] = ti.m[10] = 1.0f / nrm[0];
+  ti.m[3] = nrm[1]; ti.m[7] = nrm[2]; ti.m[11] = nrm[3];
+  std::memcpy(T, t.m, 64);
+  std::memcpy(T_inv, ti.m, 64);
+  return BPVO_OK;
+}
+
+// ---- operator-level seam --------------------------------------------------------------------------------------------
+int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int level, const float T[16], int reset_scale,
+                       float H[36], float G[6], float* f_norm, float* sigma, int* num_valid)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws); CHECK_SLOT(c, ref_slot); CHECK_SLOT(c, cur_slot); CHECK_LEVEL(c, level);
+  if(!c->frames[ref_slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
+  if(!c->frames[cur_slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  if(c->frames[ref_slot].n_host[level] <= 0) return fail(c, BPVO_ERR_NO_TEMPLATE, "you should call setData before calling computeResiduals");
+  (void) hipSetDevice(c->device);
+  int rc = upload_single_job(c, ws, ref_slot, cur_slot, level);
+  if(rc) return rc;
+  std::memcpy(c->h_T, T, 16 * sizeof(float));
+  HIP_CK(c, hipMemcpyAsync(c->d_Tinit, c->h_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_prepare_linearize(c->stream, c->d_job1, c->d_Tinit, reset_scale, level);
+  GNLaunch g;
+  g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
+  { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
+  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+  { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0, c->d_counters); }
+  HIP_CK(c, hipMemcpyAsync(c->h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  HIP_CK(c, hipGetLastError());
+  resolve_events(c);
+  const GNState& st = c->h_states[0];
+  std::memcpy(H, st.H, sizeof(st.H));
+  std::memcpy(G, st.G, sizeof(st.G));
+  *f_norm = st.f_norm;
+  *sigma = st.scale;
+  *num_valid = (int) st.n_valid;
+  c->ws[ws].last_ref = ref_slot; c->ws[ws].last_cur = cur_slot; c->ws[ws].last_level = level;
+  return BPVO_OK;
+}
+
+int bpvo_hip_get_residuals(bpvo_hip_ctx* c, int ws, float* r, size_t* n_out)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  Workspace& w = c->ws[ws];
+  if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  const int n = c->frames[w.last_ref].n_host[w.last_level], C = c->C;
+  if(n_out) *n_out = (size_t) n * C;
+  if(!r) return BPVO_OK;
+  (void) hipSetDevice(c->device);
+  std::vector<float> pm((size_t) n * C);
+  HIP_CK(c, hipMemcpyAsync(pm.data(), w.r, pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  for(int i = 0; i < n; ++i)
+    for(int ch = 0; ch < C; ++ch) r[(size_t) ch * n + i] = pm[(size_t) i * C + ch];
+  return BPVO_OK;
+}
+int bpvo_hip_get_valid(bpvo_hip_ctx* c, int ws, uint16_t* v, size_t* n_out)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  Workspace& w = c->ws[ws];
+  if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  const int n = c->frames[w.last_ref].n_host[w.last_level];
+  if(n_out) *n_out = (size_t) n;
+  if(!v) return BPVO_OK;
+  (void) hipSetDevice(c->device);
+  std::vector<uint8_t> b((size_t) n);
+  HIP_CK(c, hipMemcpyAsync(b.data(), w.valid, b.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  for(int i = 0; i < n; ++i) v[i] = b[i];
+  return BPVO_OK;
+}
+int bpvo_hip_get_weights(bpvo_hip_ctx* c, int ws, float* w, size_t* n_out)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  Workspace& wk = c->ws[ws];
+  if(wk.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  const int n0 = c->frames[wk.last_ref].n_host[wk.last_level];
+  if(n_out) *n_out = (size_t) n0 * c->C;
+  if(!w) return BPVO_OK;
+  (void) hipSetDevice(c->device);
+  std::vector<float> cm;
+  int n = 0;
+  int rc = get_weights_host(c, ws, cm, &n);
+  if(rc) return rc;
+  std::memcpy(w, cm.data(), cm.size() * sizeof(float));
+  return BPVO_OK;
+}
+int bpvo_hip_fraction_good(bpvo_hip_ctx* c, int ws, float threshold, float* frac)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  (void) hipSetDevice(c->device);
+  return fraction_good(c, ws, threshold, frac);
+}
+
+int bpvo_hip_estimate_pose(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, const float T_init[16], float T_est[16],
+                           bpvo_hip_stats* stats)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  if(!T_init || !T_est) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr pose");
+  (void) hipSetDevice(c->device);
+  return estimate_batch(c, 1, &ws, &ref_slot, &cur_slot, T_init, T_est, stats);
+}
+
+// ---- VisualOdometry -------------------------------------------------------------------------------------------------
+static int should_keyframe(bpvo_hip_ctx* c, const M44& pose, int* reason)   // reference: bpvo/vo.cc:199-224
+{
+  const bpvo_hip_params& p = c->params;
+  const float t_norm = pose.m[3] * pose.m[3] + pose.m[7] * pose.m[7] + pose.m[11] * pose.m[11];
+  if(t_norm > p.minTranslationMagToKeyFrame * p.minTranslationMagToKeyFrame) { *reason = BPVO_KF_LARGE_TRANSLATION; return BPVO_OK; }
+  // math::RotationMatrixToEulerAngles (bpvo/math_utils.h:203-216); compared in radians (Q17)
+  const float R00 = pose.m[0], R10 = pose.m[4], R20 = pose.m[8], R21 = pose.m[9];
+  const float eta = (float) (1.0 / (std::sqrt(R00 * R00 + R10 * R10)));
+  const float rz = std::asin(eta * R10), ry = std::asin(-R20), rx = std::asin(eta * R21);
+  const float r_norm = rx * rx + ry * ry + rz * rz;
+  if(r_norm > p.minRotationMagToKeyFrame * p.minRotationMagToKeyFrame) { *reason = BPVO_KF_LARGE_ROTATION; return BPVO_OK; }
+  float frac = 0.0f;
+  int rc = fraction_good(c, 0, p.goodPointThreshold, &frac);
+  if(rc) return rc;
+  *reason = (frac < p.maxFractionOfGoodPointsToKeyFrame) ? BPVO_KF_SMALL_FRAC_GOOD : BPVO_KF_NO_KEYFRAMING;
+  return BPVO_OK;
+}
+
+// getPointCloudFromRefFrame + GetColor (reference: bpvo/vo.cc:250-281)
+static int build_point_cloud(bpvo_hip_ctx* c)
+{
+  const int lvl = c->params.maxTestLevel;
+  FrameSlot& ref = c->frames[c->vo_ref];
+  const int n = ref.n_host[lvl];
+  std::vector<float> w_cm;
+  int nw = 0;
+  int rc = get_weights_host(c, 0, w_cm, &nw);
+  if(rc) return rc;
+  if((size_t) n > w_cm.size()) return fail(c, BPVO_ERR_INVALID_ARG, "size mismatch");
+  std::vector<float> pts((size_t) n * 4);
+  std::vector<uint8_t> img(c->geom[0].npix);
+  if(n) HIP_CK(c, hipMemcpyAsync(pts.data(), ref.pts[lvl], pts.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipMemcpyAsync(img.data(), ref.img[0], img.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  c->cloud.resize(n);
+  const float* Kl = c->geom[lvl].K;
+  for(int i = 0; i < n; ++i) {
+    const float* X = pts.data() + 4 * (size_t) i;
+    float x[3];
+    for(int r = 0; r < 3; ++r) {   // getImagePoint (bpvo/rigid_body_warp.h:123-128)
+      float s = Kl[r * 3 + 0] * X[0];
+      s += Kl[r * 3 + 1] * X[1];
+      s += Kl[r * 3 + 2] * X[2];
+      x[r] = s;
+    }
+    const float z_i = 1.0f / x[2];
+    const float u = z_i * x[0], v = z_i * x[1];
+    uint8_t col = 0;
+    if(v >= 0 && v < c->rows && u >= 0 && u < c->cols) col = img[(size_t) ((int) v) * c->cols + (int) u];
+    bpvo_hip_point_with_info& pw = c->cloud[i];
+    std::memset(&pw, 0, sizeof(pw));
+    std::memcpy(pw.xyzw, X, 4 * sizeof(float));
+    pw.rgba[0] = col; pw.rgba[1] = col; pw.rgba[2] = col; pw.rgba[3] = 255;
+    pw.weight = w_cm[i];
+  }
+  return BPVO_OK;
+}
+
+int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bpvo_hip_result* ret)
+{
+  CHECK_CTX(c);
+  if(!image || !disparity) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");   // bpvo/vo.cc:68-69
+  if(!ret) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr result");
+  if(c->n_frames < 3) return fail(c, BPVO_ERR_INVALID_ARG, "add_frame needs a ctx with n_frames >= 3");
+  (void) hipSetDevice(c->device);
+  const M44 I = m44_identity();
+  std::memset(ret, 0, sizeof(*ret));
+  std::memcpy(ret->pose, I.m, 64);
+  for(int i = 0; i < 36; ++i) ret->covariance[i] = (i % 7 == 0) ? 1.0f : 0.0f;   // Q16
+  ret->numLevels = c->L;
+  for(int l = 0; l < kMaxLevels; ++l) ret->optimizerStatistics[l] = bpvo_hip_stats{0, -1.0f, -1.0f, BPVO_STATUS_SOLVER_ERROR};
+  ret->isKeyFrame = 0;
+  ret->keyFramingReason = BPVO_KF_NO_KEYFRAMING;
+  ret->hasPointCloud = 0;
+
+  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, false);   // _cur_frame->setData (vo.cc:131)
+  if(rc) return rc;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+
+  if(!c->frames[c->vo_ref].has_template) {            // first frame (vo.cc:133-139)
+    std::swap(c->vo_ref, c->vo_cur);
+    rc = frames_set_template(c, c->vo_ref, 1, 1);
+    if(rc) return rc;
+    trajectory_push(c, c->T_kf);
+    ret->isKeyFrame = 1;
+    ret->keyFramingReason = BPVO_KF_FIRST_FRAME;
+    return BPVO_OK;
+  }
+
+  M44 T_est;
+  const int ws0 = 0;
+  rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, c->T_kf.m, T_est.m, ret->optimizerStatistics);
+  if(rc) return rc;
+  int reason = BPVO_KF_NO_KEYFRAMING;
+  rc = should_keyframe(c, T_est, &reason);
+  if(rc) return rc;
+  ret->keyFramingReason = reason;
+  ret->isKeyFrame = reason != BPVO_KF_NO_KEYFRAMING;
+
+  M44 pose;
+  if(!ret->isKeyFrame) {
+    std::swap(c->vo_prev, c->vo_cur);
+    pose = m44_mul(T_est, m44_inverse(c->T_kf));
+    c->T_kf = T_est;
+  } else {
+    rc = build_point_cloud(c);
+    if(rc) return rc;
+    ret->hasPointCloud = 1;
+    if(!c->frames[c->vo_prev].has_data) {               // vo.cc:161-173
+      std::swap(c->vo_cur, c->vo_ref);
+      rc = frames_set_template(c, c->vo_ref, 1, 1);
+      if(rc) return rc;
+      pose = m44_mul(T_est, m44_inverse(c->T_kf));
+      c->T_kf = m44_identity();
+    } else {                                            // vo.cc:174-188
+      std::swap(c->vo_prev, c->vo_ref);
+      c->frames[c->vo_prev].has_data = false;
+      c->frames[c->vo_prev].has_template = false;
+      rc = frames_set_template(c, c->vo_ref, 1, 1);
+      if(rc) return rc;
+      rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, I.m, T_est.m, ret->optimizerStatistics);
+      if(rc) return rc;
+      pose = T_est;
+      c->T_kf = T_est;
+    }
+  }
+  std::memcpy(ret->pose, pose.m, 64);
+  trajectory_push(c, pose);
+  if(ret->hasPointCloud) c->cloud_pose = c->trajectory.back();
+  return BPVO_OK;
+}
+
+int bpvo_hip_vo_num_points_at_level(bpvo_hip_ctx* c, int level, int* n)
+{
+  CHECK_CTX(c);
+  if(level < 0) level = c->params.maxTestLevel;
+  if(level >= c->L) return fail(c, BPVO_ERR_INVALID_ARG, "bad level");
+  *n = c->frames[c->vo_ref].has_template ? c->frames[c->vo_ref].n_host[level] : 0;
+  return BPVO_OK;
+}
+int bpvo_hip_vo_points_at_level(bpvo_hip_ctx* c, int level, float* xyzw)
+{
+  CHECK_CTX(c);
+  if(level < 0) level = c->params.maxTestLevel;
+  return bpvo_hip_get_points(c, c->vo_ref, level, xyzw);
+}
+int bpvo_hip_get_point_cloud(bpvo_hip_ctx* c, bpvo_hip_point_with_info* pts, size_t* n, float pose[16])
+{
+  CHECK_CTX(c);
+  if(n) *n = c->cloud.size();
+  if(pts) std::memcpy(pts, c->cloud.data(), c->cloud.size() * sizeof(bpvo_hip_point_with_info));
+  if(pose) std::memcpy(pose, c->cloud_pose.m, 64);
+  return BPVO_OK;
+}
+int bpvo_hip_trajectory_size(bpvo_hip_ctx* c, int* n) { CHECK_CTX(c); *n = (int) c->trajectory.size(); return BPVO_OK; }
+int bpvo_hip_get_trajectory(bpvo_hip_ctx* c, float* poses)
+{
+  CHECK_CTX(c);
+  for(size_t i = 0; i < c->trajectory.size(); ++i) std::memcpy(poses + 16 * i, c->trajectory[i].m, 64);
+  return BPVO_OK;
+}
+
+// ---- batches --------------------------------------------------------------------------------------------------------
+int bpvo_hip_batch_estimate(bpvo_hip_ctx* c, int n_pairs, const float* T_init, float* poses, bpvo_hip_stats* stats)
+{
+  CHECK_CTX(c);
+  if(n_pairs < 0 || 2 * n_pairs > c->n_frames || n_pairs > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "batch exceeds ctx capacity");
+  (void) hipSetDevice(c->device);
+  std::vector<int> wss(n_pairs), refs(n_pairs), curs(n_pairs);
+  for(int p = 0; p < n_pairs; ++p) { wss[p] = p; refs[p] = 2 * p; curs[p] = 2 * p + 1; }
+  return estimate_batch(c, n_pairs, wss.data(), refs.data(), curs.data(), T_init, poses, stats);
+}
+int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, const float* disparities, int on_device,
+                       float* poses, bpvo_hip_stats* stats)
+{
+  CHECK_CTX(c);
+  if(n_pairs < 0 || 2 * n_pairs > c->n_frames || n_pairs > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "batch exceeds ctx capacity");
+  (void) hipSetDevice(c->device);
+  int rc = frames_set_data(c, 0, 1, 2 * n_pairs, images, disparities, on_device != 0);
+  if(rc) return rc;
+  rc = frames_set_template(c, 0, 2, n_pairs);
+  if(rc) return rc;
+  return bpvo_hip_batch_estimate(c, n_pairs, nullptr, poses, stats);
+}
+int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* c, const float** d_records, int* floats_per_pair)
+{
+  CHECK_CTX(c);
+  *d_records = c->d_records;
+  *floats_per_pair = kRecordFloats;
+  return BPVO_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------------------------------------
+int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  resolve_events(c);
+  c->profiling = enable != 0;
+  for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
+  HIP_CK(c, hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+  c->total_lin = 0;
+  return BPVO_OK;
+}
+int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* c, bpvo_hip_kernel_stat* out, int max_out, int* n_out)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  resolve_events(c);
+  int rc = refresh_counters(c);
+  if(rc) return rc;
+  // algorithmic bytes per unit: unit = template point for the GN kernels, pixel otherwise
+  const double C = c->C;
+  const double bpu[KC_COUNT] = {2.0, 1.0 + 4.0 * C, 4.0 * C + 4.0 + 4.0, 16.0 + 4.0 + 5.0 * 4.0 * C + 28.0 * C, 18.0 + 24.0 * C, 4.0 * C,
+                                2.0 + 28.0 * C, 0.0};
+  int n = 0;
+  for(int k = 0; k < KC_COUNT && n < max_out; ++k, ++n) {
+    std::memset(&out[n], 0, sizeof(out[n]));
+    std::snprintf(out[n].name, sizeof(out[n].name), "%s", kKernelNames[k]);
+    out[n].launches = c->kc_launches[k];
+    out[n].total_ms = c->kc_ms[k];
+    out[n].units = c->kc_units[k];
+    out[n].bytes_per_unit = bpu[k];
+  }
+  *n_out = n;
+  return BPVO_OK;
+}
+int bpvo_hip_total_linearizations(bpvo_hip_ctx* c, uint64_t* n)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  int rc = refresh_counters(c);
+  if(rc) return rc;
+  *n = c->total_lin;
+  return BPVO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// Launchers of the HIP kernels (kernels_frame.hip, kernels_gn.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "types.h"
+
+namespace bpvo_hip {
+
+// per-frame stage (batched over frames)
+void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
+void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
+void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);
+void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes);
+void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
+                   float max_disp, int border);
+void launch_normalization(hipStream_t s, const FrameJob* jobs, int nframes, int with_normalization);
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
+
+// Gauss-Newton stage (batched over workspaces / pairs)
+struct GNLaunch {
+  const PairJob* jobs;   // device, [npairs] for the level
+  int npairs;
+  int max_points;        // max n over the pairs (grid sizing)
+  int C;
+  int loss;
+};
+int  gn_num_blocks(int max_points);
+void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
+void launch_warp_residual(hipStream_t s, const GNLaunch& g);
+void launch_median(hipStream_t s, const GNLaunch& g);
+void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
+// mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
+void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
+                    float f_tol, float g_tol, int* active_counter /*device [2]*/, int parity,
+                    unsigned long long* counters /*device [2]: points, linearisations; may be null*/);
+void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
+int  gn_pts_per_block(int npairs);
+void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
+void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
+void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records);
+
+}  // namespace bpvo_hip

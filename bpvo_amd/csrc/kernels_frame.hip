@@ -1,0 +1,471 @@
+// Per-frame kernels (gfx950): image pyramid, census / bit-planes descriptor, saliency, pixel selection,
+// 3-D points, Hartley normalisation, template (pixels + Jacobians).  All are batched over frames with blockIdx.z.
+//
+// HBM layout: the descriptor of a level is PIXEL-INTERLEAVED, desc[(y*W + x)*C + c], so that the C
+// channels of one pixel are one 32-byte record (C = 8): a bilinear gather touches 2 x 64 contiguous bytes instead
+// of 32 scattered dwords, and every kernel below writes/reads full records with 16-byte accesses.
+#include "kernels.h"
+
+namespace bpvo_hip {
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+  // cv::borderInterpolate(BORDER_REFLECT_101); one reflection suffices for the <= 3 pixel halos used here
+  if(p < 0) p = -p;
+  if(p >= len) p = 2 * len - 2 - p;
+  if(p < 0) p = 0;   // degenerate len == 1
+  return p;
+}
+
+// ---- K0: cv::pyrDown u8 (reference call site: bpvo/image_pyramid.cc:49).  [1 4 6 4 1]^2 / 256 with (s + 128) >> 8,
+// BORDER_REFLECT_101, dst = ((W+1)/2, (R+1)/2).  Integer arithmetic: evaluation order is irrelevant.
+__global__ __launch_bounds__(256) void pyrdown_u8_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
+{
+  const FrameJob& sj = src_jobs[blockIdx.z];
+  const FrameJob& dj = dst_jobs[blockIdx.z];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= dj.cols || y >= dj.rows) return;
+  const int sw = sj.cols, sh = sj.rows;
+  const uint8_t* __restrict__ s = sj.img;
+  int xs[5];
+#pragma unroll
+  for(int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, sw);
+  int acc = 0;
+  const int wgt[5] = {1, 4, 6, 4, 1};
+#pragma unroll
+  for(int k = 0; k < 5; ++k) {
+    const uint8_t* row = s + (size_t) reflect101(2 * y - 2 + k, sh) * sw;
+    const int h = row[xs[2]] * 6 + (row[xs[1]] + row[xs[3]]) * 4 + row[xs[0]] + row[xs[4]];
+    acc += wgt[k] * h;
+  }
+  ((uint8_t*) dj.img)[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
+}
+
+// ---- IntensityDescriptor::compute: u8 -> f32 (reference: bpvo/intensity_descriptor.cc:31-43)
+__global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int n = j.rows * j.cols;
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if(i >= n) return;
+  if(i + 3 < n && ((uintptr_t) (j.img + i) & 3) == 0) {
+    const uchar4 v = *reinterpret_cast<const uchar4*>(j.img + i);
+    *reinterpret_cast<float4*>(j.desc + i) = make_float4((float) v.x, (float) v.y, (float) v.z, (float) v.w);
+  } else {
+    for(int k = i; k < n && k < i + 4; ++k) j.desc[k] = (float) j.img[k];
+  }
+}
+
+// ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
+// bit k = [neighbour_k >= centre], neighbours (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); 1-px border = 0.
+__global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int W = j.cols, R = j.rows;
+  if(x >= W || y >= R) return;
+  uint8_t out = 0;
+  if(x > 0 && x < W - 1 && y > 0 && y < R - 1) {
+    const uint8_t* p = j.img + (size_t) y * W + x;
+    const uint8_t c = p[0];
+    out = (uint8_t) (((p[-W - 1] >= c) << 0) | ((p[-W] >= c) << 1) | ((p[-W + 1] >= c) << 2) | ((p[-1] >= c) << 3) |
+                     ((p[1] >= c) << 4) | ((p[W - 1] >= c) << 5) | ((p[W] >= c) << 6) | ((p[W + 1] >= c) << 7));
+  }
+  j.cen[(size_t) y * W + x] = out;
+}
+
+// ---- K1b: 8 bit-planes + cv::GaussianBlur 5x5 (reference: bpvo/bitplanes_descriptor.cc:37-57).
+// One 256-thread workgroup produces a 64 x 16 tile of 32-byte pixel records.  The census bytes of the tile + 2-px halo
+// (REFLECT_101 on the coordinates) are staged in LDS, the horizontal pass is written to LDS for all 8 planes
+// (20 rows x 64 cols x 8 f32 = 40 KB), the vertical pass streams full records to HBM with two 16-byte stores per pixel.
+// Arithmetic per plane, f32, no fusing, exactly OpenCV's symmetric 5-tap filters:
+//   row: t = S0*k0 + (S-1 + S+1)*k1 + (S-2 + S+2)*k2        column: s = k0*T0; s += k1*(T+1 + T-1); s += k2*(T+2 + T-2)
+constexpr int BP_TW = 64, BP_TH = 16, BP_HALO = 2;
+__global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2)
+{
+  __shared__ uint8_t s_cen[(BP_TH + 2 * BP_HALO) * (BP_TW + 2 * BP_HALO + 4)];
+  __shared__ float s_row[(BP_TH + 2 * BP_HALO) * BP_TW * 8];
+  constexpr int CW = BP_TW + 2 * BP_HALO + 4;   // padded LDS row pitch of the census tile
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x0 = blockIdx.x * BP_TW, y0 = blockIdx.y * BP_TH;
+  const int tid = threadIdx.x;
+
+  for(int i = tid; i < (BP_TH + 2 * BP_HALO) * (BP_TW + 2 * BP_HALO); i += 256) {
+    const int ly = i / (BP_TW + 2 * BP_HALO), lx = i - ly * (BP_TW + 2 * BP_HALO);
+    const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
+    s_cen[ly * CW + lx] = j.cen[(size_t) gy * W + gx];
+  }
+  __syncthreads();
+
+  // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
+  for(int i = tid; i < (BP_TH + 2 * BP_HALO) * BP_TW; i += 256) {
+    const int ly = i / BP_TW, lx = i - ly * BP_TW;
+    const uint8_t* c = s_cen + ly * CW + lx;   // c[0..4] = columns x-2..x+2
+    const unsigned cm2 = c[0], cm1 = c[1], c0 = c[2], cp1 = c[3], cp2 = c[4];
+    float t[8];
+#pragma unroll
+    for(int b = 0; b < 8; ++b) {
+      const float S0 = (float) ((c0 >> b) & 1u), Sm1 = (float) ((cm1 >> b) & 1u), Sp1 = (float) ((cp1 >> b) & 1u),
+                  Sm2 = (float) ((cm2 >> b) & 1u), Sp2 = (float) ((cp2 >> b) & 1u);
+      t[b] = S0 * k0 + (Sm1 + Sp1) * k1 + (Sm2 + Sp2) * k2;
+    }
+    float4* o = reinterpret_cast<float4*>(s_row + (size_t) i * 8);
+    o[0] = make_float4(t[0], t[1], t[2], t[3]);
+    o[1] = make_float4(t[4], t[5], t[6], t[7]);
+  }
+  __syncthreads();
+
+  // vertical pass: 4 pixels per thread, consecutive threads -> consecutive pixels (2 KB contiguous per wave store)
+  for(int i = tid; i < BP_TH * BP_TW; i += 256) {
+    const int ly = i / BP_TW, lx = i - ly * BP_TW;
+    const int gx = x0 + lx, gy = y0 + ly;
+    if(gx >= W || gy >= R) continue;
+    const float4* T = reinterpret_cast<const float4*>(s_row);
+    const int base = (ly * BP_TW + lx) * 2;         // row ly of s_row is image row gy-2
+    const int pitch = BP_TW * 2;
+    float4 out[2];
+#pragma unroll
+    for(int h = 0; h < 2; ++h) {
+      const float4 Tm2 = T[base + h], Tm1 = T[base + pitch + h], T0 = T[base + 2 * pitch + h], Tp1 = T[base + 3 * pitch + h],
+                   Tp2 = T[base + 4 * pitch + h];
+      float4 s;
+      s.x = k0 * T0.x; s.x += k1 * (Tp1.x + Tm1.x); s.x += k2 * (Tp2.x + Tm2.x);
+      s.y = k0 * T0.y; s.y += k1 * (Tp1.y + Tm1.y); s.y += k2 * (Tp2.y + Tm2.y);
+      s.z = k0 * T0.z; s.z += k1 * (Tp1.z + Tm1.z); s.z += k2 * (Tp2.z + Tm2.z);
+      s.w = k0 * T0.w; s.w += k1 * (Tp1.w + Tm1.w); s.w += k2 * (Tp2.w + Tm2.w);
+      out[h] = s;
+    }
+    float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
+    d[0] = out[0];
+    d[1] = out[1];
+  }
+}
+
+// sigma_bp <= 0: planes without smoothing (reference: bpvo/bitplanes_descriptor.cc:52-56 skipped)
+__global__ __launch_bounds__(256) void bitplanes_noblur_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int n = j.rows * j.cols;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= n) return;
+  const unsigned c = j.cen[i];
+  float4* d = reinterpret_cast<float4*>(j.desc + (size_t) i * 8);
+  d[0] = make_float4((float) (c & 1u), (float) ((c >> 1) & 1u), (float) ((c >> 2) & 1u), (float) ((c >> 3) & 1u));
+  d[1] = make_float4((float) ((c >> 4) & 1u), (float) ((c >> 5) & 1u), (float) ((c >> 6) & 1u), (float) ((c >> 7) & 1u));
+}
+
+// ---- K3: saliency map (reference: bpvo/dense_descriptor.cc:92-100 -> bpvo/imgproc.cc:45-74 and :104-127).
+// Closed form of the reference's memory effects, store bug of gradientAbsoluteMagnitudeAcc included (Q7, Q7b); p is the
+// linear pixel index, reads at p-1 / p+1 deliberately run across row ends like the reference's pointer arithmetic:
+//   g_c(p)    = |I_c[p-1] - I_c[p+1]| + |I_c[p-W] - I_c[p+W]|             (4-wide SSE body)
+//   tail_c(p) = |I_c[p+1] - I_c[p-1]| + |I_c[p+W] + I_c[p-W]|             (scalar tail, `+` in the y term)
+//   n = W & ~3.  rows 0, R-1 -> 0;  x = W-1 -> 0;
+//   C == 1: x < n -> g_0, else tail_0.
+//   C  > 1: 4 <= x < n -> g_0 (channel 0 only);  x < 4 -> S0(n-4+x) + g_{C-1}(n-4+x) with S0(W-1) = 0;
+//           n <= x < W-1 -> ((tail_0 + tail_1) + ...) + tail_{C-1}.
+template <int C>
+__device__ __forceinline__ float grad_abs(const float* __restrict__ I, size_t p, int W, int c)
+{
+  const float Ix = fabsf(I[(p - 1) * C + c] - I[(p + 1) * C + c]);
+  const float Iy = fabsf(I[(p - W) * C + c] - I[(p + W) * C + c]);
+  return Ix + Iy;
+}
+template <int C>
+__device__ __forceinline__ float grad_tail(const float* __restrict__ I, size_t p, int W, int c)
+{
+  return fabsf(I[(p + 1) * C + c] - I[(p - 1) * C + c]) + fabsf(I[(p + W) * C + c] + I[(p - W) * C + c]);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void saliency_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const float* __restrict__ I = j.desc;
+  const int n = W & ~3;
+  float S = 0.0f;
+  if(y >= 1 && y <= R - 2 && x != W - 1) {
+    const size_t row = (size_t) y * W;
+    if(x >= n) {
+      S = grad_tail<C>(I, row + x, W, 0);
+      for(int c = 1; c < C; ++c) S += grad_tail<C>(I, row + x, W, c);
+    } else if(C == 1 || x >= 4) {
+      S = grad_abs<C>(I, row + x, W, 0);
+    } else {
+      const int xs = n - 4 + x;
+      const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
+      S = S0 + grad_abs<C>(I, row + xs, W, C - 1);
+    }
+  }
+  j.sal[(size_t) y * W + x] = S;
+}
+
+// ---- K4: pixel selection (reference: bpvo/template_data.cc:43-89, bpvo/imgproc.h:117-160).
+// Pass 1 (select_flag_kernel): candidate flag per pixel = saliency >= minSaliency && IsLocalMax && disparity gate,
+// count per 256-pixel chunk of the row-major scan.  Pass 2 (select_scan_kernel): exclusive scan of the chunk counts,
+// N = total & ~15 (the reference drops the LAST N mod 16 points).  Pass 3 (select_write_kernel): order-preserving
+// compaction = chunk offset + in-chunk rank, keeps ranks < N, writes (y*W+x) and makePoint (rigid_body_warp.h:47-60).
+__device__ __forceinline__ bool is_local_max(const float* __restrict__ S, int W, int radius, int y, int x)
+{
+  if(radius <= 0) return true;
+  const float* p = S + (size_t) y * W + x;
+  const float v = p[0];
+  if(radius == 1) {   // WITH_SIMD form: 3 rows x 4 cols (cols -1..+2), strict > (Q8)
+    bool ok = true;
+#pragma unroll
+    for(int k = -1; k <= 2; ++k) {
+      if(k != 0) ok = ok && (v > p[k]);
+      ok = ok && (v > p[k - W]) && (v > p[k + W]);
+    }
+    return ok;
+  }
+  for(int r = -radius; r <= radius; ++r)
+    for(int c = -radius; c <= radius; ++c)
+      if(!(r == 0 && c == 0) && p[r * W + c] >= v) return false;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, float min_saliency, float min_disp,
+                                                          float max_disp, int border)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int npix = W * R;
+  bool f = false;
+  if(p < npix) {
+    const int y = p / W, x = p - y * W;
+    if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1) {
+      if(j.sal[p] >= min_saliency && is_local_max(j.sal, W, j.nms_radius, y, x)) {
+        const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+        f = (d >= min_disp && d <= max_disp);
+      }
+    }
+    j.flag[p] = f ? 1 : 0;
+  }
+  __shared__ int s_cnt[4];
+  const unsigned long long m = __ballot(f);
+  if((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if(threadIdx.x == 0 && blockIdx.x * 256 < npix) j.blk_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(1024) void select_scan_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.x];
+  const int nblk = (j.rows * j.cols + 255) / 256;
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  if(threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for(int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < nblk) ? j.blk_count[i] : 0;
+    int incl = v;   // inclusive scan in the wave
+#pragma unroll
+    for(int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if(lane >= o) incl += t;
+    }
+    if(lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for(int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int carry = s_carry;
+    if(i < nblk) j.blk_count[i] = carry + woff + incl - v;   // exclusive offset
+    __syncthreads();
+    if(threadIdx.x == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) {
+    int total = s_carry;
+    if(total > j.cap) total = j.cap;
+    *j.n_out = total & ~15;
+  }
+}
+
+__global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int npix = W * j.rows;
+  if(blockIdx.x * 256 >= npix) return;
+  const bool f = (p < npix) && j.flag[p];
+  __shared__ int s_cnt[4];
+  const unsigned long long m = __ballot(f);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if(lane == 0) s_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if(!f) return;
+  int rank = j.blk_count[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+  for(int w = 0; w < wave; ++w) rank += s_cnt[w];
+  const int N = *j.n_out;
+  if(rank >= N) return;
+  const int y = p / W, x = p - y * W;
+  const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+  const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
+  const float Bf = j.b * fx;
+  const float Z = (float) ((double) Bf * (1.0 / (double) d));
+  const float X = ((float) x - cx) * Z * (1.0f / fx);
+  const float Y = ((float) y - cy) * Z * (1.0f / fy);
+  j.pts[rank] = make_float4(X, Y, Z, 1.0f);
+  j.inds[rank] = p;
+}
+
+// ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
+// The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too: one wave
+// per (frame, level) loads 64 points at a time (coalesced float4) and every lane accumulates them in point order through
+// v_readlane broadcasts (uniform result, no LDS).  It runs once per keyframe and level.
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs, int with_normalization)
+{
+  const FrameJob& j = jobs[blockIdx.x];
+  const int N = *j.n_out;
+  const int lane = threadIdx.x;
+  if(!with_normalization || N == 0) {
+    if(lane == 0) { j.nrm[0] = 1.0f; j.nrm[1] = 0.0f; j.nrm[2] = 0.0f; j.nrm[3] = 0.0f; }
+    return;
+  }
+  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
+  for(int base = 0; base < N; base += 64) {
+    const float4 p = (base + lane < N) ? j.pts[base + lane] : make_float4(0, 0, 0, 0);
+    const int groups = min(64, N - base) >> 4;    // N is a multiple of 16
+    for(int q = 0; q < groups; ++q) {
+#pragma unroll
+      for(int k = 0; k < 16; ++k) {
+        const int l = q * 16 + k;
+        c0 += readlane_f(p.x, l);
+        c1 += readlane_f(p.y, l);
+        c2 += readlane_f(p.z, l);
+        c3 += readlane_f(p.w, l);
+      }
+    }
+  }
+  const float fN = (float) N;
+  c0 /= fN; c1 /= fN; c2 /= fN; c3 /= fN;
+  float m = 0.0f;
+  for(int base = 0; base < N; base += 64) {
+    float dist = 0.0f;
+    if(base + lane < N) {
+      const float4 p = j.pts[base + lane];
+      const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
+      dist = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    }
+    const int groups = min(64, N - base) >> 4;
+    for(int q = 0; q < groups; ++q) {
+#pragma unroll
+      for(int k = 0; k < 16; ++k) m += readlane_f(dist, q * 16 + k);
+    }
+  }
+  m /= fN;
+  const float s = (float) (sqrt(3.0) / (double) fmaxf(m, 1e-6f));
+  if(lane == 0) { j.nrm[0] = s; j.nrm[1] = c0; j.nrm[2] = c1; j.nrm[3] = c2; }
+}
+
+// ---- K5: template pixels, central-difference gradients and 1x6 Jacobians
+// (reference: bpvo/template_data.cc:102-137; Jacobian = bpvo/rigid_body_warp.cc:60-315 in the SSE code's operation
+// order with IEEE division instead of _mm_rcp_ps — SURVEY.md Q13).  Point-major outputs pix[i][c], jac[i][c][6].
+template <int C>
+__global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int N = *j.n_out;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  const int W = j.cols;
+  const int ii = j.inds[i];
+  const float4 P = j.pts[i];
+  const float fx = j.K[0], fy = j.K[4];
+  const float s = j.nrm[0], c1 = j.nrm[1], c2 = j.nrm[2], c3 = j.nrm[3];
+  const float s_i = (float) (1.0 / (double) s);
+  const float x = P.x, y = P.y, z = P.z;
+  const float z2 = z * z;
+  const float* __restrict__ D = j.desc;
+  float* __restrict__ pix = j.pix + (size_t) i * C;
+  float* __restrict__ jac = j.jac + (size_t) i * C * 6;
+  const float NN = 1.0f / 18.0f;
+#pragma unroll
+  for(int c = 0; c < C; ++c) {
+    const float* cc = D + (size_t) ii * C + c;
+    float gx, gy;
+    if(!grad_cd5) {
+      gx = 0.5f * (cc[C] - cc[-C]);
+      gy = 0.5f * (cc[(size_t) W * C] - cc[-(ptrdiff_t) W * C]);
+    } else {
+      gx = NN * (1.0f * cc[-2 * C] - 8.0f * cc[-C] + 8.0f * cc[C] - 1.0f * cc[2 * C]);
+      gy = NN * (1.0f * cc[-2 * (ptrdiff_t) W * C] - 8.0f * cc[-(ptrdiff_t) W * C] + 8.0f * cc[(ptrdiff_t) W * C] - 1.0f * cc[2 * (ptrdiff_t) W * C]);
+    }
+    pix[c] = cc[0];
+    const float Ix = fx * gx, Iy = fy * gy;
+    const float xIx_yIy = x * Ix + y * Iy;
+    float* J = jac + c * 6;
+    J[0] = (-((Iy * (z - c3)) / z)) - ((xIx_yIy * (y - c2)) / z2);
+    J[1] = ((Ix * (z - c3)) / z) + ((xIx_yIy * (x - c1)) / z2);
+    J[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) / z;
+    J[3] = Ix / (z * s);
+    J[4] = Iy / (z * s);
+    J[5] = -((s_i * xIx_yIy) / z2);
+  }
+}
+
+// ---- host-callable launchers ------------------------------------------------------------------------------------
+static inline dim3 grid2d(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 3) / 4, nz); }
+
+void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
+{
+  hipLaunchKernelGGL(pyrdown_u8_kernel, grid2d(dW, dR, nframes), dim3(256), 0, s, src, dst);
+}
+void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+{
+  hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes), dim3(256), 0, s, jobs);
+}
+void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+{
+  hipLaunchKernelGGL(census_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+}
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
+{
+  if(sigma > 0.0f)
+    hipLaunchKernelGGL(bitplanes_blur_kernel, dim3((W + BP_TW - 1) / BP_TW, (R + BP_TH - 1) / BP_TH, nframes), dim3(256), 0, s,
+                       jobs, k[0], k[1], k[2]);
+  else
+    hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
+}
+void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes)
+{
+  if(C == 1) hipLaunchKernelGGL(saliency_kernel<1>, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+  else hipLaunchKernelGGL(saliency_kernel<8>, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+}
+void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
+                   float max_disp, int border)
+{
+  const int nblk = (W * R + 255) / 256;
+  hipLaunchKernelGGL(select_flag_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs, min_saliency, min_disp, max_disp, border);
+  hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
+  hipLaunchKernelGGL(select_write_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs);
+}
+void launch_normalization(hipStream_t s, const FrameJob* jobs, int nframes, int with_normalization)
+{
+  hipLaunchKernelGGL(normalization_kernel, dim3(nframes), dim3(64), 0, s, jobs, with_normalization);
+}
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5)
+{
+  if(max_points <= 0) return;
+  const dim3 g((max_points + 255) / 256, 1, nframes);
+  if(C == 1) hipLaunchKernelGGL(template_build_kernel<1>, g, dim3(256), 0, s, jobs, grad_cd5);
+  else hipLaunchKernelGGL(template_build_kernel<8>, g, dim3(256), 0, s, jobs, grad_cd5);
+}
+
+}  // namespace bpvo_hip

@@ -1,0 +1,773 @@
+// Gauss-Newton / IRLS kernels (gfx950), batched over estimation workspaces (independent frame pairs) with blockIdx.y:
+//   warp_residual  K6  project template points with the current pose (f64), valid mask, bilinear gather of the
+//                      current frame's pixel-interleaved descriptor, residuals                     (18 + 24*C B/point)
+//   median         K7  exact median of |r| over valid entries: 3-pass radix select on the IEEE bit pattern with
+//                      LDS histograms, one workgroup per pair; robust scale + freeze rule               (4*C B/point)
+//   irls_reduce    K8  M-estimator weights fused with the J^T W J / J^T W r / sum w r^2 reduction:
+//                      in-thread accumulation, wavefront shuffle tree, LDS across waves, per-block partials (2 + 28*C B/point)
+//   gn_step        K9  deterministic f64 sum of the partials, 6x6 LDLT solve, SE(3) update and the convergence /
+//                      iteration bookkeeping of PoseEstimatorBase::run, all on the device (no host round trip of H, G)
+// No MFMA anywhere: ~1 flop/byte, HBM-bound gather + rank-1 accumulate.
+#include <float.h>
+
+#include "kernels.h"
+
+namespace bpvo_hip {
+
+constexpr int GN_BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------------------------------
+// K6 warp_residual.  reference: TemplateData::computeResiduals (bpvo/template_data.cc:174-189) =
+//   RigidBodyWarp::setPose (bpvo/rigid_body_warp.h:111-114): P = K * T[0:3,:] in f32, index-order sums
+//   PhotoError::Impl::init (bpvo/photo_error.cc:344-363): x = normHomog(P.cast<double>() * X.cast<double>()),
+//       Floor (:255-265), valid = 0 <= xi < W-1 && 0 <= yi < R-1 (kLinear)
+//   PhotoError::Impl::run kLinear (bpvo/photo_error.cc:365-389,446-449): Iw in f64, r = float(Iw - I0); invalid -> 0
+// One thread per template point; all C channels of the point are handled by the same thread because the descriptor is
+// pixel-interleaved: the 4 taps are 2 x (2*C floats) contiguous, fetched as 16-byte loads.
+template <int C>
+__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs)
+{
+  const PairJob& j = jobs[blockIdx.y];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active) return;
+  const int n = j.n;
+  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+
+  float P[12];
+#pragma unroll
+  for(int r = 0; r < 3; ++r)
+#pragma unroll
+    for(int c = 0; c < 4; ++c) {
+      float s = j.K[r * 3 + 0] * st->T[0 * 4 + c];
+      s += j.K[r * 3 + 1] * st->T[1 * 4 + c];
+      s += j.K[r * 3 + 2] * st->T[2 * 4 + c];
+      P[r * 4 + c] = s;
+    }
+
+  const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
+  if(i >= n) return;
+  const int W = j.cols, R = j.rows;
+  const float4 X = j.pts[i];
+  const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
+  double u[3];
+#pragma unroll
+  for(int r = 0; r < 3; ++r) {
+    double s = (double) P[r * 4 + 0] * X0;
+    s += (double) P[r * 4 + 1] * X1;
+    s += (double) P[r * 4 + 2] * X2;
+    s += (double) P[r * 4 + 3] * X3;
+    u[r] = s;
+  }
+  const double zi = 1.0 / u[2];
+  const double x = zi * u[0], y = zi * u[1];
+
+  // Floor(): static_cast<int> then -(i > v).  x86 yields INT_MIN for NaN / out-of-range doubles, which can never be a
+  // valid pixel; the explicit range test gives the same verdict without relying on v_cvt_i32_f64 saturation.
+  const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+  int xi = 0, yi = 0;
+  if(in_range) {
+    xi = (int) x; xi -= (xi > x);
+    yi = (int) y; yi -= (yi > y);
+  }
+  const bool valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+  j.valid[i] = valid ? 1 : 0;
+
+  float res[C];
+  if(valid) {
+    const double xf = x - (double) xi, yf = y - (double) yi;
+    const double wx = 1.0 - xf, wy = 1.0 - yf;
+    const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
+    const float* __restrict__ d1 = d0 + (size_t) W * C;
+    float I00[C], I01[C], I10[C], I11[C], I0[C];
+    if constexpr(C == 8) {
+      const float4* q0 = reinterpret_cast<const float4*>(d0);
+      const float4* q1 = reinterpret_cast<const float4*>(d1);
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix + (size_t) i * C);
+      const float4 a0 = q0[0], a1 = q0[1], a2 = q0[2], a3 = q0[3];
+      const float4 b0 = q1[0], b1 = q1[1], b2 = q1[2], b3 = q1[3];
+      const float4 t0 = p0[0], t1 = p0[1];
+      I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
+      I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
+      I10[0] = b0.x; I10[1] = b0.y; I10[2] = b0.z; I10[3] = b0.w; I10[4] = b1.x; I10[5] = b1.y; I10[6] = b1.z; I10[7] = b1.w;
+      I11[0] = b2.x; I11[1] = b2.y; I11[2] = b2.z; I11[3] = b2.w; I11[4] = b3.x; I11[5] = b3.y; I11[6] = b3.z; I11[7] = b3.w;
+      I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
+    } else {
+#pragma unroll
+      for(int c = 0; c < C; ++c) {
+        I00[c] = d0[c]; I01[c] = d0[C + c]; I10[c] = d1[c]; I11[c] = d1[C + c];
+        I0[c] = j.pix[(size_t) i * C + c];
+      }
+    }
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+      const double Iw = wy * ((double) I00[c] * wx + (double) I01[c] * xf) + yf * ((double) I10[c] * wx + (double) I11[c] * xf);
+      res[c] = (float) (Iw - (double) I0[c]);
+    }
+  } else {
+#pragma unroll
+    for(int c = 0; c < C; ++c) res[c] = 0.0f;
+  }
+  float* __restrict__ ro = j.r + (size_t) i * C;
+  if constexpr(C == 8) {
+    float4* o = reinterpret_cast<float4*>(ro);
+    o[0] = make_float4(res[0], res[1], res[2], res[3]);
+    o[1] = make_float4(res[4], res[5], res[6], res[7]);
+  } else {
+#pragma unroll
+    for(int c = 0; c < C; ++c) ro[c] = res[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K7 median + robust scale.  reference: AutoScaleEstimator::estimateScale / ScaleEstimator (bpvo/mestimator.cc:452-490)
+// and median() (bpvo/utils.h:224-252): sigma = (1.4826f * (1 + 5/(n-6))) * median(|r| : valid), n = C * #valid (size_t
+// arithmetic), sigma < 1e-6 -> 1, recomputed only while |sigma - sigma_prev| > 1e-6 (Q5, Q6).
+// The exact order statistics x[n/2] (and x[n/2-1] for even n) come from a 3-pass MSB radix select over the bit pattern of
+// |r| (monotone for non-negative floats): bits [30:20], [19:9], [8:0].  One 1024-thread workgroup per pair keeps the
+// histograms in LDS (4 privatised copies for the first pass to cut same-bin atomic serialisation), two cursors (lo, hi)
+// are refined in lock-step, and the keys that survive pass 1 are cached in LDS so pass 3 never touches HBM again.
+constexpr int MED_THREADS = 1024;
+constexpr int MED_COPIES = 4;
+constexpr int MED_BINS = 2048;
+constexpr int MED_CACHE = 20480;
+
+struct MedCursor { unsigned prefix; unsigned rank; };
+
+__device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s_wave /*[16]*/, unsigned& total)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for(int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if(lane >= o) incl += t;
+  }
+  __syncthreads();
+  if(lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  unsigned woff = 0, tot = 0;
+#pragma unroll
+  for(int w = 0; w < 16; ++w) {
+    const unsigned t = s_wave[w];
+    if(w < wave) woff += t;
+    tot += t;
+  }
+  total = tot;
+  return woff + incl - v;
+}
+
+// every thread owns bins 2t, 2t+1 of a 2048-bin histogram: find the bins holding ranks k_lo / k_hi
+__device__ __forceinline__ void find_ranks(unsigned h0, unsigned h1, unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2] in LDS*/)
+{
+  const unsigned b = 2u * threadIdx.x;
+  if(k_lo >= excl && k_lo < excl + h0) { out[0].prefix = b; out[0].rank = k_lo - excl; }
+  else if(k_lo >= excl + h0 && k_lo < excl + h0 + h1) { out[0].prefix = b + 1; out[0].rank = k_lo - excl - h0; }
+  if(k_hi >= excl && k_hi < excl + h0) { out[1].prefix = b; out[1].rank = k_hi - excl; }
+  else if(k_hi >= excl + h0 && k_hi < excl + h0 + h1) { out[1].prefix = b + 1; out[1].rank = k_hi - excl - h0; }
+}
+
+template <int C, typename F>
+__device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
+{
+  const int n = j.n;
+  if constexpr(C == 8) {
+    for(int pt = threadIdx.x; pt < n; pt += MED_THREADS) {
+      if(!j.valid[pt]) continue;
+      const float4* q = reinterpret_cast<const float4*>(j.r + (size_t) pt * 8);
+      const float4 a = q[0], b = q[1];
+      f(__float_as_uint(a.x) & 0x7fffffffu, pt); f(__float_as_uint(a.y) & 0x7fffffffu, pt);
+      f(__float_as_uint(a.z) & 0x7fffffffu, pt); f(__float_as_uint(a.w) & 0x7fffffffu, pt);
+      f(__float_as_uint(b.x) & 0x7fffffffu, pt); f(__float_as_uint(b.y) & 0x7fffffffu, pt);
+      f(__float_as_uint(b.z) & 0x7fffffffu, pt); f(__float_as_uint(b.w) & 0x7fffffffu, pt);
+    }
+  } else {
+    for(int p4 = threadIdx.x * 4; p4 < n; p4 += MED_THREADS * 4) {   // n is a multiple of 16
+      const uchar4 v = *reinterpret_cast<const uchar4*>(j.valid + p4);
+      const float4 a = *reinterpret_cast<const float4*>(j.r + p4);
+      if(v.x) f(__float_as_uint(a.x) & 0x7fffffffu, p4 + 0);
+      if(v.y) f(__float_as_uint(a.y) & 0x7fffffffu, p4 + 1);
+      if(v.z) f(__float_as_uint(a.z) & 0x7fffffffu, p4 + 2);
+      if(v.w) f(__float_as_uint(a.w) & 0x7fffffffu, p4 + 3);
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(MED_THREADS) void median_kernel(const PairJob* __restrict__ jobs)
+{
+  const PairJob& j = jobs[blockIdx.x];
+  GNState* st = j.st;
+  if(!st->active) return;
+  if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
+  unsigned* hist_hi = hist_lo + MED_COPIES * MED_BINS;                    // [MED_BINS]
+  unsigned* cache = hist_hi + MED_BINS;                                   // [MED_CACHE]
+  unsigned* s_wave = cache + MED_CACHE;                                   // [16]
+  MedCursor* cur = reinterpret_cast<MedCursor*>(s_wave + 16);             // [2]
+  unsigned* s_misc = reinterpret_cast<unsigned*>(cur + 2);                // [0] cache count, [1] first valid point
+
+  const int tid = threadIdx.x;
+  for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
+  if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
+  __syncthreads();
+
+  // ---- pass 1: bits [30:20]
+  {
+    unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
+    unsigned first = 0xffffffffu;
+    for_each_valid_key<C>(j, [&](unsigned key, int pt) {
+      atomicAdd(&h[key >> 20], 1u);
+      first = min(first, (unsigned) pt);
+    });
+    if(C == 1 && first != 0xffffffffu) atomicMin(&s_misc[1], first);
+  }
+  __syncthreads();
+  unsigned h0 = 0, h1 = 0;
+#pragma unroll
+  for(int c = 0; c < MED_COPIES; ++c) { h0 += hist_lo[c * MED_BINS + 2 * tid]; h1 += hist_lo[c * MED_BINS + 2 * tid + 1]; }
+  unsigned n_total;
+  unsigned excl = block_excl_scan_1024(h0 + h1, s_wave, n_total);
+
+  float median = 0.0f;
+  if(n_total >= 3) {
+    const unsigned k_hi = n_total / 2, k_lo = (n_total % 2 == 0) ? k_hi - 1 : k_hi;
+    find_ranks(h0, h1, excl, k_lo, k_hi, cur);
+    __syncthreads();
+    MedCursor lo = cur[0], hi = cur[1];
+    const bool split1 = lo.prefix != hi.prefix;
+    __syncthreads();
+
+    // ---- pass 2: bits [19:9] of the keys in the selected pass-1 bucket(s); survivors cached in LDS
+    for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
+    __syncthreads();
+    for_each_valid_key<C>(j, [&](unsigned key, int) {
+      const unsigned top = key >> 20;
+      const bool mlo = top == lo.prefix, mhi = top == hi.prefix;
+      if(mlo) atomicAdd(&hist_lo[(key >> 9) & 2047u], 1u);
+      else if(mhi) atomicAdd(&hist_hi[(key >> 9) & 2047u], 1u);
+      if(mlo || mhi) {
+        const unsigned idx = atomicAdd(&s_misc[0], 1u);
+        if(idx < MED_CACHE) cache[idx] = key;
+      }
+    });
+    __syncthreads();
+    {
+      unsigned dummy;
+      const unsigned a0 = hist_lo[2 * tid], a1 = hist_lo[2 * tid + 1];
+      const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
+      unsigned b0 = a0, b1 = a1, eb = ea;
+      if(split1) {
+        b0 = hist_hi[2 * tid]; b1 = hist_hi[2 * tid + 1];
+        eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
+      }
+      MedCursor tmp[2];
+      tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
+      // lo cursor in histogram a, hi cursor in histogram a (same bucket) or b (different bucket)
+      find_ranks(a0, a1, ea, lo.rank, split1 ? 0xffffffffu : hi.rank, tmp);
+      if(tmp[0].prefix != 0xffffffffu) { cur[0].prefix = (lo.prefix << 11) | tmp[0].prefix; cur[0].rank = tmp[0].rank; }
+      if(!split1 && tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << 11) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
+      if(split1) {
+        tmp[1].prefix = 0xffffffffu;
+        find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
+        if(tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << 11) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
+      }
+    }
+    __syncthreads();
+    lo = cur[0]; hi = cur[1];     // 22-bit prefixes now
+    const bool split2 = lo.prefix != hi.prefix;
+    const unsigned ncache = s_misc[0];
+    __syncthreads();
+
+    // ---- pass 3: bits [8:0]
+    for(int i = tid; i < 2 * 512; i += MED_THREADS) { if(i < 512) hist_lo[i] = 0; else hist_hi[i - 512] = 0; }
+    __syncthreads();
+    auto pass3 = [&](unsigned key) {
+      const unsigned top = key >> 9;
+      if(top == lo.prefix) atomicAdd(&hist_lo[key & 511u], 1u);
+      else if(top == hi.prefix) atomicAdd(&hist_hi[key & 511u], 1u);
+    };
+    if(ncache <= MED_CACHE) {
+      for(unsigned i = tid; i < ncache; i += MED_THREADS) pass3(cache[i]);
+    } else {
+      for_each_valid_key<C>(j, [&](unsigned key, int) { pass3(key); });
+    }
+    __syncthreads();
+    {
+      unsigned dummy;
+      const unsigned a0 = (tid < 256) ? hist_lo[2 * tid] : 0, a1 = (tid < 256) ? hist_lo[2 * tid + 1] : 0;
+      const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
+      unsigned b0 = a0, b1 = a1, eb = ea;
+      if(split2) {
+        b0 = (tid < 256) ? hist_hi[2 * tid] : 0; b1 = (tid < 256) ? hist_hi[2 * tid + 1] : 0;
+        eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
+      }
+      MedCursor tmp[2];
+      tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
+      find_ranks(a0, a1, ea, lo.rank, split2 ? 0xffffffffu : hi.rank, tmp);
+      if(tmp[0].prefix != 0xffffffffu) cur[0].prefix = (lo.prefix << 9) | tmp[0].prefix;
+      if(!split2 && tmp[1].prefix != 0xffffffffu) cur[1].prefix = (hi.prefix << 9) | tmp[1].prefix;
+      if(split2) {
+        tmp[1].prefix = 0xffffffffu;
+        find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
+        if(tmp[1].prefix != 0xffffffffu) cur[1].prefix = (hi.prefix << 9) | tmp[1].prefix;
+      }
+    }
+    __syncthreads();
+    const float v_lo = __uint_as_float(cur[0].prefix), v_hi = __uint_as_float(cur[1].prefix);
+    if(n_total % 2 != 0) median = v_hi;
+    else median = (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
+  } else if(n_total > 0) {
+    // median(): data.size() < 3 -> data[0] = first valid entry in channel-major order (Q5); only reachable for C == 1
+    __syncthreads();
+    const unsigned first = s_misc[1];
+    median = (first != 0xffffffffu) ? fabsf(j.r[(size_t) first * C]) : 0.0f;
+  }
+
+  if(tid == 0) {
+    const unsigned long long nm6 = (unsigned long long) n_total - 6ull;     // size_t wrap for n < 6 (Q5)
+    float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
+    if((double) s < 1e-6) s = 1.0f;
+    st->delta_scale = fabsf(s - st->scale);
+    st->scale = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K8 irls_reduce.  reference: MEstimator::ComputeWeights SIMD bodies (bpvo/mestimator.cc:242-282 Huber, :303-366 Tukey;
+// `valid` ignored there, Q12/Q14) fused with LinearSystemBuilderReduction::rankUpdatePoint
+// (bpvo/linear_system_builder.cc:140-205): w' = w * float(valid); H += (w' J_a) J_b (upper triangle); G += (w' r) J;
+// e += (w' r) r.  Summation order differs from the reference's serial loop (Q15): per thread over channels and points,
+// then a wavefront shuffle tree, then LDS across the 4 waves; per-block partials are combined in fixed order in f64 by
+// gn_step, so the result is deterministic run to run.
+constexpr int kNumAcc = 29;   // 21 H + 6 G + e + #valid points
+
+template <int LOSS>
+__device__ __forceinline__ float mest_weight(float r, float sigma_inv)
+{
+  if(LOSS == BPVO_LOSS_HUBER) {
+    const float k = 1.345f;
+    const float x = fabsf(r * sigma_inv);
+    return k / fmaxf(x, k);
+  } else if(LOSS == BPVO_LOSS_TUKEY) {
+    const float t = 4.685f;
+    const float t_i = (float) (1.0 / 4.685f);
+    const float x = r * sigma_inv;
+    float q = x * t_i;
+    q = 1.0f - q * q;
+    q = q * q;
+    return (fabsf(x) < t) ? q : 0.0f;
+  }
+  return 1.0f;
+}
+
+template <int C, int LOSS>
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, int pts_per_block)
+{
+  const PairJob& j = jobs[blockIdx.y];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active) return;
+  const int n = j.n;
+  const int p_begin = blockIdx.x * pts_per_block;
+  if(p_begin >= n) return;
+  const int p_end = min(n, p_begin + pts_per_block);
+  const float sigma_inv = 1.0f / st->scale;
+
+  float acc[kNumAcc];
+#pragma unroll
+  for(int k = 0; k < kNumAcc; ++k) acc[k] = 0.0f;
+
+  for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
+    const float v = (float) j.valid[i];
+    acc[28] += v;
+    const float* __restrict__ rp = j.r + (size_t) i * C;
+    const float* __restrict__ Jp = j.jac + (size_t) i * C * 6;
+    // channels are consumed in groups of G (C = 8: 4 channels = one 16-byte residual load + six 16-byte Jacobian
+    // loads, 96 contiguous bytes); the group loop is kept rolled to bound register pressure (occupancy hides latency)
+    constexpr int G = (C >= 4) ? 4 : C;
+#pragma unroll 1
+    for(int c0 = 0; c0 < C; c0 += G) {
+      float rr[G], Jg[G * 6];
+      if constexpr(G == 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(rp + c0);
+        rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
+        const float4* q = reinterpret_cast<const float4*>(Jp + c0 * 6);
+#pragma unroll
+        for(int k = 0; k < 6; ++k) {
+          const float4 t = q[k];
+          Jg[4 * k + 0] = t.x; Jg[4 * k + 1] = t.y; Jg[4 * k + 2] = t.z; Jg[4 * k + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for(int k = 0; k < G; ++k) rr[k] = rp[c0 + k];
+        const float2* q = reinterpret_cast<const float2*>(Jp + c0 * 6);
+#pragma unroll
+        for(int k = 0; k < G * 3; ++k) {
+          const float2 t = q[k];
+          Jg[2 * k + 0] = t.x; Jg[2 * k + 1] = t.y;
+        }
+      }
+#pragma unroll
+      for(int cc = 0; cc < G; ++cc) {
+        const float* J = Jg + cc * 6;
+        const float r = rr[cc];
+        const float w = mest_weight<LOSS>(r, sigma_inv) * v;
+        const float wr = w * r;
+        int idx = 0;
+#pragma unroll
+        for(int a = 0; a < 6; ++a) {
+          const float wj = w * J[a];
+#pragma unroll
+          for(int b = a; b < 6; ++b) acc[idx++] += wj * J[b];
+        }
+#pragma unroll
+        for(int a = 0; a < 6; ++a) acc[21 + a] += wr * J[a];
+        acc[27] += wr * r;
+      }
+    }
+  }
+
+  // wavefront tree (64 lanes), then LDS across the 4 waves
+#pragma unroll
+  for(int k = 0; k < kNumAcc; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for(int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
+    acc[k] = v;
+  }
+  __shared__ float s_part[4][kPartialStride];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if(lane == 0) {
+#pragma unroll
+    for(int k = 0; k < kNumAcc; ++k) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if(threadIdx.x < kNumAcc) {
+    const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+    j.partials[(size_t) blockIdx.x * kPartialStride + threadIdx.x] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K9 gn_step: PoseEstimatorBase::run as a device-side state machine (reference: bpvo/pose_estimator_base.h:324-407 with
+// testConvergence :258-282, PoseEstimatorData_::solve :90-148, RigidBodyWarp::paramsToPose bpvo/rigid_body_warp.h:130-138).
+// One wave per workspace: lanes 0..28 sum the per-block partials in block order in f64 (deterministic), lane 0 runs the
+// 6x6 solve, pose update and bookkeeping — Q1 (pose updated again after convergence) and Q2 (iteration count) included.
+__device__ __forceinline__ float inf_norm6(const float* g)
+{
+  float m = 0.0f;
+  for(int i = 0; i < 6; ++i) m = fmaxf(m, fabsf(g[i]));
+  return m;
+}
+
+__device__ void gn_update_pose(GNState* st, const float* nrm)
+{
+  float mdp[6];
+  for(int i = 0; i < 6; ++i) mdp[i] = -st->dp[i];
+  M44 T;
+  for(int i = 0; i < 16; ++i) T.m[i] = st->T[i];
+  const M44 Tn = m44_mul(T, params_to_pose(nrm, mdp));
+  for(int i = 0; i < 16; ++i) st->T[i] = Tn.m[i];
+}
+
+__device__ void gn_finalize(GNState* st)
+{
+  if(st->status != BPVO_STATUS_SOLVER_ERROR)
+    for(int i = 0; i < 16; ++i) st->T_out[i] = st->T[i];
+  st->num_iterations -= 1;
+  bpvo_hip_stats& s = st->stats[st->level];
+  s.numIterations = st->num_iterations;
+  s.finalError = st->f_norm;
+  s.firstOrderOptimality = st->g_norm;
+  s.status = st->status;
+  st->phase = PHASE_DONE;
+  st->active = 0;
+}
+
+__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
+                                                     int max_iterations, int max_fun_evals, float p_tol, float f_tol,
+                                                     float g_tol_param, int* active_counter, int parity,
+                                                     unsigned long long* counters)
+{
+  const PairJob& j = jobs[blockIdx.x];
+  GNState* st = j.st;
+  if(active_counter && blockIdx.x == 0 && threadIdx.x == 0) active_counter[parity ^ 1] = 0;
+  if(!st->active) return;
+  if(counters && threadIdx.x == 0) {     // measurement: points and linearisations processed (bench.py roofline)
+    atomicAdd(&counters[0], (unsigned long long) j.n);
+    atomicAdd(&counters[1], 1ull);
+  }
+
+  __shared__ float s_sum[kPartialStride];
+  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
+  if(threadIdx.x < kNumAcc) {
+    double s = 0.0;
+    for(int b = 0; b < nblk; ++b) s += (double) j.partials[(size_t) b * kPartialStride + threadIdx.x];
+    s_sum[threadIdx.x] = (float) s;
+  }
+  __syncthreads();
+  if(threadIdx.x != 0) return;
+
+  // unpack: upper triangle -> symmetric H (toEigen + selfadjointView<Upper>, linear_system_builder.cc:207-221)
+  {
+    int idx = 0;
+    for(int a = 0; a < 6; ++a)
+      for(int b = a; b < 6; ++b) {
+        st->H[a * 6 + b] = s_sum[idx];
+        st->H[b * 6 + a] = s_sum[idx];
+        ++idx;
+      }
+    for(int a = 0; a < 6; ++a) st->G[a] = s_sum[21 + a];
+  }
+  const float f_norm = sqrtf(s_sum[27]);               // LinearSystemBuilder::Run returns sqrt (:349)
+  st->f_norm = f_norm;
+  st->n_valid = (uint32_t) s_sum[28];
+  st->num_fun_evals += 1;
+  if(mode == 1) return;
+
+  const float sqrt_eps = sqrtf(FLT_EPSILON);
+  bool go_loop_top = false;
+
+  if(st->phase == PHASE_FIRST) {
+    const float g_norm = inf_norm6(st->G);
+    st->g_norm = g_norm;
+    st->g_tol = g_tol_param * fmaxf(g_norm, sqrt_eps);
+    if(g_norm < st->g_tol) {                            // :343-354 initial value is optimal
+      bpvo_hip_stats& s = st->stats[st->level];
+      s.status = BPVO_STATUS_GRADIENT_TOL; s.finalError = f_norm; s.numIterations = 1; s.firstOrderOptimality = g_norm;
+      st->status = BPVO_STATUS_GRADIENT_TOL;
+      st->phase = PHASE_DONE; st->active = 0;
+      return;
+    }
+    if(!solve_system(st->H, st->G, st->dp)) {           // :356-362
+      bpvo_hip_stats& s = st->stats[st->level];
+      s.status = BPVO_STATUS_SOLVER_ERROR; s.finalError = f_norm; s.numIterations = 0; s.firstOrderOptimality = 0.0f;
+      st->status = BPVO_STATUS_SOLVER_ERROR;
+      st->phase = PHASE_DONE; st->active = 0;
+      return;
+    }
+    st->f_norm_prev = 0.0f;
+    st->dp_norm_prev = 0.0f;
+    st->has_converged = 0;
+    gn_update_pose(st, j.nrm);                          // :371
+    go_loop_top = true;
+  } else {
+    // runIteration's solve (pose_estimator_gn.h:89-97)
+    if(!solve_system(st->H, st->G, st->dp)) {
+      st->status = BPVO_STATUS_SOLVER_ERROR;
+      gn_finalize(st);                                  // `break`: no ++ on the way out
+      return;
+    }
+    gn_update_pose(st, j.nrm);                          // :390
+    const bool cont = (st->num_iterations++ < max_iterations) && !st->has_converged && (st->num_fun_evals < max_fun_evals);
+    if(cont) go_loop_top = true;
+    else { gn_finalize(st); return; }
+  }
+
+  if(go_loop_top) {
+    // top of the do-loop body (:374-383)
+    float dp_norm = 0.0f;
+    for(int i = 0; i < 6; ++i) dp_norm += st->dp[i] * st->dp[i];
+    dp_norm = sqrtf(dp_norm);
+    const float g_norm = inf_norm6(st->G);
+    st->g_norm = g_norm;
+    bool conv = false;
+    if(dp_norm < p_tol || dp_norm < p_tol * (sqrt_eps + st->dp_norm_prev)) {
+      st->status = BPVO_STATUS_PARAMETER_TOL; conv = true;
+    } else if(f_norm < f_tol || f_norm < f_tol * (sqrt_eps + st->f_norm_prev) || fabsf(f_norm - st->f_norm_prev) < f_tol) {
+      st->status = BPVO_STATUS_FUNCTION_TOL; conv = true;
+    } else if(g_norm < st->g_tol) {
+      st->status = BPVO_STATUS_GRADIENT_TOL; conv = true;
+    }
+    st->has_converged = conv ? 1 : 0;
+    st->dp_norm_prev = dp_norm;
+    st->f_norm_prev = f_norm;
+    if(!conv) {
+      st->phase = PHASE_LOOP;                           // next launch: linearize at the updated pose
+      if(active_counter) atomicAdd(&active_counter[parity], 1);
+      return;
+    }
+    gn_update_pose(st, j.nrm);                          // Q1: applied again with the stale dp
+    st->num_iterations++;                               // the `numIterations++ <` of the failing while test
+    gn_finalize(st);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p >= n) return;
+  GNState* st = jobs[p].st;
+  for(int i = 0; i < 16; ++i) st->T_out[i] = T_init ? T_init[p * 16 + i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+  for(int l = 0; l < kMaxLevels; ++l) {                 // OptimizerStatistics() defaults (bpvo/types.cc:306-310)
+    st->stats[l].numIterations = 0;
+    st->stats[l].finalError = -1.0f;
+    st->stats[l].firstOrderOptimality = -1.0f;
+    st->stats[l].status = BPVO_STATUS_SOLVER_ERROR;
+  }
+}
+
+// PoseEstimatorBase::reset + the head of run() (bpvo/pose_estimator_base.h:287-293,327-335)
+__global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p >= npairs) return;
+  GNState* st = jobs[p].st;
+  st->scale = 1.0f;
+  st->delta_scale = 1e10f;
+  st->f_norm_prev = 0.0f;
+  st->g_tol = 0.0f;
+  st->g_norm = 0.0f;
+  st->num_fun_evals = 0;
+  st->num_iterations = 0;
+  st->status = BPVO_STATUS_MAX_ITERATIONS;
+  st->phase = PHASE_FIRST;
+  st->has_converged = 0;
+  st->level = level;
+  for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
+  for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
+  st->active = (jobs[p].n > 0) ? 1 : 0;
+}
+
+// operator-level seam (bpvo_hip_linearize): pose in, optional AutoScaleEstimator::reset
+__global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int reset_scale, int level)
+{
+  if(threadIdx.x != 0 || blockIdx.x != 0) return;
+  GNState* st = job->st;
+  for(int i = 0; i < 16; ++i) st->T[i] = T[i];
+  if(reset_scale) { st->scale = 1.0f; st->delta_scale = 1e10f; }
+  st->level = level;
+  st->active = 1;
+}
+
+// weights of the last linearisation, recomputed from r / valid / sigma on request
+// (VisualOdometryPoseEstimator::getWeights, bpvo/vo_pose_estimator.cc:95-99; invalid entries have r = 0 -> w = 1, Q12)
+template <int LOSS>
+__global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, int total, float* w_out)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if(e >= total) return;
+  const float sigma_inv = 1.0f / job->st->scale;
+  w_out[e] = mest_weight<LOSS>(job->r[e], sigma_inv);
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, int total, float thr, unsigned int* count)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  bool good = false;
+  if(e < total) good = mest_weight<LOSS>(job->r[e], 1.0f / job->st->scale) > thr;
+  const unsigned long long m = __ballot(good);
+  if((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned) __popcll(m));
+}
+
+// 32-float result record per pair for the RCCL gather: pose 3x4 (12), numIterations per level (8), status per level (8),
+// total function evaluations are not kept per level so [28..31] = {finalError of the finest level, n_valid, 0, 0}
+__global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* records)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p >= n) return;
+  const GNState* st = jobs[p].st;
+  float* o = records + (size_t) p * kRecordFloats;
+  for(int i = 0; i < 12; ++i) o[i] = st->T_out[i];
+  for(int l = 0; l < 8; ++l) {
+    o[12 + l] = (l < L) ? (float) st->stats[l].numIterations : 0.0f;
+    o[20 + l] = (l < L) ? (float) st->stats[l].status : 0.0f;
+  }
+  o[28] = st->stats[0].finalError;
+  o[29] = (float) st->n_valid;
+  o[30] = 0.0f;
+  o[31] = 0.0f;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------
+int gn_pts_per_block(int npairs) { return npairs >= 8 ? 1024 : 256; }
+int gn_num_blocks(int max_points) { return (max_points + 255) / 256; }   // upper bound for any pts_per_block >= 256
+
+void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)
+{
+  hipLaunchKernelGGL(set_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, T_init, n);
+}
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level)
+{
+  hipLaunchKernelGGL(level_begin_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, jobs, npairs, level);
+}
+void launch_warp_residual(hipStream_t s, const GNLaunch& g)
+{
+  if(g.max_points <= 0) return;
+  const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
+  if(g.C == 1) hipLaunchKernelGGL(warp_residual_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs);
+  else hipLaunchKernelGGL(warp_residual_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs);
+}
+static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
+void launch_median(hipStream_t s, const GNLaunch& g)
+{
+  if(g.max_points <= 0) return;
+  static bool attr_set = false;
+  if(!attr_set) {
+    (void) hipFuncSetAttribute((const void*) median_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    (void) hipFuncSetAttribute((const void*) median_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    attr_set = true;
+  }
+  if(g.C == 1) hipLaunchKernelGGL(median_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
+  else hipLaunchKernelGGL(median_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
+}
+
+template <int C>
+static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
+{
+  const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
+  switch(g.loss) {
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
+    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
+  }
+}
+void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
+{
+  if(g.max_points <= 0) return;
+  const int ppb = gn_pts_per_block(g.npairs);
+  if(g.C == 1) launch_irls_c<1>(s, g, ppb);
+  else launch_irls_c<8>(s, g, ppb);
+}
+void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
+                    float f_tol, float g_tol, int* active_counter, int parity, unsigned long long* counters)
+{
+  const int ppb = gn_pts_per_block(g.npairs);
+  hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
+                     f_tol, g_tol, active_counter, parity, counters);
+}
+void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
+{
+  hipLaunchKernelGGL(prepare_linearize_kernel, dim3(1), dim3(64), 0, s, job, T, reset_scale, level);
+}
+void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out)
+{
+  const int total = n * C;
+  if(total <= 0) return;
+  const dim3 grid((total + 255) / 256);
+  switch(loss) {
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_HUBER>, grid, dim3(256), 0, s, job, total, w_out); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_TUKEY>, grid, dim3(256), 0, s, job, total, w_out); break;
+    default: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_L2>, grid, dim3(256), 0, s, job, total, w_out); break;
+  }
+}
+void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
+{
+  const int total = n * C;
+  if(total <= 0) return;
+  const dim3 grid((total + 255) / 256);
+  switch(loss) {
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_HUBER>, grid, dim3(256), 0, s, job, total, thr, count); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_TUKEY>, grid, dim3(256), 0, s, job, total, thr, count); break;
+    default: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_L2>, grid, dim3(256), 0, s, job, total, thr, count); break;
+  }
+}
+void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records)
+{
+  hipLaunchKernelGGL(pack_records_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, n, L, records);
+}
+
+}  // namespace bpvo_hip

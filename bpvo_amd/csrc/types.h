@@ -1,0 +1,77 @@
+// Device-resident data model of libbpvo_hip.  Plain structs shared by the host driver and the kernels.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/bpvo_hip/c_api.h"
+#include "device_math.h"
+
+namespace bpvo_hip {
+
+constexpr int kMaxLevels = BPVO_HIP_MAX_LEVELS;
+constexpr int kHistBins1 = 2048;   // radix-select pass 1: |r| bits [30:20]
+constexpr int kReduceVals = 28;    // 21 upper-triangular H + 6 G + sum w r^2
+constexpr int kPartialStride = 32;
+constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hip_batch_result_records_device)
+
+// phases of the device-side PoseEstimatorBase::run state machine (gn_step kernel)
+enum { PHASE_FIRST = 0, PHASE_LOOP = 1, PHASE_DONE = 2 };
+
+// PoseEstimatorBase + PoseEstimatorData_ + AutoScaleEstimator state of ONE estimation workspace
+// (reference: bpvo/pose_estimator_base.h:67-151,190-206; bpvo/mestimator.h:62-88), device resident.
+struct GNState {
+  float T[16];           // data.T, row-major
+  float H[36];
+  float G[6];
+  float dp[6];
+  float f_norm, f_norm_prev, dp_norm_prev, g_tol, g_norm;
+  float scale, delta_scale;                 // AutoScaleEstimator::_scale, _delta_scale
+  int   num_fun_evals, num_iterations, status, phase, active, has_converged;
+  uint32_t n_valid;                          // valid points of the last linearisation
+  int   level;
+  bpvo_hip_stats stats[kMaxLevels];
+  float T_out[16];                           // pose handed back (T in/out of run())
+};
+
+// everything a kernel needs to know about one (workspace, level) linearisation
+struct PairJob {
+  // template (reference frame) at this level
+  const float4* pts;      // [N] (X,Y,Z,1)
+  const float*  pix;      // [N][C] point-major
+  const float*  jac;      // [N][C][6]
+  const float*  nrm;      // (s, c1, c2, c3) Hartley normalisation of the level
+  int           n;        // number of points (multiple of 16)
+  // current frame descriptor at this level, pixel-interleaved [rows*cols][C]
+  const float*  desc;
+  int           rows, cols;
+  float         K[9];     // level intrinsics (K * 0.5^l, K(2,2) = 1)
+  // workspace
+  float*        r;        // [N][C] residuals, point-major
+  uint8_t*      valid;    // [N]
+  float*        partials; // [nblocks][kPartialStride]
+  GNState*      st;
+};
+
+// selection / template-build job for one (frame, level)
+struct FrameJob {
+  const uint8_t* img;       // level image u8
+  uint8_t*       cen;       // census scratch u8 (BitPlanes)
+  float*         desc;      // [rows*cols][C]
+  float*         sal;       // [rows*cols]
+  uint8_t*       flag;      // [rows*cols] candidate flags
+  int*           blk_count; // [nblk] then exclusive offsets
+  int*           n_out;     // device: number of points kept (multiple of 16)
+  const float*   disp;      // full-resolution disparity
+  float4*        pts;
+  int*           inds;
+  float*         pix;
+  float*         jac;
+  float*         nrm;       // (s, c1, c2, c3)
+  int            rows, cols, level, disp_cols;
+  int            cap;       // capacity of pts/inds
+  int            nms_radius;   // <= 0: NMS off for this level
+  float          K[9];
+  float          b;
+};
+
+}  // namespace bpvo_hip

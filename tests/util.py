@@ -1,0 +1,46 @@
+"""Helpers shared by the parity tests."""
+import numpy as np
+
+from bpvo_amd import capi, synth
+
+# pose tolerance of BASELINE.json's north_star: 1e-4 rad / 1e-3 m against the reference CPU path (= the oracle)
+ROT_TOL = 1e-4
+TRANS_TOL = 1e-3
+
+
+def make_params(b, descriptor="bitplanes", loss="tukey", levels=4, **kw):
+    p = b.default_params()
+    p.numPyramidLevels = levels
+    p.descriptor = capi.DESC_BITPLANES if descriptor == "bitplanes" else capi.DESC_INTENSITY
+    p.lossFunction = {"tukey": capi.LOSS_TUKEY, "huber": capi.LOSS_HUBER, "l2": capi.LOSS_L2}[loss]
+    p.verbosity = capi.VERB_SILENT
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def setup_pair(b, rows, cols, index=0, n_frames=2, n_pairs=1, **pk):
+    d = synth.make_pair(rows, cols, index)
+    p = make_params(b, **pk)
+    ctx = b.create(d["K"], d["b"], rows, cols, p, device=0, n_frames=n_frames, n_pairs=n_pairs)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    ctx.frame_set_template(0)
+    ctx.frame_set_data(1, d["imgB"], d["dispB"])
+    return ctx, d, p
+
+
+def rot_angle(Ra, Rb):
+    """Angle of Ra^T Rb (radians), robust for tiny angles."""
+    E = np.asarray(Ra, np.float64).T @ np.asarray(Rb, np.float64)
+    w = np.array([E[2, 1] - E[1, 2], E[0, 2] - E[2, 0], E[1, 0] - E[0, 1]]) * 0.5
+    return float(np.arcsin(min(1.0, np.linalg.norm(w))))
+
+
+def pose_error(Ta, Tb):
+    return rot_angle(Ta[:3, :3], Tb[:3, :3]), float(np.linalg.norm(np.asarray(Ta, np.float64)[:3, 3] - np.asarray(Tb, np.float64)[:3, 3]))
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
