@@ -298,6 +298,7 @@ void resolve_events(bpvo_hip_ctx* c)   // call after a stream sync
 // slots: first, first+stride, ...; uploads the FrameJob table [L][count] and returns its device base
 int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count)
 {
+  HIP_CK(c, hipStreamSynchronize(c->stream));   // the pinned staging table may still feed an earlier async copy
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < count; ++i) c->h_fjobs[(size_t) l * c->n_frames + i] = make_frame_job(c, c->frames[first + i * stride], l);
   HIP_CK(c, hipMemcpyAsync(c->d_fjobs, c->h_fjobs, sizeof(FrameJob) * (size_t) c->L * c->n_frames, hipMemcpyHostToDevice, c->stream));
@@ -414,6 +415,7 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   }
   const int NP = c->n_pairs;
+  HIP_CK(c, hipStreamSynchronize(c->stream));   // pinned staging reuse (see upload_frame_jobs)
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < n; ++i) {
@@ -1059,6 +1061,8 @@ int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* dispa
   ret->isKeyFrame = 0;
   ret->keyFramingReason = BPVO_KF_NO_KEYFRAMING;
   ret->hasPointCloud = 0;
+  c->cloud.clear();                 // the point cloud belongs to one Result (bpvo/types.h:549-563)
+  c->cloud_pose = I;
 
   int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, false);   // _cur_frame->setData (vo.cc:131)
   if(rc) return rc;

@@ -56,6 +56,16 @@ def test_template_bit_exact(hip, orc, rows, cols, levels, descriptor):
         assert bits_equal(Jh, Jo), f"jacobians level {l}: max |d| = {np.abs(Jh - Jo).max()}"
 
 
+def normal_equations_f64(J, r, w, valid, C):
+    """J^T W J, J^T W r, sqrt(sum w r^2) in float64 from the reference-layout arrays ([C*N][6], [C*N], [C*N], [N])."""
+    J = np.asarray(J, np.float64).reshape(-1, 6)
+    r = np.asarray(r, np.float64).reshape(-1)
+    wv = np.asarray(w, np.float64).reshape(-1) * np.tile(np.asarray(valid, np.float64), C)
+    H = (J * wv[:, None]).T @ J
+    G = J.T @ (wv * r)
+    return H, G, float(np.sqrt(np.sum(wv * r * r)))
+
+
 def _perturbed_pose(scale):
     tw = np.array([0.004, -0.003, 0.002, 0.02, -0.015, 0.03]) * scale
     return synth.twist_to_matrix(tw).astype(np.float32)
@@ -75,10 +85,17 @@ def test_linearize_parity(hip, orc, rows, cols, levels, descriptor, loss):
             assert bits_equal(ch.get_residuals(0), co.get_residuals(0)), f"residuals level {l}"
             assert a["sigma"] == b["sigma"], f"sigma level {l}: {a['sigma']} vs {b['sigma']}"   # exact median
             assert bits_equal(ch.get_weights(0), co.get_weights(0)), f"weights level {l}"
-            scale = np.abs(b["H"]).max()
-            assert np.abs(a["H"] - b["H"]).max() <= 2e-5 * scale, f"H level {l}"
-            assert np.abs(a["G"] - b["G"]).max() <= 2e-5 * max(np.abs(b["G"]).max(), 1e-3 * scale), f"G level {l}"
-            assert abs(a["f_norm"] - b["f_norm"]) <= 2e-5 * max(b["f_norm"], 1e-6)
+            # H, G, f_norm: the reference sums serially in f32 (rounding error grows with N*C), the GPU sums a tree and
+            # combines block partials in f64.  Both are checked against an f64 evaluation of the same (bit-identical)
+            # J, r, w, valid arrays: the GPU tightly, the oracle within its own serial-summation error.
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, ch.Cn)
+            scale = np.abs(H64).max()
+            gscale = max(np.abs(G64).max(), 1e-3 * scale)
+            assert np.abs(a["H"] - H64).max() <= 4e-6 * scale, f"H level {l} (hip vs f64)"
+            assert np.abs(a["G"] - G64).max() <= 4e-6 * gscale, f"G level {l} (hip vs f64)"
+            assert abs(a["f_norm"] - f64) <= 4e-6 * max(f64, 1e-6)
+            assert np.abs(b["H"] - H64).max() <= 2e-4 * scale and np.abs(b["G"] - G64).max() <= 2e-4 * gscale
+            assert np.allclose(a["H"], a["H"].T)
             assert abs(ch.fraction_good(0, 0.85) - co.fraction_good(0, 0.85)) < 1e-6
 
 
@@ -107,7 +124,7 @@ def test_estimate_pose_parity(hip, orc, rows, cols, levels, descriptor, loss):
     assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans, sh, so)
     # against ground truth both must be reasonable (sanity of the synthetic scene, not a parity bar)
     rg, tg = pose_error(Th, d["T_gt"])
-    assert rg < 5e-3 and tg < 2e-2, (rg, tg)
+    assert rg < 1e-2 and tg < 1e-1, (rg, tg)
     # per-iteration trace: linearise the HIP path at every pose the oracle visited
     step = max(1, len(trace) // 24)
     prev_level = -1
@@ -122,8 +139,8 @@ def test_estimate_pose_parity(hip, orc, rows, cols, levels, descriptor, loss):
             prev_level = level
         assert abs(a["f_norm"] - rec[58]) <= 1e-3 * max(rec[58], 1e-6) or a["sigma"] != rec[59]
         if a["sigma"] == rec[59]:
-            assert np.abs(a["H"] - Ho).max() <= 5e-5 * scale
-            assert np.abs(a["G"] - Go).max() <= 5e-5 * max(np.abs(Go).max(), 1e-3 * scale)
+            assert np.abs(a["H"] - Ho).max() <= 2e-4 * scale
+            assert np.abs(a["G"] - Go).max() <= 2e-4 * max(np.abs(Go).max(), 1e-3 * scale)
 
 
 def test_estimate_pose_nonzero_workspace_and_init(hip, orc):
