@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py — Gauss-Newton iterations/s of the dense photometric alignment hot path on MI355X.
+
+Workload (BASELINE.json configs[3]/[4]): batches of independent KITTI-shaped 1241x376 stereo pairs, BitPlanes
+descriptor (8 channels), 4 pyramid levels, Tukey IRLS, AlgorithmParameters() defaults otherwise.  One "step" =
+one pass of the hot path over the rank's batch with the inputs already resident in HBM:
+    setData(A), setData(B)  (image pyramid + descriptor pyramid)          for every pair
+    setTemplate(A)          (saliency, NMS selection, points, Jacobians)  for every pair
+    estimatePose(A, B, I)   (coarse-to-fine GN / IRLS to convergence)     for every pair
+    + for N > 1: ONE RCCL gather of the 32-float result records to rank 0.
+Pairs are sharded across ranks (weak scaling: --pairs-per-gpu each, seeds 1000 + global pair index); there is no
+data-path collective.  value = GN iterations (linearise + solve + pose update, counted like the reference's
+_num_fun_evals, bpvo/pose_estimator_gn.h:78) of the whole job per second of step time.
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs-per-gpu", type=int, default=128, help="1024-pair batch of config 5 / 8 GPUs")
+    ap.add_argument("--rows", type=int, default=376)
+    ap.add_argument("--cols", type=int, default=1241)
+    ap.add_argument("--descriptor", default="bitplanes", choices=["bitplanes", "intensity"])
+    ap.add_argument("--loss", default="tukey", choices=["tukey", "huber", "l2"])
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--fixed-iters", type=int, default=0,
+                    help="throughput mode: tolerances 0 and maxIterations=K (K+2 linearisations per level); 0 = converge")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--gen-workers", type=int, default=0)
+    return ap.parse_args()
+
+
+def make_params(binding, args):
+    from bpvo_amd import capi
+    p = binding.default_params()
+    p.numPyramidLevels = args.levels
+    p.descriptor = capi.DESC_BITPLANES if args.descriptor == "bitplanes" else capi.DESC_INTENSITY
+    p.lossFunction = {"tukey": capi.LOSS_TUKEY, "huber": capi.LOSS_HUBER, "l2": capi.LOSS_L2}[args.loss]
+    p.verbosity = capi.VERB_SILENT
+    if args.fixed_iters > 0:
+        p.maxIterations = args.fixed_iters
+        p.parameterTolerance = 0.0
+        p.functionTolerance = 0.0
+        p.gradientTolerance = 0.0
+    return p
+
+
+def cpu_baseline(args, batch, n_sample):
+    """The CPU oracle (port of the reference path, -O3 -msse4.1 -mavx) on a bounded sample of the same workload."""
+    import __graft_entry__ as ge
+    from bpvo_amd import capi
+    if not os.path.exists(ge.ORACLE_LIB):
+        ge.build_oracle()
+    orc = capi.Binding(ge.ORACLE_LIB, "bpvo_orc_")
+    p = make_params(orc, args)
+    n = min(n_sample, batch["images"].shape[0] // 2)
+    out = {}
+    ncores = os.cpu_count() or 1
+    for label, threads in (("1", 1), ("all", ncores)):
+        ctx = orc.create(batch["K"], batch["b"], args.rows, args.cols, p, n_frames=2 * n, n_pairs=n)
+        ctx.call("set_num_threads", threads)
+        t0 = time.perf_counter()
+        ctx.batch_run(batch["images"][: 2 * n], batch["disparities"][: 2 * n])
+        dt = time.perf_counter() - t0
+        out[label] = dict(gn_iters=ctx.total_linearizations(), seconds=dt, threads=threads)
+        ctx.close()
+    one = out["1"]
+    allc = out["all"]
+    return {
+        "value": one["gn_iters"] / one["seconds"], "unit": "GN iterations/s", "cores": 1, "kind": "port",
+        "sample": f"{n} pairs of the same workload (seeds 1000..{999 + n}), oracle/ C++ restatement single-threaded "
+                  f"(= the reference's default build, WITH_TBB OFF): {one['gn_iters']} GN iterations in {one['seconds']:.2f} s",
+        "frames_per_s": n / one["seconds"],
+        "all_cores": {"value": allc["gn_iters"] / allc["seconds"], "cores": allc["threads"], "seconds": allc["seconds"],
+                      "note": "OpenMP over the 8 channels / range-split reduction, the reference's TBB decomposition"},
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    from bpvo_amd import synth
+    from bpvo_amd.distributed import RECORD_FLOATS, gather_records, records_to_poses, shard_range
+
+    # ---- synthetic inputs for this rank's shard (rendered on the CPU before anything touches the GPU)
+    P = args.pairs_per_gpu
+    lo, hi = shard_range(P * world, rank, world)
+    workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
+    t0 = time.perf_counter()
+    batch = synth.make_batch(args.rows, args.cols, hi - lo, first_index=lo, workers=workers)
+    t_gen = time.perf_counter() - t0
+
+    import torch
+    import torch.distributed as dist
+    import bpvo_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    hip = bpvo_amd.load()
+    p = make_params(hip, args)
+    ctx = hip.create(batch["K"], batch["b"], args.rows, args.cols, p, device=local_rank, n_frames=2 * P, n_pairs=P)
+
+    d_images = torch.from_numpy(batch["images"]).to(dev)
+    d_disps = torch.from_numpy(batch["disparities"]).to(dev)
+    d_records = torch.zeros((P, RECORD_FLOATS), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        poses, stats = ctx.batch_run_device(P, d_images.data_ptr(), d_disps.data_ptr())
+        gathered = None
+        if world > 1:
+            ctx.batch_copy_records_device(d_records.data_ptr(), P)
+            gathered = gather_records(d_records, dst=0)
+        return poses, stats, gathered
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profiling(not args.no_profile)     # resets the counters; HIP events on the library's own stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        poses, stats, gathered = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    gn_local = ctx.total_linearizations()
+    kstats = {k["name"]: k for k in ctx.kernel_stats()} if not args.no_profile else {}
+    t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed_max, gn_total = float(tmax[0]), float(tsum[1])
+    else:
+        elapsed_max, gn_total = elapsed, float(gn_local)
+
+    if rank == 0:
+        n_pairs_total = P * world
+        pose_err = None
+        T_gt = batch["T_gt"]
+        dT = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - T_gt[:, :3, 3], axis=1)
+        pose_err = {"median_trans_err_vs_gt_m": float(np.median(dT)), "max_trans_err_vs_gt_m": float(dT.max())}
+        if gathered is not None:
+            gp, _, _ = records_to_poses(gathered)
+            assert gp.shape[0] == n_pairs_total and np.array_equal(gp[:P, :3, :], poses[:, :3, :])
+
+        roofline = None
+        kernels = {}
+        for name, k in kstats.items():
+            if k["launches"] == 0:
+                continue
+            avg_ms = k["total_ms"] / k["launches"]
+            bytes_per_launch = k["units"] * k["bytes_per_unit"] / k["launches"]
+            kernels[name] = {"launches": int(k["launches"]), "avg_ms": avg_ms, "total_ms": k["total_ms"],
+                             "units_per_launch": k["units"] / k["launches"],
+                             "algorithmic_GBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else None}
+        if "warp_residual" in kernels:
+            k = kernels["warp_residual"]
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("warp_residual_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "warp_residual_kernel<8>" if args.descriptor == "bitplanes" else "warp_residual_kernel<1>",
+                        "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": k["algorithmic_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
+                        "bytes_per_point": 18 + 24 * (8 if args.descriptor == "bitplanes" else 1),
+                        "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"]}
+
+        cpu = None
+        if args.cpu_pairs > 0:
+            cpu = cpu_baseline(args, batch, args.cpu_pairs)
+
+        iters = stats["numIterations"].astype(np.float64)
+        out = {
+            "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS)"
+            if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s",
+            "value": gn_total / elapsed_max, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (+f64 projection/interpolation)", "data": "synthetic",
+            "config": {"workload": f"batch of {n_pairs_total} independent {args.cols}x{args.rows} stereo pairs "
+                                   f"({P} per GPU), {args.descriptor} descriptor, {args.levels} pyramid levels, {args.loss} loss, "
+                                   + ("converge with AlgorithmParameters() tolerances" if args.fixed_iters == 0 else
+                                      f"fixed {args.fixed_iters} iterations/level (tolerances 0)"),
+                       "pairs_per_gpu": P, "sharding": f"pairs/{world} ranks, one RCCL gather of 32-float records" if world > 1 else "single GPU",
+                       "step": "setData(A,B) + setTemplate(A) + estimatePose(A,B) per pair, inputs resident in HBM"},
+            "frames_per_s": 2.0 * n_pairs_total * args.steps / elapsed_max,
+            "pairs_per_s": n_pairs_total * args.steps / elapsed_max,
+            "gn_iterations_per_step": gn_total / args.steps,
+            "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
+            "pose_check": pose_err,
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+            "setup": {"synth_seconds": t_gen, "gen_workers": workers},
+        }
+        print(json.dumps(out))
+
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

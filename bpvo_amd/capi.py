@@ -350,6 +350,9 @@ class Context:
         self.call("batch_result_records_device", C.byref(p), C.byref(n))
         return p.value, n.value
 
+    def batch_copy_records_device(self, d_dst_ptr, n_pairs):
+        self.call("batch_copy_records_device", C.c_void_p(d_dst_ptr), int(n_pairs))
+
     # -- measurement
     def profiling(self, enable=True):
         self.call("profiling", int(bool(enable)))

@@ -1181,6 +1181,16 @@ int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* c, const float** d_record
   return BPVO_OK;
 }
 
+int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* c, float* d_dst, int n_pairs)
+{
+  CHECK_CTX(c);
+  if(!d_dst || n_pairs < 0 || n_pairs > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "bad record copy");
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipMemcpyAsync(d_dst, c->d_records, sizeof(float) * kRecordFloats * (size_t) n_pairs, hipMemcpyDeviceToDevice, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------------------------------------
 int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
 {

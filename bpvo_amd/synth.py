@@ -42,15 +42,23 @@ def _hash01(ix, iy, salt):
 
 
 def _value_noise(u, v, cell, salt):
-    """Bilinear value noise with lattice spacing `cell` (same units as u, v)."""
+    """Bilinear value noise with lattice spacing `cell` (same units as u, v).
+
+    The lattice hash is evaluated once on the bounding box of lattice nodes the image touches and gathered per pixel
+    (identical values to hashing per pixel, ~4x faster for the 128-pair benchmark batches)."""
     fu, fv = u / cell, v / cell
     iu, iv = np.floor(fu), np.floor(fv)
     a, b = fu - iu, fv - iv
     iu, iv = iu.astype(np.int64), iv.astype(np.int64)
-    n00 = _hash01(iu, iv, salt)
-    n10 = _hash01(iu + 1, iv, salt)
-    n01 = _hash01(iu, iv + 1, salt)
-    n11 = _hash01(iu + 1, iv + 1, salt)
+    u0, v0 = int(iu.min()), int(iv.min())
+    gu, gv = np.meshgrid(np.arange(u0, int(iu.max()) + 2, dtype=np.int64), np.arange(v0, int(iv.max()) + 2, dtype=np.int64),
+                         indexing="ij")
+    table = _hash01(gu, gv, salt)
+    ju, jv = iu - u0, iv - v0
+    n00 = table[ju, jv]
+    n10 = table[ju + 1, jv]
+    n01 = table[ju, jv + 1]
+    n11 = table[ju + 1, jv + 1]
     return (1 - b) * ((1 - a) * n00 + a * n10) + b * ((1 - a) * n01 + a * n11)
 
 
@@ -129,16 +137,29 @@ def make_sequence(rows: int, cols: int, n_frames: int, index: int = 0, step_rot:
     return dict(K=K, b=b, frames=frames, poses=poses)
 
 
-def make_batch(rows: int, cols: int, n_pairs: int, first_index: int = 0):
-    """n_pairs pairs packed as the batch API wants them: images [2n, R, W] = A0,B0,A1,B1,..., disparities likewise."""
+def _pair_for_batch(args):
+    rows, cols, idx = args
+    d = make_pair(rows, cols, idx)
+    return d["imgA"], d["imgB"], d["dispA"], d["dispB"], d["T_gt"]
+
+
+def make_batch(rows: int, cols: int, n_pairs: int, first_index: int = 0, workers: int = 1):
+    """n_pairs pairs packed as the batch API wants them: images [2n, R, W] = A0,B0,A1,B1,..., disparities likewise.
+
+    workers > 1 renders the pairs in a process pool (fork; call it before anything initialises the GPU)."""
     imgs = np.empty((2 * n_pairs, rows, cols), dtype=np.uint8)
     disps = np.empty((2 * n_pairs, rows, cols), dtype=np.float32)
     T_gt = np.empty((n_pairs, 4, 4), dtype=np.float64)
-    K = b = None
-    for p in range(n_pairs):
-        d = make_pair(rows, cols, first_index + p)
-        K, b = d["K"], d["b"]
-        imgs[2 * p], imgs[2 * p + 1] = d["imgA"], d["imgB"]
-        disps[2 * p], disps[2 * p + 1] = d["dispA"], d["dispB"]
-        T_gt[p] = d["T_gt"]
+    K, b = calibration(rows, cols)
+    jobs = [(rows, cols, first_index + p) for p in range(n_pairs)]
+    if workers > 1 and n_pairs > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, n_pairs)) as pool:
+            results = pool.map(_pair_for_batch, jobs, chunksize=1)
+    else:
+        results = map(_pair_for_batch, jobs)
+    for p, (ia, ib, da, db, tg) in enumerate(results):
+        imgs[2 * p], imgs[2 * p + 1] = ia, ib
+        disps[2 * p], disps[2 * p + 1] = da, db
+        T_gt[p] = tg
     return dict(K=K, b=b, images=imgs, disparities=disps, T_gt=T_gt)

@@ -206,6 +206,9 @@ int bpvo_hip_batch_estimate(bpvo_hip_ctx* ctx, int n_pairs, const float* T_init 
 /* device address of the packed result records of the last batch (32 floats per pair:
  * pose 3x4 row-major (12), twist-free pad, per-level numIterations (4..), status ...) for an RCCL gather. */
 int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* ctx, const float** d_records, int* floats_per_pair);
+/* device-to-device copy of the first n_pairs records into caller-owned device memory (e.g. the tensor handed to
+ * the RCCL gather), complete on return */
+int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* ctx, float* d_dst, int n_pairs);
 
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx's own stream */
 typedef struct bpvo_hip_kernel_stat {
