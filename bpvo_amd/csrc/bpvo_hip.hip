@@ -58,10 +58,10 @@ struct Workspace {
   int last_ref = -1, last_cur = -1, last_level = -1;
 };
 
-enum KernelClass { KC_PYRAMID = 0, KC_DESCRIPTOR, KC_SALIENCY_SELECT, KC_TEMPLATE, KC_WARP_RESIDUAL, KC_MEDIAN, KC_IRLS_REDUCE,
-                   KC_GN_STEP, KC_COUNT };
-const char* kKernelNames[KC_COUNT] = {"pyramid", "descriptor", "saliency_select", "template_build", "warp_residual", "median",
-                                      "irls_reduce", "gn_step"};
+enum KernelClass { KC_PYRAMID = 0, KC_DESCRIPTOR, KC_SALIENCY_SELECT, KC_NORMALIZATION, KC_TEMPLATE, KC_WARP_RESIDUAL, KC_MEDIAN,
+                   KC_IRLS_REDUCE, KC_GN_STEP, KC_COUNT };
+const char* kKernelNames[KC_COUNT] = {"pyramid", "descriptor", "saliency_select", "normalization", "template_build", "warp_residual",
+                                      "median", "irls_reduce", "gn_step"};
 
 struct EventPair { hipEvent_t a, b; int kc; double units; };
 
@@ -367,16 +367,18 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
   for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
     const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
     const LevelGeom& g = c->geom[l];
-    {
-      ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count);
-      launch_saliency(c->stream, jobs, c->C, g.cols, g.rows, count);
-      launch_select(c->stream, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
-      launch_normalization(c->stream, jobs, count, p.withNormalization);
-    }
-    {
-      ScopedTimer t(c, KC_TEMPLATE, 0.0);
-      launch_template_build(c->stream, jobs, c->C, g.cap, count, p.gradientEstimation == BPVO_GRAD_CD5);
-    }
+    ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count);
+    launch_saliency(c->stream, jobs, c->C, g.cols, g.rows, count);
+    launch_select(c->stream, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
+  }
+  {
+    // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
+    ScopedTimer t(c, KC_NORMALIZATION, 0.0);
+    launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, p.withNormalization);
+  }
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    ScopedTimer t(c, KC_TEMPLATE, 0.0);
+    launch_template_build(c->stream, c->d_fjobs + (size_t) l * NF, c->C, c->geom[l].cap, count, p.gradientEstimation == BPVO_GRAD_CD5);
   }
   // one read-back of the point counts (host needs them to size the GN grids)
   for(int i = 0; i < count; ++i)
@@ -393,6 +395,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
       pts += f.n_host[l];
     }
     c->kc_units[KC_TEMPLATE] += c->profiling ? pts : 0.0;
+    c->kc_units[KC_NORMALIZATION] += c->profiling ? pts : 0.0;
     f.has_template = true;
   }
   return BPVO_OK;
@@ -444,15 +447,23 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     launch_level_begin(c->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     HIP_CK(c, hipMemsetAsync(c->d_active, 0, 2 * sizeof(int), c->stream));
+    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues
+    // kItersPerSync iterations back to back and only then reads the "workspaces still active" counter: blocks of
+    // finished workspaces exit on their first load, so a few speculative launches cost less than a round trip per
+    // iteration.
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
-    for(int it = 0; it < max_lin; ++it) {
-      const int parity = it & 1;
-      { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-      { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
-      { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-      { ScopedTimer t(c, KC_GN_STEP, 0.0);
-        launch_gn_step(c->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                       p.gradientTolerance, c->d_active, parity, c->d_counters); }
+    constexpr int kItersPerSync = 4;
+    for(int it = 0; it < max_lin;) {
+      int parity = 0;
+      for(int k = 0; k < kItersPerSync && it < max_lin; ++k, ++it) {
+        parity = it & 1;
+        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
+        { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+        { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+        { ScopedTimer t(c, KC_GN_STEP, 0.0);
+          launch_gn_step(c->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                         p.gradientTolerance, c->d_active, parity, c->d_counters); }
+      }
       HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_CK(c, hipStreamSynchronize(c->stream));
       if(c->h_ints[0] == 0) break;
@@ -1214,8 +1225,8 @@ int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* c, bpvo_hip_kernel_stat* out, int ma
   if(rc) return rc;
   // algorithmic bytes per unit: unit = template point for the GN kernels, pixel otherwise
   const double C = c->C;
-  const double bpu[KC_COUNT] = {2.0, 1.0 + 4.0 * C, 4.0 * C + 4.0 + 4.0, 16.0 + 4.0 + 5.0 * 4.0 * C + 28.0 * C, 18.0 + 24.0 * C, 4.0 * C,
-                                2.0 + 28.0 * C, 0.0};
+  const double bpu[KC_COUNT] = {2.0, 1.0 + 4.0 * C, 4.0 * C + 4.0 + 4.0, 32.0, 16.0 + 4.0 + 5.0 * 4.0 * C + 28.0 * C, 18.0 + 24.0 * C,
+                                4.0 * C, 2.0 + 28.0 * C, 0.0};
   int n = 0;
   for(int k = 0; k < KC_COUNT && n < max_out; ++k, ++n) {
     std::memset(&out[n], 0, sizeof(out[n]));

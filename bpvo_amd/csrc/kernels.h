@@ -15,7 +15,8 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes);
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border);
-void launch_normalization(hipStream_t s, const FrameJob* jobs, int nframes, int with_normalization);
+void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
+                          int num_levels, int with_normalization);
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
 
 // Gauss-Newton stage (batched over workspaces / pairs)

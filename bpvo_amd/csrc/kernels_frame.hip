@@ -329,9 +329,10 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-__global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs, int with_normalization)
+__global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
+                                                           int with_normalization)
 {
-  const FrameJob& j = jobs[blockIdx.x];
+  const FrameJob& j = jobs[(size_t) (first_level + blockIdx.y) * job_pitch + blockIdx.x];
   const int N = *j.n_out;
   const int lane = threadIdx.x;
   if(!with_normalization || N == 0) {
@@ -456,9 +457,11 @@ void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
   hipLaunchKernelGGL(select_write_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs);
 }
-void launch_normalization(hipStream_t s, const FrameJob* jobs, int nframes, int with_normalization)
+void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels,
+                          int with_normalization)
 {
-  hipLaunchKernelGGL(normalization_kernel, dim3(nframes), dim3(64), 0, s, jobs, with_normalization);
+  hipLaunchKernelGGL(normalization_kernel, dim3(nframes, num_levels - first_level), dim3(64), 0, s, jobs, job_pitch, first_level,
+                     with_normalization);
 }
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5)
 {

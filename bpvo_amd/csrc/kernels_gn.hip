@@ -485,30 +485,11 @@ __device__ void gn_finalize(GNState* st)
   st->active = 0;
 }
 
-__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
-                                                     int max_iterations, int max_fun_evals, float p_tol, float f_tol,
-                                                     float g_tol_param, int* active_counter, int parity,
-                                                     unsigned long long* counters)
+// the serial part of gn_step, executed by lane 0 on the LDS copy of the state; returns true if another linearisation
+// is requested (the workspace stays active)
+__device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, int mode, int max_iterations, int max_fun_evals,
+                         float p_tol, float f_tol, float g_tol_param)
 {
-  const PairJob& j = jobs[blockIdx.x];
-  GNState* st = j.st;
-  if(active_counter && blockIdx.x == 0 && threadIdx.x == 0) active_counter[parity ^ 1] = 0;
-  if(!st->active) return;
-  if(counters && threadIdx.x == 0) {     // measurement: points and linearisations processed (bench.py roofline)
-    atomicAdd(&counters[0], (unsigned long long) j.n);
-    atomicAdd(&counters[1], 1ull);
-  }
-
-  __shared__ float s_sum[kPartialStride];
-  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
-  if(threadIdx.x < kNumAcc) {
-    double s = 0.0;
-    for(int b = 0; b < nblk; ++b) s += (double) j.partials[(size_t) b * kPartialStride + threadIdx.x];
-    s_sum[threadIdx.x] = (float) s;
-  }
-  __syncthreads();
-  if(threadIdx.x != 0) return;
-
   // unpack: upper triangle -> symmetric H (toEigen + selfadjointView<Upper>, linear_system_builder.cc:207-221)
   {
     int idx = 0;
@@ -524,10 +505,9 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   st->f_norm = f_norm;
   st->n_valid = (uint32_t) s_sum[28];
   st->num_fun_evals += 1;
-  if(mode == 1) return;
+  if(mode == 1) return true;
 
   const float sqrt_eps = sqrtf(FLT_EPSILON);
-  bool go_loop_top = false;
 
   if(st->phase == PHASE_FIRST) {
     const float g_norm = inf_norm6(st->G);
@@ -538,60 +518,99 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
       s.status = BPVO_STATUS_GRADIENT_TOL; s.finalError = f_norm; s.numIterations = 1; s.firstOrderOptimality = g_norm;
       st->status = BPVO_STATUS_GRADIENT_TOL;
       st->phase = PHASE_DONE; st->active = 0;
-      return;
+      return false;
     }
     if(!solve_system(st->H, st->G, st->dp)) {           // :356-362
       bpvo_hip_stats& s = st->stats[st->level];
       s.status = BPVO_STATUS_SOLVER_ERROR; s.finalError = f_norm; s.numIterations = 0; s.firstOrderOptimality = 0.0f;
       st->status = BPVO_STATUS_SOLVER_ERROR;
       st->phase = PHASE_DONE; st->active = 0;
-      return;
+      return false;
     }
     st->f_norm_prev = 0.0f;
     st->dp_norm_prev = 0.0f;
     st->has_converged = 0;
-    gn_update_pose(st, j.nrm);                          // :371
-    go_loop_top = true;
+    gn_update_pose(st, nrm);                            // :371
   } else {
     // runIteration's solve (pose_estimator_gn.h:89-97)
     if(!solve_system(st->H, st->G, st->dp)) {
       st->status = BPVO_STATUS_SOLVER_ERROR;
       gn_finalize(st);                                  // `break`: no ++ on the way out
-      return;
+      return false;
     }
-    gn_update_pose(st, j.nrm);                          // :390
+    gn_update_pose(st, nrm);                            // :390
     const bool cont = (st->num_iterations++ < max_iterations) && !st->has_converged && (st->num_fun_evals < max_fun_evals);
-    if(cont) go_loop_top = true;
-    else { gn_finalize(st); return; }
+    if(!cont) { gn_finalize(st); return false; }
   }
 
-  if(go_loop_top) {
-    // top of the do-loop body (:374-383)
-    float dp_norm = 0.0f;
-    for(int i = 0; i < 6; ++i) dp_norm += st->dp[i] * st->dp[i];
-    dp_norm = sqrtf(dp_norm);
-    const float g_norm = inf_norm6(st->G);
-    st->g_norm = g_norm;
-    bool conv = false;
-    if(dp_norm < p_tol || dp_norm < p_tol * (sqrt_eps + st->dp_norm_prev)) {
-      st->status = BPVO_STATUS_PARAMETER_TOL; conv = true;
-    } else if(f_norm < f_tol || f_norm < f_tol * (sqrt_eps + st->f_norm_prev) || fabsf(f_norm - st->f_norm_prev) < f_tol) {
-      st->status = BPVO_STATUS_FUNCTION_TOL; conv = true;
-    } else if(g_norm < st->g_tol) {
-      st->status = BPVO_STATUS_GRADIENT_TOL; conv = true;
-    }
-    st->has_converged = conv ? 1 : 0;
-    st->dp_norm_prev = dp_norm;
-    st->f_norm_prev = f_norm;
-    if(!conv) {
-      st->phase = PHASE_LOOP;                           // next launch: linearize at the updated pose
-      if(active_counter) atomicAdd(&active_counter[parity], 1);
-      return;
-    }
-    gn_update_pose(st, j.nrm);                          // Q1: applied again with the stale dp
-    st->num_iterations++;                               // the `numIterations++ <` of the failing while test
-    gn_finalize(st);
+  // top of the do-loop body (:374-383)
+  float dp_norm = 0.0f;
+  for(int i = 0; i < 6; ++i) dp_norm += st->dp[i] * st->dp[i];
+  dp_norm = sqrtf(dp_norm);
+  const float g_norm = inf_norm6(st->G);
+  st->g_norm = g_norm;
+  bool conv = false;
+  if(dp_norm < p_tol || dp_norm < p_tol * (sqrt_eps + st->dp_norm_prev)) {
+    st->status = BPVO_STATUS_PARAMETER_TOL; conv = true;
+  } else if(f_norm < f_tol || f_norm < f_tol * (sqrt_eps + st->f_norm_prev) || fabsf(f_norm - st->f_norm_prev) < f_tol) {
+    st->status = BPVO_STATUS_FUNCTION_TOL; conv = true;
+  } else if(g_norm < st->g_tol) {
+    st->status = BPVO_STATUS_GRADIENT_TOL; conv = true;
   }
+  st->has_converged = conv ? 1 : 0;
+  st->dp_norm_prev = dp_norm;
+  st->f_norm_prev = f_norm;
+  if(!conv) {
+    st->phase = PHASE_LOOP;                             // next launch: linearize at the updated pose
+    return true;
+  }
+  gn_update_pose(st, nrm);                              // Q1: applied again with the stale dp
+  st->num_iterations++;                                 // the `numIterations++ <` of the failing while test
+  gn_finalize(st);
+  return false;
+}
+
+__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
+                                                     int max_iterations, int max_fun_evals, float p_tol, float f_tol,
+                                                     float g_tol_param, int* active_counter, int parity,
+                                                     unsigned long long* counters)
+{
+  const PairJob& j = jobs[blockIdx.x];
+  GNState* gst = j.st;
+  if(active_counter && blockIdx.x == 0 && threadIdx.x == 0) active_counter[parity ^ 1] = 0;
+  if(!gst->active) return;
+
+  // the state lives in HBM between launches; the serial bookkeeping runs on an LDS copy (global-memory round trips
+  // would otherwise dominate this kernel: every field access is a dependent ~1 us load)
+  constexpr int kWords = (int) (sizeof(GNState) / sizeof(uint32_t));
+  static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
+  __shared__ uint32_t s_state[kWords];
+  __shared__ float s_sum[kPartialStride];
+  __shared__ float s_nrm[4];
+  for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
+  if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
+
+  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
+  if(threadIdx.x < kNumAcc) {                        // deterministic: block order, f64
+    double s = 0.0;
+    const float* __restrict__ pp = j.partials + threadIdx.x;
+#pragma unroll 8
+    for(int b = 0; b < nblk; ++b) s += (double) pp[(size_t) b * kPartialStride];
+    s_sum[threadIdx.x] = (float) s;
+  }
+  __syncthreads();
+
+  if(threadIdx.x == 0) {
+    GNState* st = reinterpret_cast<GNState*>(s_state);
+    const bool again = gn_logic(st, s_nrm, s_sum, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
+    if(again && mode == 0 && active_counter) atomicAdd(&active_counter[parity], 1);
+    if(counters) {     // measurement: points and linearisations processed (bench.py roofline)
+      atomicAdd(&counters[0], (unsigned long long) j.n);
+      atomicAdd(&counters[1], 1ull);
+    }
+  }
+  __syncthreads();
+  for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
