@@ -487,6 +487,21 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
   return BPVO_OK;
 }
 
+// tiled device layout (types.h tile_index) -> reference channel-major layout: out[(ch*n + i)*E + e] for records of
+// C*E floats per point cut in V-float pieces
+void detile_to_channel_major(const float* src, int n, int C, int E, int V, float* out)
+{
+  const int W = C * E, pieces = W / V;
+  for(int i = 0; i < n; ++i)
+    for(int w = 0; w < W; ++w) {
+      const int piece = w / V, within = w - piece * V;
+      const float v = src[(((size_t) (i >> 6) * pieces + piece) * 64 + (size_t) (i & 63)) * V + within];
+      const int ch = w / E, e = w - ch * E;
+      out[((size_t) ch * n + i) * E + e] = v;
+    }
+}
+size_t tiled_floats(int n, int floats_per_point) { return (size_t) ((n + kTile - 1) / kTile) * kTile * floats_per_point; }
+
 int refresh_counters(bpvo_hip_ctx* c)
 {
   unsigned long long h[2] = {0, 0};
@@ -666,7 +681,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       g.nms_radius = nms ? c->params.nonMaxSuppRadius : -1;
       // strict local maxima: at most one per 2x2 block (two adjacent pixels cannot both be strict maxima)
       const size_t cap = nms ? (size_t) ((r + 1) / 2) * ((w + 1) / 2) : g.npix;
-      g.cap = (int) ((cap + 15) / 16 * 16);
+      g.cap = (int) ((cap + kTile - 1) / kTile * kTile);   // whole 64-point tiles (tiled per-point layout, types.h)
       std::memcpy(g.K, Kp, sizeof(Kp));
       g.b = bp;
       c->cap_max = std::max(c->cap_max, g.cap);
@@ -865,22 +880,20 @@ int bpvo_hip_get_pixels(bpvo_hip_ctx* c, int slot, int level, float* pixels)
 {
   TMPL(c, slot, level);
   const int C = c->C;
-  std::vector<float> pm((size_t) n * C);
-  if(n) HIP_CK(c, hipMemcpyAsync(pm.data(), f.pix[level], pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> t(tiled_floats(n, C));
+  if(n) HIP_CK(c, hipMemcpyAsync(t.data(), f.pix[level], t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  for(int i = 0; i < n; ++i)
-    for(int ch = 0; ch < C; ++ch) pixels[(size_t) ch * n + i] = pm[(size_t) i * C + ch];   // -> channel-major
+  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : 1, pixels);
   return BPVO_OK;
 }
 int bpvo_hip_get_jacobians(bpvo_hip_ctx* c, int slot, int level, float* J)
 {
   TMPL(c, slot, level);
   const int C = c->C;
-  std::vector<float> pm((size_t) n * C * 6);
-  if(n) HIP_CK(c, hipMemcpyAsync(pm.data(), f.jac[level], pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> t(tiled_floats(n, C * 6));
+  if(n) HIP_CK(c, hipMemcpyAsync(t.data(), f.jac[level], t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  for(int i = 0; i < n; ++i)
-    for(int ch = 0; ch < C; ++ch) std::memcpy(J + ((size_t) ch * n + i) * 6, pm.data() + ((size_t) i * C + ch) * 6, 6 * sizeof(float));
+  detile_to_channel_major(t.data(), n, C, 6, C == 8 ? 4 : 2, J);
   return BPVO_OK;
 }
 int bpvo_hip_get_normalization(bpvo_hip_ctx* c, int slot, int level, float T[16], float T_inv[16])
@@ -943,11 +956,10 @@ int bpvo_hip_get_residuals(bpvo_hip_ctx* c, int ws, float* r, size_t* n_out)
   if(n_out) *n_out = (size_t) n * C;
   if(!r) return BPVO_OK;
   (void) hipSetDevice(c->device);
-  std::vector<float> pm((size_t) n * C);
-  HIP_CK(c, hipMemcpyAsync(pm.data(), w.r, pm.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  std::vector<float> t(tiled_floats(n, C));
+  if(n) HIP_CK(c, hipMemcpyAsync(t.data(), w.r, t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  for(int i = 0; i < n; ++i)
-    for(int ch = 0; ch < C; ++ch) r[(size_t) ch * n + i] = pm[(size_t) i * C + ch];
+  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : 1, r);
   return BPVO_OK;
 }
 int bpvo_hip_get_valid(bpvo_hip_ctx* c, int ws, uint16_t* v, size_t* n_out)

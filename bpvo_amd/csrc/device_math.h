@@ -121,6 +121,7 @@ BPVO_HD M44 params_to_pose(const float nrm[4], const float p[6])
 template <typename T>
 struct LDLT6 {
   T m[36];
+  T temp[6];
   int tr[6];
   BPVO_HD void compute(const T* A, T eps)
   {
@@ -150,7 +151,6 @@ struct LDLT6 {
       }
       const int rs = 6 - k - 1;
       if(k > 0) {
-        T temp[6];
         for(int c = 0; c < k; ++c) temp[c] = m[c * 6 + c] * m[k * 6 + c];
         T dot = 0;
         for(int c = 0; c < k; ++c) dot += m[k * 6 + c] * temp[c];
@@ -190,36 +190,39 @@ struct LDLT6 {
 template <typename T>
 BPVO_HD bool is_approx_Hdp_G(const T* H, const T* dp, const T* G, T prec)
 {
-  T a[6];
-  for(int i = 0; i < 6; ++i) {
-    T s = 0;
-    for(int k = 0; k < 6; ++k) s += H[i * 6 + k] * dp[k];
-    a[i] = s;
-  }
   T d2 = 0, na = 0, nb = 0;
-  for(int i = 0; i < 6; ++i) { d2 += (a[i] - G[i]) * (a[i] - G[i]); na += a[i] * a[i]; nb += G[i] * G[i]; }
+  for(int i = 0; i < 6; ++i) {
+    T a = 0;
+    for(int k = 0; k < 6; ++k) a += H[i * 6 + k] * dp[k];
+    d2 += (a - G[i]) * (a - G[i]); na += a * a; nb += G[i] * G[i];
+  }
   const T mn = na < nb ? na : nb;
   return d2 <= prec * prec * mn;
 }
 
+// Working storage of solve_system.  The factorisation indexes its arrays with run-time pivots, which would put
+// function-local arrays into (slow) scratch memory on the GPU: the device caller hands in an LDS-resident instance.
+struct SolveScratch {
+  LDLT6<float> f;
+  LDLT6<double> d;
+  double Hd[36], Gd[6], dpd[6];
+};
+
 // PoseEstimatorData_::solve + solve2Augmented(0.001) (reference: bpvo/pose_estimator_base.h:90-111,136-148).
-BPVO_HD bool solve_system(const float H[36], const float G[6], float dp[6])
+BPVO_HD bool solve_system(const float H[36], const float G[6], float dp[6], SolveScratch* ws)
 {
-  LDLT6<float> s;
-  s.compute(H, 1.1920928955078125e-07f);
-  s.solve(G, dp, 1.0f / 3.4028234663852886e+38f);
+  ws->f.compute(H, 1.1920928955078125e-07f);
+  ws->f.solve(G, dp, 1.0f / 3.4028234663852886e+38f);
   if(is_approx_Hdp_G<float>(H, dp, G, 1e-5f)) return true;
   float maxd = H[0];
   for(int i = 1; i < 6; ++i) maxd = H[i * 6 + i] > maxd ? H[i * 6 + i] : maxd;
   const double u = 0.001 * (double) maxd;
-  double Hd[36], Gd[6], dpd[6];
-  for(int i = 0; i < 36; ++i) Hd[i] = (double) H[i];
-  for(int i = 0; i < 6; ++i) { Gd[i] = (double) G[i]; Hd[i * 6 + i] += u; }
-  LDLT6<double> sd;
-  sd.compute(Hd, 2.220446049250313e-16);
-  sd.solve(Gd, dpd, 1.0 / 1.7976931348623157e+308);
-  const bool ok = is_approx_Hdp_G<double>(Hd, dpd, Gd, 1e-12);
-  for(int i = 0; i < 6; ++i) dp[i] = (float) dpd[i];
+  for(int i = 0; i < 36; ++i) ws->Hd[i] = (double) H[i];
+  for(int i = 0; i < 6; ++i) { ws->Gd[i] = (double) G[i]; ws->Hd[i * 6 + i] += u; }
+  ws->d.compute(ws->Hd, 2.220446049250313e-16);
+  ws->d.solve(ws->Gd, ws->dpd, 1.0 / 1.7976931348623157e+308);
+  const bool ok = is_approx_Hdp_G<double>(ws->Hd, ws->dpd, ws->Gd, 1e-12);
+  for(int i = 0; i < 6; ++i) dp[i] = (float) ws->dpd[i];
   return ok;
 }
 

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs,
 
 // ---- K5: template pixels, central-difference gradients and 1x6 Jacobians
 // (reference: bpvo/template_data.cc:102-137; Jacobian = bpvo/rigid_body_warp.cc:60-315 in the SSE code's operation
-// order with IEEE division instead of _mm_rcp_ps — SURVEY.md Q13).  Point-major outputs pix[i][c], jac[i][c][6].
+// order with IEEE division instead of _mm_rcp_ps — SURVEY.md Q13).  Outputs pix / jac in the tiled layout of types.h.
 template <int C>
 __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5)
 {
@@ -394,8 +394,7 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   const float x = P.x, y = P.y, z = P.z;
   const float z2 = z * z;
   const float* __restrict__ D = j.desc;
-  float* __restrict__ pix = j.pix + (size_t) i * C;
-  float* __restrict__ jac = j.jac + (size_t) i * C * 6;
+  float pixv[C], J[C * 6];
   const float NN = 1.0f / 18.0f;
 #pragma unroll
   for(int c = 0; c < C; ++c) {
@@ -408,16 +407,30 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
       gx = NN * (1.0f * cc[-2 * C] - 8.0f * cc[-C] + 8.0f * cc[C] - 1.0f * cc[2 * C]);
       gy = NN * (1.0f * cc[-2 * (ptrdiff_t) W * C] - 8.0f * cc[-(ptrdiff_t) W * C] + 8.0f * cc[(ptrdiff_t) W * C] - 1.0f * cc[2 * (ptrdiff_t) W * C]);
     }
-    pix[c] = cc[0];
+    pixv[c] = cc[0];
     const float Ix = fx * gx, Iy = fy * gy;
     const float xIx_yIy = x * Ix + y * Iy;
-    float* J = jac + c * 6;
-    J[0] = (-((Iy * (z - c3)) / z)) - ((xIx_yIy * (y - c2)) / z2);
-    J[1] = ((Ix * (z - c3)) / z) + ((xIx_yIy * (x - c1)) / z2);
-    J[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) / z;
-    J[3] = Ix / (z * s);
-    J[4] = Iy / (z * s);
-    J[5] = -((s_i * xIx_yIy) / z2);
+    float* Jc = J + c * 6;
+    Jc[0] = (-((Iy * (z - c3)) / z)) - ((xIx_yIy * (y - c2)) / z2);
+    Jc[1] = ((Ix * (z - c3)) / z) + ((xIx_yIy * (x - c1)) / z2);
+    Jc[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) / z;
+    Jc[3] = Ix / (z * s);
+    Jc[4] = Iy / (z * s);
+    Jc[5] = -((s_i * xIx_yIy) / z2);
+  }
+  // tiled stores (types.h tile_index): consecutive lanes write consecutive vectors
+  if constexpr(C == 8) {
+    float4* pv = reinterpret_cast<float4*>(j.pix);
+    pv[tile_index<2>(i, 0)] = make_float4(pixv[0], pixv[1], pixv[2], pixv[3]);
+    pv[tile_index<2>(i, 1)] = make_float4(pixv[4], pixv[5], pixv[6], pixv[7]);
+    float4* jv = reinterpret_cast<float4*>(j.jac);
+#pragma unroll
+    for(int k = 0; k < 12; ++k) jv[tile_index<12>(i, k)] = make_float4(J[4 * k], J[4 * k + 1], J[4 * k + 2], J[4 * k + 3]);
+  } else {
+    j.pix[i] = pixv[0];
+    float2* jv = reinterpret_cast<float2*>(j.jac);
+#pragma unroll
+    for(int k = 0; k < 3; ++k) jv[tile_index<3>(i, k)] = make_float2(J[2 * k], J[2 * k + 1]);
   }
 }
 

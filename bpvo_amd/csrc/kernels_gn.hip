@@ -82,10 +82,10 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     if constexpr(C == 8) {
       const float4* q0 = reinterpret_cast<const float4*>(d0);
       const float4* q1 = reinterpret_cast<const float4*>(d1);
-      const float4* p0 = reinterpret_cast<const float4*>(j.pix + (size_t) i * C);
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
       const float4 a0 = q0[0], a1 = q0[1], a2 = q0[2], a3 = q0[3];
       const float4 b0 = q1[0], b1 = q1[1], b2 = q1[2], b3 = q1[3];
-      const float4 t0 = p0[0], t1 = p0[1];
+      const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
       I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
       I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
       I10[0] = b0.x; I10[1] = b0.y; I10[2] = b0.z; I10[3] = b0.w; I10[4] = b1.x; I10[5] = b1.y; I10[6] = b1.z; I10[7] = b1.w;
@@ -107,14 +107,12 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 #pragma unroll
     for(int c = 0; c < C; ++c) res[c] = 0.0f;
   }
-  float* __restrict__ ro = j.r + (size_t) i * C;
-  if constexpr(C == 8) {
-    float4* o = reinterpret_cast<float4*>(ro);
-    o[0] = make_float4(res[0], res[1], res[2], res[3]);
-    o[1] = make_float4(res[4], res[5], res[6], res[7]);
+  if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
+    float4* o = reinterpret_cast<float4*>(j.r);
+    o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
+    o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
   } else {
-#pragma unroll
-    for(int c = 0; c < C; ++c) ro[c] = res[c];
+    j.r[i] = res[0];
   }
 }
 
@@ -171,14 +169,28 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
 {
   const int n = j.n;
   if constexpr(C == 8) {
-    for(int pt = threadIdx.x; pt < n; pt += MED_THREADS) {
-      if(!j.valid[pt]) continue;
-      const float4* q = reinterpret_cast<const float4*>(j.r + (size_t) pt * 8);
-      const float4 a = q[0], b = q[1];
-      f(__float_as_uint(a.x) & 0x7fffffffu, pt); f(__float_as_uint(a.y) & 0x7fffffffu, pt);
-      f(__float_as_uint(a.z) & 0x7fffffffu, pt); f(__float_as_uint(a.w) & 0x7fffffffu, pt);
-      f(__float_as_uint(b.x) & 0x7fffffffu, pt); f(__float_as_uint(b.y) & 0x7fffffffu, pt);
-      f(__float_as_uint(b.z) & 0x7fffffffu, pt); f(__float_as_uint(b.w) & 0x7fffffffu, pt);
+    const float4* q = reinterpret_cast<const float4*>(j.r);
+    constexpr int U = 4;   // points in flight per thread: all loads of a round are issued before any is consumed
+    for(int base = threadIdx.x; base < n; base += MED_THREADS * U) {
+      unsigned char v[U];
+      float4 a[U], b[U];
+#pragma unroll
+      for(int u = 0; u < U; ++u) {
+        const int pt = base + u * MED_THREADS;
+        const bool in = pt < n;
+        v[u] = in ? j.valid[pt] : (unsigned char) 0;
+        a[u] = in ? q[tile_index<2>(pt, 0)] : make_float4(0, 0, 0, 0);
+        b[u] = in ? q[tile_index<2>(pt, 1)] : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for(int u = 0; u < U; ++u) {
+        if(!v[u]) continue;
+        const int pt = base + u * MED_THREADS;
+        f(__float_as_uint(a[u].x) & 0x7fffffffu, pt); f(__float_as_uint(a[u].y) & 0x7fffffffu, pt);
+        f(__float_as_uint(a[u].z) & 0x7fffffffu, pt); f(__float_as_uint(a[u].w) & 0x7fffffffu, pt);
+        f(__float_as_uint(b[u].x) & 0x7fffffffu, pt); f(__float_as_uint(b[u].y) & 0x7fffffffu, pt);
+        f(__float_as_uint(b[u].z) & 0x7fffffffu, pt); f(__float_as_uint(b[u].w) & 0x7fffffffu, pt);
+      }
     }
   } else {
     for(int p4 = threadIdx.x * 4; p4 < n; p4 += MED_THREADS * 4) {   // n is a multiple of 16
@@ -381,30 +393,27 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
     const float v = (float) j.valid[i];
     acc[28] += v;
-    const float* __restrict__ rp = j.r + (size_t) i * C;
-    const float* __restrict__ Jp = j.jac + (size_t) i * C * 6;
-    // channels are consumed in groups of G (C = 8: 4 channels = one 16-byte residual load + six 16-byte Jacobian
-    // loads, 96 contiguous bytes); the group loop is kept rolled to bound register pressure (occupancy hides latency)
+    // channels are consumed in groups of G (C = 8: 4 channels = one 16-byte residual vector + six 16-byte Jacobian
+    // vectors, all tiled -> coalesced); the group loop is kept rolled to bound register pressure
     constexpr int G = (C >= 4) ? 4 : C;
 #pragma unroll 1
     for(int c0 = 0; c0 < C; c0 += G) {
       float rr[G], Jg[G * 6];
       if constexpr(G == 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(rp + c0);
+        const float4 t4 = reinterpret_cast<const float4*>(j.r)[tile_index<2>(i, c0 >> 2)];
         rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
-        const float4* q = reinterpret_cast<const float4*>(Jp + c0 * 6);
+        const float4* q = reinterpret_cast<const float4*>(j.jac);
 #pragma unroll
         for(int k = 0; k < 6; ++k) {
-          const float4 t = q[k];
+          const float4 t = q[tile_index<12>(i, (c0 >> 2) * 6 + k)];
           Jg[4 * k + 0] = t.x; Jg[4 * k + 1] = t.y; Jg[4 * k + 2] = t.z; Jg[4 * k + 3] = t.w;
         }
       } else {
+        rr[0] = j.r[i];
+        const float2* q = reinterpret_cast<const float2*>(j.jac);
 #pragma unroll
-        for(int k = 0; k < G; ++k) rr[k] = rp[c0 + k];
-        const float2* q = reinterpret_cast<const float2*>(Jp + c0 * 6);
-#pragma unroll
-        for(int k = 0; k < G * 3; ++k) {
-          const float2 t = q[k];
+        for(int k = 0; k < 3; ++k) {
+          const float2 t = q[tile_index<3>(i, k)];
           Jg[2 * k + 0] = t.x; Jg[2 * k + 1] = t.y;
         }
       }
@@ -487,8 +496,8 @@ __device__ void gn_finalize(GNState* st)
 
 // the serial part of gn_step, executed by lane 0 on the LDS copy of the state; returns true if another linearisation
 // is requested (the workspace stays active)
-__device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, int mode, int max_iterations, int max_fun_evals,
-                         float p_tol, float f_tol, float g_tol_param)
+__device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, SolveScratch* scratch, int mode, int max_iterations,
+                         int max_fun_evals, float p_tol, float f_tol, float g_tol_param)
 {
   // unpack: upper triangle -> symmetric H (toEigen + selfadjointView<Upper>, linear_system_builder.cc:207-221)
   {
@@ -520,7 +529,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, int 
       st->phase = PHASE_DONE; st->active = 0;
       return false;
     }
-    if(!solve_system(st->H, st->G, st->dp)) {           // :356-362
+    if(!solve_system(st->H, st->G, st->dp, scratch)) {           // :356-362
       bpvo_hip_stats& s = st->stats[st->level];
       s.status = BPVO_STATUS_SOLVER_ERROR; s.finalError = f_norm; s.numIterations = 0; s.firstOrderOptimality = 0.0f;
       st->status = BPVO_STATUS_SOLVER_ERROR;
@@ -533,7 +542,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, int 
     gn_update_pose(st, nrm);                            // :371
   } else {
     // runIteration's solve (pose_estimator_gn.h:89-97)
-    if(!solve_system(st->H, st->G, st->dp)) {
+    if(!solve_system(st->H, st->G, st->dp, scratch)) {
       st->status = BPVO_STATUS_SOLVER_ERROR;
       gn_finalize(st);                                  // `break`: no ++ on the way out
       return false;
@@ -587,6 +596,7 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   __shared__ uint32_t s_state[kWords];
   __shared__ float s_sum[kPartialStride];
   __shared__ float s_nrm[4];
+  __shared__ SolveScratch s_scratch;
   for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
   if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
 
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
 
   if(threadIdx.x == 0) {
     GNState* st = reinterpret_cast<GNState*>(s_state);
-    const bool again = gn_logic(st, s_nrm, s_sum, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
+    const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
     if(again && mode == 0 && active_counter) atomicAdd(&active_counter[parity], 1);
     if(counters) {     // measurement: points and linearisations processed (bench.py roofline)
       atomicAdd(&counters[0], (unsigned long long) j.n);
@@ -663,23 +673,46 @@ __global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int
 
 // weights of the last linearisation, recomputed from r / valid / sigma on request
 // (VisualOdometryPoseEstimator::getWeights, bpvo/vo_pose_estimator.cc:95-99; invalid entries have r = 0 -> w = 1, Q12)
-template <int LOSS>
-__global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, int total, float* w_out)
+template <int C, int LOSS>
+__global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, float* w_out /*[n][C] point-major*/)
 {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if(e >= total) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= job->n) return;
   const float sigma_inv = 1.0f / job->st->scale;
-  w_out[e] = mest_weight<LOSS>(job->r[e], sigma_inv);
+  if constexpr(C == 8) {
+    const float4* q = reinterpret_cast<const float4*>(job->r);
+    const float4 a = q[tile_index<2>(i, 0)], b = q[tile_index<2>(i, 1)];
+    float* o = w_out + (size_t) i * 8;
+    o[0] = mest_weight<LOSS>(a.x, sigma_inv); o[1] = mest_weight<LOSS>(a.y, sigma_inv);
+    o[2] = mest_weight<LOSS>(a.z, sigma_inv); o[3] = mest_weight<LOSS>(a.w, sigma_inv);
+    o[4] = mest_weight<LOSS>(b.x, sigma_inv); o[5] = mest_weight<LOSS>(b.y, sigma_inv);
+    o[6] = mest_weight<LOSS>(b.z, sigma_inv); o[7] = mest_weight<LOSS>(b.w, sigma_inv);
+  } else {
+    w_out[i] = mest_weight<LOSS>(job->r[i], sigma_inv);
+  }
 }
 
-template <int LOSS>
-__global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, int total, float thr, unsigned int* count)
+template <int C, int LOSS>
+__global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, float thr, unsigned int* count)
 {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  bool good = false;
-  if(e < total) good = mest_weight<LOSS>(job->r[e], 1.0f / job->st->scale) > thr;
-  const unsigned long long m = __ballot(good);
-  if((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned) __popcll(m));
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned good = 0;
+  if(i < job->n) {
+    const float sigma_inv = 1.0f / job->st->scale;
+    if constexpr(C == 8) {
+      const float4* q = reinterpret_cast<const float4*>(job->r);
+      const float4 a = q[tile_index<2>(i, 0)], b = q[tile_index<2>(i, 1)];
+      good = (mest_weight<LOSS>(a.x, sigma_inv) > thr) + (mest_weight<LOSS>(a.y, sigma_inv) > thr) +
+             (mest_weight<LOSS>(a.z, sigma_inv) > thr) + (mest_weight<LOSS>(a.w, sigma_inv) > thr) +
+             (mest_weight<LOSS>(b.x, sigma_inv) > thr) + (mest_weight<LOSS>(b.y, sigma_inv) > thr) +
+             (mest_weight<LOSS>(b.z, sigma_inv) > thr) + (mest_weight<LOSS>(b.w, sigma_inv) > thr);
+    } else {
+      good = mest_weight<LOSS>(job->r[i], sigma_inv) > thr;
+    }
+  }
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) good += __shfl_down(good, o);
+  if((threadIdx.x & 63) == 0 && good) atomicAdd(count, good);
 }
 
 // 32-float result record per pair for the RCCL gather: pose 3x4 (12), numIterations per level (8), status per level (8),
@@ -762,27 +795,37 @@ void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T,
 {
   hipLaunchKernelGGL(prepare_linearize_kernel, dim3(1), dim3(64), 0, s, job, T, reset_scale, level);
 }
+template <int C>
+static void launch_weights_c(hipStream_t s, const PairJob* job, int n, int loss, float* w_out)
+{
+  const dim3 grid((n + 255) / 256);
+  switch(loss) {
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((weights_kernel<C, BPVO_LOSS_HUBER>), grid, dim3(256), 0, s, job, w_out); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((weights_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(256), 0, s, job, w_out); break;
+    default: hipLaunchKernelGGL((weights_kernel<C, BPVO_LOSS_L2>), grid, dim3(256), 0, s, job, w_out); break;
+  }
+}
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out)
 {
-  const int total = n * C;
-  if(total <= 0) return;
-  const dim3 grid((total + 255) / 256);
+  if(n <= 0) return;
+  if(C == 1) launch_weights_c<1>(s, job, n, loss, w_out);
+  else launch_weights_c<8>(s, job, n, loss, w_out);
+}
+template <int C>
+static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int loss, float thr, unsigned int* count)
+{
+  const dim3 grid((n + 255) / 256);
   switch(loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_HUBER>, grid, dim3(256), 0, s, job, total, w_out); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_TUKEY>, grid, dim3(256), 0, s, job, total, w_out); break;
-    default: hipLaunchKernelGGL(weights_kernel<BPVO_LOSS_L2>, grid, dim3(256), 0, s, job, total, w_out); break;
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_HUBER>), grid, dim3(256), 0, s, job, thr, count); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(256), 0, s, job, thr, count); break;
+    default: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_L2>), grid, dim3(256), 0, s, job, thr, count); break;
   }
 }
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
 {
-  const int total = n * C;
-  if(total <= 0) return;
-  const dim3 grid((total + 255) / 256);
-  switch(loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_HUBER>, grid, dim3(256), 0, s, job, total, thr, count); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_TUKEY>, grid, dim3(256), 0, s, job, total, thr, count); break;
-    default: hipLaunchKernelGGL(count_good_kernel<BPVO_LOSS_L2>, grid, dim3(256), 0, s, job, total, thr, count); break;
-  }
+  if(n <= 0) return;
+  if(C == 1) launch_count_good_c<1>(s, job, n, loss, thr, count);
+  else launch_count_good_c<8>(s, job, n, loss, thr, count);
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records)
 {

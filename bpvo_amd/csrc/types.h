@@ -14,6 +14,20 @@ constexpr int kReduceVals = 28;    // 21 upper-triangular H + 6 G + sum w r^2
 constexpr int kPartialStride = 32;
 constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hip_batch_result_records_device)
 
+// TILED per-point layout.  Template pixels, Jacobians and residuals are records of W floats per point
+// (W = C, 6*C, C).  A record is cut into V-float vector pieces (V = 4 for C = 8; 1 or 2 for C = 1) and points are grouped
+// in tiles of 64 (= one wavefront); inside a tile the layout is piece-major:
+//     vec[((i >> 6) * PIECES + piece) * 64 + (i & 63)]
+// so that lane l of a wave reading piece k of its point touches one contiguous 64*V*4-byte segment: every wave-level
+// load/store of these arrays is fully coalesced (a plain point-major record layout makes each 16-byte load of a
+// wave hit 64 different cache lines).
+template <int PIECES>
+__host__ __device__ inline size_t tile_index(int i, int piece)
+{
+  return ((size_t) (i >> 6) * PIECES + piece) * 64 + (size_t) (i & 63);
+}
+constexpr int kTile = 64;
+
 // phases of the device-side PoseEstimatorBase::run state machine (gn_step kernel)
 enum { PHASE_FIRST = 0, PHASE_LOOP = 1, PHASE_DONE = 2 };
 
@@ -37,8 +51,8 @@ struct GNState {
 struct PairJob {
   // template (reference frame) at this level
   const float4* pts;      // [N] (X,Y,Z,1)
-  const float*  pix;      // [N][C] point-major
-  const float*  jac;      // [N][C][6]
+  const float*  pix;      // [N][C] tiled (see tile_index)
+  const float*  jac;      // [N][C][6] tiled
   const float*  nrm;      // (s, c1, c2, c3) Hartley normalisation of the level
   int           n;        // number of points (multiple of 16)
   // current frame descriptor at this level, pixel-interleaved [rows*cols][C]
@@ -46,7 +60,7 @@ struct PairJob {
   int           rows, cols;
   float         K[9];     // level intrinsics (K * 0.5^l, K(2,2) = 1)
   // workspace
-  float*        r;        // [N][C] residuals, point-major
+  float*        r;        // [N][C] residuals, tiled
   uint8_t*      valid;    // [N]
   float*        partials; // [nblocks][kPartialStride]
   GNState*      st;
