@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--fixed-iters", type=int, default=0,
                     help="throughput mode: tolerances 0 and maxIterations=K (K+2 linearisations per level); 0 = converge")
     ap.add_argument("--cpu-pairs", type=int, default=24, help="bounded sample for the CPU baseline (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-profile", action="store_true", help="do not record HIP events at all")
+    ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel (diagnostics, slower)")
     ap.add_argument("--gen-workers", type=int, default=0)
     return ap.parse_args()
 
@@ -152,7 +153,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profiling(not args.no_profile)     # resets the counters; HIP events on the library's own stream
+    ctx.profiling(0 if args.no_profile else (2 if args.profile_all else 1))   # resets counters; events on the library's streams
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -354,8 +354,9 @@ class Context:
         self.call("batch_copy_records_device", C.c_void_p(d_dst_ptr), int(n_pairs))
 
     # -- measurement
-    def profiling(self, enable=True):
-        self.call("profiling", int(bool(enable)))
+    def profiling(self, level=1):
+        """0 off, 1 = HIP events around warp_residual + frame stages, 2 = around every kernel. Resets the counters."""
+        self.call("profiling", int(level))
 
     def kernel_stats(self):
         arr = (KernelStat * 32)()

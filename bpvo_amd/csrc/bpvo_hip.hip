@@ -8,9 +8,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -45,7 +47,7 @@ struct FrameSlot {
   float4* pts[kMaxLevels] = {};
   int* inds[kMaxLevels] = {};
   float* pix[kMaxLevels] = {};
-  float* jac[kMaxLevels] = {};
+  float* grad[kMaxLevels] = {};
   float* nrm = nullptr;    // [L][4]
   int* n_dev = nullptr;    // [L]
   int n_host[kMaxLevels] = {};
@@ -65,6 +67,26 @@ const char* kKernelNames[KC_COUNT] = {"pyramid", "descriptor", "saliency_select"
 
 struct EventPair { hipEvent_t a, b; int kc; double units; };
 
+// An estimation lane: one HIP stream plus the host staging it needs.  Batches of independent pairs are split over
+// several lanes driven by their own host threads, so that the narrow per-pair kernels of one group (median select,
+// gn_step: one workgroup per pair) overlap with the chip-filling kernels (warp_residual, irls_reduce) of another.
+struct Lane {
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  PairJob* h_pjobs = nullptr;      // pinned [L][n_pairs]
+  PairJob* d_pjobs = nullptr;      // [L][n_pairs]
+  float* h_T = nullptr;            // pinned [n_pairs][16]
+  float* d_Tinit = nullptr;
+  int* d_active = nullptr;         // [2]
+  int* h_active = nullptr;         // pinned [4]
+  GNState* h_states = nullptr;     // pinned [n_pairs]
+  std::vector<EventPair> ev_pending;
+  std::vector<hipEvent_t> ev_pool;
+  std::string err;
+};
+constexpr int kMaxLanes = 4;
+constexpr int kMinPairsPerLane = 8;
+
 }  // namespace
 
 struct bpvo_hip_ctx {
@@ -80,20 +102,15 @@ struct bpvo_hip_ctx {
   std::vector<Workspace> ws;
   GNState* d_states = nullptr;
   FrameJob* d_fjobs = nullptr;     // [L][n_frames]
-  PairJob* d_pjobs = nullptr;      // [L][n_pairs]
+  std::vector<Lane> lanes;         // lanes[0] shares the ctx stream
   PairJob* d_job1 = nullptr;       // scratch single job (linearize / weights)
-  float* d_Tinit = nullptr;        // [n_pairs][16]
   float* d_records = nullptr;      // [n_pairs][kRecordFloats]
   float* d_wtmp = nullptr;         // [cap_max * C] weights scratch
-  int* d_active = nullptr;         // [2]
   unsigned int* d_count = nullptr;
   unsigned long long* d_counters = nullptr;   // [2] points, linearisations
   // pinned staging
   FrameJob* h_fjobs = nullptr;
-  PairJob* h_pjobs = nullptr;
-  GNState* h_states = nullptr;
   int* h_ints = nullptr;           // [max(n_frames*L, 16)]
-  float* h_T = nullptr;            // [n_pairs*16]
   int cap_max = 0;
   // VisualOdometry state (bpvo/vo.cc:45-52)
   int vo_ref = 0, vo_cur = 1, vo_prev = 2;
@@ -102,9 +119,8 @@ struct bpvo_hip_ctx {
   std::vector<bpvo_hip_point_with_info> cloud;
   M44 cloud_pose;
   // measurement
-  bool profiling = false;
-  std::vector<EventPair> ev_pending;
-  std::vector<hipEvent_t> ev_pool;
+  bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
+  bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
   double kc_ms[KC_COUNT] = {};
   double kc_units[KC_COUNT] = {};
   uint64_t kc_launches[KC_COUNT] = {};
@@ -182,7 +198,7 @@ void carve_frame_tmpl(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
     f.pts[l] = cv.take<float4>(g.cap);
     f.inds[l] = cv.take<int>(g.cap);
     f.pix[l] = cv.take<float>((size_t) g.cap * c->C);
-    f.jac[l] = cv.take<float>((size_t) g.cap * c->C * 6);
+    f.grad[l] = cv.take<float>((size_t) g.cap * c->C * 2);
   }
   f.nrm = cv.take<float>(4 * kMaxLevels);
   f.n_dev = cv.take<int>(kMaxLevels);
@@ -217,7 +233,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   j.pts = f.pts[l];
   j.inds = f.inds[l];
   j.pix = f.pix[l];
-  j.jac = f.jac[l];
+  j.grad = f.grad[l];
   j.nrm = f.nrm ? f.nrm + 4 * l : nullptr;
   j.rows = g.rows; j.cols = g.cols; j.level = l; j.disp_cols = c->cols;
   j.cap = g.cap;
@@ -236,7 +252,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   std::memset(&j, 0, sizeof(j));
   j.pts = fr.pts[l];
   j.pix = fr.pix[l];
-  j.jac = fr.jac[l];
+  j.grad = fr.grad[l];
   j.nrm = fr.nrm + 4 * l;
   j.n = fr.n_host[l];
   j.desc = fc.desc[l];
@@ -250,11 +266,11 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
 }
 
 // ---- measurement: HIP events on the ctx stream around kernel classes ------------------------------------------------
-hipEvent_t take_event(bpvo_hip_ctx* c)
+hipEvent_t take_event(Lane* ln)
 {
-  if(!c->ev_pool.empty()) {
-    hipEvent_t e = c->ev_pool.back();
-    c->ev_pool.pop_back();
+  if(!ln->ev_pool.empty()) {
+    hipEvent_t e = ln->ev_pool.back();
+    ln->ev_pool.pop_back();
     return e;
   }
   hipEvent_t e;
@@ -262,36 +278,38 @@ hipEvent_t take_event(bpvo_hip_ctx* c)
   return e;
 }
 struct ScopedTimer {
-  bpvo_hip_ctx* c;
+  Lane* ln;
   EventPair ep;
   bool on;
-  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units) : c(c_), on(c_->profiling)
+  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units, Lane* lane = nullptr) : ln(lane ? lane : &c_->lanes[0]), on(c_->profiling)
   {
     if(!on) return;
     ep.kc = kc; ep.units = units;
-    ep.a = take_event(c); ep.b = take_event(c);
-    (void) hipEventRecord(ep.a, c->stream);
+    ep.a = take_event(ln); ep.b = take_event(ln);
+    (void) hipEventRecord(ep.a, ln->stream);
   }
   ~ScopedTimer()
   {
     if(!on) return;
-    (void) hipEventRecord(ep.b, c->stream);
-    c->ev_pending.push_back(ep);
+    (void) hipEventRecord(ep.b, ln->stream);
+    ln->ev_pending.push_back(ep);
   }
 };
-void resolve_events(bpvo_hip_ctx* c)   // call after a stream sync
+void resolve_events(bpvo_hip_ctx* c)   // call from the API thread after the lanes' streams are synchronised
 {
-  for(auto& ep : c->ev_pending) {
-    float ms = 0.0f;
-    if(hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-      c->kc_ms[ep.kc] += ms;
-      c->kc_units[ep.kc] += ep.units;
-      c->kc_launches[ep.kc] += 1;
+  for(auto& ln : c->lanes) {
+    for(auto& ep : ln.ev_pending) {
+      float ms = 0.0f;
+      if(hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+        c->kc_ms[ep.kc] += ms;
+        c->kc_units[ep.kc] += ep.units;
+        c->kc_launches[ep.kc] += 1;
+      }
+      ln.ev_pool.push_back(ep.a);
+      ln.ev_pool.push_back(ep.b);
     }
-    c->ev_pool.push_back(ep.a);
-    c->ev_pool.push_back(ep.b);
+    ln.ev_pending.clear();
   }
-  c->ev_pending.clear();
 }
 
 // ---- frame stages ---------------------------------------------------------------------------------------------------
@@ -402,51 +420,53 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 }
 
 // ---- estimatePose ---------------------------------------------------------------------------------------------------
-// VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93) for `n` workspaces at once.
-// refs[i], curs[i]: frame slots; workspace i.  T_init host [n][16] or null (Identity).
-int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
-                   bpvo_hip_stats* stats)
+#define LANE_CK(ln_, expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if(e_ != hipSuccess) {                                                                  \
+      (ln_)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+      return BPVO_ERR_DEVICE;                                                               \
+    }                                                                                       \
+  } while(0)
+
+// VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93) for a group of `n` workspaces on one
+// lane.  wss[i]: workspace, refs[i] / curs[i]: frame slots.  T_init host [n][16] or null (Identity).
+int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init,
+                   float* poses, bpvo_hip_stats* stats, float* d_records_out)
 {
   if(n <= 0) return BPVO_OK;
-  if(n > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "more pairs than workspaces");
-  for(int i = 0; i < n; ++i)
-    if(wss[i] < 0 || wss[i] >= c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "bad workspace");
+  (void) hipSetDevice(c->device);
   const bpvo_hip_params& p = c->params;
-  for(int i = 0; i < n; ++i) {
-    if(refs[i] < 0 || refs[i] >= c->n_frames || curs[i] < 0 || curs[i] >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot");
-    if(!c->frames[refs[i]].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
-    if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
-  }
   const int NP = c->n_pairs;
-  HIP_CK(c, hipStreamSynchronize(c->stream));   // pinned staging reuse (see upload_frame_jobs)
+  LANE_CK(ln, hipStreamSynchronize(ln->stream));   // pinned staging reuse
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < n; ++i) {
-      c->h_pjobs[(size_t) l * NP + i] = make_pair_job(c, wss[i], refs[i], curs[i], l);
-      max_pts[l] = std::max(max_pts[l], c->h_pjobs[(size_t) l * NP + i].n);
+      ln->h_pjobs[(size_t) l * NP + i] = make_pair_job(c, wss[i], refs[i], curs[i], l);
+      max_pts[l] = std::max(max_pts[l], ln->h_pjobs[(size_t) l * NP + i].n);
     }
-  HIP_CK(c, hipMemcpyAsync(c->d_pjobs, c->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, c->stream));
+  LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
   const float* dT = nullptr;
   if(T_init) {
-    std::memcpy(c->h_T, T_init, sizeof(float) * 16 * n);
-    HIP_CK(c, hipMemcpyAsync(c->d_Tinit, c->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, c->stream));
-    dT = c->d_Tinit;
+    std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
+    LANE_CK(ln, hipMemcpyAsync(ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, ln->stream));
+    dT = ln->d_Tinit;
   }
-  launch_set_pose(c->stream, c->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
+  launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
 
   // PoseEstimatorParameters(AlgorithmParameters) (bpvo/pose_estimator_params.cc:27-33): maxFuncEvals stays 6*200 (Q4);
   // the low-res parameter set equals the full-res one (Q3).
   const int max_fun_evals = 6 * 200;
   for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
     GNLaunch g;
-    g.jobs = c->d_pjobs + (size_t) l * NP;
+    g.jobs = ln->d_pjobs + (size_t) l * NP;
     g.npairs = n;
     g.max_points = max_pts[l];
     g.C = c->C;
     g.loss = p.lossFunction;
-    launch_level_begin(c->stream, g.jobs, n, l);
+    launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
-    HIP_CK(c, hipMemsetAsync(c->d_active, 0, 2 * sizeof(int), c->stream));
+    LANE_CK(ln, hipMemsetAsync(ln->d_active, 0, 2 * sizeof(int), ln->stream));
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues
     // kItersPerSync iterations back to back and only then reads the "workspaces still active" counter: blocks of
     // finished workspaces exit on their first load, so a few speculative launches cost less than a round trip per
@@ -457,28 +477,71 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
       int parity = 0;
       for(int k = 0; k < kItersPerSync && it < max_lin; ++k, ++it) {
         parity = it & 1;
-        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-        { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
-        { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-        { ScopedTimer t(c, KC_GN_STEP, 0.0);
-          launch_gn_step(c->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                         p.gradientTolerance, c->d_active, parity, c->d_counters); }
+        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln); launch_warp_residual(ln->stream, g); }
+        if(c->profile_all) {
+          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
+          { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
+          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
+            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                           p.gradientTolerance, ln->d_active, parity, c->d_counters); }
+        } else {
+          launch_median(ln->stream, g);
+          launch_irls_reduce(ln->stream, g);
+          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                         p.gradientTolerance, ln->d_active, parity, c->d_counters);
+        }
       }
-      HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIP_CK(c, hipStreamSynchronize(c->stream));
-      if(c->h_ints[0] == 0) break;
+      LANE_CK(ln, hipMemcpyAsync(ln->h_active, ln->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
+      LANE_CK(ln, hipStreamSynchronize(ln->stream));
+      if(ln->h_active[0] == 0) break;
     }
   }
-  launch_pack_records(c->stream, c->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, c->d_records);
-  HIP_CK(c, hipMemcpyAsync(c->h_states, c->d_states, sizeof(GNState) * c->n_pairs, hipMemcpyDeviceToHost, c->stream));
-  HIP_CK(c, hipStreamSynchronize(c->stream));
-  HIP_CK(c, hipGetLastError());
-  resolve_events(c);
+  launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
+  LANE_CK(ln, hipMemcpyAsync(ln->h_states, c->d_states, sizeof(GNState) * c->n_pairs, hipMemcpyDeviceToHost, ln->stream));
+  LANE_CK(ln, hipStreamSynchronize(ln->stream));
+  LANE_CK(ln, hipGetLastError());
   for(int i = 0; i < n; ++i) {
-    const GNState& st = c->h_states[wss[i]];
+    const GNState& st = ln->h_states[wss[i]];
     if(poses) std::memcpy(poses + 16 * (size_t) i, st.T_out, 16 * sizeof(float));
     if(stats)
       for(int l = 0; l < c->L; ++l) stats[(size_t) i * c->L + l] = st.stats[l];
+  }
+  return BPVO_OK;
+}
+
+int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
+                   bpvo_hip_stats* stats)
+{
+  if(n <= 0) return BPVO_OK;
+  if(n > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "more pairs than workspaces");
+  const bpvo_hip_params& p = c->params;
+  for(int i = 0; i < n; ++i) {
+    if(wss[i] < 0 || wss[i] >= c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "bad workspace");
+    if(refs[i] < 0 || refs[i] >= c->n_frames || curs[i] < 0 || curs[i] >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot");
+    if(!c->frames[refs[i]].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
+    if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  }
+  HIP_CK(c, hipStreamSynchronize(c->stream));   // frame stages run on the ctx stream; lanes start from a quiet device
+  const int nl = std::max(1, std::min((int) c->lanes.size(), n / kMinPairsPerLane));
+  std::vector<int> rcs(nl, BPVO_OK);
+  auto run = [&](int k) {
+    const int lo = (int) ((long long) n * k / nl), hi = (int) ((long long) n * (k + 1) / nl);
+    rcs[k] = estimate_group(c, &c->lanes[k], hi - lo, wss + lo, refs + lo, curs + lo, T_init ? T_init + 16 * (size_t) lo : nullptr,
+                            poses ? poses + 16 * (size_t) lo : nullptr, stats ? stats + (size_t) lo * c->L : nullptr,
+                            c->d_records + (size_t) kRecordFloats * lo);
+  };
+  if(nl == 1) {
+    run(0);
+  } else {
+    std::vector<std::thread> th;
+    for(int k = 1; k < nl; ++k) th.emplace_back(run, k);
+    run(0);
+    for(auto& t : th) t.join();
+  }
+  for(int k = 0; k < nl; ++k)
+    if(rcs[k]) { c->err = c->lanes[k].err; return rcs[k]; }
+  resolve_events(c);
+  for(int i = 0; i < n; ++i) {
     Workspace& w = c->ws[wss[i]];
     w.last_ref = refs[i];
     w.last_cur = curs[i];
@@ -517,8 +580,8 @@ int refresh_counters(bpvo_hip_ctx* c)
 
 int upload_single_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int level)
 {
-  c->h_pjobs[0] = make_pair_job(c, ws, ref, cur, level);
-  HIP_CK(c, hipMemcpyAsync(c->d_job1, c->h_pjobs, sizeof(PairJob), hipMemcpyHostToDevice, c->stream));
+  c->lanes[0].h_pjobs[0] = make_pair_job(c, ws, ref, cur, level);
+  HIP_CK(c, hipMemcpyAsync(c->d_job1, c->lanes[0].h_pjobs, sizeof(PairJob), hipMemcpyHostToDevice, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));   // h_pjobs is reused by the next call
   return BPVO_OK;
 }
@@ -714,20 +777,31 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
-  CREATE_CK(hipMalloc((void**) &cp->d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
-  CREATE_CK(hipMalloc((void**) &cp->d_Tinit, sizeof(float) * 16 * n_pairs));
+  {
+    int max_lanes = kMaxLanes;
+    if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
+    cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
+  }
+  for(size_t k = 0; k < cp->lanes.size(); ++k) {
+    Lane& ln = cp->lanes[k];
+    if(k == 0) { ln.stream = cp->stream; ln.owns_stream = false; }
+    else { CREATE_CK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
+    CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
+    CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
+    CREATE_CK(hipMalloc((void**) &ln.d_active, 2 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
+  }
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
-  CREATE_CK(hipMalloc((void**) &cp->d_active, 2 * sizeof(int)));
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
   CREATE_CK(hipMalloc((void**) &cp->d_counters, 2 * sizeof(unsigned long long)));
   CREATE_CK(hipMemset(cp->d_counters, 0, 2 * sizeof(unsigned long long)));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
-  CREATE_CK(hipHostMalloc((void**) &cp->h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
-  CREATE_CK(hipHostMalloc((void**) &cp->h_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
-  CREATE_CK(hipHostMalloc((void**) &cp->h_T, sizeof(float) * 16 * n_pairs));
 #undef CREATE_CK
   cp->T_kf = m44_identity();
   cp->cloud_pose = m44_identity();
@@ -742,13 +816,18 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
   for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.partials); }
-  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_pjobs); (void) hipFree(c->d_job1);
-  (void) hipFree(c->d_Tinit); (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp); (void) hipFree(c->d_active);
+  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
+  (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
-  (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_pjobs); (void) hipHostFree(c->h_states); (void) hipHostFree(c->h_ints);
-  (void) hipHostFree(c->h_T);
-  for(auto& ep : c->ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
-  for(auto e : c->ev_pool) (void) hipEventDestroy(e);
+  (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints);
+  for(auto& ln : c->lanes) {
+    if(ln.stream) (void) hipStreamSynchronize(ln.stream);
+    (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active);
+    (void) hipHostFree(ln.h_pjobs); (void) hipHostFree(ln.h_T); (void) hipHostFree(ln.h_active); (void) hipHostFree(ln.h_states);
+    for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
+    for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
+    if(ln.owns_stream && ln.stream) (void) hipStreamDestroy(ln.stream);
+  }
   if(c->stream) (void) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -889,11 +968,21 @@ int bpvo_hip_get_pixels(bpvo_hip_ctx* c, int slot, int level, float* pixels)
 int bpvo_hip_get_jacobians(bpvo_hip_ctx* c, int slot, int level, float* J)
 {
   TMPL(c, slot, level);
-  const int C = c->C;
-  std::vector<float> t(tiled_floats(n, C * 6));
-  if(n) HIP_CK(c, hipMemcpyAsync(t.data(), f.jac[level], t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if(n == 0) return BPVO_OK;
+  // the rows are not stored: evaluate them on the device from (point, Ix, Iy) exactly like irls_reduce does
+  const size_t bytes = sizeof(float) * 6 * (size_t) n * c->C;
+  float* d_out = nullptr;
+  HIP_CK(c, hipMalloc((void**) &d_out, bytes));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  detile_to_channel_major(t.data(), n, C, 6, C == 8 ? 4 : 2, J);
+  c->h_fjobs[0] = make_frame_job(c, f, level);
+  hipError_t e = hipMemcpyAsync(c->d_fjobs, c->h_fjobs, sizeof(FrameJob), hipMemcpyHostToDevice, c->stream);
+  if(e == hipSuccess) {
+    launch_export_jacobians(c->stream, c->d_fjobs, c->C, n, d_out);
+    e = hipMemcpyAsync(J, d_out, bytes, hipMemcpyDeviceToHost, c->stream);
+  }
+  if(e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void) hipFree(d_out);
+  HIP_CK(c, e);
   return BPVO_OK;
 }
 int bpvo_hip_get_normalization(bpvo_hip_ctx* c, int slot, int level, float T[16], float T_inv[16])
@@ -924,20 +1013,21 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   (void) hipSetDevice(c->device);
   int rc = upload_single_job(c, ws, ref_slot, cur_slot, level);
   if(rc) return rc;
-  std::memcpy(c->h_T, T, 16 * sizeof(float));
-  HIP_CK(c, hipMemcpyAsync(c->d_Tinit, c->h_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  launch_prepare_linearize(c->stream, c->d_job1, c->d_Tinit, reset_scale, level);
+  Lane& l0 = c->lanes[0];
+  std::memcpy(l0.h_T, T, 16 * sizeof(float));
+  HIP_CK(c, hipMemcpyAsync(l0.d_Tinit, l0.h_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  launch_prepare_linearize(c->stream, c->d_job1, l0.d_Tinit, reset_scale, level);
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
   { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
   { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0, c->d_counters); }
-  HIP_CK(c, hipMemcpyAsync(c->h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   HIP_CK(c, hipGetLastError());
   resolve_events(c);
-  const GNState& st = c->h_states[0];
+  const GNState& st = l0.h_states[0];
   std::memcpy(H, st.H, sizeof(st.H));
   std::memcpy(G, st.G, sizeof(st.G));
   *f_norm = st.f_norm;
@@ -1222,6 +1312,7 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   HIP_CK(c, hipStreamSynchronize(c->stream));
   resolve_events(c);
   c->profiling = enable != 0;
+  c->profile_all = enable >= 2;
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
   HIP_CK(c, hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
   c->total_lin = 0;

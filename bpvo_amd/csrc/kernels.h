@@ -17,6 +17,7 @@ void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
                    float max_disp, int border);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
                           int num_levels, int with_normalization);
+void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
 
 // Gauss-Newton stage (batched over workspaces / pairs)

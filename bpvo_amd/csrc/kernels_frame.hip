@@ -377,7 +377,8 @@ __global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs,
 
 // ---- K5: template pixels, central-difference gradients and 1x6 Jacobians
 // (reference: bpvo/template_data.cc:102-137; Jacobian = bpvo/rigid_body_warp.cc:60-315 in the SSE code's operation
-// order with IEEE division instead of _mm_rcp_ps — SURVEY.md Q13).  Outputs pix / jac in the tiled layout of types.h.
+// gradients pre-multiplied by fx, fy).  The 1x6 Jacobian rows themselves are recomputed on the fly by irls_reduce (types.h
+// jac_row), so only pix and (Ix, Iy) are stored, in the tiled layout of types.h.
 template <int C>
 __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5)
 {
@@ -387,14 +388,9 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   if(i >= N) return;
   const int W = j.cols;
   const int ii = j.inds[i];
-  const float4 P = j.pts[i];
   const float fx = j.K[0], fy = j.K[4];
-  const float s = j.nrm[0], c1 = j.nrm[1], c2 = j.nrm[2], c3 = j.nrm[3];
-  const float s_i = (float) (1.0 / (double) s);
-  const float x = P.x, y = P.y, z = P.z;
-  const float z2 = z * z;
   const float* __restrict__ D = j.desc;
-  float pixv[C], J[C * 6];
+  float pixv[C], Ix[C], Iy[C];
   const float NN = 1.0f / 18.0f;
 #pragma unroll
   for(int c = 0; c < C; ++c) {
@@ -408,29 +404,52 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
       gy = NN * (1.0f * cc[-2 * (ptrdiff_t) W * C] - 8.0f * cc[-(ptrdiff_t) W * C] + 8.0f * cc[(ptrdiff_t) W * C] - 1.0f * cc[2 * (ptrdiff_t) W * C]);
     }
     pixv[c] = cc[0];
-    const float Ix = fx * gx, Iy = fy * gy;
-    const float xIx_yIy = x * Ix + y * Iy;
-    float* Jc = J + c * 6;
-    Jc[0] = (-((Iy * (z - c3)) / z)) - ((xIx_yIy * (y - c2)) / z2);
-    Jc[1] = ((Ix * (z - c3)) / z) + ((xIx_yIy * (x - c1)) / z2);
-    Jc[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) / z;
-    Jc[3] = Ix / (z * s);
-    Jc[4] = Iy / (z * s);
-    Jc[5] = -((s_i * xIx_yIy) / z2);
+    Ix[c] = fx * gx;      // Ix = _mm_mul_ps(FX, Ix) (rigid_body_warp.cc:103-104)
+    Iy[c] = fy * gy;
   }
   // tiled stores (types.h tile_index): consecutive lanes write consecutive vectors
   if constexpr(C == 8) {
     float4* pv = reinterpret_cast<float4*>(j.pix);
     pv[tile_index<2>(i, 0)] = make_float4(pixv[0], pixv[1], pixv[2], pixv[3]);
     pv[tile_index<2>(i, 1)] = make_float4(pixv[4], pixv[5], pixv[6], pixv[7]);
-    float4* jv = reinterpret_cast<float4*>(j.jac);
-#pragma unroll
-    for(int k = 0; k < 12; ++k) jv[tile_index<12>(i, k)] = make_float4(J[4 * k], J[4 * k + 1], J[4 * k + 2], J[4 * k + 3]);
+    float4* gv = reinterpret_cast<float4*>(j.grad);
+    gv[tile_index<4>(i, 0)] = make_float4(Ix[0], Ix[1], Ix[2], Ix[3]);
+    gv[tile_index<4>(i, 1)] = make_float4(Ix[4], Ix[5], Ix[6], Ix[7]);
+    gv[tile_index<4>(i, 2)] = make_float4(Iy[0], Iy[1], Iy[2], Iy[3]);
+    gv[tile_index<4>(i, 3)] = make_float4(Iy[4], Iy[5], Iy[6], Iy[7]);
   } else {
     j.pix[i] = pixv[0];
-    float2* jv = reinterpret_cast<float2*>(j.jac);
+    reinterpret_cast<float2*>(j.grad)[i] = make_float2(Ix[0], Iy[0]);
+  }
+}
+
+// Jacobians in the reference layout for the C ABI accessor (bpvo_hip_get_jacobians): J[(c*N + i)*6 + k]
+template <int C>
+__global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* job, float* out)
+{
+  const FrameJob& j = *job;
+  const int N = *j.n_out;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  const float4 P = j.pts[i];
+  const JacPoint jp = jac_point(P.x, P.y, P.z, j.nrm);
+  float Ix[C], Iy[C];
+  if constexpr(C == 8) {
+    const float4* gv = reinterpret_cast<const float4*>(j.grad);
+    const float4 a = gv[tile_index<4>(i, 0)], b = gv[tile_index<4>(i, 1)], c = gv[tile_index<4>(i, 2)], d = gv[tile_index<4>(i, 3)];
+    Ix[0] = a.x; Ix[1] = a.y; Ix[2] = a.z; Ix[3] = a.w; Ix[4] = b.x; Ix[5] = b.y; Ix[6] = b.z; Ix[7] = b.w;
+    Iy[0] = c.x; Iy[1] = c.y; Iy[2] = c.z; Iy[3] = c.w; Iy[4] = d.x; Iy[5] = d.y; Iy[6] = d.z; Iy[7] = d.w;
+  } else {
+    const float2 g = reinterpret_cast<const float2*>(j.grad)[i];
+    Ix[0] = g.x; Iy[0] = g.y;
+  }
 #pragma unroll
-    for(int k = 0; k < 3; ++k) jv[tile_index<3>(i, k)] = make_float2(J[2 * k], J[2 * k + 1]);
+  for(int c = 0; c < C; ++c) {
+    float J[6];
+    jac_row(jp, Ix[c], Iy[c], J);
+    float* o = out + ((size_t) c * N + i) * 6;
+#pragma unroll
+    for(int k = 0; k < 6; ++k) o[k] = J[k];
   }
 }
 
@@ -482,6 +501,14 @@ void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_p
   const dim3 g((max_points + 255) / 256, 1, nframes);
   if(C == 1) hipLaunchKernelGGL(template_build_kernel<1>, g, dim3(256), 0, s, jobs, grad_cd5);
   else hipLaunchKernelGGL(template_build_kernel<8>, g, dim3(256), 0, s, jobs, grad_cd5);
+}
+
+void launch_export_jacobians(hipStream_t s, const FrameJob* job, int C, int n, float* out)
+{
+  if(n <= 0) return;
+  const dim3 g((n + 255) / 256);
+  if(C == 1) hipLaunchKernelGGL(export_jacobians_kernel<1>, g, dim3(256), 0, s, job, out);
+  else hipLaunchKernelGGL(export_jacobians_kernel<8>, g, dim3(256), 0, s, job, out);
 }
 
 }  // namespace bpvo_hip

@@ -4,7 +4,8 @@
 //   median         K7  exact median of |r| over valid entries: 3-pass radix select on the IEEE bit pattern with
 //                      LDS histograms, one workgroup per pair; robust scale + freeze rule               (4*C B/point)
 //   irls_reduce    K8  M-estimator weights fused with the J^T W J / J^T W r / sum w r^2 reduction:
-//                      in-thread accumulation, wavefront shuffle tree, LDS across waves, per-block partials (2 + 28*C B/point)
+//                      Jacobian rows recomputed from (point, Ix, Iy); in-thread accumulation, wavefront shuffle tree,
+//                      LDS across waves, per-block partials            (algorithmic 2 + 28*C B/point; moved 18 + 12*C)
 //   gn_step        K9  deterministic f64 sum of the partials, 6x6 LDLT solve, SE(3) update and the convergence /
 //                      iteration bookkeeping of PoseEstimatorBase::run, all on the device (no host round trip of H, G)
 // No MFMA anywhere: ~1 flop/byte, HBM-bound gather + rank-1 accumulate.
@@ -385,6 +386,7 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   if(p_begin >= n) return;
   const int p_end = min(n, p_begin + pts_per_block);
   const float sigma_inv = 1.0f / st->scale;
+  const float s_nrm[4] = {j.nrm[0], j.nrm[1], j.nrm[2], j.nrm[3]};
 
   float acc[kNumAcc];
 #pragma unroll
@@ -393,33 +395,30 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
     const float v = (float) j.valid[i];
     acc[28] += v;
-    // channels are consumed in groups of G (C = 8: 4 channels = one 16-byte residual vector + six 16-byte Jacobian
-    // vectors, all tiled -> coalesced); the group loop is kept rolled to bound register pressure
+    // per point: 16 B point + 2*C gradient floats + C residuals (all tiled / coalesced); the six Jacobian entries of a
+    // channel are recomputed from them (jac_row: same IEEE operations as at template-build time, bit-identical)
+    const float4 P = j.pts[i];
+    const JacPoint jp = jac_point(P.x, P.y, P.z, s_nrm);
     constexpr int G = (C >= 4) ? 4 : C;
 #pragma unroll 1
     for(int c0 = 0; c0 < C; c0 += G) {
-      float rr[G], Jg[G * 6];
+      float rr[G], Ix[G], Iy[G];
       if constexpr(G == 4) {
         const float4 t4 = reinterpret_cast<const float4*>(j.r)[tile_index<2>(i, c0 >> 2)];
         rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
-        const float4* q = reinterpret_cast<const float4*>(j.jac);
-#pragma unroll
-        for(int k = 0; k < 6; ++k) {
-          const float4 t = q[tile_index<12>(i, (c0 >> 2) * 6 + k)];
-          Jg[4 * k + 0] = t.x; Jg[4 * k + 1] = t.y; Jg[4 * k + 2] = t.z; Jg[4 * k + 3] = t.w;
-        }
+        const float4* q = reinterpret_cast<const float4*>(j.grad);
+        const float4 gx = q[tile_index<4>(i, c0 >> 2)], gy = q[tile_index<4>(i, 2 + (c0 >> 2))];
+        Ix[0] = gx.x; Ix[1] = gx.y; Ix[2] = gx.z; Ix[3] = gx.w;
+        Iy[0] = gy.x; Iy[1] = gy.y; Iy[2] = gy.z; Iy[3] = gy.w;
       } else {
         rr[0] = j.r[i];
-        const float2* q = reinterpret_cast<const float2*>(j.jac);
-#pragma unroll
-        for(int k = 0; k < 3; ++k) {
-          const float2 t = q[tile_index<3>(i, k)];
-          Jg[2 * k + 0] = t.x; Jg[2 * k + 1] = t.y;
-        }
+        const float2 g2 = reinterpret_cast<const float2*>(j.grad)[i];
+        Ix[0] = g2.x; Iy[0] = g2.y;
       }
 #pragma unroll
       for(int cc = 0; cc < G; ++cc) {
-        const float* J = Jg + cc * 6;
+        float J[6];
+        jac_row(jp, Ix[cc], Iy[cc], J);
         const float r = rr[cc];
         const float w = mest_weight<LOSS>(r, sigma_inv) * v;
         const float wr = w * r;

@@ -28,6 +28,37 @@ __host__ __device__ inline size_t tile_index(int i, int piece)
 }
 constexpr int kTile = 64;
 
+// One row of the template Jacobian (reference: RigidBodyWarp::computeJacobian, bpvo/rigid_body_warp.cc:60-315; same formulas
+// as the scalar jacobian() of bpvo/rigid_body_warp.h:94-106).  The reference's SSE code divides with
+// div_ps(a, b) = _mm_mul_ps(a, _mm_rcp_ps(b)) (rigid_body_warp.cc:47-58): a multiply by an APPROXIMATE (12-bit, vendor
+// specific) reciprocal.  Here the operation structure is kept — a * (1/b) — with the correctly rounded reciprocal
+// 1.0f / b in place of _mm_rcp_ps: deterministic, and only three reciprocals per point (1/z, 1/z^2,
+// 1/(z*s)).  Ix, Iy are the channel gradients already multiplied by fx, fy.
+// Deterministic IEEE arithmetic: evaluating a row again in irls_reduce gives bit-identical values to evaluating it once
+// at template-build time, so the 24-byte rows are never stored.
+struct JacPoint { float x, y, rz, rz2, rzs, xc1, yc2, zc3, s_i; };
+__host__ __device__ inline JacPoint jac_point(float x, float y, float z, const float* nrm /* s, c1, c2, c3 */)
+{
+  JacPoint p;
+  p.x = x; p.y = y;
+  p.rz = 1.0f / z;
+  p.rz2 = 1.0f / (z * z);
+  p.rzs = 1.0f / (z * nrm[0]);
+  p.xc1 = x - nrm[1]; p.yc2 = y - nrm[2]; p.zc3 = z - nrm[3];
+  p.s_i = (float) (1.0 / (double) nrm[0]);
+  return p;
+}
+__host__ __device__ inline void jac_row(const JacPoint& p, float Ix, float Iy, float* J)
+{
+  const float xIx_yIy = p.x * Ix + p.y * Iy;
+  J[0] = (-((Iy * p.zc3) * p.rz)) - ((xIx_yIy * p.yc2) * p.rz2);     // rigid_body_warp.cc:80-96
+  J[1] = ((Ix * p.zc3) * p.rz) + ((xIx_yIy * p.xc1) * p.rz2);        // :131-137
+  J[2] = ((Iy * p.xc1) - (Ix * p.yc2)) * p.rz;                       // :173-178
+  J[3] = Ix * p.rzs;                                                 // :205-206
+  J[4] = Iy * p.rzs;                                                 // :232-233
+  J[5] = -((p.s_i * xIx_yIy) * p.rz2);                               // :295-299
+}
+
 // phases of the device-side PoseEstimatorBase::run state machine (gn_step kernel)
 enum { PHASE_FIRST = 0, PHASE_LOOP = 1, PHASE_DONE = 2 };
 
@@ -52,7 +83,7 @@ struct PairJob {
   // template (reference frame) at this level
   const float4* pts;      // [N] (X,Y,Z,1)
   const float*  pix;      // [N][C] tiled (see tile_index)
-  const float*  jac;      // [N][C][6] tiled
+  const float*  grad;     // [N][2][C] tiled: (fx*Ix[c]), (fy*Iy[c]) — the 1x6 Jacobians are recomputed from these
   const float*  nrm;      // (s, c1, c2, c3) Hartley normalisation of the level
   int           n;        // number of points (multiple of 16)
   // current frame descriptor at this level, pixel-interleaved [rows*cols][C]
@@ -79,7 +110,7 @@ struct FrameJob {
   float4*        pts;
   int*           inds;
   float*         pix;
-  float*         jac;
+  float*         grad;
   float*         nrm;       // (s, c1, c2, c3)
   int            rows, cols, level, disp_cols;
   int            cap;       // capacity of pts/inds

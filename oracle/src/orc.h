@@ -15,7 +15,8 @@
  * fixed-size products), which nothing in the reference pins.
  *
  * Deviations from the reference, all deliberate:
- *   Q13  Jacobians use IEEE division in the SSE code's operation order instead of _mm_rcp_ps.
+ *   Q13  Jacobians keep the SSE code's a * rcp(b) structure with the exact reciprocal 1.0f/b instead of the
+ *        approximate, vendor-specific _mm_rcp_ps.
  *   Q15  the serial (non-TBB) index-order reduction is what is restated.
  */
 #ifndef BPVO_ORACLE_ORC_H

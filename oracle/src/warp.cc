@@ -121,9 +121,11 @@ void Warp::setPose(const M44& pose)
     }
 }
 
-// RigidBodyWarp::computeJacobian (bpvo/rigid_body_warp.cc:60-315), operation order of the six SSE passes, with
-// IEEE division where the reference multiplies by _mm_rcp_ps (Q13 deviation).  The formulas equal the scalar
-// jacobian() of bpvo/rigid_body_warp.h:94-106.  Output [N][6] row-major (rigid_body_warp.cc:304-305).
+// RigidBodyWarp::computeJacobian (bpvo/rigid_body_warp.cc:60-315), operation order of the six SSE passes.  The
+// reference's div_ps(a, b) is _mm_mul_ps(a, _mm_rcp_ps(b)) (:47-58): a multiply by an approximate, vendor-specific
+// 12-bit reciprocal.  Q13 deviation: the multiply structure is kept with the correctly rounded reciprocal 1.0f / b in
+// place of _mm_rcp_ps.  The formulas equal the scalar jacobian() of bpvo/rigid_body_warp.h:94-106.
+// Output [N][6] row-major (rigid_body_warp.cc:304-305).
 void Warp::computeJacobian(const float* pts, int N, const float* IxIy, float* J) const
 {
   const float fx = K[0], fy = K[4];
@@ -134,14 +136,14 @@ void Warp::computeJacobian(const float* pts, int N, const float* IxIy, float* J)
     const float Ix = fx * IxIy[2 * i + 0];
     const float Iy = fy * IxIy[2 * i + 1];
     const float xIx_yIy = x * Ix + y * Iy;
-    const float z2 = z * z;
+    const float rz = 1.0f / z, rz2 = 1.0f / (z * z), rzs = 1.0f / (z * s);
     float* Ji = J + 6 * (size_t) i;
-    Ji[0] = (-((Iy * (z - c3)) / z)) - ((xIx_yIy * (y - c2)) / z2);          // :80-96
-    Ji[1] = ((Ix * (z - c3)) / z) + ((xIx_yIy * (x - c1)) / z2);             // :131-137
-    Ji[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) / z;                         // :173-178
-    Ji[3] = Ix / (z * s);                                                    // :205-206
-    Ji[4] = Iy / (z * s);                                                    // :232-233
-    Ji[5] = -((s_i * xIx_yIy) / z2);                                         // :295-299
+    Ji[0] = (-((Iy * (z - c3)) * rz)) - ((xIx_yIy * (y - c2)) * rz2);        // :80-96
+    Ji[1] = ((Ix * (z - c3)) * rz) + ((xIx_yIy * (x - c1)) * rz2);           // :131-137
+    Ji[2] = ((Iy * (x - c1)) - (Ix * (y - c2))) * rz;                        // :173-178
+    Ji[3] = Ix * rzs;                                                        // :205-206
+    Ji[4] = Iy * rzs;                                                        // :232-233
+    Ji[5] = -((s_i * xIx_yIy) * rz2);                                        // :295-299
   }
 }
 
