@@ -1,8 +1,8 @@
 """ctypes view of the C ABI declared in include/bpvo_hip/c_api.h.
 
-`Binding(lib_path, prefix)` is prefix-agnostic so that the tests can point the very same wrapper at the CPU oracle
-(prefix ``bpvo_orc_``) and compare call by call; the product (`bpvo_amd.load()`) only ever loads libbpvo_hip.so and
-raises if it is missing — there is no CPU fallback.
+`Binding(lib_path, prefix)` is prefix-agnostic so that the tests can point the very same wrapper at a second library
+with the same call shapes (the CPU checker used by tests/) and compare call by call; the product (`bpvo_amd.load()`)
+only ever loads libbpvo_hip.so and raises if it is missing — there is no CPU fallback.
 """
 from __future__ import annotations
 

@@ -62,11 +62,18 @@ def _value_noise(u, v, cell, salt):
     return (1 - b) * ((1 - a) * n00 + a * n10) + b * ((1 - a) * n01 + a * n11)
 
 
+# lattice spacing in pixels at the plane's nominal depth, amplitude weight (sum 1)
+OCTAVES = ((3.0, 0.30), (6.0, 0.25), (12.0, 0.20), (24.0, 0.15), (48.0, 0.10))
+
+
 def _texture(u, v, seed, px_size):
-    """Three octaves, lattice 8/16/32 pixels at the plane's nominal depth, mapped to [16, 240]."""
-    t = (0.5 * _value_noise(u, v, 8.0 * px_size, seed * 7919 + 1)
-         + 0.3 * _value_noise(u, v, 16.0 * px_size, seed * 7919 + 2)
-         + 0.2 * _value_noise(u, v, 32.0 * px_size, seed * 7919 + 3))
+    """Five octaves of value noise (lattice 3..48 px at the nominal depth), mapped to [16, 240].
+
+    The fine octaves matter for the census-based descriptor: with only coarse (>= 8 px) bilinear cells the sign pattern of
+    a 3x3 neighbourhood is constant inside a cell and the bit-planes carry almost no signal."""
+    t = 0.0
+    for k, (cell, wgt) in enumerate(OCTAVES):
+        t = t + wgt * _value_noise(u, v, cell * px_size, seed * 7919 + 1 + k)
     return 16.0 + 224.0 * t
 
 

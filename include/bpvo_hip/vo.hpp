@@ -1,0 +1,248 @@
+/*
+ * bpvo_hip/vo.hpp — header-only C++11 facade over the C ABI (c_api.h) with the reference's class names, argument
+ * meaning and error behaviour, so that code written against bpvo/vo.h keeps compiling after swapping the include:
+ *
+ *   bpvo::VisualOdometry                (reference: bpvo/vo.h:31-105, bpvo/vo.cc:66-94)
+ *   bpvo::VisualOdometryFrame           (reference: bpvo/vo_frame.h:21-90)
+ *   bpvo::VisualOdometryPoseEstimator   (reference: bpvo/vo_pose_estimator.h:34-64)
+ *   bpvo::AlgorithmParameters, Result, OptimizerStatistics, PointWithInfo, PointCloud, Trajectory, ImageSize, enums
+ *                                       (reference: bpvo/types.h:127-589, bpvo/point_cloud.h, bpvo/trajectory.h)
+ *
+ * Differences a caller sees:
+ *   - no Eigen / OpenCV in the interface: Matrix33 / Matrix44 are row-major std::array<float,9|16>
+ *     (an Eigen user maps them with Eigen::Map<const Eigen::Matrix<float,4,4,Eigen::RowMajor>>);
+ *   - frames live on the GPU: VisualOdometryFrame is a handle (device context + slot), not a host container;
+ *   - a non-zero C status becomes bpvo::Error (std::logic_error) exactly where the reference uses THROW_ERROR
+ *     (bpvo/utils.h:211-220), e.g. null image/disparity pointers (bpvo/vo.cc:68-69).
+ */
+#ifndef BPVO_HIP_VO_HPP
+#define BPVO_HIP_VO_HPP
+
+#include <array>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "c_api.h"
+
+namespace bpvo {
+
+struct Error : public std::logic_error {                       // bpvo/utils.h:205-209
+  explicit Error(const std::string& what) : std::logic_error(what) {}
+};
+
+typedef std::array<float, 9> Matrix33;                          // row-major
+typedef std::array<float, 16> Matrix44;                         // row-major
+typedef Matrix44 Pose;
+typedef std::array<float, 36> PoseCovariance;
+typedef std::array<float, 4> Point;                             // (X, Y, Z, 1)  bpvo/types.h:84
+typedef std::vector<Point> PointVector;
+typedef std::vector<float> WeightsVector;
+
+enum LossFunctionType { kHuber = BPVO_LOSS_HUBER, kTukey = BPVO_LOSS_TUKEY, kL2 = BPVO_LOSS_L2 };
+enum VerbosityType { kIteration = BPVO_VERB_ITERATION, kFinal, kSilent, kDebug };
+enum DescriptorType { kIntensity = BPVO_DESC_INTENSITY, kBitPlanes = BPVO_DESC_BITPLANES };
+enum GradientEstimationType { kCentralDifference_3 = BPVO_GRAD_CD3, kCentralDifference_5 = BPVO_GRAD_CD5 };
+enum InterpolationType { kLinear = BPVO_INTERP_LINEAR, kCosine, kCubic, kCubicHermite };
+enum PoseEstimationStatus { kParameterTolReached = BPVO_STATUS_PARAMETER_TOL, kFunctionTolReached, kGradientTolReached,
+                            kMaxIterations, kSolverError };
+enum KeyFramingReason { kLargeTranslation = BPVO_KF_LARGE_TRANSLATION, kLargeRotation, kSmallFracOfGoodPoints, kNoKeyFraming,
+                        kFirstFrame };
+
+struct ImageSize {                                              // bpvo/types.h:572-582
+  int rows, cols;
+  ImageSize(int r = 0, int c = 0) : rows(r), cols(c) {}
+  int numel() const { return rows * cols; }
+};
+
+/* bpvo::AlgorithmParameters (bpvo/types.h:171-413): the same 35 fields; defaults = bpvo/types.cc:31-66 */
+struct AlgorithmParameters : public bpvo_hip_params {
+  AlgorithmParameters() { bpvo_hip_default_params(this); }
+};
+
+struct OptimizerStatistics {                                    // bpvo/types.h:444-482
+  int numIterations;
+  float finalError;
+  float firstOrderOptimality;
+  PoseEstimationStatus status;
+  OptimizerStatistics() : numIterations(0), finalError(-1.0f), firstOrderOptimality(-1.0f), status(kSolverError) {}
+  explicit OptimizerStatistics(const bpvo_hip_stats& s)
+      : numIterations(s.numIterations), finalError(s.finalError), firstOrderOptimality(s.firstOrderOptimality),
+        status(static_cast<PoseEstimationStatus>(s.status)) {}
+};
+
+typedef bpvo_hip_point_with_info PointWithInfo;                 // bpvo/point_cloud.h:30-62 (32-byte record)
+
+class PointCloud {                                              // bpvo/point_cloud.h:67-120
+ public:
+  PointCloud() { setIdentity(); }
+  const std::vector<PointWithInfo>& points() const { return _points; }
+  std::vector<PointWithInfo>& points() { return _points; }
+  size_t size() const { return _points.size(); }
+  bool empty() const { return _points.empty(); }
+  const Matrix44& pose() const { return _pose; }
+  Matrix44& pose() { return _pose; }
+ private:
+  void setIdentity() { _pose.fill(0.0f); _pose[0] = _pose[5] = _pose[10] = _pose[15] = 1.0f; }
+  std::vector<PointWithInfo> _points;
+  Matrix44 _pose;
+};
+
+struct Result {                                                 // bpvo/types.h:489-563 (move-only)
+  Pose pose;
+  PoseCovariance covariance;
+  std::vector<OptimizerStatistics> optimizerStatistics;
+  bool isKeyFrame;
+  KeyFramingReason keyFramingReason;
+  std::unique_ptr<PointCloud> pointCloud;
+  Result() : isKeyFrame(false), keyFramingReason(kNoKeyFraming) {}
+  Result(Result&&) = default;
+  Result& operator=(Result&&) = default;
+  Result(const Result&) = delete;
+  Result& operator=(const Result&) = delete;
+};
+
+class Trajectory {                                              // bpvo/trajectory.h
+ public:
+  size_t size() const { return _poses.size(); }
+  const Matrix44& operator[](size_t i) const { return _poses[i]; }
+  const Matrix44& back() const { return _poses.back(); }
+  const std::vector<Matrix44>& poses() const { return _poses; }
+ private:
+  friend class VisualOdometry;
+  std::vector<Matrix44> _poses;
+};
+
+namespace detail {
+/* owns one bpvo_hip_ctx; maps a non-zero status to bpvo::Error (THROW_ERROR, bpvo/utils.h:211-220) */
+class Device {
+ public:
+  Device(const Matrix33& K, float baseline, ImageSize size, const AlgorithmParameters& p, int n_frames, int n_pairs, int device = 0)
+      : _ctx(nullptr), _size(size)
+  {
+    const int rc = bpvo_hip_create(&_ctx, K.data(), baseline, size.rows, size.cols, &p, device, n_frames, n_pairs);
+    if(rc != BPVO_OK) throw Error(std::string("bpvo_hip_create: ") + bpvo_hip_last_error(nullptr));
+  }
+  ~Device() { bpvo_hip_destroy(_ctx); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+  bpvo_hip_ctx* ctx() const { return _ctx; }
+  ImageSize imageSize() const { return _size; }
+  void check(int rc) const { if(rc != BPVO_OK) throw Error(bpvo_hip_last_error(_ctx)); }
+ private:
+  bpvo_hip_ctx* _ctx;
+  ImageSize _size;
+};
+}  // namespace detail
+
+/* bpvo::VisualOdometryFrame (bpvo/vo_frame.h:21-90): a device-resident frame = slot of a Device */
+class VisualOdometryFrame {
+ public:
+  VisualOdometryFrame(std::shared_ptr<detail::Device> dev, int slot) : _dev(dev), _slot(slot) {}
+  void setData(const uint8_t* image, const float* disparity) { _dev->check(bpvo_hip_frame_set_data(_dev->ctx(), _slot, image, disparity)); }
+  void setTemplate() { _dev->check(bpvo_hip_frame_set_template(_dev->ctx(), _slot)); }
+  void clear() { _dev->check(bpvo_hip_frame_clear(_dev->ctx(), _slot)); }
+  bool empty() const { int d = 0, t = 0; _dev->check(bpvo_hip_frame_state(_dev->ctx(), _slot, &d, &t)); return !d; }
+  bool hasTemplate() const { int d = 0, t = 0; _dev->check(bpvo_hip_frame_state(_dev->ctx(), _slot, &d, &t)); return t != 0; }
+  int numLevels() const { return bpvo_hip_num_levels(_dev->ctx()); }
+  int numPointsAtLevel(int level) const { int n = 0; _dev->check(bpvo_hip_num_points(_dev->ctx(), _slot, level, &n)); return n; }
+  int slot() const { return _slot; }
+  const std::shared_ptr<detail::Device>& device() const { return _dev; }
+ private:
+  std::shared_ptr<detail::Device> _dev;
+  int _slot;
+};
+
+/* bpvo::VisualOdometryPoseEstimator (bpvo/vo_pose_estimator.h:34-64) */
+class VisualOdometryPoseEstimator {
+ public:
+  explicit VisualOdometryPoseEstimator(std::shared_ptr<detail::Device> dev, int workspace = 0) : _dev(dev), _ws(workspace) {}
+  std::vector<OptimizerStatistics> estimatePose(const VisualOdometryFrame* ref_frame, const VisualOdometryFrame* cur_frame,
+                                                const Matrix44& T_init, Matrix44& T_est)
+  {
+    std::vector<bpvo_hip_stats> st(bpvo_hip_num_levels(_dev->ctx()));
+    _dev->check(bpvo_hip_estimate_pose(_dev->ctx(), _ws, ref_frame->slot(), cur_frame->slot(), T_init.data(), T_est.data(), st.data()));
+    std::vector<OptimizerStatistics> ret;
+    for(const auto& s : st) ret.push_back(OptimizerStatistics(s));
+    return ret;
+  }
+  float getFractionOfGoodPoints(float thresh) const
+  {
+    float f = 0.0f;
+    _dev->check(bpvo_hip_fraction_good(_dev->ctx(), _ws, thresh, &f));
+    return f;
+  }
+  const WeightsVector& getWeights() const
+  {
+    size_t n = 0;
+    _dev->check(bpvo_hip_get_weights(_dev->ctx(), _ws, nullptr, &n));
+    _weights.resize(n);
+    if(n) _dev->check(bpvo_hip_get_weights(_dev->ctx(), _ws, _weights.data(), &n));
+    return _weights;
+  }
+ private:
+  std::shared_ptr<detail::Device> _dev;
+  int _ws;
+  mutable WeightsVector _weights;
+};
+
+/* bpvo::VisualOdometry (bpvo/vo.h:31-105).  The keyframe state machine of bpvo/vo.cc:125-224 runs inside the library
+ * on three device-resident frames. */
+class VisualOdometry {
+ public:
+  VisualOdometry(const Matrix33& K, float baseline, ImageSize image_size, const AlgorithmParameters& params = AlgorithmParameters(),
+                 int device = 0)
+      : _dev(std::make_shared<detail::Device>(K, baseline, image_size, params, 3, 1, device)), _max_test_level(params.maxTestLevel) {}
+
+  /* reference: Result addFrame(const uint8_t* image, const float* disparity) (bpvo/vo.h:71, bpvo/vo.cc:66-72) */
+  Result addFrame(const uint8_t* image, const float* disparity)
+  {
+    if(image == nullptr || disparity == nullptr) throw Error("nullptr image/disparity");
+    bpvo_hip_result r;
+    _dev->check(bpvo_hip_add_frame(_dev->ctx(), image, disparity, &r));
+    Result ret;
+    std::memcpy(ret.pose.data(), r.pose, sizeof(r.pose));
+    std::memcpy(ret.covariance.data(), r.covariance, sizeof(r.covariance));
+    for(int i = 0; i < r.numLevels; ++i) ret.optimizerStatistics.push_back(OptimizerStatistics(r.optimizerStatistics[i]));
+    ret.isKeyFrame = r.isKeyFrame != 0;
+    ret.keyFramingReason = static_cast<KeyFramingReason>(r.keyFramingReason);
+    if(r.hasPointCloud) {
+      size_t n = 0;
+      _dev->check(bpvo_hip_get_point_cloud(_dev->ctx(), nullptr, &n, nullptr));
+      ret.pointCloud.reset(new PointCloud);
+      ret.pointCloud->points().resize(n);
+      _dev->check(bpvo_hip_get_point_cloud(_dev->ctx(), ret.pointCloud->points().data(), &n, ret.pointCloud->pose().data()));
+    }
+    int nt = 0;
+    _dev->check(bpvo_hip_trajectory_size(_dev->ctx(), &nt));
+    _trajectory._poses.resize(nt);
+    if(nt) _dev->check(bpvo_hip_get_trajectory(_dev->ctx(), _trajectory._poses[0].data()));
+    return ret;
+  }
+
+  int numPointsAtLevel(int level = -1) const                     // bpvo/vo.h:86
+  {
+    int n = 0;
+    _dev->check(bpvo_hip_vo_num_points_at_level(_dev->ctx(), level, &n));
+    return n;
+  }
+  const PointVector& pointsAtLevel(int level = -1) const         // bpvo/vo.h:92
+  {
+    _points.resize(numPointsAtLevel(level));
+    if(!_points.empty()) _dev->check(bpvo_hip_vo_points_at_level(_dev->ctx(), level, _points[0].data()));
+    return _points;
+  }
+  const Trajectory& trajectory() const { return _trajectory; }   // bpvo/vo.h:98
+
+ private:
+  std::shared_ptr<detail::Device> _dev;
+  int _max_test_level;
+  Trajectory _trajectory;
+  mutable PointVector _points;
+};
+
+}  // namespace bpvo
+
+#endif  // BPVO_HIP_VO_HPP

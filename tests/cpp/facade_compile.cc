@@ -1,0 +1,26 @@
+// Compile-only check of the C++ facade: every public member of the reference's API surface is instantiated.
+#include <bpvo_hip/vo.hpp>
+
+int facade_surface()
+{
+  bpvo::AlgorithmParameters p;
+  p.numPyramidLevels = 2;
+  p.descriptor = bpvo::kBitPlanes;
+  p.lossFunction = bpvo::kTukey;
+  const bpvo::Matrix33 K = {{100.f, 0.f, 32.f, 0.f, 100.f, 32.f, 0.f, 0.f, 1.f}};
+  bpvo::VisualOdometry vo(K, 0.1f, bpvo::ImageSize(64, 64), p);
+  bpvo::Result r = vo.addFrame(nullptr, nullptr);
+  (void) vo.numPointsAtLevel();
+  (void) vo.pointsAtLevel(-1).size();
+  (void) vo.trajectory().size();
+  auto dev = std::make_shared<bpvo::detail::Device>(K, 0.1f, bpvo::ImageSize(64, 64), p, 2, 1);
+  bpvo::VisualOdometryFrame ref(dev, 0), cur(dev, 1);
+  ref.setData(nullptr, nullptr); ref.setTemplate(); (void) ref.hasTemplate(); (void) cur.empty(); cur.clear(); (void) ref.numLevels();
+  bpvo::VisualOdometryPoseEstimator est(dev);
+  bpvo::Matrix44 T0, T1;
+  T0.fill(0.f);
+  std::vector<bpvo::OptimizerStatistics> st = est.estimatePose(&ref, &cur, T0, T1);
+  (void) est.getFractionOfGoodPoints(0.8f);
+  (void) est.getWeights().size();
+  return (int) st.size() + (r.pointCloud ? (int) r.pointCloud->size() : 0) + (int) r.keyFramingReason;
+}
