@@ -162,6 +162,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     gn_local = ctx.total_linearizations()
+    med_paths = ctx.median_path_counts()
     kstats = {k["name"]: k for k in ctx.kernel_stats()} if not args.no_profile else {}
     t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -230,6 +231,7 @@ def main():
             "gn_iterations_per_step": gn_total / args.steps,
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,
+            "median_selections": {"bracketed": med_paths[0], "full": med_paths[1]},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

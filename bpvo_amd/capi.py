@@ -365,6 +365,11 @@ class Context:
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, total_ms=arr[i].total_ms, units=arr[i].units,
                      bytes_per_unit=arr[i].bytes_per_unit) for i in range(n.value)]
 
+    def median_path_counts(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.call("median_path_counts", C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def total_linearizations(self):
         n = C.c_uint64()
         self.call("total_linearizations", C.byref(n))

@@ -56,6 +56,8 @@ struct FrameSlot {
 struct Workspace {
   float* r = nullptr;
   uint8_t* valid = nullptr;
+  uint32_t* cand = nullptr;
+  uint32_t* med_blk = nullptr;
   float* partials = nullptr;
   int last_ref = -1, last_cur = -1, last_level = -1;
 };
@@ -107,7 +109,7 @@ struct bpvo_hip_ctx {
   float* d_records = nullptr;      // [n_pairs][kRecordFloats]
   float* d_wtmp = nullptr;         // [cap_max * C] weights scratch
   unsigned int* d_count = nullptr;
-  unsigned long long* d_counters = nullptr;   // [2] points, linearisations
+  unsigned long long* d_counters = nullptr;   // [4] points, linearisations, bracketed / full median selections
   // pinned staging
   FrameJob* h_fjobs = nullptr;
   int* h_ints = nullptr;           // [max(n_frames*L, 16)]
@@ -124,7 +126,7 @@ struct bpvo_hip_ctx {
   double kc_ms[KC_COUNT] = {};
   double kc_units[KC_COUNT] = {};
   uint64_t kc_launches[KC_COUNT] = {};
-  uint64_t total_lin = 0;
+  uint64_t total_lin = 0, median_bracketed = 0, median_full = 0;
   std::string err;
 };
 
@@ -260,6 +262,8 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   std::memcpy(j.K, g.K, sizeof(j.K));
   j.r = c->ws[ws].r;
   j.valid = c->ws[ws].valid;
+  j.cand = c->ws[ws].cand;
+  j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
   return j;
@@ -479,13 +483,13 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         parity = it & 1;
         { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln); launch_warp_residual(ln->stream, g); }
         if(c->profile_all) {
-          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
+          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g, c->d_counters); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
           { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
             launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
                            p.gradientTolerance, ln->d_active, parity, c->d_counters); }
         } else {
-          launch_median(ln->stream, g);
+          launch_median(ln->stream, g, c->d_counters);
           launch_irls_reduce(ln->stream, g);
           launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
                          p.gradientTolerance, ln->d_active, parity, c->d_counters);
@@ -567,8 +571,10 @@ size_t tiled_floats(int n, int floats_per_point) { return (size_t) ((n + kTile -
 
 int refresh_counters(bpvo_hip_ctx* c)
 {
-  unsigned long long h[2] = {0, 0};
+  unsigned long long h[4] = {0, 0, 0, 0};
   HIP_CK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  c->median_bracketed = h[2];
+  c->median_full = h[3];
   c->total_lin = h[1];
   // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
   c->kc_units[KC_WARP_RESIDUAL] = (double) h[0];
@@ -772,6 +778,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   for(auto& w : cp->ws) {
     CREATE_CK(hipMalloc((void**) &w.r, sizeof(float) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
+    CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * (size_t) cp->cap_max * cp->C));
+    CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max));
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
@@ -798,8 +806,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
-  CREATE_CK(hipMalloc((void**) &cp->d_counters, 2 * sizeof(unsigned long long)));
-  CREATE_CK(hipMemset(cp->d_counters, 0, 2 * sizeof(unsigned long long)));
+  CREATE_CK(hipMalloc((void**) &cp->d_counters, 4 * sizeof(unsigned long long)));
+  CREATE_CK(hipMemset(cp->d_counters, 0, 4 * sizeof(unsigned long long)));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
 #undef CREATE_CK
@@ -815,7 +823,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipSetDevice(c->device);
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
-  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.partials); }
+  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.partials); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
@@ -1020,7 +1028,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g, c->d_counters); }
   { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
   { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0, c->d_counters); }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
@@ -1314,7 +1322,7 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   c->profiling = enable != 0;
   c->profile_all = enable >= 2;
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
-  HIP_CK(c, hipMemset(c->d_counters, 0, 2 * sizeof(unsigned long long)));
+  HIP_CK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
   c->total_lin = 0;
   return BPVO_OK;
 }
@@ -1340,6 +1348,17 @@ int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* c, bpvo_hip_kernel_stat* out, int ma
     out[n].bytes_per_unit = bpu[k];
   }
   *n_out = n;
+  return BPVO_OK;
+}
+int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* full)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  int rc = refresh_counters(c);
+  if(rc) return rc;
+  *bracketed = c->median_bracketed;
+  *full = c->median_full;
   return BPVO_OK;
 }
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* c, uint64_t* n)

@@ -32,7 +32,7 @@ int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
 void launch_warp_residual(hipStream_t s, const GNLaunch& g);
-void launch_median(hipStream_t s, const GNLaunch& g);
+void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters /*device [4] or null*/);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,

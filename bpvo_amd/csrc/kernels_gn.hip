@@ -121,10 +121,18 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 // K7 median + robust scale.  reference: AutoScaleEstimator::estimateScale / ScaleEstimator (bpvo/mestimator.cc:452-490)
 // and median() (bpvo/utils.h:224-252): sigma = (1.4826f * (1 + 5/(n-6))) * median(|r| : valid), n = C * #valid (size_t
 // arithmetic), sigma < 1e-6 -> 1, recomputed only while |sigma - sigma_prev| > 1e-6 (Q5, Q6).
-// The exact order statistics x[n/2] (and x[n/2-1] for even n) come from a 3-pass MSB radix select over the bit pattern of
-// |r| (monotone for non-negative floats): bits [30:20], [19:9], [8:0].  One 1024-thread workgroup per pair keeps the
-// histograms in LDS (4 privatised copies for the first pass to cut same-bin atomic serialisation), two cursors (lo, hi)
-// are refined in lock-step, and the keys that survive pass 1 are cached in LDS so pass 3 never touches HBM again.
+//
+// The order statistics x[n/2] (and x[n/2-1] for even n) are EXACT; they are found by MSB radix selection on the bit
+// pattern of |r| (monotone for non-negative floats), with two cursors (lo, hi) refined in lock-step.  Two paths:
+//
+//  bracketed (every linearisation of a level but the first): the median moves little between GN iterations, so K7a
+//    (median_bracket_kernel, chip-wide, one thread per point) only COUNTS the keys below a bracket [lo, hi) around the
+//    previous median and compacts the few keys inside it into a per-workspace candidate list (one atomic per wave);
+//    K7b then selects among the candidates only.  If the wanted ranks fall outside the bracket the full path runs — the
+//    result is exact either way; the bracket width adapts to the last observed change.
+//  full (first linearisation of a level, bracket miss): 3 passes over all keys, bits [30:20], [19:9], [8:0], one
+//    1024-thread workgroup per workspace with LDS histograms (4 privatised copies in pass 1 to cut same-bin atomic
+//    serialisation); keys surviving pass 1 are cached in LDS so pass 3 never touches HBM again.
 constexpr int MED_THREADS = 1024;
 constexpr int MED_COPIES = 4;
 constexpr int MED_BINS = 2048;
@@ -155,8 +163,8 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s
   return woff + incl - v;
 }
 
-// every thread owns bins 2t, 2t+1 of a 2048-bin histogram: find the bins holding ranks k_lo / k_hi
-__device__ __forceinline__ void find_ranks(unsigned h0, unsigned h1, unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2] in LDS*/)
+// every thread owns bins 2t, 2t+1 of a (<= 2048)-bin histogram: find the bins holding ranks k_lo / k_hi
+__device__ __forceinline__ void find_ranks(unsigned h0, unsigned h1, unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2]*/)
 {
   const unsigned b = 2u * threadIdx.x;
   if(k_lo >= excl && k_lo < excl + h0) { out[0].prefix = b; out[0].rank = k_lo - excl; }
@@ -205,8 +213,128 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
   }
 }
 
+// One refinement pass of the two-cursor radix select.  A key takes part in cursor X iff its bits above (shift + width)
+// equal X.prefix; its digit is (key >> shift) & (2^width - 1), width <= 11.  On return the cursors carry the extended
+// prefix and the rank inside the selected digit bin.  Block-wide (1024 threads); `src(f)` calls f(key) for every key.
+template <typename Src>
+__device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned width, MedCursor& lo, MedCursor& hi, unsigned* hist_lo,
+                                            unsigned* hist_hi, unsigned* s_wave, MedCursor* cur)
+{
+  const int tid = threadIdx.x;
+  const bool split = lo.prefix != hi.prefix;
+  const unsigned nbins = 1u << width, up = shift + width;
+  __syncthreads();
+  for(unsigned i = tid; i < nbins; i += MED_THREADS) { hist_lo[i] = 0; hist_hi[i] = 0; }
+  __syncthreads();
+  src([&](unsigned key) {
+    const unsigned top = (up >= 32u) ? 0u : (key >> up);
+    const unsigned dg = (key >> shift) & (nbins - 1u);
+    if(top == lo.prefix) atomicAdd(&hist_lo[dg], 1u);
+    else if(split && top == hi.prefix) atomicAdd(&hist_hi[dg], 1u);
+  });
+  __syncthreads();
+  unsigned dummy;
+  const bool own = 2u * tid < nbins;
+  const unsigned a0 = own ? hist_lo[2 * tid] : 0u, a1 = own ? hist_lo[2 * tid + 1] : 0u;
+  const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
+  unsigned b0 = a0, b1 = a1, eb = ea;
+  if(split) {
+    b0 = own ? hist_hi[2 * tid] : 0u; b1 = own ? hist_hi[2 * tid + 1] : 0u;
+    eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
+  }
+  MedCursor tmp[2];
+  tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
+  if(own) {
+    find_ranks(a0, a1, ea, lo.rank, split ? 0xffffffffu : hi.rank, tmp);
+    if(tmp[0].prefix != 0xffffffffu) { cur[0].prefix = (lo.prefix << width) | tmp[0].prefix; cur[0].rank = tmp[0].rank; }
+    if(!split && tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
+    if(split) {
+      tmp[1].prefix = 0xffffffffu;
+      find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
+      if(tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
+    }
+  }
+  __syncthreads();
+  lo = cur[0];
+  hi = cur[1];
+  __syncthreads();
+}
+
+// K7a: bracket counting + candidate compaction, one thread per template point, chip-wide.  No global atomics: block b of
+// a workspace owns med_blk[b] = {#keys below the bracket, #keys inside, #valid points} and the candidate segment
+// cand[b * 256 * C ...]; the compaction inside the block is a wave scan + LDS offsets.
 template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_kernel(const PairJob* __restrict__ jobs)
+__global__ __launch_bounds__(GN_BLOCK) void median_bracket_kernel(const PairJob* __restrict__ jobs)
+{
+  const PairJob& j = jobs[blockIdx.y];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active || !(st->delta_scale > 1e-6f) || !st->median_valid) return;
+  const int n = j.n;
+  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+  const unsigned lo = st->lo_key, hi = st->hi_key;
+  const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const bool v = (i < n) && j.valid[i];
+  unsigned keys[C];
+  if constexpr(C == 8) {
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    if(v) {
+      const float4* q = reinterpret_cast<const float4*>(j.r);
+      a = q[tile_index<2>(i, 0)];
+      b = q[tile_index<2>(i, 1)];
+    }
+    keys[0] = __float_as_uint(a.x); keys[1] = __float_as_uint(a.y); keys[2] = __float_as_uint(a.z); keys[3] = __float_as_uint(a.w);
+    keys[4] = __float_as_uint(b.x); keys[5] = __float_as_uint(b.y); keys[6] = __float_as_uint(b.z); keys[7] = __float_as_uint(b.w);
+  } else {
+    keys[0] = v ? __float_as_uint(j.r[i]) : 0u;
+  }
+  unsigned below = 0, cnt = 0, mask = 0;
+#pragma unroll
+  for(int c = 0; c < C; ++c) {
+    const unsigned k = keys[c] & 0x7fffffffu;
+    keys[c] = k;
+    const bool in = v && (k >= lo) && (k < hi);
+    below += (v && k < lo) ? 1u : 0u;
+    cnt += in ? 1u : 0u;
+    mask |= (in ? 1u : 0u) << c;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u;
+#pragma unroll
+  for(int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if(lane >= o) incl += t;
+  }
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) {
+    sum_below += __shfl_down(sum_below, o);
+    sum_valid += __shfl_down(sum_valid, o);
+  }
+  __shared__ unsigned s_in[4], s_below[4], s_valid[4];
+  if(lane == 63) s_in[wave] = incl;
+  if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
+  __syncthreads();
+  unsigned woff = 0;
+  for(int w = 0; w < wave; ++w) woff += s_in[w];
+  if(threadIdx.x == 0) {
+    uint4 o;
+    o.x = s_below[0] + s_below[1] + s_below[2] + s_below[3];
+    o.y = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+    o.z = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+    o.w = 0;
+    reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
+  }
+  if(cnt) {
+    unsigned* seg = j.cand + (size_t) blockIdx.x * GN_BLOCK * C;
+    unsigned pos = woff + incl - cnt;
+#pragma unroll
+    for(int c = 0; c < C; ++c)
+      if(mask & (1u << c)) seg[pos++] = keys[c];
+  }
+}
+
+// K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
+template <int C>
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, unsigned long long* counters)
 {
   const PairJob& j = jobs[blockIdx.x];
   GNState* st = j.st;
@@ -222,128 +350,124 @@ __global__ __launch_bounds__(MED_THREADS) void median_kernel(const PairJob* __re
   unsigned* s_misc = reinterpret_cast<unsigned*>(cur + 2);                // [0] cache count, [1] first valid point
 
   const int tid = threadIdx.x;
-  for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
-  if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
-  __syncthreads();
-
-  // ---- pass 1: bits [30:20]
-  {
-    unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
-    unsigned first = 0xffffffffu;
-    for_each_valid_key<C>(j, [&](unsigned key, int pt) {
-      atomicAdd(&h[key >> 20], 1u);
-      first = min(first, (unsigned) pt);
-    });
-    if(C == 1 && first != 0xffffffffu) atomicMin(&s_misc[1], first);
-  }
-  __syncthreads();
-  unsigned h0 = 0, h1 = 0;
-#pragma unroll
-  for(int c = 0; c < MED_COPIES; ++c) { h0 += hist_lo[c * MED_BINS + 2 * tid]; h1 += hist_lo[c * MED_BINS + 2 * tid + 1]; }
-  unsigned n_total;
-  unsigned excl = block_excl_scan_1024(h0 + h1, s_wave, n_total);
-
   float median = 0.0f;
-  if(n_total >= 3) {
-    const unsigned k_hi = n_total / 2, k_lo = (n_total % 2 == 0) ? k_hi - 1 : k_hi;
-    find_ranks(h0, h1, excl, k_lo, k_hi, cur);
-    __syncthreads();
-    MedCursor lo = cur[0], hi = cur[1];
-    const bool split1 = lo.prefix != hi.prefix;
-    __syncthreads();
+  unsigned n_total = 0;
+  bool done = false;
 
-    // ---- pass 2: bits [19:9] of the keys in the selected pass-1 bucket(s); survivors cached in LDS
+  // ---- bracketed path
+  if(st->median_valid) {
+    // totals of the per-block counters written by median_bracket_kernel
+    const int nblk = (j.n + GN_BLOCK - 1) / GN_BLOCK;
+    unsigned c_below = 0, c_in = 0, c_valid = 0;
+    for(int b = tid; b < nblk; b += MED_THREADS) {
+      const uint4 o = reinterpret_cast<const uint4*>(j.med_blk)[b];
+      c_below += o.x; c_in += o.y; c_valid += o.z;
+    }
+    unsigned t_below, t_in, t_valid;
+    (void) block_excl_scan_1024(c_below, s_wave, t_below);
+    (void) block_excl_scan_1024(c_in, s_wave, t_in);
+    (void) block_excl_scan_1024(c_valid, s_wave, t_valid);
+    const unsigned nt = (unsigned) C * t_valid, below = t_below, m = t_in;
+    const unsigned lo_key = st->lo_key, range = st->hi_key - st->lo_key;
+    const unsigned k_hi = nt / 2, k_lo = (nt % 2 == 0 && nt > 0) ? k_hi - 1 : k_hi;
+    if(nt >= 3 && k_lo >= below && k_hi < below + m && range > 0) {
+      MedCursor lo, hi;
+      lo.prefix = 0; hi.prefix = 0; lo.rank = k_lo - below; hi.rank = k_hi - below;
+      const unsigned nbits = 32u - (unsigned) __clz((int) range);        // offsets d = key - lo_key are < range < 2^nbits
+      // candidates sit in per-block segments of 256*C slots; wave w walks segments w, w+16, ...
+      auto src = [&](auto f) {
+        const int lane = tid & 63, wave = tid >> 6;
+        for(int b = wave; b < nblk; b += MED_THREADS / 64) {
+          const unsigned mb = reinterpret_cast<const uint4*>(j.med_blk)[b].y;
+          const unsigned* seg = j.cand + (size_t) b * GN_BLOCK * C;
+          for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
+        }
+      };
+      unsigned remaining = nbits;
+      while(remaining > 0) {
+        const unsigned width = remaining > 11u ? 11u : remaining;
+        remaining -= width;
+        refine_pass(src, remaining, width, lo, hi, hist_lo, hist_hi, s_wave, cur);
+      }
+      const float v_lo = __uint_as_float(lo_key + lo.prefix), v_hi = __uint_as_float(lo_key + hi.prefix);
+      median = (nt % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);
+      n_total = nt;
+      done = true;
+    }
+  }
+
+  // ---- full path
+  if(!done) {
     for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
+    if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
     __syncthreads();
-    for_each_valid_key<C>(j, [&](unsigned key, int) {
-      const unsigned top = key >> 20;
-      const bool mlo = top == lo.prefix, mhi = top == hi.prefix;
-      if(mlo) atomicAdd(&hist_lo[(key >> 9) & 2047u], 1u);
-      else if(mhi) atomicAdd(&hist_hi[(key >> 9) & 2047u], 1u);
-      if(mlo || mhi) {
-        const unsigned idx = atomicAdd(&s_misc[0], 1u);
-        if(idx < MED_CACHE) cache[idx] = key;
-      }
-    });
-    __syncthreads();
-    {
-      unsigned dummy;
-      const unsigned a0 = hist_lo[2 * tid], a1 = hist_lo[2 * tid + 1];
-      const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
-      unsigned b0 = a0, b1 = a1, eb = ea;
-      if(split1) {
-        b0 = hist_hi[2 * tid]; b1 = hist_hi[2 * tid + 1];
-        eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
-      }
-      MedCursor tmp[2];
-      tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
-      // lo cursor in histogram a, hi cursor in histogram a (same bucket) or b (different bucket)
-      find_ranks(a0, a1, ea, lo.rank, split1 ? 0xffffffffu : hi.rank, tmp);
-      if(tmp[0].prefix != 0xffffffffu) { cur[0].prefix = (lo.prefix << 11) | tmp[0].prefix; cur[0].rank = tmp[0].rank; }
-      if(!split1 && tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << 11) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
-      if(split1) {
-        tmp[1].prefix = 0xffffffffu;
-        find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
-        if(tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << 11) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
-      }
+    {   // pass 1: bits [30:20], privatised histogram copies
+      unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
+      unsigned first = 0xffffffffu;
+      for_each_valid_key<C>(j, [&](unsigned key, int pt) {
+        atomicAdd(&h[key >> 20], 1u);
+        first = min(first, (unsigned) pt);
+      });
+      if(C == 1 && first != 0xffffffffu) atomicMin(&s_misc[1], first);
     }
     __syncthreads();
-    lo = cur[0]; hi = cur[1];     // 22-bit prefixes now
-    const bool split2 = lo.prefix != hi.prefix;
-    const unsigned ncache = s_misc[0];
-    __syncthreads();
-
-    // ---- pass 3: bits [8:0]
-    for(int i = tid; i < 2 * 512; i += MED_THREADS) { if(i < 512) hist_lo[i] = 0; else hist_hi[i - 512] = 0; }
-    __syncthreads();
-    auto pass3 = [&](unsigned key) {
-      const unsigned top = key >> 9;
-      if(top == lo.prefix) atomicAdd(&hist_lo[key & 511u], 1u);
-      else if(top == hi.prefix) atomicAdd(&hist_hi[key & 511u], 1u);
-    };
-    if(ncache <= MED_CACHE) {
-      for(unsigned i = tid; i < ncache; i += MED_THREADS) pass3(cache[i]);
-    } else {
-      for_each_valid_key<C>(j, [&](unsigned key, int) { pass3(key); });
+    unsigned h0 = 0, h1 = 0;
+#pragma unroll
+    for(int c = 0; c < MED_COPIES; ++c) { h0 += hist_lo[c * MED_BINS + 2 * tid]; h1 += hist_lo[c * MED_BINS + 2 * tid + 1]; }
+    const unsigned excl = block_excl_scan_1024(h0 + h1, s_wave, n_total);
+    if(n_total >= 3) {
+      const unsigned k_hi = n_total / 2, k_lo = (n_total % 2 == 0) ? k_hi - 1 : k_hi;
+      find_ranks(h0, h1, excl, k_lo, k_hi, cur);
+      __syncthreads();
+      MedCursor lo = cur[0], hi = cur[1];
+      __syncthreads();
+      // pass 2: bits [19:9] of the keys in the selected pass-1 bucket(s); survivors cached in LDS
+      const unsigned p_lo = lo.prefix, p_hi = hi.prefix;
+      refine_pass([&](auto f) {
+        for_each_valid_key<C>(j, [&](unsigned key, int) {
+          const unsigned top = key >> 20;
+          if(top == p_lo || top == p_hi) {
+            const unsigned idx = atomicAdd(&s_misc[0], 1u);
+            if(idx < MED_CACHE) cache[idx] = key;
+          }
+          f(key);
+        });
+      }, 9u, 11u, lo, hi, hist_lo, hist_hi, s_wave, cur);
+      const unsigned ncache = s_misc[0];
+      // pass 3: bits [8:0]
+      refine_pass([&](auto f) {
+        if(ncache <= MED_CACHE) { for(unsigned i = tid; i < ncache; i += MED_THREADS) f(cache[i]); }
+        else for_each_valid_key<C>(j, [&](unsigned key, int) { f(key); });
+      }, 0u, 9u, lo, hi, hist_lo, hist_hi, s_wave, cur);
+      const float v_lo = __uint_as_float(lo.prefix), v_hi = __uint_as_float(hi.prefix);
+      median = (n_total % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
+    } else if(n_total > 0) {
+      // median(): data.size() < 3 -> data[0] = first valid entry in channel-major order (Q5); only reachable for C == 1
+      __syncthreads();
+      const unsigned first = s_misc[1];
+      median = (first != 0xffffffffu) ? fabsf(j.r[(size_t) first * C]) : 0.0f;
     }
-    __syncthreads();
-    {
-      unsigned dummy;
-      const unsigned a0 = (tid < 256) ? hist_lo[2 * tid] : 0, a1 = (tid < 256) ? hist_lo[2 * tid + 1] : 0;
-      const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
-      unsigned b0 = a0, b1 = a1, eb = ea;
-      if(split2) {
-        b0 = (tid < 256) ? hist_hi[2 * tid] : 0; b1 = (tid < 256) ? hist_hi[2 * tid + 1] : 0;
-        eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
-      }
-      MedCursor tmp[2];
-      tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
-      find_ranks(a0, a1, ea, lo.rank, split2 ? 0xffffffffu : hi.rank, tmp);
-      if(tmp[0].prefix != 0xffffffffu) cur[0].prefix = (lo.prefix << 9) | tmp[0].prefix;
-      if(!split2 && tmp[1].prefix != 0xffffffffu) cur[1].prefix = (hi.prefix << 9) | tmp[1].prefix;
-      if(split2) {
-        tmp[1].prefix = 0xffffffffu;
-        find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
-        if(tmp[1].prefix != 0xffffffffu) cur[1].prefix = (hi.prefix << 9) | tmp[1].prefix;
-      }
-    }
-    __syncthreads();
-    const float v_lo = __uint_as_float(cur[0].prefix), v_hi = __uint_as_float(cur[1].prefix);
-    if(n_total % 2 != 0) median = v_hi;
-    else median = (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
-  } else if(n_total > 0) {
-    // median(): data.size() < 3 -> data[0] = first valid entry in channel-major order (Q5); only reachable for C == 1
-    __syncthreads();
-    const unsigned first = s_misc[1];
-    median = (first != 0xffffffffu) ? fabsf(j.r[(size_t) first * C]) : 0.0f;
   }
 
   if(tid == 0) {
+    if(counters) atomicAdd(&counters[done ? 2 : 3], 1ull);                  // measurement: bracketed vs full selections
     const unsigned long long nm6 = (unsigned long long) n_total - 6ull;     // size_t wrap for n < 6 (Q5)
     float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
     if((double) s < 1e-6) s = 1.0f;
     st->delta_scale = fabsf(s - st->scale);
     st->scale = s;
+    // bracket for the next linearisation of this level: centred on this median, as wide as 2.5x the last relative
+    // change + 2 % (first use: 25 %), at most 50 %
+    if(n_total >= 3 && median > 0.0f) {
+      float rel = 0.25f;
+      if(st->median_valid && st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
+      st->last_median = median;
+      st->lo_key = __float_as_uint(median * (1.0f - rel));
+      st->hi_key = __float_as_uint(median * (1.0f + rel)) + 1u;
+      st->median_valid = 1;
+    } else {
+      st->median_valid = 0;
+    }
   }
 }
 
@@ -654,6 +778,7 @@ __global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level)
   st->phase = PHASE_FIRST;
   st->has_converged = 0;
   st->level = level;
+  st->median_valid = 0;
   for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
   for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
   st->active = (jobs[p].n > 0) ? 1 : 0;
@@ -666,6 +791,7 @@ __global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int
   GNState* st = job->st;
   for(int i = 0; i < 16; ++i) st->T[i] = T[i];
   if(reset_scale) { st->scale = 1.0f; st->delta_scale = 1e10f; }
+  if(reset_scale || st->level != level) st->median_valid = 0;
   st->level = level;
   st->active = 1;
 }
@@ -753,17 +879,23 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   else hipLaunchKernelGGL(warp_residual_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
-void launch_median(hipStream_t s, const GNLaunch& g)
+void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters)
 {
   if(g.max_points <= 0) return;
   static bool attr_set = false;
   if(!attr_set) {
-    (void) hipFuncSetAttribute((const void*) median_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
-    (void) hipFuncSetAttribute((const void*) median_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    (void) hipFuncSetAttribute((const void*) median_finish_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     attr_set = true;
   }
-  if(g.C == 1) hipLaunchKernelGGL(median_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
-  else hipLaunchKernelGGL(median_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
+  const dim3 grid_a((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
+  if(g.C == 1) {
+    hipLaunchKernelGGL(median_bracket_kernel<1>, grid_a, dim3(GN_BLOCK), 0, s, g.jobs);
+    hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
+  } else {
+    hipLaunchKernelGGL(median_bracket_kernel<8>, grid_a, dim3(GN_BLOCK), 0, s, g.jobs);
+    hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
+  }
 }
 
 template <int C>

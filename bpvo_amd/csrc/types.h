@@ -74,6 +74,11 @@ struct GNState {
   int   num_fun_evals, num_iterations, status, phase, active, has_converged;
   uint32_t n_valid;                          // valid points of the last linearisation
   int   level;
+  // bracketed median selection (kernels_gn.hip K7): bracket [lo_key, hi_key) on the bit pattern of |r| around the
+  // previous median of the level, counters filled by median_bracket_kernel and consumed by median_finish_kernel
+  float last_median;
+  uint32_t lo_key, hi_key;
+  int   median_valid;
   bpvo_hip_stats stats[kMaxLevels];
   float T_out[16];                           // pose handed back (T in/out of run())
 };
@@ -93,6 +98,8 @@ struct PairJob {
   // workspace
   float*        r;        // [N][C] residuals, tiled
   uint8_t*      valid;    // [N]
+  uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
+  uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, -} of the bracket pass
   float*        partials; // [nblocks][kPartialStride]
   GNState*      st;
 };

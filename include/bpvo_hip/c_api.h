@@ -221,6 +221,8 @@ typedef struct bpvo_hip_kernel_stat {
 int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);        /* 0 off, 1 warp_residual + frame stages, 2 every kernel; resets counters */
 int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int max_out, int* n_out);
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */
+/* exact median selections served by the bracketed path / by the full 3-pass path since the last counter reset */
+int bpvo_hip_median_path_counts(bpvo_hip_ctx* ctx, uint64_t* bracketed, uint64_t* full);
 
 #ifdef __cplusplus
 }
