@@ -519,44 +519,59 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
     const float v = (float) j.valid[i];
     acc[28] += v;
-    // per point: 16 B point + 2*C gradient floats + C residuals (all tiled / coalesced); the six Jacobian entries of a
-    // channel are recomputed from them (jac_row: same IEEE operations as at template-build time, bit-identical)
+    // per point: 16 B point + 2*C gradient floats + C residuals (all tiled / coalesced), ALL issued before the first use
+    // (7 independent 16-byte loads in flight per lane for C = 8).
+    //
+    // Rank-2 structure: every channel's 1x6 Jacobian row at a point is J_c = Ix_c * A + Iy_c * B with A, B depending on
+    // the point only (jac_row in types.h expanded in Ix, Iy).  Hence
+    //    sum_c w_c J_c^T J_c = Sxx A A^T + Sxy (A B^T + B A^T) + Syy B B^T,   sum_c w_c r_c J_c^T = Gx A + Gy B
+    // with the channel sums Sxx = sum w Ix^2, Sxy = sum w Ix Iy, Syy = sum w Iy^2, Gx = sum w r Ix, Gy = sum w r Iy.
+    // Per (point, channel) that is 6 multiply-adds instead of the 27 of the reference's rankUpdatePoint; the 6x6 outer
+    // products are formed once per point.  Algebraically identical, rounding differs at the 1e-7 level like any other
+    // summation order (H, G are tolerance-compared).
     const float4 P = j.pts[i];
+    float rr[C], Ix[C], Iy[C];
+    if constexpr(C == 8) {
+      const float4* qr = reinterpret_cast<const float4*>(j.r);
+      const float4* qg = reinterpret_cast<const float4*>(j.grad);
+      const float4 r0 = qr[tile_index<2>(i, 0)], r1 = qr[tile_index<2>(i, 1)];
+      const float4 gx0 = qg[tile_index<4>(i, 0)], gx1 = qg[tile_index<4>(i, 1)], gy0 = qg[tile_index<4>(i, 2)], gy1 = qg[tile_index<4>(i, 3)];
+      rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+      Ix[0] = gx0.x; Ix[1] = gx0.y; Ix[2] = gx0.z; Ix[3] = gx0.w; Ix[4] = gx1.x; Ix[5] = gx1.y; Ix[6] = gx1.z; Ix[7] = gx1.w;
+      Iy[0] = gy0.x; Iy[1] = gy0.y; Iy[2] = gy0.z; Iy[3] = gy0.w; Iy[4] = gy1.x; Iy[5] = gy1.y; Iy[6] = gy1.z; Iy[7] = gy1.w;
+    } else {
+      rr[0] = j.r[i];
+      const float2 g2 = reinterpret_cast<const float2*>(j.grad)[i];
+      Ix[0] = g2.x; Iy[0] = g2.y;
+    }
+    float Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, Gx = 0.0f, Gy = 0.0f;
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+      const float r = rr[c];
+      const float w = mest_weight<LOSS>(r, sigma_inv) * v;
+      const float wx = w * Ix[c], wy = w * Iy[c];
+      Sxx += wx * Ix[c];
+      Sxy += wx * Iy[c];
+      Syy += wy * Iy[c];
+      Gx += wx * r;
+      Gy += wy * r;
+      acc[27] += (w * r) * r;
+    }
     const JacPoint jp = jac_point(P.x, P.y, P.z, s_nrm);
-    constexpr int G = (C >= 4) ? 4 : C;
-#pragma unroll 1
-    for(int c0 = 0; c0 < C; c0 += G) {
-      float rr[G], Ix[G], Iy[G];
-      if constexpr(G == 4) {
-        const float4 t4 = reinterpret_cast<const float4*>(j.r)[tile_index<2>(i, c0 >> 2)];
-        rr[0] = t4.x; rr[1] = t4.y; rr[2] = t4.z; rr[3] = t4.w;
-        const float4* q = reinterpret_cast<const float4*>(j.grad);
-        const float4 gx = q[tile_index<4>(i, c0 >> 2)], gy = q[tile_index<4>(i, 2 + (c0 >> 2))];
-        Ix[0] = gx.x; Ix[1] = gx.y; Ix[2] = gx.z; Ix[3] = gx.w;
-        Iy[0] = gy.x; Iy[1] = gy.y; Iy[2] = gy.z; Iy[3] = gy.w;
-      } else {
-        rr[0] = j.r[i];
-        const float2 g2 = reinterpret_cast<const float2*>(j.grad)[i];
-        Ix[0] = g2.x; Iy[0] = g2.y;
+    const float t_xz2 = jp.x * jp.rz2, t_yz2 = jp.y * jp.rz2;
+    const float A[6] = {-(t_xz2 * jp.yc2), jp.zc3 * jp.rz + t_xz2 * jp.xc1, -(jp.yc2 * jp.rz), jp.rzs, 0.0f, -(jp.s_i * t_xz2)};
+    const float B[6] = {-(jp.zc3 * jp.rz) - t_yz2 * jp.yc2, t_yz2 * jp.xc1, jp.xc1 * jp.rz, 0.0f, jp.rzs, -(jp.s_i * t_yz2)};
+    {
+      int idx = 0;
+#pragma unroll
+      for(int a = 0; a < 6; ++a) {
+        const float pa = Sxx * A[a] + Sxy * B[a];      // coefficient of A[b]
+        const float qa = Sxy * A[a] + Syy * B[a];      // coefficient of B[b]
+#pragma unroll
+        for(int b = a; b < 6; ++b) acc[idx++] += pa * A[b] + qa * B[b];
       }
 #pragma unroll
-      for(int cc = 0; cc < G; ++cc) {
-        float J[6];
-        jac_row(jp, Ix[cc], Iy[cc], J);
-        const float r = rr[cc];
-        const float w = mest_weight<LOSS>(r, sigma_inv) * v;
-        const float wr = w * r;
-        int idx = 0;
-#pragma unroll
-        for(int a = 0; a < 6; ++a) {
-          const float wj = w * J[a];
-#pragma unroll
-          for(int b = a; b < 6; ++b) acc[idx++] += wj * J[b];
-        }
-#pragma unroll
-        for(int a = 0; a < 6; ++a) acc[21 + a] += wr * J[a];
-        acc[27] += wr * r;
-      }
+      for(int a = 0; a < 6; ++a) acc[21 + a] += Gx * A[a] + Gy * B[a];
     }
   }
 
