@@ -163,7 +163,9 @@ def main():
 
     gn_local = ctx.total_linearizations()
     med_paths = ctx.median_path_counts()
-    kstats = {k["name"]: k for k in ctx.kernel_stats()} if not args.no_profile else {}
+    all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
+    points_linearized = all_kstats["warp_residual"]["units"]     # device-side count: sum over linearisations of N
+    kstats = all_kstats if not args.no_profile else {}
     t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone()
@@ -196,11 +198,13 @@ def main():
                              "algorithmic_GBps": (bytes_per_launch / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else None}
         if "warp_residual" in kernels:
             k = kernels["warp_residual"]
+            # HBM bytes per launch from the PMC passes (profiles/collect_profiles.sh): measured per template point on a
+            # bounded run of the same kernel, scaled to this run's points per launch
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.descriptor == "bitplanes":
                 try:
-                    traffic = json.load(open(tpath)).get("warp_residual_bytes_per_launch")
+                    traffic = json.load(open(tpath))["warp_residual_hbm_bytes_per_point"] * k["units_per_launch"]
                 except Exception:
                     traffic = None
             roofline = {"bound": "hbm", "kernel": "warp_residual_kernel<8>" if args.descriptor == "bitplanes" else "warp_residual_kernel<1>",
@@ -229,6 +233,7 @@ def main():
             "frames_per_s": 2.0 * n_pairs_total * args.steps / elapsed_max,
             "pairs_per_s": n_pairs_total * args.steps / elapsed_max,
             "gn_iterations_per_step": gn_total / args.steps,
+            "points_linearized_rank0": points_linearized,
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,
             "median_selections": {"bracketed": med_paths[0], "full": med_paths[1]},

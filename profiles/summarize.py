@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 databases written by collect_profiles.sh into small text/JSON summaries.
+
+usage: summarize.py <gpurun_out/profiles_TAG> <TAG>   -> writes <dir>/<TAG>_kernel_trace_stats.txt,
+       <TAG>_pmc_summary.txt and <TAG>_traffic.json (copy them into profiles/ to commit)."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+out = []
+
+
+def db_of(sub):
+    fs = sorted(glob.glob(os.path.join(src, sub, "*", "*_results.db")))
+    return sqlite3.connect(fs[-1]) if fs else None
+
+
+db = db_of("trace")
+if db:
+    rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0   (durations in us)",
+             "%-100s %8s %14s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
+    for r in rows:
+        lines.append("%-100s %8d %14.1f %10.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
+    try:
+        bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+        lines.append("")
+        lines.append("bench.py line of the same run: value=%.1f %s, ms_per_step=%.3f, roofline=%s" %
+                     (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])))
+    except Exception as e:  # noqa: BLE001
+        lines.append("(no bench json: %s)" % e)
+    open(os.path.join(src, f"{tag}_kernel_trace_stats.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:12]))
+
+per = {}
+for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
+    if not os.path.isdir(sub):
+        continue
+    d = db_of(os.path.basename(sub))
+    if not d:
+        continue
+    q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration), avg(grid_size) from counters_collection "
+         "group by kernel_name, counter_name")
+    for k, c, n, v, dur, grid in d.execute(q):
+        if "bpvo_hip" not in k:
+            continue
+        per.setdefault(k, {})[c] = dict(launches=n, avg=v, avg_duration_ns=dur)
+lines = ["PMC averages per launch; bounded config: bench.py --pairs-per-gpu 64 --fixed-iters 2 --steps 1 (all pairs active in",
+         "every launch: 64 x mean N = points per launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them."]
+for k in sorted(per):
+    lines.append("")
+    lines.append(k[:120])
+    for c in sorted(per[k]):
+        e = per[k][c]
+        lines.append("    %-40s %14.6g   (n=%d, avg kernel %.1f us)" % (c, e["avg"], e["launches"], (e["avg_duration_ns"] or 0) / 1e3))
+open(os.path.join(src, f"{tag}_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
+
+# HBM traffic of warp_residual per point (exact request sizes) for bench.py's roofline.traffic
+traffic = {}
+for k, cs in per.items():
+    if "warp_residual_kernel<8>" in k and "TCC_EA0_RDREQ_128B_sum" in cs:
+        rd = 128 * cs["TCC_EA0_RDREQ_128B_sum"]["avg"] + 64 * cs["TCC_EA0_RDREQ_64B_sum"]["avg"] + 32 * cs["TCC_EA0_RDREQ_32B_sum"]["avg"]
+        wr64 = cs.get("TCC_EA0_WRREQ_64B_sum", {}).get("avg", 0.0)
+        wr = cs.get("TCC_EA0_WRREQ_sum", {}).get("avg", 0.0)
+        wbytes = 64 * wr64 + 32 * max(0.0, wr - wr64)
+        traffic["warp_residual_read_bytes_per_launch"] = rd
+        traffic["warp_residual_write_bytes_per_launch"] = wbytes
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic["guide_corrected_bytes_per_launch"] = 1024.0 * (2.0 * cs["FETCH_SIZE"]["avg"] + cs["WRITE_SIZE"]["avg"])
+            traffic["fetch_size_kib_raw"] = cs["FETCH_SIZE"]["avg"]
+            traffic["write_size_kib_raw"] = cs["WRITE_SIZE"]["avg"]
+try:
+    pj = json.loads(open(os.path.join(src, "pmc3.json")).read().strip().splitlines()[-1])
+    k6 = [k for k in per if "warp_residual_kernel<8>" in k][0]
+    launches = per[k6]["TCC_EA0_RDREQ_128B_sum"]["launches"]
+    pts_per_launch = pj["points_linearized_rank0"] / launches
+    traffic["pmc_config"] = pj["config"]["workload"]
+    traffic["points_per_launch"] = pts_per_launch
+    traffic["warp_residual_hbm_bytes_per_point"] = (traffic["warp_residual_read_bytes_per_launch"]
+                                                    + traffic["warp_residual_write_bytes_per_launch"]) / pts_per_launch
+    if "guide_corrected_bytes_per_launch" in traffic:
+        traffic["guide_corrected_bytes_per_point"] = traffic["guide_corrected_bytes_per_launch"] / pts_per_launch
+    traffic["algorithmic_bytes_per_point"] = 210
+except Exception as e:  # noqa: BLE001
+    traffic["error"] = str(e)
+open(os.path.join(src, f"{tag}_traffic.json"), "w").write(json.dumps(traffic, indent=1) + "\n")
+print(json.dumps(traffic))
