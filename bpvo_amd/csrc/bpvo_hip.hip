@@ -86,7 +86,7 @@ struct Lane {
   std::vector<hipEvent_t> ev_pool;
   std::string err;
 };
-constexpr int kMaxLanes = 4;
+constexpr int kDefaultLanes = 1;   // BPVO_HIP_LANES=2 gains ~5 % on 128-pair batches but makes per-launch timings overlap
 constexpr int kMinPairsPerLane = 8;
 
 }  // namespace
@@ -787,7 +787,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
   {
-    int max_lanes = kMaxLanes;
+    int max_lanes = kDefaultLanes;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
