@@ -200,6 +200,106 @@ BPVO_HD bool is_approx_Hdp_G(const T* H, const T* dp, const T* G, T prec)
   return d2 <= prec * prec * mn;
 }
 
+// The same f32 factorisation + solve with every array index a compile-time constant: loops are fully unrolled and the
+// pivot transpositions are applied as conditional swaps over the (statically enumerated) candidates, so the 6x6 matrix
+// lives in registers on the GPU (no LDS / scratch round trips in the serial gn_step).  Operation order identical to
+// LDLT6<float>::compute + solve above.
+#define BPVO_SWAPF(a, b) do { const float t_ = (a); (a) = (b); (b) = t_; } while(0)
+BPVO_HD void ldlt6_solve_f32(const float* A, const float* rhs, float* x)
+{
+  const float eps = 1.1920928955078125e-07f, tolerance = 1.0f / 3.4028234663852886e+38f;
+  float m[36];
+  int tr[6];
+#pragma unroll
+  for(int i = 0; i < 36; ++i) m[i] = A[i];
+  float cutoff = 0.0f;
+  bool stopped = false;
+#pragma unroll
+  for(int k = 0; k < 6; ++k) {
+    int idx = k;
+    if(!stopped) {
+      float biggest = fabsf(m[k * 6 + k]);
+#pragma unroll
+      for(int i = k + 1; i < 6; ++i) {
+        const float v = fabsf(m[i * 6 + i]);
+        if(v > biggest) { biggest = v; idx = i; }
+      }
+      if(k == 0) cutoff = fabsf(eps * biggest);
+      if(biggest < cutoff) { stopped = true; idx = k; }
+    }
+    tr[k] = idx;
+    if(!stopped) {
+#pragma unroll
+      for(int i = k + 1; i < 6; ++i) {
+        if(idx == i) {     // symmetric transposition k <-> i on the lower triangle (static indices)
+#pragma unroll
+          for(int c = 0; c < k; ++c) BPVO_SWAPF(m[k * 6 + c], m[i * 6 + c]);
+#pragma unroll
+          for(int r = i + 1; r < 6; ++r) BPVO_SWAPF(m[r * 6 + k], m[r * 6 + i]);
+          BPVO_SWAPF(m[k * 6 + k], m[i * 6 + i]);
+#pragma unroll
+          for(int t = k + 1; t < i; ++t) BPVO_SWAPF(m[t * 6 + k], m[i * 6 + t]);
+        }
+      }
+      float temp[6];
+      if(k > 0) {
+#pragma unroll
+        for(int c = 0; c < k; ++c) temp[c] = m[c * 6 + c] * m[k * 6 + c];
+        float dot = 0.0f;
+#pragma unroll
+        for(int c = 0; c < k; ++c) dot += m[k * 6 + c] * temp[c];
+        m[k * 6 + k] -= dot;
+#pragma unroll
+        for(int r = k + 1; r < 6; ++r) {
+          float d2 = 0.0f;
+#pragma unroll
+          for(int c = 0; c < k; ++c) d2 += m[r * 6 + c] * temp[c];
+          m[r * 6 + k] -= d2;
+        }
+      }
+      if(k < 5 && fabsf(m[k * 6 + k]) > cutoff) {
+#pragma unroll
+        for(int r = k + 1; r < 6; ++r) m[r * 6 + k] /= m[k * 6 + k];
+      }
+    }
+  }
+  float v[6];
+#pragma unroll
+  for(int i = 0; i < 6; ++i) v[i] = rhs[i];
+#pragma unroll
+  for(int i = 0; i < 6; ++i) {          // P b
+#pragma unroll
+    for(int q = i + 1; q < 6; ++q) if(tr[i] == q) BPVO_SWAPF(v[i], v[q]);
+  }
+#pragma unroll
+  for(int i = 0; i < 6; ++i) {          // L^-1
+    float s = v[i];
+#pragma unroll
+    for(int c = 0; c < i; ++c) s -= m[i * 6 + c] * v[c];
+    v[i] = s;
+  }
+#pragma unroll
+  for(int i = 0; i < 6; ++i) {          // D^-1 (pseudo-inverse)
+    if(fabsf(m[i * 6 + i]) > tolerance) v[i] /= m[i * 6 + i];
+    else v[i] = 0.0f;
+  }
+#pragma unroll
+  for(int i = 5; i >= 0; --i) {         // L^-T
+    float s = v[i];
+#pragma unroll
+    for(int c = i + 1; c < 6; ++c) s -= m[c * 6 + i] * v[c];
+    v[i] = s;
+  }
+#pragma unroll
+  for(int i = 5; i >= 0; --i) {         // P^T
+#pragma unroll
+    for(int q = i + 1; q < 6; ++q) if(tr[i] == q) BPVO_SWAPF(v[i], v[q]);
+  }
+#pragma unroll
+  for(int i = 0; i < 6; ++i) x[i] = v[i];
+}
+#undef BPVO_SWAPF
+
 // Working storage of solve_system.  The factorisation indexes its arrays with run-time pivots, which would put
 // function-local arrays into (slow) scratch memory on the GPU: the device caller hands in an LDS-resident instance.
 struct SolveScratch {
@@ -211,8 +311,7 @@ struct SolveScratch {
 // PoseEstimatorData_::solve + solve2Augmented(0.001) (reference: bpvo/pose_estimator_base.h:90-111,136-148).
 BPVO_HD bool solve_system(const float H[36], const float G[6], float dp[6], SolveScratch* ws)
 {
-  ws->f.compute(H, 1.1920928955078125e-07f);
-  ws->f.solve(G, dp, 1.0f / 3.4028234663852886e+38f);
+  ldlt6_solve_f32(H, G, dp);
   if(is_approx_Hdp_G<float>(H, dp, G, 1e-5f)) return true;
   float maxd = H[0];
   for(int i = 1; i < 6; ++i) maxd = H[i * 6 + i] > maxd ? H[i * 6 + i] : maxd;

@@ -321,58 +321,62 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
 }
 
 // ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
-// The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too: one wave
-// per (frame, level) loads 64 points at a time (coalesced float4) and every lane accumulates them in point order through
-// v_readlane broadcasts (uniform result, no LDS).  It runs once per keyframe and level.
-__device__ __forceinline__ float readlane_f(float v, int lane)
-{
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__global__ __launch_bounds__(64) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
-                                                           int with_normalization)
+// The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too (LDS-staged
+// chunks, one wave adding in point order).  It runs once per keyframe and level, all levels and frames side by side.
+constexpr int NRM_THREADS = 256, NRM_CHUNK = 1024;
+__global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
+                                                                    int with_normalization)
 {
   const FrameJob& j = jobs[(size_t) (first_level + blockIdx.y) * job_pitch + blockIdx.x];
   const int N = *j.n_out;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   if(!with_normalization || N == 0) {
-    if(lane == 0) { j.nrm[0] = 1.0f; j.nrm[1] = 0.0f; j.nrm[2] = 0.0f; j.nrm[3] = 0.0f; }
+    if(tid == 0) { j.nrm[0] = 1.0f; j.nrm[1] = 0.0f; j.nrm[2] = 0.0f; j.nrm[3] = 0.0f; }
     return;
   }
+  // Chunks of 1024 points are staged in LDS with coalesced loads; wave 0 then adds them strictly in point order, every
+  // lane reading the same LDS address (a broadcast, no bank conflict) so the result is uniform across the wave.
+  __shared__ float4 s_pts[NRM_CHUNK];
+  __shared__ float s_dist[NRM_CHUNK];
+  __shared__ float s_c[4];
   float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-  for(int base = 0; base < N; base += 64) {
-    const float4 p = (base + lane < N) ? j.pts[base + lane] : make_float4(0, 0, 0, 0);
-    const int groups = min(64, N - base) >> 4;    // N is a multiple of 16
-    for(int q = 0; q < groups; ++q) {
-#pragma unroll
-      for(int k = 0; k < 16; ++k) {
-        const int l = q * 16 + k;
-        c0 += readlane_f(p.x, l);
-        c1 += readlane_f(p.y, l);
-        c2 += readlane_f(p.z, l);
-        c3 += readlane_f(p.w, l);
+  for(int base = 0; base < N; base += NRM_CHUNK) {
+    const int cnt = min(NRM_CHUNK, N - base);
+    __syncthreads();
+    for(int k = tid; k < cnt; k += NRM_THREADS) s_pts[k] = j.pts[base + k];
+    __syncthreads();
+    if(tid < 64) {
+#pragma unroll 8
+      for(int k = 0; k < cnt; ++k) {
+        const float4 p = s_pts[k];
+        c0 += p.x; c1 += p.y; c2 += p.z; c3 += p.w;
       }
     }
   }
   const float fN = (float) N;
-  c0 /= fN; c1 /= fN; c2 /= fN; c3 /= fN;
+  if(tid == 0) { s_c[0] = c0 / fN; s_c[1] = c1 / fN; s_c[2] = c2 / fN; s_c[3] = c3 / fN; }
+  __syncthreads();
+  c0 = s_c[0]; c1 = s_c[1]; c2 = s_c[2]; c3 = s_c[3];
   float m = 0.0f;
-  for(int base = 0; base < N; base += 64) {
-    float dist = 0.0f;
-    if(base + lane < N) {
-      const float4 p = j.pts[base + lane];
+  for(int base = 0; base < N; base += NRM_CHUNK) {
+    const int cnt = min(NRM_CHUNK, N - base);
+    __syncthreads();
+    for(int k = tid; k < cnt; k += NRM_THREADS) {
+      const float4 p = j.pts[base + k];
       const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
-      dist = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      s_dist[k] = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
     }
-    const int groups = min(64, N - base) >> 4;
-    for(int q = 0; q < groups; ++q) {
-#pragma unroll
-      for(int k = 0; k < 16; ++k) m += readlane_f(dist, q * 16 + k);
+    __syncthreads();
+    if(tid < 64) {
+#pragma unroll 8
+      for(int k = 0; k < cnt; ++k) m += s_dist[k];
     }
   }
-  m /= fN;
-  const float s = (float) (sqrt(3.0) / (double) fmaxf(m, 1e-6f));
-  if(lane == 0) { j.nrm[0] = s; j.nrm[1] = c0; j.nrm[2] = c1; j.nrm[3] = c2; }
+  if(tid == 0) {
+    m /= fN;
+    const float s = (float) (sqrt(3.0) / (double) fmaxf(m, 1e-6f));
+    j.nrm[0] = s; j.nrm[1] = c0; j.nrm[2] = c1; j.nrm[3] = c2;
+  }
 }
 
 // ---- K5: template pixels, central-difference gradients and 1x6 Jacobians
@@ -492,7 +496,7 @@ void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
 void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels,
                           int with_normalization)
 {
-  hipLaunchKernelGGL(normalization_kernel, dim3(nframes, num_levels - first_level), dim3(64), 0, s, jobs, job_pitch, first_level,
+  hipLaunchKernelGGL(normalization_kernel, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
                      with_normalization);
 }
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5)

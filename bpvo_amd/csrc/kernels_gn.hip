@@ -364,9 +364,21 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
       c_below += o.x; c_in += o.y; c_valid += o.z;
     }
     unsigned t_below, t_in, t_valid;
-    (void) block_excl_scan_1024(c_below, s_wave, t_below);
-    (void) block_excl_scan_1024(c_in, s_wave, t_in);
-    (void) block_excl_scan_1024(c_valid, s_wave, t_valid);
+    {   // three block sums with one LDS round
+#pragma unroll
+      for(int o = 32; o >= 1; o >>= 1) {
+        c_below += __shfl_down(c_below, o);
+        c_in += __shfl_down(c_in, o);
+        c_valid += __shfl_down(c_valid, o);
+      }
+      __syncthreads();
+      if((tid & 63) == 0) { cache[(tid >> 6) * 3 + 0] = c_below; cache[(tid >> 6) * 3 + 1] = c_in; cache[(tid >> 6) * 3 + 2] = c_valid; }
+      __syncthreads();
+      t_below = t_in = t_valid = 0;
+#pragma unroll
+      for(int w = 0; w < 16; ++w) { t_below += cache[w * 3 + 0]; t_in += cache[w * 3 + 1]; t_valid += cache[w * 3 + 2]; }
+      __syncthreads();
+    }
     const unsigned nt = (unsigned) C * t_valid, below = t_below, m = t_in;
     const unsigned lo_key = st->lo_key, range = st->hi_key - st->lo_key;
     const unsigned k_hi = nt / 2, k_lo = (nt % 2 == 0 && nt > 0) ? k_hi - 1 : k_hi;
@@ -384,10 +396,52 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
         }
       };
       unsigned remaining = nbits;
+      bool first = true;
       while(remaining > 0) {
         const unsigned width = remaining > 11u ? 11u : remaining;
+        const bool was_split = lo.prefix != hi.prefix;
         remaining -= width;
         refine_pass(src, remaining, width, lo, hi, hist_lo, hist_hi, s_wave, cur);
+        if(!first || remaining == 0) continue;
+        first = false;
+        // After the first digit the selected bins usually hold a handful of keys: finish by direct ranking (each thread
+        // ranks one key of the bin by counting the smaller ones) instead of more histogram passes.
+        const unsigned dmask = (1u << width) - 1u;
+        const unsigned n_lo = hist_lo[lo.prefix & dmask];
+        const unsigned n_hi = was_split ? hist_hi[hi.prefix & dmask] : hist_lo[hi.prefix & dmask];
+        if(n_lo > (unsigned) MED_THREADS || n_hi > (unsigned) MED_THREADS) continue;
+        unsigned* list_lo = cache;                    // [MED_THREADS]
+        unsigned* list_hi = cache + MED_THREADS;      // [MED_THREADS]
+        const bool same_bin = lo.prefix == hi.prefix;
+        __syncthreads();
+        if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
+        __syncthreads();
+        const unsigned p_lo = lo.prefix, p_hi = hi.prefix, sh = remaining;
+        src([&](unsigned d) {
+          const unsigned top = d >> sh;
+          if(top == p_lo) list_lo[atomicAdd(&s_misc[0], 1u)] = d;
+          else if(!same_bin && top == p_hi) list_hi[atomicAdd(&s_misc[1], 1u)] = d;
+        });
+        __syncthreads();
+        // rank of list[t] = #{smaller} + #{equal with smaller index}; exactly one element has the wanted rank
+        auto pick = [&](const unsigned* list, unsigned cnt, unsigned want, unsigned* out) {
+          if((unsigned) tid < cnt) {
+            const unsigned mine = list[tid];
+            unsigned rk = 0;
+            for(unsigned q = 0; q < cnt; ++q) {
+              const unsigned o = list[q];
+              rk += (o < mine || (o == mine && q < (unsigned) tid)) ? 1u : 0u;
+            }
+            if(rk == want) *out = mine;
+          }
+        };
+        pick(list_lo, n_lo, lo.rank, &cur[0].prefix);
+        if(same_bin) pick(list_lo, n_lo, hi.rank, &cur[1].prefix);
+        else pick(list_hi, n_hi, hi.rank, &cur[1].prefix);
+        __syncthreads();
+        lo.prefix = cur[0].prefix; hi.prefix = cur[1].prefix;     // full offsets d now
+        __syncthreads();
+        remaining = 0;
       }
       const float v_lo = __uint_as_float(lo_key + lo.prefix), v_hi = __uint_as_float(lo_key + hi.prefix);
       median = (nt % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);
