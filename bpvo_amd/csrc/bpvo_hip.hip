@@ -58,6 +58,8 @@ struct Workspace {
   uint8_t* valid = nullptr;
   uint32_t* cand = nullptr;
   uint32_t* med_blk = nullptr;
+  uint32_t* tapkey = nullptr;
+  float* tapcache = nullptr;
   float* partials = nullptr;
   int last_ref = -1, last_cur = -1, last_level = -1;
 };
@@ -263,6 +265,8 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.r = c->ws[ws].r;
   j.valid = c->ws[ws].valid;
   j.cand = c->ws[ws].cand;
+  j.tapkey = c->ws[ws].tapkey;
+  j.tapcache = c->ws[ws].tapcache;
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
@@ -470,6 +474,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.loss = p.lossFunction;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
+    launch_reset_tapkeys(ln->stream, g);
     LANE_CK(ln, hipMemsetAsync(ln->d_active, 0, 2 * sizeof(int), ln->stream));
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues
     // kItersPerSync iterations back to back and only then reads the "workspaces still active" counter: blocks of
@@ -780,6 +785,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
     CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max));
+    if(cp->C == 8) {
+      CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
+      CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 32 * (size_t) cp->cap_max));
+    }
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
@@ -823,7 +832,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipSetDevice(c->device);
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
-  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.partials); }
+  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
@@ -1027,6 +1036,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   launch_prepare_linearize(c->stream, c->d_job1, l0.d_Tinit, reset_scale, level);
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
+  launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g, c->d_counters); }
   { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }

@@ -31,6 +31,7 @@ struct GNLaunch {
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
+void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 void launch_warp_residual(hipStream_t s, const GNLaunch& g);
 void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters /*device [4] or null*/);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);

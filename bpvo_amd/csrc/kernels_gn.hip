@@ -17,6 +17,61 @@ namespace bpvo_hip {
 
 constexpr int GN_BLOCK = 256;
 
+// K7a (fused into warp_residual): bracket counting + candidate compaction for the exact median of the NEXT kernel.
+// The median moves little between GN iterations, so while the residuals are still in registers every block counts its
+// keys (bit patterns of |r| of valid points) below the bracket [lo, hi) around the previous median and compacts the keys
+// inside it.  No global atomics: block b of a workspace owns med_blk[b] = {#below, #inside, #valid points} and the
+// candidate segment cand[b * 256 * C ...]; the in-block compaction is a wave scan + LDS offsets.  All 256 threads of the
+// block must call it.
+template <int C>
+__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, const float (&res)[C])
+{
+  unsigned keys[C];
+  unsigned below = 0, cnt = 0, mask = 0;
+#pragma unroll
+  for(int c = 0; c < C; ++c) {
+    const unsigned k = __float_as_uint(res[c]) & 0x7fffffffu;
+    keys[c] = k;
+    const bool in = v && (k >= lo) && (k < hi);
+    below += (v && k < lo) ? 1u : 0u;
+    cnt += in ? 1u : 0u;
+    mask |= (in ? 1u : 0u) << c;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u;
+#pragma unroll
+  for(int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(incl, o);
+    if(lane >= o) incl += t;
+  }
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) {
+    sum_below += __shfl_down(sum_below, o);
+    sum_valid += __shfl_down(sum_valid, o);
+  }
+  __shared__ unsigned s_in[4], s_below[4], s_valid[4];
+  if(lane == 63) s_in[wave] = incl;
+  if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
+  __syncthreads();
+  unsigned woff = 0;
+  for(int w = 0; w < wave; ++w) woff += s_in[w];
+  if(threadIdx.x == 0) {
+    uint4 o;
+    o.x = s_below[0] + s_below[1] + s_below[2] + s_below[3];
+    o.y = s_in[0] + s_in[1] + s_in[2] + s_in[3];
+    o.z = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
+    o.w = 0;
+    reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
+  }
+  if(cnt) {
+    unsigned* seg = j.cand + (size_t) blockIdx.x * GN_BLOCK * C;
+    unsigned pos = woff + incl - cnt;
+#pragma unroll
+    for(int c = 0; c < C; ++c)
+      if(mask & (1u << c)) seg[pos++] = keys[c];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // K6 warp_residual.  reference: TemplateData::computeResiduals (bpvo/template_data.cc:174-189) =
 //   RigidBodyWarp::setPose (bpvo/rigid_body_warp.h:111-114): P = K * T[0:3,:] in f32, index-order sums
@@ -45,8 +100,11 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
       P[r * 4 + c] = s;
     }
 
-  const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
-  if(i >= n) return;
+  // lanes past the end of the last block redo the last point (loads only) so that the whole block reaches the
+  // block-level bracket step below; their stores are masked
+  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const bool in_block = i_raw < n;
+  const int i = in_block ? i_raw : n - 1;
   const int W = j.cols, R = j.rows;
   const float4 X = j.pts[i];
   const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
@@ -71,7 +129,7 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     yi = (int) y; yi -= (yi > y);
   }
   const bool valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
-  j.valid[i] = valid ? 1 : 0;
+  if(in_block) j.valid[i] = valid ? 1 : 0;
 
   float res[C];
   if(valid) {
@@ -81,11 +139,29 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     const float* __restrict__ d1 = d0 + (size_t) W * C;
     float I00[C], I01[C], I10[C], I11[C], I0[C];
     if constexpr(C == 8) {
-      const float4* q0 = reinterpret_cast<const float4*>(d0);
-      const float4* q1 = reinterpret_cast<const float4*>(d1);
+      // Tap cache: the integer footprint (xi, yi) of a point rarely changes between consecutive GN iterations of a level
+      // (sub-pixel pose updates), and then the four taps are the same 128 bytes.  They are kept per point in a tiled,
+      // fully coalesced buffer keyed by (yi << 16 | xi): a hit replaces the gather — two 64-byte segments that cost
+      // 2.3 128-byte HBM lines on average (profiles/r01_pmc_summary.txt) — by one coalesced 128-byte read.
+      const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+      const bool hit = j.tapkey[i] == key;
+      float4 a0, a1, a2, a3, b0, b1, b2, b3;
+      float4* tc = reinterpret_cast<float4*>(j.tapcache);
+      if(hit) {
+        a0 = tc[tile_index<8>(i, 0)]; a1 = tc[tile_index<8>(i, 1)]; a2 = tc[tile_index<8>(i, 2)]; a3 = tc[tile_index<8>(i, 3)];
+        b0 = tc[tile_index<8>(i, 4)]; b1 = tc[tile_index<8>(i, 5)]; b2 = tc[tile_index<8>(i, 6)]; b3 = tc[tile_index<8>(i, 7)];
+      } else {
+        const float4* q0 = reinterpret_cast<const float4*>(d0);
+        const float4* q1 = reinterpret_cast<const float4*>(d1);
+        a0 = q0[0]; a1 = q0[1]; a2 = q0[2]; a3 = q0[3];
+        b0 = q1[0]; b1 = q1[1]; b2 = q1[2]; b3 = q1[3];
+        if(in_block) {
+          tc[tile_index<8>(i, 0)] = a0; tc[tile_index<8>(i, 1)] = a1; tc[tile_index<8>(i, 2)] = a2; tc[tile_index<8>(i, 3)] = a3;
+          tc[tile_index<8>(i, 4)] = b0; tc[tile_index<8>(i, 5)] = b1; tc[tile_index<8>(i, 6)] = b2; tc[tile_index<8>(i, 7)] = b3;
+          j.tapkey[i] = key;
+        }
+      }
       const float4* p0 = reinterpret_cast<const float4*>(j.pix);
-      const float4 a0 = q0[0], a1 = q0[1], a2 = q0[2], a3 = q0[3];
-      const float4 b0 = q1[0], b1 = q1[1], b2 = q1[2], b3 = q1[3];
       const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
       I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
       I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
@@ -108,13 +184,17 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 #pragma unroll
     for(int c = 0; c < C; ++c) res[c] = 0.0f;
   }
-  if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
-    float4* o = reinterpret_cast<float4*>(j.r);
-    o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
-    o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
-  } else {
-    j.r[i] = res[0];
+  if(in_block) {
+    if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
+      float4* o = reinterpret_cast<float4*>(j.r);
+      o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
+      o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
+    } else {
+      j.r[i] = res[0];
+    }
   }
+  // bracket pass of the exact median (see bracket_block) while the residuals are in registers
+  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -125,10 +205,10 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 // The order statistics x[n/2] (and x[n/2-1] for even n) are EXACT; they are found by MSB radix selection on the bit
 // pattern of |r| (monotone for non-negative floats), with two cursors (lo, hi) refined in lock-step.  Two paths:
 //
-//  bracketed (every linearisation of a level but the first): the median moves little between GN iterations, so K7a
-//    (median_bracket_kernel, chip-wide, one thread per point) only COUNTS the keys below a bracket [lo, hi) around the
-//    previous median and compacts the few keys inside it into a per-workspace candidate list (one atomic per wave);
-//    K7b then selects among the candidates only.  If the wanted ranks fall outside the bracket the full path runs — the
+//  bracketed (every linearisation of a level but the first): the median moves little between GN iterations, so the
+//    bracket step fused into warp_residual (bracket_block) only COUNTS the keys below a bracket [lo, hi) around the
+//    previous median and compacts the few keys inside it into per-block candidate segments; K7b (median_finish_kernel)
+//    then selects among the candidates only.  If the wanted ranks fall outside the bracket the full path runs — the
 //    result is exact either way; the bracket width adapts to the last observed change.
 //  full (first linearisation of a level, bracket miss): 3 passes over all keys, bits [30:20], [19:9], [8:0], one
 //    1024-thread workgroup per workspace with LDS histograms (4 privatised copies in pass 1 to cut same-bin atomic
@@ -260,78 +340,6 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
   __syncthreads();
 }
 
-// K7a: bracket counting + candidate compaction, one thread per template point, chip-wide.  No global atomics: block b of
-// a workspace owns med_blk[b] = {#keys below the bracket, #keys inside, #valid points} and the candidate segment
-// cand[b * 256 * C ...]; the compaction inside the block is a wave scan + LDS offsets.
-template <int C>
-__global__ __launch_bounds__(GN_BLOCK) void median_bracket_kernel(const PairJob* __restrict__ jobs)
-{
-  const PairJob& j = jobs[blockIdx.y];
-  const GNState* __restrict__ st = j.st;
-  if(!st->active || !(st->delta_scale > 1e-6f) || !st->median_valid) return;
-  const int n = j.n;
-  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
-  const unsigned lo = st->lo_key, hi = st->hi_key;
-  const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
-  const bool v = (i < n) && j.valid[i];
-  unsigned keys[C];
-  if constexpr(C == 8) {
-    float4 a = make_float4(0, 0, 0, 0), b = a;
-    if(v) {
-      const float4* q = reinterpret_cast<const float4*>(j.r);
-      a = q[tile_index<2>(i, 0)];
-      b = q[tile_index<2>(i, 1)];
-    }
-    keys[0] = __float_as_uint(a.x); keys[1] = __float_as_uint(a.y); keys[2] = __float_as_uint(a.z); keys[3] = __float_as_uint(a.w);
-    keys[4] = __float_as_uint(b.x); keys[5] = __float_as_uint(b.y); keys[6] = __float_as_uint(b.z); keys[7] = __float_as_uint(b.w);
-  } else {
-    keys[0] = v ? __float_as_uint(j.r[i]) : 0u;
-  }
-  unsigned below = 0, cnt = 0, mask = 0;
-#pragma unroll
-  for(int c = 0; c < C; ++c) {
-    const unsigned k = keys[c] & 0x7fffffffu;
-    keys[c] = k;
-    const bool in = v && (k >= lo) && (k < hi);
-    below += (v && k < lo) ? 1u : 0u;
-    cnt += in ? 1u : 0u;
-    mask |= (in ? 1u : 0u) << c;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u;
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
-  }
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) {
-    sum_below += __shfl_down(sum_below, o);
-    sum_valid += __shfl_down(sum_valid, o);
-  }
-  __shared__ unsigned s_in[4], s_below[4], s_valid[4];
-  if(lane == 63) s_in[wave] = incl;
-  if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
-  __syncthreads();
-  unsigned woff = 0;
-  for(int w = 0; w < wave; ++w) woff += s_in[w];
-  if(threadIdx.x == 0) {
-    uint4 o;
-    o.x = s_below[0] + s_below[1] + s_below[2] + s_below[3];
-    o.y = s_in[0] + s_in[1] + s_in[2] + s_in[3];
-    o.z = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
-    o.w = 0;
-    reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
-  }
-  if(cnt) {
-    unsigned* seg = j.cand + (size_t) blockIdx.x * GN_BLOCK * C;
-    unsigned pos = woff + incl - cnt;
-#pragma unroll
-    for(int c = 0; c < C; ++c)
-      if(mask & (1u << c)) seg[pos++] = keys[c];
-  }
-}
-
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
 template <int C>
 __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, unsigned long long* counters)
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
 
   // ---- bracketed path
   if(st->median_valid) {
-    // totals of the per-block counters written by median_bracket_kernel
+    // totals of the per-block counters written by the bracket step of warp_residual (bracket_block)
     const int nblk = (j.n + GN_BLOCK - 1) / GN_BLOCK;
     unsigned c_below = 0, c_in = 0, c_valid = 0;
     for(int b = tid; b < nblk; b += MED_THREADS) {
@@ -853,6 +861,14 @@ __global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level)
   st->active = (jobs[p].n > 0) ? 1 : 0;
 }
 
+// invalidates the tap cache keys of every workspace of a launch (start of a level / of a linearize call)
+__global__ __launch_bounds__(GN_BLOCK) void reset_tapkeys_kernel(const PairJob* jobs)
+{
+  const PairJob& j = jobs[blockIdx.y];
+  const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
+  if(i < j.n && j.tapkey) j.tapkey[i] = 0xffffffffu;
+}
+
 // operator-level seam (bpvo_hip_linearize): pose in, optional AutoScaleEstimator::reset
 __global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int reset_scale, int level)
 {
@@ -940,6 +956,11 @@ void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int leve
 {
   hipLaunchKernelGGL(level_begin_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, jobs, npairs, level);
 }
+void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
+{
+  if(g.max_points <= 0 || g.C != 8) return;
+  hipLaunchKernelGGL(reset_tapkeys_kernel, dim3((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs), dim3(GN_BLOCK), 0, s, g.jobs);
+}
 void launch_warp_residual(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
@@ -957,14 +978,8 @@ void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counter
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     attr_set = true;
   }
-  const dim3 grid_a((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
-  if(g.C == 1) {
-    hipLaunchKernelGGL(median_bracket_kernel<1>, grid_a, dim3(GN_BLOCK), 0, s, g.jobs);
-    hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
-  } else {
-    hipLaunchKernelGGL(median_bracket_kernel<8>, grid_a, dim3(GN_BLOCK), 0, s, g.jobs);
-    hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
-  }
+  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
+  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
 }
 
 template <int C>

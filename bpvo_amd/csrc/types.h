@@ -75,7 +75,7 @@ struct GNState {
   uint32_t n_valid;                          // valid points of the last linearisation
   int   level;
   // bracketed median selection (kernels_gn.hip K7): bracket [lo_key, hi_key) on the bit pattern of |r| around the
-  // previous median of the level, counters filled by median_bracket_kernel and consumed by median_finish_kernel
+  // previous median of the level, per-block counters filled by warp_residual (bracket_block) and consumed by median_finish_kernel
   float last_median;
   uint32_t lo_key, hi_key;
   int   median_valid;
@@ -98,6 +98,8 @@ struct PairJob {
   // workspace
   float*        r;        // [N][C] residuals, tiled
   uint8_t*      valid;    // [N]
+  uint32_t*     tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 only)
+  float*        tapcache; // [N][32] tiled: the 4 taps x 8 channels of the footprint last gathered for the point
   uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, -} of the bracket pass
   float*        partials; // [nblocks][kPartialStride]
