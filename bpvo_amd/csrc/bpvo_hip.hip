@@ -338,15 +338,17 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
   if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
   if(!images || !disps) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
   const size_t npix = c->geom[0].npix;
-  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  for(int i = 0; i < count; ++i) {
-    FrameSlot& f = c->frames[first + i * stride];
-    HIP_CK(c, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, kind, c->stream));
-    HIP_CK(c, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), kind, c->stream));
+  if(!on_device) {
+    for(int i = 0; i < count; ++i) {
+      FrameSlot& f = c->frames[first + i * stride];
+      HIP_CK(c, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, hipMemcpyHostToDevice, c->stream));
+      HIP_CK(c, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
   }
   int rc = upload_frame_jobs(c, first, stride, count);
   if(rc) return rc;
   const int NF = c->n_frames;
+  if(on_device) launch_ingest(c->stream, c->d_fjobs, images, disps, npix, count);   // one launch instead of 2 copies per frame
   {
     double px = 0;
     for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
@@ -402,28 +404,31 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
     ScopedTimer t(c, KC_NORMALIZATION, 0.0);
     launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, p.withNormalization);
   }
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
-    ScopedTimer t(c, KC_TEMPLATE, 0.0);
-    launch_template_build(c->stream, c->d_fjobs + (size_t) l * NF, c->C, c->geom[l].cap, count, p.gradientEstimation == BPVO_GRAD_CD5);
-  }
-  // one read-back of the point counts (host needs them to size the GN grids)
+  // one read-back of the point counts: the host needs them to size the template-build and GN grids
   for(int i = 0; i < count; ++i)
     HIP_CK(c, hipMemcpyAsync(c->h_ints + (size_t) i * kMaxLevels, c->frames[first + i * stride].n_dev, sizeof(int) * kMaxLevels,
                              hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  HIP_CK(c, hipGetLastError());
-  resolve_events(c);
+  std::vector<int> max_n(c->L, 0);
   for(int i = 0; i < count; ++i) {
     FrameSlot& f = c->frames[first + i * stride];
     double pts = 0;
     for(int l = 0; l < c->L; ++l) {
       f.n_host[l] = (l >= p.maxTestLevel) ? c->h_ints[(size_t) i * kMaxLevels + l] : 0;
+      max_n[l] = std::max(max_n[l], f.n_host[l]);
       pts += f.n_host[l];
     }
     c->kc_units[KC_TEMPLATE] += c->profiling ? pts : 0.0;
     c->kc_units[KC_NORMALIZATION] += c->profiling ? pts : 0.0;
-    f.has_template = true;
   }
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    ScopedTimer t(c, KC_TEMPLATE, 0.0);
+    launch_template_build(c->stream, c->d_fjobs + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5);
+  }
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  HIP_CK(c, hipGetLastError());
+  resolve_events(c);
+  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_template = true;
   return BPVO_OK;
 }
 

@@ -8,6 +8,7 @@
 namespace bpvo_hip {
 
 // per-frame stage (batched over frames)
+void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes);
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);

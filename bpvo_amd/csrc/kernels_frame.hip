@@ -4,6 +4,8 @@
 // HBM layout: the descriptor of a level is PIXEL-INTERLEAVED, desc[(y*W + x)*C + c], so that the C
 // channels of one pixel are one 32-byte record (C = 8): a bilinear gather touches 2 x 64 contiguous bytes instead
 // of 32 scattered dwords, and every kernel below writes/reads full records with 16-byte accesses.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace bpvo_hip {
@@ -15,6 +17,35 @@ __device__ __forceinline__ int reflect101(int p, int len)
   if(p >= len) p = 2 * len - 2 - p;
   if(p < 0) p = 0;   // degenerate len == 1
   return p;
+}
+
+// ---- input ingest: one launch copies the u8 image and f32 disparity of every frame of a batch from a packed device
+// buffer ([frame][rows*cols]) into the frame slots (VisualOdometryFrame::setData's image.copyTo / disparity.copyTo,
+// reference: bpvo/vo_frame.cc:50-51) instead of 2 memcpy calls per frame.
+__global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const uint8_t* images, const float* disps, size_t npix)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const uint8_t* __restrict__ si = images + (size_t) blockIdx.z * npix;
+  const float* __restrict__ sd = disps + (size_t) blockIdx.z * npix;
+  uint8_t* __restrict__ di = const_cast<uint8_t*>(j.img);
+  float* __restrict__ dd = const_cast<float*>(j.disp);
+  const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x, stride = (size_t) gridDim.x * 256;
+  const bool w4 = (npix % 4 == 0) && (((uintptr_t) si | (uintptr_t) di) % 4 == 0);
+  if(w4) {
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(si);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(di);
+    for(size_t k = t; k < npix / 4; k += stride) d4[k] = s4[k];
+  } else {
+    for(size_t k = t; k < npix; k += stride) di[k] = si[k];
+  }
+  const bool f4 = (npix % 4 == 0) && (((uintptr_t) sd | (uintptr_t) dd) % 16 == 0);
+  if(f4) {
+    const float4* s4 = reinterpret_cast<const float4*>(sd);
+    float4* d4 = reinterpret_cast<float4*>(dd);
+    for(size_t k = t; k < npix / 4; k += stride) d4[k] = s4[k];
+  } else {
+    for(size_t k = t; k < npix; k += stride) dd[k] = sd[k];
+  }
 }
 
 // ---- K0: cv::pyrDown u8 (reference call site: bpvo/image_pyramid.cc:49).  [1 4 6 4 1]^2 / 256 with (s + 128) >> 8,
@@ -77,12 +108,13 @@ __global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
 }
 
 // ---- K1b: 8 bit-planes + cv::GaussianBlur 5x5 (reference: bpvo/bitplanes_descriptor.cc:37-57).
-// One 256-thread workgroup produces a 64 x 16 tile of 32-byte pixel records.  The census bytes of the tile + 2-px halo
+// One 256-thread workgroup produces a 64 x 8 tile of 32-byte pixel records.  The census bytes of the tile + 2-px halo
 // (REFLECT_101 on the coordinates) are staged in LDS, the horizontal pass is written to LDS for all 8 planes
-// (20 rows x 64 cols x 8 f32 = 40 KB), the vertical pass streams full records to HBM with two 16-byte stores per pixel.
+// (12 rows x 64 cols x 8 f32 = 24 KB, 6 workgroups per CU), the vertical pass streams full records to HBM with two 16-byte
+// stores per pixel.
 // Arithmetic per plane, f32, no fusing, exactly OpenCV's symmetric 5-tap filters:
 //   row: t = S0*k0 + (S-1 + S+1)*k1 + (S-2 + S+2)*k2        column: s = k0*T0; s += k1*(T+1 + T-1); s += k2*(T+2 + T-2)
-constexpr int BP_TW = 64, BP_TH = 16, BP_HALO = 2;
+constexpr int BP_TW = 64, BP_TH = 8, BP_HALO = 2;
 __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2)
 {
   __shared__ uint8_t s_cen[(BP_TH + 2 * BP_HALO) * (BP_TW + 2 * BP_HALO + 4)];
@@ -460,6 +492,11 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 // ---- host-callable launchers ------------------------------------------------------------------------------------
 static inline dim3 grid2d(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 3) / 4, nz); }
 
+void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes)
+{
+  const int blocks = (int) std::min<size_t>(256, (npix / 4 + 255) / 256);
+  hipLaunchKernelGGL(ingest_kernel, dim3(blocks, 1, nframes), dim3(256), 0, s, jobs_level0, d_images, d_disps, npix);
+}
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {
   hipLaunchKernelGGL(pyrdown_u8_kernel, grid2d(dW, dR, nframes), dim3(256), 0, s, src, dst);
