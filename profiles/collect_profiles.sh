@@ -2,8 +2,8 @@
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'bash profiles/collect_profiles.sh r01'
 # 1. kernel trace + stats of the default bench command (the run bench.py's numbers are compared with);
-# 2. PMC passes (counters in their own runs, --kernel-trace only) on a BOUNDED configuration — 64 pairs, 2 fixed
-#    iterations per level, synthetic pairs rendered without a fork pool (the profiler initialises the GPU before python
+# 2. PMC passes (counters in their own runs, --kernel-trace only) on a BOUNDED configuration — 64 pairs, 20 fixed
+#    iterations per level (22 linearisations: the tap cache of warp_residual is as warm as in the converge-mode bench), synthetic pairs rendered without a fork pool (the profiler initialises the GPU before python
 #    starts, forking afterwards hangs) — each under its own timeout.
 # Raw output goes to gpurun_out/profiles_<tag>/; profiles/summarize.py turns it into the committed summaries.
 set -u
@@ -12,7 +12,8 @@ R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 \
+# (--gen-workers 1: no fork pool under the profiler)
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 \
     > "$O/trace_bench.json" 2> "$O/trace.err"; echo "trace rc=$?"
 export BPVO_HIP_LANES=1
 i=0
@@ -23,7 +24,7 @@ for CNT in "FETCH_SIZE" "WRITE_SIZE" \
            "TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc$i" -- python3 "$R/bench.py" --pairs-per-gpu 64 --fixed-iters 2 \
+  timeout 150 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc$i" -- python3 "$R/bench.py" --pairs-per-gpu 64 --fixed-iters 20 \
       --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --gen-workers 1 > "$O/pmc$i.json" 2> "$O/pmc$i.err"
   echo "pmc$i ($CNT) rc=$?"
 done

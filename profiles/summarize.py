@@ -21,7 +21,7 @@ def db_of(sub):
 db = db_of("trace")
 if db:
     rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0   (durations in us)",
+    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1   (durations in us)",
              "%-100s %8s %14s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
     for r in rows:
         lines.append("%-100s %8d %14.1f %10.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
@@ -48,7 +48,7 @@ for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
         if "bpvo_hip" not in k:
             continue
         per.setdefault(k, {})[c] = dict(launches=n, avg=v, avg_duration_ns=dur)
-lines = ["PMC averages per launch; bounded config: bench.py --pairs-per-gpu 64 --fixed-iters 2 --steps 1 (all pairs active in",
+lines = ["PMC averages per launch; bounded config: bench.py --pairs-per-gpu 64 --fixed-iters 20 --steps 1 (all pairs active in",
          "every launch: 64 x mean N = points per launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them."]
 for k in sorted(per):
     lines.append("")
