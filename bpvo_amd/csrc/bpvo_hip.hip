@@ -1113,11 +1113,22 @@ int bpvo_hip_fraction_good(bpvo_hip_ctx* c, int ws, float threshold, float* frac
   return fraction_good(c, ws, threshold, frac);
 }
 
+// TemplateData::computeResiduals throws on an empty template (reference: bpvo/template_data.cc:177).  The single-pair entry
+// points mirror that; the batch entry points skip such levels of the affected pair (its statistics keep kSolverError).
+static int check_template_not_empty(bpvo_hip_ctx* c, int ref_slot)
+{
+  if(ref_slot < 0 || ref_slot >= c->n_frames || !c->frames[ref_slot].has_template) return BPVO_OK;   // reported elsewhere
+  for(int l = c->params.maxTestLevel; l < c->L; ++l)
+    if(c->frames[ref_slot].n_host[l] <= 0) return fail(c, BPVO_ERR_NO_TEMPLATE, "you should call setData before calling computeResiduals");
+  return BPVO_OK;
+}
+
 int bpvo_hip_estimate_pose(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, const float T_init[16], float T_est[16],
                            bpvo_hip_stats* stats)
 {
   CHECK_CTX(c); CHECK_WS(c, ws);
   if(!T_init || !T_est) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr pose");
+  if(int rc = check_template_not_empty(c, ref_slot)) return rc;
   (void) hipSetDevice(c->device);
   return estimate_batch(c, 1, &ws, &ref_slot, &cur_slot, T_init, T_est, stats);
 }
@@ -1216,6 +1227,8 @@ int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* dispa
 
   M44 T_est;
   const int ws0 = 0;
+  rc = check_template_not_empty(c, c->vo_ref);
+  if(rc) return rc;
   rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, c->T_kf.m, T_est.m, ret->optimizerStatistics);
   if(rc) return rc;
   int reason = BPVO_KF_NO_KEYFRAMING;

@@ -945,7 +945,8 @@ __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* re
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
-int gn_pts_per_block(int npairs) { return npairs >= 8 ? 1024 : 256; }
+// fixed, so that a pair's block partials (and hence its rounding) do not depend on the size of the batch it is in
+int gn_pts_per_block(int /*npairs*/) { return 512; }
 int gn_num_blocks(int max_points) { return (max_points + 255) / 256; }   // upper bound for any pts_per_block >= 256
 
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)

@@ -286,3 +286,104 @@ def test_batch_matches_single_and_records(hip, orc):
     # packed records that the RCCL gather moves
     ptr, nf = ctx.batch_result_records_device()
     assert nf == 32 and ptr
+
+
+def test_config1_vo_perf_plumbing_two_frames(hip, orc):
+    """BASELINE.json configs[0]: 640x480, Intensity, 1 pyramid level, L2 loss, two addFrame calls (apps/vo_perf.cc loop)."""
+    rows, cols = 480, 640
+    d = synth.make_pair(rows, cols, 0)
+    out = []
+    for b in (hip, orc):
+        p = make_params(b, descriptor="intensity", loss="l2", levels=1)
+        ctx = b.create(d["K"], d["b"], rows, cols, p, n_frames=3, n_pairs=1)
+        r0 = ctx.add_frame(d["imgA"], d["dispA"])
+        r1 = ctx.add_frame(d["imgB"], d["dispB"])
+        out.append((r0, r1, ctx.vo_num_points_at_level(0)))
+    (h0, h1, nh), (o0, o1, no_) = out
+    assert nh == no_ and nh > 0
+    assert h0["keyFramingReason"] == o0["keyFramingReason"] == capi.KF_FIRST_FRAME
+    assert h1["keyFramingReason"] == o1["keyFramingReason"]
+    assert h1["stats"][0]["numIterations"] == o1["stats"][0]["numIterations"]
+    rot, trans = pose_error(h1["pose"], o1["pose"])
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+@pytest.mark.parametrize("descriptor", ["intensity", "bitplanes"])
+def test_cd5_gradients_bit_exact(hip, orc, descriptor):
+    """kCentralDifference_5 (bpvo/template_data.cc:123-130): Jacobians bit-exact, pose within the bar."""
+    rows, cols, levels = 120, 160, 3
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, gradientEstimation=capi.GRAD_CD5)
+    for l in range(levels):
+        assert bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l)), f"CD5 jacobians level {l}"
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"])
+
+
+def test_no_nms_and_no_normalization_variants(hip, orc):
+    rows, cols, levels = 120, 160, 2
+    for kw in (dict(nonMaxSuppRadius=0), dict(withNormalization=0), dict(nonMaxSuppRadius=2, minNumPixelsForNonMaximaSuppression=100),
+               dict(maxTestLevel=1), dict(minSaliency=0.6)):
+        ch, co, d = both(hip, orc, rows, cols, levels, descriptor="bitplanes", **kw)
+        first = kw.get("maxTestLevel", 0)
+        for l in range(first, levels):
+            assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l)), (kw, l)
+            assert bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l)), (kw, l)
+        Th, sh = ch.estimate_pose(0, 0, 1)
+        To, so = co.estimate_pose(0, 0, 1)
+        rot, trans = pose_error(Th, To)
+        assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (kw, rot, trans)
+        assert [s["status"] for s in sh][:first] == [capi.STATUS_SOLVER_ERROR] * first      # untouched levels keep the default stats
+
+
+def test_empty_template_errors_like_the_reference(hip, orc):
+    """No pixel passes the saliency gate -> N = 0 -> computeResiduals throws (bpvo/template_data.cc:177)."""
+    for b in (hip, orc):
+        ctx, d, _ = setup_pair(b, 120, 160, levels=2, descriptor="bitplanes", minSaliency=50.0)
+        assert ctx.num_points(0, 0) == 0 and ctx.num_points(0, 1) == 0
+        with pytest.raises(capi.BpvoError):
+            ctx.estimate_pose(0, 0, 1)
+    # the batch entry point keeps going: the affected pair reports kSolverError and an unchanged pose
+    batch = synth.make_batch(120, 160, 2, first_index=3)
+    p = make_params(hip, levels=2, descriptor="bitplanes", minSaliency=50.0)
+    ctx = hip.create(batch["K"], batch["b"], 120, 160, p, n_frames=4, n_pairs=2)
+    poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
+    assert np.array_equal(poses[0], np.eye(4, dtype=np.float32)) and (stats["status"] == capi.STATUS_SOLVER_ERROR).all()
+
+
+def test_full_size_batch_properties(hip):
+    """Config 5 shape at full image size (a 24-pair shard of the 1024-pair KITTI batch): size-independent properties —
+    determinism, independence of the pairs from batch composition / order, result records = poses, sane accuracy."""
+    rows, cols, levels, n = 376, 1241, 4, 24
+    batch = synth.make_batch(rows, cols, n, first_index=100, workers=8)
+    p = make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels)
+    ctx = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
+    poses2, stats2 = ctx.batch_run(batch["images"], batch["disparities"])
+    assert np.array_equal(poses, poses2) and np.array_equal(stats["numIterations"], stats2["numIterations"])   # deterministic
+    # reversed pair order in a second context: every pair's result is unchanged bit for bit
+    perm = np.arange(n)[::-1]
+    idx = np.stack([2 * perm, 2 * perm + 1], axis=1).reshape(-1)
+    ctx_r = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    poses_r, stats_r = ctx_r.batch_run(batch["images"][idx], batch["disparities"][idx])
+    assert np.array_equal(poses_r[::-1], poses)
+    assert np.array_equal(stats_r["numIterations"][::-1], stats["numIterations"])
+    # a sub-batch gives the same results as the same pairs inside the big batch
+    ctx_s = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=8, n_pairs=4)
+    poses_s, _ = ctx_s.batch_run(batch["images"][:8], batch["disparities"][:8])
+    assert np.array_equal(poses_s, poses[:4])
+    # rigid transforms, bounded iterations, accuracy against the scene's ground truth
+    R = poses[:, :3, :3].astype(np.float64)
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+    assert np.array_equal(poses[:, 3], np.tile(np.array([0, 0, 0, 1], np.float32), (n, 1)))
+    assert stats["numIterations"].max() <= 50 and stats["numIterations"].min() >= 0
+    dt = np.linalg.norm(poses[:, :3, 3] - batch["T_gt"][:, :3, 3], axis=1)
+    assert np.median(dt) < 5e-3 and dt.max() < 5e-2, (np.median(dt), dt.max())
+    # the packed records on the device are the poses
+    import torch
+    from bpvo_amd.distributed import records_to_poses
+    rec = torch.zeros((n, 32), dtype=torch.float32, device="cuda:0")
+    ctx.batch_copy_records_device(rec.data_ptr(), n)
+    rp, it, _ = records_to_poses(rec)
+    assert np.array_equal(rp[:, :3, :], poses[:, :3, :]) and np.array_equal(it[:, :levels], stats["numIterations"])
