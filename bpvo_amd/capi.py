@@ -130,6 +130,10 @@ class Context:
     def call(self, name, *args):
         self._ck(self.b.fn(name)(self.h, *args))
 
+    def set_warp_formulation(self, mode):
+        """0 = PhotoError f64 (active reference path, default), 1 = projectPoints / BilinearInterp all-f32 formulation."""
+        self.call("set_warp_formulation", int(mode))
+
     # -- geometry
     def level_size(self, level):
         r, c = C.c_int(), C.c_int()

@@ -123,6 +123,7 @@ struct bpvo_hip_ctx {
   std::vector<bpvo_hip_point_with_info> cloud;
   M44 cloud_pose;
   // measurement
+  int fast_warp = 0;           // bpvo_hip_set_warp_formulation
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
   double kc_ms[KC_COUNT] = {};
@@ -477,6 +478,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.max_points = max_pts[l];
     g.C = c->C;
     g.loss = p.lossFunction;
+    g.fast_warp = c->fast_warp;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
@@ -1041,6 +1043,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   launch_prepare_linearize(c->stream, c->d_job1, l0.d_Tinit, reset_scale, level);
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
+  g.fast_warp = c->fast_warp;
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g, c->d_counters); }
@@ -1120,6 +1123,14 @@ static int check_template_not_empty(bpvo_hip_ctx* c, int ref_slot)
   if(ref_slot < 0 || ref_slot >= c->n_frames || !c->frames[ref_slot].has_template) return BPVO_OK;   // reported elsewhere
   for(int l = c->params.maxTestLevel; l < c->L; ++l)
     if(c->frames[ref_slot].n_host[l] <= 0) return fail(c, BPVO_ERR_NO_TEMPLATE, "you should call setData before calling computeResiduals");
+  return BPVO_OK;
+}
+
+int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* c, int mode)
+{
+  CHECK_CTX(c);
+  if(mode != BPVO_WARP_PHOTO_ERROR_F64 && mode != BPVO_WARP_PROJECT_POINTS_F32) return fail(c, BPVO_ERR_INVALID_ARG, "unknown warp formulation");
+  c->fast_warp = (mode == BPVO_WARP_PROJECT_POINTS_F32) ? 1 : 0;
   return BPVO_OK;
 }
 

@@ -28,6 +28,7 @@ struct GNLaunch {
   int max_points;        // max n over the pairs (grid sizing)
   int C;
   int loss;
+  int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);

@@ -80,7 +80,13 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
 //   PhotoError::Impl::run kLinear (bpvo/photo_error.cc:365-389,446-449): Iw in f64, r = float(Iw - I0); invalid -> 0
 // One thread per template point; all C channels of the point are handled by the same thread because the descriptor is
 // pixel-interleaved: the 4 taps are 2 x (2*C floats) contiguous, fetched as 16-byte loads.
-template <int C>
+// FAST selects the reference's alternative all-f32 formulation (inactive there, PHOTO_ERROR_OPT = 0): projectPoints
+// (bpvo/project_points.cc:180-214: x = P*X in f32, w = 1.0f/x2, xi = (int) xf — truncation, not floor — valid =
+// 0 <= xi < W-1 && 0 <= yi < R-1, coefficients C = [xf*yf - yf - xf + 1, xf - xf*yf, yf - xf*yf, xf*yf]) followed by
+// PhotoError::Impl::operator() / run of that branch (bpvo/photo_error.cc:118-214; same arithmetic as BilinearInterp,
+// bpvo/interp_util.h:49-71,93-96,184-203): Iw = dp_ps(C, [I00, I01, I10, I11]) = (C0*I00 + C1*I01) + (C2*I10 + C3*I11),
+// r = Iw - I0, and for an invalid point Iw = 0, i.e. r = -I0.
+template <int C, bool FAST>
 __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs)
 {
   const PairJob& j = jobs[blockIdx.y];
@@ -107,33 +113,56 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
   const int i = in_block ? i_raw : n - 1;
   const int W = j.cols, R = j.rows;
   const float4 X = j.pts[i];
-  const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
-  double u[3];
-#pragma unroll
-  for(int r = 0; r < 3; ++r) {
-    double s = (double) P[r * 4 + 0] * X0;
-    s += (double) P[r * 4 + 1] * X1;
-    s += (double) P[r * 4 + 2] * X2;
-    s += (double) P[r * 4 + 3] * X3;
-    u[r] = s;
-  }
-  const double zi = 1.0 / u[2];
-  const double x = zi * u[0], y = zi * u[1];
-
-  // Floor(): static_cast<int> then -(i > v).  x86 yields INT_MIN for NaN / out-of-range doubles, which can never be a
-  // valid pixel; the explicit range test gives the same verdict without relying on v_cvt_i32_f64 saturation.
-  const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
   int xi = 0, yi = 0;
-  if(in_range) {
-    xi = (int) x; xi -= (xi > x);
-    yi = (int) y; yi -= (yi > y);
+  bool valid;
+  double xf = 0.0, yf = 0.0;       // fractional parts (standard formulation)
+  float cf[4] = {0, 0, 0, 0};      // interpolation coefficients (FAST formulation)
+  if constexpr(!FAST) {
+    const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
+    double u[3];
+#pragma unroll
+    for(int r = 0; r < 3; ++r) {
+      double s = (double) P[r * 4 + 0] * X0;
+      s += (double) P[r * 4 + 1] * X1;
+      s += (double) P[r * 4 + 2] * X2;
+      s += (double) P[r * 4 + 3] * X3;
+      u[r] = s;
+    }
+    const double zi = 1.0 / u[2];
+    const double x = zi * u[0], y = zi * u[1];
+    // Floor(): static_cast<int> then -(i > v).  x86 yields INT_MIN for NaN / out-of-range doubles, which can never be a
+    // valid pixel; the explicit range test gives the same verdict without relying on v_cvt_i32_f64 saturation.
+    const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+    if(in_range) {
+      xi = (int) x; xi -= (xi > x);
+      yi = (int) y; yi -= (yi > y);
+    }
+    valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+    xf = x - (double) xi; yf = y - (double) yi;
+  } else {
+    float u[3];
+#pragma unroll
+    for(int r = 0; r < 3; ++r) {
+      float s = P[r * 4 + 0] * X.x;
+      s += P[r * 4 + 1] * X.y;
+      s += P[r * 4 + 2] * X.z;
+      s += P[r * 4 + 3] * X.w;
+      u[r] = s;
+    }
+    const float w_i = 1.0f / u[2];
+    float fx = w_i * u[0], fy = w_i * u[1];
+    // (int) xf: cvttss2si gives INT_MIN for NaN / out-of-range, never a valid pixel
+    const bool in_range = (fx > -2147483648.0f) && (fx < 2147483648.0f) && (fy > -2147483648.0f) && (fy < 2147483648.0f);
+    if(in_range) { xi = (int) fx; yi = (int) fy; }
+    valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+    fx -= (float) xi; fy -= (float) yi;
+    const float xfyf = fx * fy;
+    cf[0] = xfyf - fy - fx + 1.0f; cf[1] = fx - xfyf; cf[2] = fy - xfyf; cf[3] = xfyf;
   }
-  const bool valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
   if(in_block) j.valid[i] = valid ? 1 : 0;
 
   float res[C];
   if(valid) {
-    const double xf = x - (double) xi, yf = y - (double) yi;
     const double wx = 1.0 - xf, wy = 1.0 - yf;
     const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
     const float* __restrict__ d1 = d0 + (size_t) W * C;
@@ -177,12 +206,28 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     }
 #pragma unroll
     for(int c = 0; c < C; ++c) {
-      const double Iw = wy * ((double) I00[c] * wx + (double) I01[c] * xf) + yf * ((double) I10[c] * wx + (double) I11[c] * xf);
-      res[c] = (float) (Iw - (double) I0[c]);
+      if constexpr(!FAST) {
+        const double Iw = wy * ((double) I00[c] * wx + (double) I01[c] * xf) + yf * ((double) I10[c] * wx + (double) I11[c] * xf);
+        res[c] = (float) (Iw - (double) I0[c]);
+      } else {
+        const float Iw = (cf[0] * I00[c] + cf[1] * I01[c]) + (cf[2] * I10[c] + cf[3] * I11[c]);
+        res[c] = Iw - I0[c];
+      }
     }
   } else {
+    if constexpr(!FAST) {
 #pragma unroll
-    for(int c = 0; c < C; ++c) res[c] = 0.0f;
+      for(int c = 0; c < C; ++c) res[c] = 0.0f;
+    } else {   // operator() returns 0 for an invalid point and run() still subtracts I0 (photo_error.cc:203-210)
+      if constexpr(C == 8) {
+        const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+        const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
+        res[0] = 0.0f - t0.x; res[1] = 0.0f - t0.y; res[2] = 0.0f - t0.z; res[3] = 0.0f - t0.w;
+        res[4] = 0.0f - t1.x; res[5] = 0.0f - t1.y; res[6] = 0.0f - t1.z; res[7] = 0.0f - t1.w;
+      } else {
+        res[0] = 0.0f - j.pix[i];
+      }
+    }
   }
   if(in_block) {
     if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
@@ -966,8 +1011,13 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
-  if(g.C == 1) hipLaunchKernelGGL(warp_residual_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs);
-  else hipLaunchKernelGGL(warp_residual_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs);
+  if(g.fast_warp) {
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+  } else {
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+  }
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
 void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters)

@@ -179,6 +179,15 @@ int bpvo_hip_get_valid(bpvo_hip_ctx* ctx, int ws, uint16_t* v /*[N]*/, size_t* n
 int bpvo_hip_get_weights(bpvo_hip_ctx* ctx, int ws, float* w /*[C*N]*/, size_t* n);          /* vo_pose_estimator.cc:95-99 */
 int bpvo_hip_fraction_good(bpvo_hip_ctx* ctx, int ws, float threshold, float* frac);         /* vo_pose_estimator.cc:101-107 */
 
+/* Selects how template points are warped and interpolated (both formulations exist in the reference):
+ *   BPVO_WARP_PHOTO_ERROR_F64 (default) — the ACTIVE reference path: PhotoError "standard" branch, projection and bilinear
+ *       interpolation in double, Floor(), invalid -> r = 0 (bpvo/photo_error.cc:336-459);
+ *   BPVO_WARP_PROJECT_POINTS_F32 — the inactive all-float path (PHOTO_ERROR_OPT): projectPoints + interpolation
+ *       coefficients + dot product (bpvo/project_points.cc:180-214, bpvo/photo_error.cc:82-214, bpvo/interp_util.h:49-71):
+ *       (int) truncation, C = [(1-xf)(1-yf), xf(1-yf), (1-xf)yf, xf*yf] in its expanded form, invalid -> r = -I0. */
+enum { BPVO_WARP_PHOTO_ERROR_F64 = 0, BPVO_WARP_PROJECT_POINTS_F32 = 1 };
+int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* ctx, int mode);
+
 /* ---- VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93):
  * coarse-to-fine PoseEstimatorGN::run (pose_estimator_base.h:324-407). stats[numLevels]. */
 int bpvo_hip_estimate_pose(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, const float T_init[16],

@@ -96,6 +96,16 @@ int bpvo_orc_set_num_threads(bpvo_orc_ctx* c, int n)
   return 0;
 }
 
+int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* c, int mode)
+{
+  if(mode != 0 && mode != 1) return fail(c, "unknown warp formulation");
+  for(auto& f : c->frames)
+    for(auto& td : f->tdata) td.fast_warp = mode;
+  for(Frame* f : {c->vo.ref.get(), c->vo.cur.get(), c->vo.prev.get()})
+    for(auto& td : f->tdata) td.fast_warp = mode;
+  return 0;
+}
+
 int bpvo_orc_num_levels(const bpvo_orc_ctx* c) { return c->params.numPyramidLevels; }
 int bpvo_orc_num_channels(const bpvo_orc_ctx* c) { return c->params.descriptor == kBitPlanes ? 8 : 1; }
 int bpvo_orc_level_size(const bpvo_orc_ctx* c, int level, int* rows, int* cols)

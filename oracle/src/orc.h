@@ -104,6 +104,7 @@ struct TemplateData {
   std::vector<float> jacobians;   // [C*N][6] (+ the reference's zero pad is not materialised, Q10)
   std::vector<float> saliency;    // kept for parity inspection
   int numChannels = 0;
+  int fast_warp = 0;              // 1: projectPoints / BilinearInterp all-f32 formulation (PHOTO_ERROR_OPT branch)
   int numPoints() const { return (int)(points.size() / 4); }
   void setData(const Descriptor& desc, const float* D, int Dcols);        // template_data.cc:37-142
   // template_data.cc:174-189 + photo_error.cc:344-451 (standard branch)

@@ -101,6 +101,57 @@ void TemplateData::computeResiduals(const Descriptor& desc, const M44& pose, std
   valid.resize(N);
   residuals.resize(pixels.size());
 
+  if(fast_warp) {
+    // The reference's inactive all-float branch (PHOTO_ERROR_OPT): PhotoError::Impl::init -> projectPoints scalar form
+    // (bpvo/project_points.cc:180-214), run / operator() (bpvo/photo_error.cc:118-214), dot = _mm_dp_ps(.., 0xff)
+    // = (a0*b0 + a1*b1) + (a2*b2 + a3*b3); load order (p[0], p[1], p[stride], p[stride+1]).
+    const int rows = desc.rows, cols = desc.cols;
+    const int max_rows = rows - 1, max_cols = cols - 1;
+    std::vector<int> inds_w(N);
+    std::vector<float> Cc(4 * (size_t) N);
+    for(int i = 0; i < N; ++i) {
+      const float* X = points.data() + 4 * (size_t) i;
+      float x[3];
+      for(int r = 0; r < 3; ++r) {
+        float s = warp.P[r * 4 + 0] * X[0];
+        s += warp.P[r * 4 + 1] * X[1];
+        s += warp.P[r * 4 + 2] * X[2];
+        s += warp.P[r * 4 + 3] * X[3];
+        x[r] = s;
+      }
+      const float w_i = 1.0f / x[2];
+      float xf = w_i * x[0], yf = w_i * x[1];
+      // (int) of a float that does not fit is UB in C++; cvttss2si returns INT_MIN, restated explicitly
+      const bool in_range = (xf > -2147483648.0f) && (xf < 2147483648.0f) && (yf > -2147483648.0f) && (yf < 2147483648.0f);
+      const int xi = in_range ? (int) xf : INT32_MIN, yi = in_range ? (int) yf : INT32_MIN;
+      valid[i] = (uint16_t) (xi >= 0 && xi < max_cols && yi >= 0 && yi < max_rows);
+      inds_w[i] = valid[i] ? yi * cols + xi : 0;
+      xf -= (float) xi;
+      yf -= (float) yi;
+      const float xfyf = xf * yf;
+      Cc[4 * i + 0] = xfyf - yf - xf + 1.0f;
+      Cc[4 * i + 1] = xf - xfyf;
+      Cc[4 * i + 2] = yf - xfyf;
+      Cc[4 * i + 3] = xfyf;
+    }
+    const int C = desc.numChannels();
+    for(int c = 0; c < C; ++c) {
+      const float* I0_ptr = pixels.data() + (size_t) c * N;
+      const float* I1_ptr = desc.ch[c].data();
+      float* r_ptr = residuals.data() + (size_t) c * N;
+      for(int i = 0; i < N; ++i) {
+        float Iw = 0.0f;
+        if(valid[i]) {
+          const float* p = I1_ptr + inds_w[i];
+          const float* k = Cc.data() + 4 * (size_t) i;
+          Iw = (k[0] * p[0] + k[1] * p[1]) + (k[2] * p[cols] + k[3] * p[cols + 1]);
+        }
+        r_ptr[i] = Iw - I0_ptr[i];
+      }
+    }
+    return;
+  }
+
   const int rows = desc.rows, cols = desc.cols;
   const int border_lo = 0, border_hi = 1;                                // kLinear (photo_error.cc:347-348)
   double P[12];

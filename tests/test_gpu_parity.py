@@ -387,3 +387,37 @@ def test_full_size_batch_properties(hip):
     ctx.batch_copy_records_device(rec.data_ptr(), n)
     rp, it, _ = records_to_poses(rec)
     assert np.array_equal(rp[:, :3, :], poses[:, :3, :]) and np.array_equal(it[:, :levels], stats["numIterations"])
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("descriptor,loss", [("intensity", "huber"), ("bitplanes", "tukey")])
+def test_project_points_f32_formulation_parity(hip, orc, rows, cols, levels, descriptor, loss):
+    """The reference's inactive all-float warp (projectPoints + interpolation coefficients + dot product,
+    bpvo/project_points.cc:180-214, bpvo/photo_error.cc:82-214) as an optional mode: bit-exact against its restatement."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss=loss)
+    ch.set_warp_formulation(1)
+    co.set_warp_formulation(1)
+    for l in range(levels):
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(1.0), _perturbed_pose(8.0)):
+            a = ch.linearize(0, 0, 1, l, T)
+            b = co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo)
+            assert bits_equal(ch.get_residuals(0), co.get_residuals(0)), f"residuals level {l}"
+            assert a["sigma"] == b["sigma"] and a["num_valid"] == b["num_valid"]
+            assert bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, ch.Cn)
+            assert np.abs(a["H"] - H64).max() <= 4e-6 * np.abs(H64).max()
+    r = co.get_residuals(0).reshape(ch.Cn, -1)
+    inv = co.get_valid(0) == 0
+    if inv.any():   # invalid points carry r = -I0 in this formulation
+        assert np.array_equal(r[:, inv], -co.get_pixels(0, levels - 1)[:, inv])
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+    # and it agrees with the active f64 formulation up to float rounding
+    ch.set_warp_formulation(0)
+    T0, _ = ch.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, T0)
+    assert rot <= 5e-4 and trans <= 5 * trans_tol(d["K"]), (rot, trans)

@@ -322,3 +322,21 @@ def test_visual_odometry_sequence_cpu(orc):
         rot, trans = pose_error(res[k]["pose"], gt)
         assert rot < 5e-3 and trans < 5e-2, (k, rot, trans)
     assert ctx.add_frame_null() != 0
+
+
+def test_f32_formulation_close_to_f64_formulation(orc):
+    """projectPoints/BilinearInterp (all float, truncation) vs PhotoError (double, floor): same residuals up to rounding on
+    points that are valid in both; differences only in the handling of invalid points and of x in (-1, 0)."""
+    ctx, d, _ = setup_pair(orc, 96, 128, descriptor="bitplanes", levels=2)
+    T = synth.twist_to_matrix([0.004, -0.003, 0.002, 0.02, -0.015, 0.03]).astype(np.float32)
+    ctx.linearize(0, 0, 1, 0, T)
+    v64, r64 = ctx.get_valid(0).astype(bool), ctx.get_residuals(0).reshape(8, -1)
+    ctx.set_warp_formulation(1)
+    ctx.linearize(0, 0, 1, 0, T)
+    v32, r32 = ctx.get_valid(0).astype(bool), ctx.get_residuals(0).reshape(8, -1)
+    both_valid = v64 & v32
+    assert both_valid.sum() > 0.9 * len(v64)
+    assert (v64 != v32).sum() <= 0.01 * len(v64)
+    assert np.abs(r64[:, both_valid] - r32[:, both_valid]).max() < 2e-4
+    pix = ctx.get_pixels(0, 0)
+    assert np.array_equal(r32[:, ~v32], -pix[:, ~v32]) and np.all(r64[:, ~v64] == 0)
