@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events at all")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel (diagnostics, slower)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test only: every rank uses GPU 0 (needs --dist-backend gloo)")
     return ap.parse_args()
 
 
@@ -123,14 +127,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where collective tensors live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     hip = bpvo_amd.load()
     p = make_params(hip, args)
-    ctx = hip.create(batch["K"], batch["b"], args.rows, args.cols, p, device=local_rank, n_frames=2 * P, n_pairs=P)
+    ctx = hip.create(batch["K"], batch["b"], args.rows, args.cols, p, device=dev_index, n_frames=2 * P, n_pairs=P)
 
     d_images = torch.from_numpy(batch["images"]).to(dev)
     d_disps = torch.from_numpy(batch["disparities"]).to(dev)
@@ -142,7 +151,7 @@ def main():
         gathered = None
         if world > 1:
             ctx.batch_copy_records_device(d_records.data_ptr(), P)
-            gathered = gather_records(d_records, dst=0)
+            gathered = gather_records(d_records if coll_dev.type == "cuda" else d_records.cpu(), dst=0)
         return poses, stats, gathered
 
     def sync_all():
@@ -166,7 +175,7 @@ def main():
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
     points_linearized = all_kstats["warp_residual"]["units"]     # device-side count: sum over linearisations of N
     kstats = all_kstats if not args.no_profile else {}
-    t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
