@@ -479,6 +479,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.C = c->C;
     g.loss = p.lossFunction;
     g.fast_warp = c->fast_warp;
+    g.interp = p.interp;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
@@ -733,7 +734,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
   if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES)
     return unsupported("descriptor: only Intensity and BitPlanes are on the device path");
-  if(c->params.interp != BPVO_INTERP_LINEAR) return unsupported("interp: only kLinear is on the device path");
+  if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
   if(c->params.descriptor == BPVO_DESC_BITPLANES && c->params.sigmaPriorToCensusTransform > 0.0f)
     return unsupported("sigmaPriorToCensusTransform > 0 (OpenCV-version-dependent u8 blur) is not on the device path");
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
@@ -1044,6 +1045,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   g.fast_warp = c->fast_warp;
+  g.interp = c->params.interp;
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g, c->d_counters); }
@@ -1130,6 +1132,8 @@ int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* c, int mode)
 {
   CHECK_CTX(c);
   if(mode != BPVO_WARP_PHOTO_ERROR_F64 && mode != BPVO_WARP_PROJECT_POINTS_F32) return fail(c, BPVO_ERR_INVALID_ARG, "unknown warp formulation");
+  if(mode == BPVO_WARP_PROJECT_POINTS_F32 && c->params.interp != BPVO_INTERP_LINEAR)
+    return fail(c, BPVO_ERR_UNSUPPORTED, "the projectPoints f32 formulation is kLinear only (bpvo/photo_error.cc:118-214)");
   c->fast_warp = (mode == BPVO_WARP_PROJECT_POINTS_F32) ? 1 : 0;
   return BPVO_OK;
 }

@@ -28,6 +28,7 @@ struct GNLaunch {
   int max_points;        // max n over the pairs (grid sizing)
   int C;
   int loss;
+  int interp = 0;        // BPVO_INTERP_* (kLinear uses the tap-cached kernel, the others warp_residual_interp_kernel)
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
 };
 int  gn_num_blocks(int max_points);

@@ -243,6 +243,158 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// K6' warp_residual for the other interpolation types of the standard PhotoError branch (bpvo/photo_error.cc:391-444):
+// kCosine (2 x 2 taps, f32 coefficients from a double cosine), kCubic (4 x 4 taps, OpenCV-style cubic with A = -0.5)
+// and kCubicHermite (4 x 4 taps, Bourke's Hermite form, bias = tension = 0).  The projection, Floor and the validity
+// test are the f64 ones of kLinear with (border_lo, border_hi) = (0, 1) for kCosine and (1, 3) for the cubic ones
+// (:347-348); the interpolation itself is f32.  The 4-tap forms read columns xi .. xi+3 and rows yi-1 .. yi+2 exactly as
+// the reference addresses them; row yi+2 can be one past the image there (yi < rows-1 is all `valid` guarantees) —
+// that row index is clamped to rows-1 here and in the oracle (Q21).  No tap cache: these are operator variants, not the
+// benchmarked configuration; the taps are gathered straight from the pixel-interleaved descriptor.
+__device__ __forceinline__ void interp_cosine(float x, float (&c)[2])
+{
+  const double m = (1.0 - cos((double) x * 3.14159265358979323846)) / 2.0;
+  c[0] = (float) (1.0 - m);
+  c[1] = (float) m;
+}
+__device__ __forceinline__ void interp_cubic(float x, float (&c)[4])
+{
+  const float A = -0.5f;
+  c[0] = ((A * (x + 1.0f) - 5.0f * A) * (x + 1.0f) + 8.0f * A) * (x + 1.0f) - 4.0f * A;
+  c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  c[2] = ((A + 2.0f) * (1.0f - x) - (A + 3.0f)) * (1.0f - x) * (1.0f - x) + 1.0f;
+  c[3] = 1.0f - c[0] - c[1] - c[2];
+}
+__device__ __forceinline__ float interp_hermite(float y0, float y1, float y2, float y3, float mu)
+{
+  const float mu2 = mu * mu;
+  const float mu3 = mu * mu2;
+  const float m0 = (float) (((double) (y1 - y0) / 2.0) + ((double) (y2 - y1) / 2.0));
+  const float m1 = (float) (((double) (y2 - y1) / 2.0) + ((double) (y3 - y2) / 2.0));
+  const float a0 = 2 * mu3 - 3 * mu2 + 1;
+  const float a1 = mu3 - 2 * mu2 + mu;
+  const float a2 = mu3 - mu2;
+  const float a3 = -2 * mu3 + 3 * mu2;
+  return a0 * y1 + a1 * m0 + a2 * m1 + a3 * y2;
+}
+// Eigen 3.2 fixed 4-float dot: one packet product reduced with haddps twice -> (a0 + a1) + (a2 + a3)
+__device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, const float (&b)[4])
+{
+  return (a0 * b[0] + a1 * b[1]) + (a2 * b[2] + a3 * b[3]);
+}
+
+template <int C>
+__global__ __launch_bounds__(GN_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, int interp)
+{
+  const PairJob& j = jobs[blockIdx.y];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active) return;
+  const int n = j.n;
+  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+
+  float P[12];
+#pragma unroll
+  for(int r = 0; r < 3; ++r)
+#pragma unroll
+    for(int c = 0; c < 4; ++c) {
+      float s = j.K[r * 3 + 0] * st->T[0 * 4 + c];
+      s += j.K[r * 3 + 1] * st->T[1 * 4 + c];
+      s += j.K[r * 3 + 2] * st->T[2 * 4 + c];
+      P[r * 4 + c] = s;
+    }
+
+  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const bool in_block = i_raw < n;
+  const int i = in_block ? i_raw : n - 1;
+  const int W = j.cols, R = j.rows;
+  const float4 X = j.pts[i];
+  const bool two_tap = interp == BPVO_INTERP_COSINE;
+  const int border_lo = two_tap ? 0 : 1, border_hi = two_tap ? 1 : 3;
+  int xi = 0, yi = 0;
+  const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
+  double u[3];
+#pragma unroll
+  for(int r = 0; r < 3; ++r) {
+    double s = (double) P[r * 4 + 0] * X0;
+    s += (double) P[r * 4 + 1] * X1;
+    s += (double) P[r * 4 + 2] * X2;
+    s += (double) P[r * 4 + 3] * X3;
+    u[r] = s;
+  }
+  const double zi = 1.0 / u[2];
+  const double x = zi * u[0], y = zi * u[1];
+  const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+  if(in_range) {
+    xi = (int) x; xi -= (xi > x);
+    yi = (int) y; yi -= (yi > y);
+  }
+  const bool valid = in_range && xi >= border_lo && xi < W - border_hi && yi >= border_lo && yi < R - 1;
+  const float xf = (float) (x - (double) xi), yf = (float) (y - (double) yi);
+  if(in_block) j.valid[i] = valid ? 1 : 0;
+
+  float res[C];
+#pragma unroll
+  for(int c = 0; c < C; ++c) res[c] = 0.0f;
+  if(valid) {
+    float I0[C];
+    if constexpr(C == 8) {
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+      const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
+      I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
+    } else {
+      I0[0] = j.pix[i];
+    }
+    if(two_tap) {
+      float Cx[2], Cy[2];
+      interp_cosine(xf, Cx);
+      interp_cosine(yf, Cy);
+      const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
+      const float* __restrict__ d1 = d0 + (size_t) W * C;
+#pragma unroll
+      for(int c = 0; c < C; ++c) {
+        const float e1 = d0[c] * Cx[0] + d0[C + c] * Cx[1];
+        const float e2 = d1[c] * Cx[0] + d1[C + c] * Cx[1];
+        res[c] = (Cy[0] * e1 + Cy[1] * e2) - I0[c];
+      }
+    } else {
+      const float* __restrict__ rowp[4];
+#pragma unroll
+      for(int k = 0; k < 4; ++k) rowp[k] = j.desc + ((size_t) min(yi - 1 + k, R - 1) * W + xi) * C;
+      if(interp == BPVO_INTERP_CUBIC) {
+        float Cx[4], Cy[4];
+        interp_cubic(xf, Cx);
+        interp_cubic(yf, Cy);
+#pragma unroll
+        for(int c = 0; c < C; ++c) {
+          float d[4];
+#pragma unroll
+          for(int k = 0; k < 4; ++k) d[k] = dot4(rowp[k][c], rowp[k][C + c], rowp[k][2 * C + c], rowp[k][3 * C + c], Cx);
+          res[c] = dot4(Cy[0], Cy[1], Cy[2], Cy[3], d) - I0[c];
+        }
+      } else {
+#pragma unroll
+        for(int c = 0; c < C; ++c) {
+          float V[4];
+#pragma unroll
+          for(int k = 0; k < 4; ++k) V[k] = interp_hermite(rowp[k][c], rowp[k][C + c], rowp[k][2 * C + c], rowp[k][3 * C + c], xf);
+          res[c] = interp_hermite(V[0], V[1], V[2], V[3], yf) - I0[c];
+        }
+      }
+    }
+  }
+  if(in_block) {
+    if constexpr(C == 8) {
+      float4* o = reinterpret_cast<float4*>(j.r);
+      o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
+      o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
+    } else {
+      j.r[i] = res[0];
+    }
+  }
+  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // K7 median + robust scale.  reference: AutoScaleEstimator::estimateScale / ScaleEstimator (bpvo/mestimator.cc:452-490)
 // and median() (bpvo/utils.h:224-252): sigma = (1.4826f * (1 + 5/(n-6))) * median(|r| : valid), n = C * #valid (size_t
 // arithmetic), sigma < 1e-6 -> 1, recomputed only while |sigma - sigma_prev| > 1e-6 (Q5, Q6).
@@ -1011,6 +1163,11 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
+  if(g.interp != BPVO_INTERP_LINEAR) {
+    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.interp);
+    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.interp);
+    return;
+  }
   if(g.fast_warp) {
     if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
     else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);

@@ -87,6 +87,50 @@ static inline int FloorD(double v)
   return i - (i > v);
 }
 
+// Interpolation kernels of the standard PhotoError branch (bpvo/photo_error.cc:267-334), T = float.
+// interpolateCosine: `auto m = (T(1) - std::cos(x*M_PI)) / 2.0` is a double (x*M_PI promotes); stored back as float.
+static inline void interpolateCosine(float x, float* coeffs)
+{
+  const double m = (1.0 - std::cos((double) x * M_PI)) / 2.0;            // T(1) - double -> double
+  coeffs[0] = (float) (1.0 - m);                                         // T(1) - m
+  coeffs[1] = (float) m;
+}
+
+// interpolateCubic (:267-279): all float, A = -0.5; integer literals convert to float.
+static inline void interpolateCubic(float x, float* coeffs)
+{
+  const float A = -0.5f;
+  coeffs[0] = ((A * (x + 1.0f) - 5.0f * A) * (x + 1.0f) + 8.0f * A) * (x + 1.0f) - 4.0f * A;
+  coeffs[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  coeffs[2] = ((A + 2.0f) * (1.0f - x) - (A + 3.0f)) * (1.0f - x) * (1.0f - x) + 1.0f;
+  coeffs[3] = 1.0f - coeffs[0] - coeffs[1] - coeffs[2];
+}
+
+// interpolateCubicHermite value form (:311-334), bias = tension = 0: the tangent terms divide by the double literal 2.0,
+// so each is evaluated in double and their sum is rounded to float on assignment to `T m0, m1`.
+static inline float interpolateCubicHermite(const float* y, float mu)
+{
+  const float bias = 0.0f, tension = 0.0f;
+  const float mu2 = mu * mu;
+  const float mu3 = mu * mu2;
+  const float m0 = (float) (((double) ((y[1] - y[0]) * (1 + bias) * (1 - tension)) / 2.0) +
+                            ((double) ((y[2] - y[1]) * (1 - bias) * (1 - tension)) / 2.0));
+  const float m1 = (float) (((double) ((y[2] - y[1]) * (1 + bias) * (1 - tension)) / 2.0) +
+                            ((double) ((y[3] - y[2]) * (1 - bias) * (1 - tension)) / 2.0));
+  const float a0 = 2 * mu3 - 3 * mu2 + 1;
+  const float a1 = mu3 - 2 * mu2 + mu;
+  const float a2 = mu3 - mu2;
+  const float a3 = -2 * mu3 + 3 * mu2;
+  return a0 * y[1] + a1 * m0 + a2 * m1 + a3 * y[2];
+}
+
+// Eigen 3.2 fixed-size 4-float dot product [ext]: cwiseProduct().sum() is vectorised (one Packet4f) and reduced with
+// predux, which under SSE3 (the reference builds with -msse4.1 -mavx) is two haddps: (a0 + a1) + (a2 + a3).
+static inline float dot4(const float* a, const float* b)
+{
+  return (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
+}
+
 // TemplateData::computeResiduals (bpvo/template_data.cc:174-189):
 //   warp.setPose(pose); PhotoError::init (bpvo/photo_error.cc:344-363) in double; per channel PhotoError::run
 //   (bpvo/photo_error.cc:365-389,446-449, kLinear) in the reference's parallel_for over channels (:188) -> OpenMP.
@@ -95,7 +139,7 @@ void TemplateData::computeResiduals(const Descriptor& desc, const M44& pose, std
 {
   const int N = numPoints();
   if(N == 0) throw std::logic_error("you should call setData before calling computeResiduals");   // :177
-  if(params.interp != kLinear) throw std::runtime_error("oracle: only kLinear interpolation is restated");
+  if(fast_warp && params.interp != kLinear) throw std::runtime_error("oracle: the projectPoints f32 formulation is kLinear only");
   warp.setPose(pose);
 
   valid.resize(N);
@@ -153,7 +197,9 @@ void TemplateData::computeResiduals(const Descriptor& desc, const M44& pose, std
   }
 
   const int rows = desc.rows, cols = desc.cols;
-  const int border_lo = 0, border_hi = 1;                                // kLinear (photo_error.cc:347-348)
+  const int interp = params.interp;
+  const bool two_tap = interp == kLinear || interp == kCosine;
+  const int border_lo = two_tap ? 0 : 1, border_hi = two_tap ? 1 : 3;    // photo_error.cc:347-348
   double P[12];
   for(int k = 0; k < 12; ++k) P[k] = (double) warp.P[k];
   std::vector<double> xy(2 * (size_t) N);
@@ -191,10 +237,41 @@ void TemplateData::computeResiduals(const Descriptor& desc, const M44& pose, std
         xf -= (double) xi;
         yf -= (double) yi;
         const int ii = yi * stride + xi;
-        const double wx = (1.0 - xf);
-        const double Iw = (1.0 - yf) * (I1_ptr[ii] * wx + I1_ptr[ii + 1] * xf) +
-                          yf * (I1_ptr[ii + stride] * wx + I1_ptr[ii + stride + 1] * xf);
-        r_ptr[i] = (float) (Iw - (double) I0_ptr[i]);
+        if(interp == kLinear) {                                          // :381-388
+          const double wx = (1.0 - xf);
+          const double Iw = (1.0 - yf) * (I1_ptr[ii] * wx + I1_ptr[ii + 1] * xf) +
+                            yf * (I1_ptr[ii + stride] * wx + I1_ptr[ii + stride + 1] * xf);
+          r_ptr[i] = (float) (Iw - (double) I0_ptr[i]);
+        } else if(interp == kCosine) {                                   // :391-404
+          float Cx[2], Cy[2];
+          interpolateCosine((float) xf, Cx);
+          interpolateCosine((float) yf, Cy);
+          const float* p1 = I1_ptr + ii;
+          const float* p2 = p1 + stride;
+          const float d1 = p1[0] * Cx[0] + p1[1] * Cx[1];                // Eigen 2-vector dot: scalar, index order
+          const float d2 = p2[0] * Cx[0] + p2[1] * Cx[1];
+          const float Iw = Cy[0] * d1 + Cy[1] * d2;
+          r_ptr[i] = Iw - I0_ptr[i];
+        } else {
+          // The four rows are yi-1 .. yi+2 and the four columns xi .. xi+3 (NOT xi-1 .. xi+2: the Map starts at xi,
+          // :415-418 — restated as written).  valid only guarantees yi < rows-1, so for yi == rows-2 the reference reads
+          // row `rows`, one past the image (undefined behaviour there); here that row index is clamped to rows-1 (Q21).
+          const float* p[4];
+          for(int k = 0; k < 4; ++k) p[k] = I1_ptr + (size_t) std::min(yi - 1 + k, rows - 1) * stride + xi;
+          float Iw;
+          if(interp == kCubic) {                                         // :406-424
+            float Cx[4], Cy[4], d[4];
+            interpolateCubic((float) xf, Cx);
+            interpolateCubic((float) yf, Cy);
+            for(int k = 0; k < 4; ++k) d[k] = dot4(p[k], Cx);
+            Iw = dot4(Cy, d);
+          } else {                                                       // kCubicHermite :426-441
+            float V[4];
+            for(int k = 0; k < 4; ++k) V[k] = interpolateCubicHermite(p[k], (float) xf);
+            Iw = interpolateCubicHermite(V, (float) yf);
+          }
+          r_ptr[i] = Iw - I0_ptr[i];
+        }
       } else {
         r_ptr[i] = 0.0f;
       }

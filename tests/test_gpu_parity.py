@@ -421,3 +421,38 @@ def test_project_points_f32_formulation_parity(hip, orc, rows, cols, levels, des
     T0, _ = ch.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, T0)
     assert rot <= 5e-4 and trans <= 5 * trans_tol(d["K"]), (rot, trans)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("interp", ["cosine", "cubic", "cubic_hermite"])
+@pytest.mark.parametrize("descriptor,loss", [("intensity", "huber"), ("bitplanes", "tukey")])
+def test_interpolation_variants_parity(hip, orc, rows, cols, levels, interp, descriptor, loss):
+    """kCosine / kCubic / kCubicHermite of PhotoError::Impl::run (bpvo/photo_error.cc:391-444): masks with the
+    (1, 3) borders bit-exact, f32 interpolation bit-exact for the polynomial forms; kCosine goes through a double
+    cos() whose last bit may differ between libm and the device library, so its residuals get a 1-ulp-of-a-coefficient bar."""
+    it = {"cosine": capi.INTERP_COSINE, "cubic": capi.INTERP_CUBIC, "cubic_hermite": capi.INTERP_CUBIC_HERMITE}[interp]
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss=loss, interp=it)
+    for l in range(levels):
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(1.0), _perturbed_pose(8.0)):
+            a = ch.linearize(0, 0, 1, l, T)
+            b = co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo), f"valid level {l}"
+            assert a["num_valid"] == b["num_valid"]
+            rh, ro = ch.get_residuals(0), co.get_residuals(0)
+            if interp == "cosine":
+                assert np.abs(rh - ro).max() <= 4e-7 * max(1.0, np.abs(ro).max()), f"residuals level {l}"
+                assert abs(a["sigma"] - b["sigma"]) <= 1e-6 * b["sigma"]
+            else:
+                assert bits_equal(rh, ro), f"residuals level {l}"
+                assert a["sigma"] == b["sigma"]
+                assert bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), ro, co.get_weights(0), vo, ch.Cn)
+            assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
+    Th, sh = ch.estimate_pose(0, 0, 1)
+    To, so = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans, sh, so)
+    # the projectPoints f32 formulation exists for kLinear only
+    with pytest.raises(capi.BpvoError):
+        ch.set_warp_formulation(1)

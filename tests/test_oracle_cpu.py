@@ -340,3 +340,100 @@ def test_f32_formulation_close_to_f64_formulation(orc):
     assert np.abs(r64[:, both_valid] - r32[:, both_valid]).max() < 2e-4
     pix = ctx.get_pixels(0, 0)
     assert np.array_equal(r32[:, ~v32], -pix[:, ~v32]) and np.all(r64[:, ~v64] == 0)
+
+
+# --------------------------------------------------------------------------------------- interpolation variants (8f.3)
+def _np_project(ctx, d, T, level=0):
+    """f64 projection of PhotoError::Impl::init with the oracle's own P = K*T[0:3] in f32."""
+    K = d["K"].astype(np.float32)
+    P = np.zeros((3, 4), np.float32)
+    for r in range(3):
+        for c in range(4):
+            s = K[r, 0] * T[0, c]
+            s = np.float32(s + K[r, 1] * T[1, c])
+            s = np.float32(s + K[r, 2] * T[2, c])
+            P[r, c] = s
+    X = ctx.get_points(0, level).astype(np.float64)
+    u = X @ P.astype(np.float64).T
+    zi = 1.0 / u[:, 2]
+    return u[:, 0] * zi, u[:, 1] * zi
+
+
+def _cubic_coeffs(x):
+    x = x.astype(np.float32)
+    A = np.float32(-0.5)
+    one = np.float32(1)
+    c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+    c3 = one - c0 - c1 - c2
+    return [c0, c1, c2, c3]
+
+
+def _hermite(y, mu):
+    mu = mu.astype(np.float32)
+    mu2 = mu * mu
+    mu3 = mu * mu2
+    half = lambda a: a.astype(np.float64) / 2.0
+    m0 = (half(y[1] - y[0]) + half(y[2] - y[1])).astype(np.float32)
+    m1 = (half(y[2] - y[1]) + half(y[3] - y[2])).astype(np.float32)
+    two, three, one = np.float32(2), np.float32(3), np.float32(1)
+    a0 = two * mu3 - three * mu2 + one
+    a1 = mu3 - two * mu2 + mu
+    a2 = mu3 - mu2
+    a3 = -two * mu3 + three * mu2
+    return a0 * y[1] + a1 * m0 + a2 * m1 + a3 * y[2]
+
+
+@pytest.mark.parametrize("interp", ["cosine", "cubic", "cubic_hermite"])
+def test_interpolation_variants_against_numpy(orc, interp):
+    """PhotoError::Impl::run for kCosine / kCubic / kCubicHermite (bpvo/photo_error.cc:391-444) restated a second time
+    in numpy: borders (0,1) vs (1,3), rows yi-1..yi+2, columns xi..xi+3 (the reference's Map starts at xi), f32
+    coefficient arithmetic, pairwise 4-float dot products."""
+    it = {"cosine": capi.INTERP_COSINE, "cubic": capi.INTERP_CUBIC, "cubic_hermite": capi.INTERP_CUBIC_HERMITE}[interp]
+    rows, cols = 96, 128
+    ctx, d, _ = setup_pair(orc, rows, cols, descriptor="intensity", levels=1, interp=it)
+    T = synth.twist_to_matrix([0.01, -0.02, 0.03, 0.3, -0.2, 0.1]).astype(np.float32)
+    ctx.linearize(0, 0, 1, 0, T)
+    v = ctx.get_valid(0).astype(bool)
+    r = ctx.get_residuals(0).reshape(-1)
+    x, y = _np_project(ctx, d, T)
+    xi, yi = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+    lo, hi = (0, 1) if interp == "cosine" else (1, 3)
+    ref_valid = (xi >= lo) & (xi < cols - hi) & (yi >= lo) & (yi < rows - 1)
+    assert np.array_equal(v, ref_valid)
+    assert 0 < v.sum() < len(v)
+    I1 = ctx.get_descriptor_channel(1, 0, 0)
+    I0 = ctx.get_pixels(0, 0)[0]
+    xf = (x - xi).astype(np.float32)[v]
+    yf = (y - yi).astype(np.float32)[v]
+    xv, yv = xi[v], yi[v]
+    if interp == "cosine":
+        def cosc(t):
+            m = (1.0 - np.cos(t.astype(np.float64) * np.pi)) / 2.0
+            return (1.0 - m).astype(np.float32), m.astype(np.float32)
+        cx0, cx1 = cosc(xf)
+        cy0, cy1 = cosc(yf)
+        d1 = I1[yv, xv] * cx0 + I1[yv, xv + 1] * cx1
+        d2 = I1[yv + 1, xv] * cx0 + I1[yv + 1, xv + 1] * cx1
+        Iw = cy0 * d1 + cy1 * d2
+        assert np.abs((Iw - I0[v]) - r[v]).max() <= 3e-7 * 255      # libm vs numpy cos may differ in the last double bit
+    else:
+        rowsel = [np.minimum(yv - 1 + k, rows - 1) for k in range(4)]
+        taps = [[I1[rowsel[k], xv + m] for m in range(4)] for k in range(4)]
+        if interp == "cubic":
+            cx, cy = _cubic_coeffs(xf), _cubic_coeffs(yf)
+            dot4 = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3])
+            dd = [dot4(taps[k], cx) for k in range(4)]
+            Iw = dot4(cy, dd)
+        else:
+            V = [_hermite(taps[k], xf) for k in range(4)]
+            Iw = _hermite(V, yf)
+        assert Iw.dtype == np.float32
+        assert bits_equal((Iw - I0[v]).astype(np.float32), r[v])
+    assert np.all(r[~v] == 0.0)
+    # the pose is still recovered with every interpolation type (the cubic forms carry the reference's one-column
+    # offset, so they are only asked to stay in the neighbourhood)
+    Te, st = ctx.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Te, d["T_gt"])
+    assert rot < 2e-2 and trans < 0.5, (rot, trans)
