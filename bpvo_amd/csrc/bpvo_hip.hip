@@ -124,6 +124,7 @@ struct bpvo_hip_ctx {
   M44 cloud_pose;
   // measurement
   int fast_warp = 0;           // bpvo_hip_set_warp_formulation
+  int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
   double kc_ms[KC_COUNT] = {};
@@ -367,7 +368,7 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
       if(c->C == 1) {
         launch_intensity(c->stream, jobs, g.cols, g.rows, count);
       } else {
-        launch_census(c->stream, jobs, g.cols, g.rows, count);
+        launch_census(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
         launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k);
       }
     }
@@ -735,13 +736,21 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES)
     return unsupported("descriptor: only Intensity and BitPlanes are on the device path");
   if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
-  if(c->params.descriptor == BPVO_DESC_BITPLANES && c->params.sigmaPriorToCensusTransform > 0.0f)
-    return unsupported("sigmaPriorToCensusTransform > 0 (OpenCV-version-dependent u8 blur) is not on the device path");
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
     return unsupported("unknown lossFunction");
   if(c->params.gradientEstimation != BPVO_GRAD_CD3 && c->params.gradientEstimation != BPVO_GRAD_CD5) return unsupported("unknown gradientEstimation");
   c->C = (c->params.descriptor == BPVO_DESC_BITPLANES) ? 8 : 1;
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
+  if(c->params.sigmaPriorToCensusTransform > 0.0f) {   // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
+    const double sg = c->params.sigmaPriorToCensusTransform, scale2X = -0.5 / (sg * sg);
+    float kk[3];
+    double sum = 0;
+    for(int i = 0; i < 3; ++i) { const double x = i - 1.0; kk[i] = (float) std::exp(scale2X * x * x); sum += kk[i]; }
+    sum = 1. / sum;
+    for(int i = 0; i < 3; ++i) kk[i] = (float) (kk[i] * sum);
+    c->census_taps[0] = (int) std::nearbyint((double) kk[1] * 256.0);
+    c->census_taps[1] = (int) std::nearbyint((double) kk[2] * 256.0);
+  }
 
   // level geometry (bpvo/vo_frame.cc:21-28: K *= 0.5, K(2,2) = 1, b *= 2; pyrDown sizes)
   {

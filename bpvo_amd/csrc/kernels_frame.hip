@@ -107,6 +107,57 @@ __global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
   j.cen[(size_t) y * W + x] = out;
 }
 
+// ---- K1a': census of the 3x3-smoothed image, sigmaPriorToCensusTransform > 0 (reference: bpvo/census.cc:63-66 ->
+// cv::GaussianBlur(u8, Size(3,3), s, s) [ext: OpenCV 2.4 8-bit separable filter in fixed point: taps round(k * 256),
+// row pass u8 -> int, column pass (sum + 2^15) >> 16, saturated; BORDER_REFLECT_101]).  The smoothed image is never
+// written out: a 64 x 4 output tile stages its source pixels + 2-px halo (reflected coordinates) in LDS, the row and
+// column passes run in LDS, and the census reads the 66 x 6 smoothed tile.
+constexpr int CB_TW = 64, CB_TH = 4;
+__global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, int kc, int ks)
+{
+  __shared__ uint8_t s_src[(CB_TH + 4) * (CB_TW + 4)];
+  __shared__ int s_tmp[(CB_TH + 4) * (CB_TW + 2)];
+  __shared__ uint8_t s_b[(CB_TH + 2) * (CB_TW + 2)];
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x0 = blockIdx.x * CB_TW, y0 = blockIdx.y * CB_TH;
+  const int tid = threadIdx.x;
+  // source tile: rows y0-2 .. y0+CB_TH+1, columns x0-2 .. x0+CB_TW+1
+  for(int i = tid; i < (CB_TH + 4) * (CB_TW + 4); i += 256) {
+    const int ly = i / (CB_TW + 4), lx = i - ly * (CB_TW + 4);
+    const int gy = reflect101(min(y0 + ly - 2, R + 1), R), gx = reflect101(min(x0 + lx - 2, W + 1), W);
+    s_src[i] = j.img[(size_t) gy * W + gx];
+  }
+  __syncthreads();
+  // row pass at columns x0-1 .. x0+CB_TW for every staged row
+  for(int i = tid; i < (CB_TH + 4) * (CB_TW + 2); i += 256) {
+    const int ly = i / (CB_TW + 2), lx = i - ly * (CB_TW + 2);
+    const uint8_t* p = s_src + ly * (CB_TW + 4) + lx + 1;    // centre = column x0-1+lx
+    s_tmp[i] = (int) p[0] * kc + ((int) p[-1] + (int) p[1]) * ks;
+  }
+  __syncthreads();
+  // column pass at rows y0-1 .. y0+CB_TH
+  for(int i = tid; i < (CB_TH + 2) * (CB_TW + 2); i += 256) {
+    const int ly = i / (CB_TW + 2), lx = i - ly * (CB_TW + 2);
+    const int* t = s_tmp + (ly + 1) * (CB_TW + 2) + lx;
+    const int v = (t[0] * kc + (t[-(CB_TW + 2)] + t[CB_TW + 2]) * ks + (1 << 15)) >> 16;
+    s_b[i] = (uint8_t) min(255, max(0, v));
+  }
+  __syncthreads();
+  const int lx = tid & 63, ly = tid >> 6;
+  const int x = x0 + lx, y = y0 + ly;
+  if(x >= W || y >= R) return;
+  uint8_t out = 0;
+  if(x > 0 && x < W - 1 && y > 0 && y < R - 1) {
+    constexpr int P = CB_TW + 2;
+    const uint8_t* p = s_b + (ly + 1) * P + lx + 1;
+    const uint8_t c = p[0];
+    out = (uint8_t) (((p[-P - 1] >= c) << 0) | ((p[-P] >= c) << 1) | ((p[-P + 1] >= c) << 2) | ((p[-1] >= c) << 3) |
+                     ((p[1] >= c) << 4) | ((p[P - 1] >= c) << 5) | ((p[P] >= c) << 6) | ((p[P + 1] >= c) << 7));
+  }
+  j.cen[(size_t) y * W + x] = out;
+}
+
 // ---- K1b: 8 bit-planes + cv::GaussianBlur 5x5 (reference: bpvo/bitplanes_descriptor.cc:37-57).
 // One 256-thread workgroup produces a 64 x 8 tile of 32-byte pixel records.  The census bytes of the tile + 2-px halo
 // (REFLECT_101 on the coordinates) are staged in LDS, the horizontal pass is written to LDS for all 8 planes
@@ -505,9 +556,13 @@ void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 {
   hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes), dim3(256), 0, s, jobs);
 }
-void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {
-  hipLaunchKernelGGL(census_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+  if(blur_taps)
+    hipLaunchKernelGGL(census_blur_kernel, dim3((W + CB_TW - 1) / CB_TW, (R + CB_TH - 1) / CB_TH, nframes), dim3(256), 0, s,
+                       jobs, blur_taps[0], blur_taps[1]);
+  else
+    hipLaunchKernelGGL(census_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
 }
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
 {

@@ -249,7 +249,11 @@ def test_edge_cases(hip, orc):
 def test_unsupported_and_invalid_create(hip):
     K, b = synth.calibration(120, 160)
     p = make_params(hip, levels=3)
-    p.interp = 2
+    p.interp = 7
+    with pytest.raises(capi.BpvoError):
+        hip.create(K, b, 120, 160, p)
+    p = make_params(hip, levels=3)
+    p.descriptor = 0x34      # kLatch (bpvo/types.h:148), a research descriptor: not on the device path
     with pytest.raises(capi.BpvoError):
         hip.create(K, b, 120, 160, p)
     p = make_params(hip, levels=3)
@@ -456,3 +460,27 @@ def test_interpolation_variants_parity(hip, orc, rows, cols, levels, interp, des
     # the projectPoints f32 formulation exists for kLinear only
     with pytest.raises(capi.BpvoError):
         ch.set_warp_formulation(1)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("sigma_ct,sigma_bp", [(0.75, 0.5), (1.5, -1.0)])
+def test_census_of_smoothed_image_bit_exact(hip, orc, rows, cols, levels, sigma_ct, sigma_bp):
+    """sigmaPriorToCensusTransform > 0: cv::GaussianBlur(u8, 3x3) in fixed point before the census (bpvo/census.cc:63-66),
+    fused into the census kernel.  Descriptor, selection and pose all follow bit-exactly / within the pose bar."""
+    kw = dict(descriptor="bitplanes", loss="tukey", sigmaPriorToCensusTransform=sigma_ct, sigmaBitPlanes=sigma_bp)
+    ch, co, d = both(hip, orc, rows, cols, levels, **kw)
+    plain, _, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss="tukey", sigmaBitPlanes=sigma_bp)
+    differs = False
+    for l in range(levels):
+        for c in range(8):
+            a, b = ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)
+            assert bits_equal(a, b), f"descriptor level {l} channel {c}"
+            differs |= not np.array_equal(a, plain.get_descriptor_channel(1, l, c))
+            if sigma_bp <= 0:
+                assert set(np.unique(a)) <= {0.0, 1.0}
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+    assert differs            # the smoothing is really applied
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
