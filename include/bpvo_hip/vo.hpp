@@ -110,6 +110,28 @@ class Trajectory {                                              // bpvo/trajecto
   const Matrix44& operator[](size_t i) const { return _poses[i]; }
   const Matrix44& back() const { return _poses.back(); }
   const std::vector<Matrix44>& poses() const { return _poses; }
+  /* Trajectory::push_back (bpvo/trajectory.cc:29-50): appends back() * InvertPose(T) with InvertPose as written there,
+   * R' = R^T, t' = -(R'^T) t = -R t.  VisualOdometry fills its trajectory on the device side with the same rule; this
+   * member is for callers that assemble a trajectory themselves (apps/eval_kitti.cc:120-130). */
+  void push_back(const Matrix44& T)
+  {
+    Matrix44 Ti;
+    for(int i = 0; i < 3; ++i)
+      for(int j = 0; j < 3; ++j) Ti[i * 4 + j] = T[j * 4 + i];
+    for(int i = 0; i < 3; ++i) Ti[i * 4 + 3] = -((T[i * 4 + 0] * T[3] + T[i * 4 + 1] * T[7]) + T[i * 4 + 2] * T[11]);
+    Ti[12] = Ti[13] = Ti[14] = 0.0f;
+    Ti[15] = 1.0f;
+    if(_poses.empty()) { _poses.push_back(Ti); return; }
+    const Matrix44& A = _poses.back();
+    Matrix44 C;
+    for(int r = 0; r < 4; ++r)
+      for(int c = 0; c < 4; ++c) {
+        float acc = A[r * 4 + 0] * Ti[0 * 4 + c];
+        for(int k = 1; k < 4; ++k) acc += A[r * 4 + k] * Ti[k * 4 + c];
+        C[r * 4 + c] = acc;
+      }
+    _poses.push_back(C);
+  }
  private:
   friend class VisualOdometry;
   std::vector<Matrix44> _poses;

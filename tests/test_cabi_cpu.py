@@ -2,6 +2,8 @@
 loudly without a device (no CPU fallback), and nothing in the product imports the oracle."""
 import ctypes as C
 import os
+
+import numpy as np
 import re
 import subprocess
 
@@ -132,3 +134,73 @@ def test_config_file_reader_matches_reference_semantics(tmp_path):
     assert out.returncode == 1 and "Malformed ConfigFile line" in out.stdout
     out = subprocess.run([exe, str(tmp_path / "missing.cfg")], capture_output=True, text=True)
     assert out.returncode == 1 and "could not open file" in out.stdout
+
+
+def test_io_formats_and_kitti_metric(tmp_path):
+    """include/bpvo_hip/io.hpp: PLY (bpvo/point_cloud.cc:135-177), trajectory text (bpvo/trajectory.cc:53-97) and the KITTI
+    segment-error metric (utils/kitti_eval.cc:80-167) against an independent numpy evaluation of the same files."""
+    exe = str(tmp_path / "io_test")
+    csrc = os.path.join(ROOT, "bpvo_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "io_test.cc"),
+                        "-o", exe, "-L", csrc, "-lbpvo_hip", f"-Wl,-rpath,{csrc}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-500:])
+
+    # PLY: header + 5 records of 3 x f32 + 4 x u8
+    raw = (tmp_path / "cloud.ply").read_bytes()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0" and lines[2] == "comment generated by bpvo"
+    assert lines[3] == "comment io_test" and lines[4] == "element vertex 5"
+    assert lines[5:] == ["property float x", "property float y", "property float z", "property uchar red", "property uchar green",
+                         "property uchar blue", "property uchar alpha"]
+    rec = np.frombuffer(body, dtype=np.dtype([("xyz", "<f4", 3), ("rgba", "u1", 4)]))
+    assert len(rec) == 5 and np.allclose(rec["xyz"][3], [1.5, -3.0, 5.0]) and list(rec["rgba"][2]) == [20, 20, 20, 255]
+
+    traj = np.loadtxt(tmp_path / "traj.txt").reshape(-1, 4, 4)
+    path = np.loadtxt(tmp_path / "path.txt")
+    gt = np.loadtxt(tmp_path / "gt" / "00.txt").reshape(-1, 3, 4)
+    assert traj.shape[0] == 1200 and np.allclose(traj[:, :3, 3], path, atol=1e-3) and np.allclose(traj[:, :3, :], gt, atol=2e-3, rtol=1e-5)
+    assert np.allclose(traj[:, 3], [0, 0, 0, 1])
+    # the first pose is InvertPose(T) as written in the reference: R^T and -R t
+    yaw = -0.002
+    R = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+    assert np.allclose(traj[0, :3, :3], R.T, atol=1e-6) and np.allclose(traj[0, :3, 3], -R @ np.array([0, 0, -1.0]), atol=1e-6)
+
+    # KITTI metric, second implementation
+    def load(p):
+        a = np.loadtxt(p).reshape(-1, 3, 4)
+        T = np.tile(np.eye(4), (len(a), 1, 1))
+        T[:, :3, :] = a
+        return T
+
+    def inv(T):      # utils/kitti_eval.cc:41-51 as written
+        r = np.eye(4)
+        r[:3, :3] = T[:3, :3].T
+        r[:3, 3] = -T[:3, :3] @ T[:3, 3]
+        return r
+
+    G, E = load(tmp_path / "gt" / "00.txt"), load(tmp_path / "est" / "00.txt")
+    d = np.concatenate([[0], np.cumsum(np.linalg.norm(np.diff(G[:, :3, 3], axis=0), axis=1))])
+    want = []
+    for f in range(0, len(G), 10):
+        for L in (100, 200, 300, 400, 500, 600, 700, 800):
+            idx = np.nonzero(d[f:] > d[f] + L)[0]
+            if len(idx) == 0:
+                continue
+            fl = f + idx[0]
+            Terr = inv(inv(E[f]) @ E[fl]) @ (inv(G[f]) @ G[fl])
+            rr = np.arccos(np.clip(0.5 * (np.trace(Terr[:3, :3]) - 1), -1, 1))
+            want.append((f, rr / L, np.linalg.norm(Terr[:3, 3]) / L, L, L / (0.1 * (fl - f + 1))))
+    got = [tuple(float(x) for x in l.split()[1:]) for l in out.stdout.splitlines() if l.startswith("ERR")]
+    assert len(got) == len(want) > 100
+    got, want = np.array(got), np.array(want)
+    assert np.array_equal(got[:, 0], want[:, 0]) and np.array_equal(got[:, 3], want[:, 3])
+    assert np.allclose(got[:, 2], want[:, 2], rtol=2e-3, atol=1e-6) and np.allclose(got[:, 4], want[:, 4], rtol=1e-5)
+    assert np.allclose(got[:, 1], want[:, 1], atol=5e-6)          # acos of a float near 1
+    tl = np.loadtxt(tmp_path / "plot_tl.txt")
+    # (the values are large because InvertPose, as written in the reference, is not the rigid inverse for R != I; the
+    # metric is restated, not repaired)
+    assert tl.shape[1] == 2 and tl[0, 0] == 100 and abs(tl[0, 1] - want[want[:, 3] == 100][:, 2].mean()) <= 2e-3 * tl[0, 1]
+    assert (tmp_path / "plot_rs.txt").exists() and (tmp_path / "plot_ts.txt").stat().st_size > 0
