@@ -173,7 +173,7 @@ def main():
     gn_local = ctx.total_linearizations()
     med_paths = ctx.median_path_counts()
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
-    points_linearized = all_kstats["warp_residual"]["units"]     # device-side count: sum over linearisations of N
+    points_linearized = all_kstats["irls_reduce"]["units"]     # device-side count: sum over linearisations of N
     kstats = all_kstats if not args.no_profile else {}
     t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=coll_dev)
     if world > 1:

@@ -86,6 +86,7 @@ struct Lane {
   GNState* h_states = nullptr;     // pinned [n_pairs]
   std::vector<EventPair> ev_pending;
   std::vector<hipEvent_t> ev_pool;
+  unsigned k6_seq = 0;             // warp_residual launches of this lane since bpvo_hip_profiling (event sampling)
   std::string err;
 };
 constexpr int kDefaultLanes = 1;   // BPVO_HIP_LANES=2 gains ~5 % on 128-pair batches but makes per-launch timings overlap
@@ -291,7 +292,8 @@ struct ScopedTimer {
   Lane* ln;
   EventPair ep;
   bool on;
-  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units, Lane* lane = nullptr) : ln(lane ? lane : &c_->lanes[0]), on(c_->profiling)
+  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units, Lane* lane = nullptr, bool sampled = true)
+      : ln(lane ? lane : &c_->lanes[0]), on(c_->profiling && sampled)
   {
     if(!on) return;
     ep.kc = kc; ep.units = units;
@@ -491,11 +493,15 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // iteration.
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
     constexpr int kItersPerSync = 4;
+    constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
     for(int it = 0; it < max_lin;) {
       int parity = 0;
       for(int k = 0; k < kItersPerSync && it < max_lin; ++k, ++it) {
         parity = it & 1;
-        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln); launch_warp_residual(ln->stream, g); }
+        // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
+        // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
+        const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
+        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
         if(c->profile_all) {
           { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g, c->d_counters); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
@@ -591,7 +597,12 @@ int refresh_counters(bpvo_hip_ctx* c)
   c->median_full = h[3];
   c->total_lin = h[1];
   // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
-  c->kc_units[KC_WARP_RESIDUAL] = (double) h[0];
+  // warp_residual at profiling level 1 is timed on a 1-in-kProfileEvery sample of its launches: its units are scaled to
+  // the sampled launches so that units / launches stays the points of an average launch
+  double all_k6 = 0;
+  for(const auto& ln : c->lanes) all_k6 += ln.k6_seq;
+  const bool sampled = c->profiling && !c->profile_all && all_k6 > 0;
+  c->kc_units[KC_WARP_RESIDUAL] = sampled ? (double) h[0] * (double) c->kc_launches[KC_WARP_RESIDUAL] / all_k6 : (double) h[0];
   c->kc_units[KC_IRLS_REDUCE] = (double) h[0];
   c->kc_units[KC_MEDIAN] = (double) h[0];
   c->kc_units[KC_GN_STEP] = (double) h[1];
@@ -1376,6 +1387,7 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
   HIP_CK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
   c->total_lin = 0;
+  for(auto& ln : c->lanes) ln.k6_seq = 0;
   return BPVO_OK;
 }
 int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* c, bpvo_hip_kernel_stat* out, int max_out, int* n_out)

@@ -227,7 +227,9 @@ typedef struct bpvo_hip_kernel_stat {
   double   units;             /* units processed (points or pixels), summed over launches */
   double   bytes_per_unit;    /* algorithmic bytes per unit */
 } bpvo_hip_kernel_stat;
-int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);        /* 0 off, 1 warp_residual + frame stages, 2 every kernel; resets counters */
+/* 0 off; 1: HIP events around the frame stages and around every 5th warp_residual launch of a batch estimate (the
+ * reported units are scaled to the sampled launches); 2: around every launch of every kernel.  Resets the counters. */
+int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);
 int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int max_out, int* n_out);
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */
 /* exact median selections served by the bracketed path / by the full 3-pass path since the last counter reset */
