@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=128, help="1024-pair batch of config 5 / 8 GPUs")
+    ap.add_argument("--pairs-per-gpu", type=int, default=1024, help="pairs per GPU (default: the whole 1024-pair batch of BASELINE.json config 5 on every GPU)")
     ap.add_argument("--rows", type=int, default=376)
     ap.add_argument("--cols", type=int, default=1241)
     ap.add_argument("--descriptor", default="bitplanes", choices=["bitplanes", "intensity"])
@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events at all")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel (diagnostics, slower)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--input-cache", default="", help="directory holding the rendered synthetic inputs of this exact shard; "
+                    "written on first use (lets the rocprofv3 runs skip the CPU rendering, which must not fork under the profiler)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--single-device", action="store_true",
@@ -118,7 +120,16 @@ def main():
     lo, hi = shard_range(P * world, rank, world)
     workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
     t0 = time.perf_counter()
-    batch = synth.make_batch(args.rows, args.cols, hi - lo, first_index=lo, workers=workers)
+    cache = os.path.join(args.input_cache, f"synth_{args.rows}x{args.cols}_{lo}_{hi}") if args.input_cache else ""
+    if cache and os.path.exists(cache + ".ok"):
+        K, b = synth.calibration(args.rows, args.cols)
+        batch = dict(K=K, b=b, images=np.load(cache + "_img.npy"), disparities=np.load(cache + "_disp.npy"), T_gt=np.load(cache + "_gt.npy"))
+    else:
+        batch = synth.make_batch(args.rows, args.cols, hi - lo, first_index=lo, workers=workers)
+        if cache:
+            os.makedirs(args.input_cache, exist_ok=True)
+            np.save(cache + "_img.npy", batch["images"]); np.save(cache + "_disp.npy", batch["disparities"]); np.save(cache + "_gt.npy", batch["T_gt"])
+            open(cache + ".ok", "w").close()
     t_gen = time.perf_counter() - t0
 
     import torch

@@ -834,7 +834,8 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
     }
   }
 
-  // wavefront tree (64 lanes), then LDS across the 4 waves
+  // wavefront tree (64 lanes; the compiler lowers these shuffles to DPP adds — a reduce-scatter over ds_bpermute was 2.5x
+  // slower), then LDS across the 4 waves
 #pragma unroll
   for(int k = 0; k < kNumAcc; ++k) {
     float v = acc[k];
@@ -1143,7 +1144,7 @@ __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* re
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
 // fixed, so that a pair's block partials (and hence its rounding) do not depend on the size of the batch it is in
-int gn_pts_per_block(int /*npairs*/) { return 512; }
+int gn_pts_per_block(int /*npairs*/) { return 512; }   // 1024 / 2048 measured within 3 % of this
 int gn_num_blocks(int max_points) { return (max_points + 255) / 256; }   // upper bound for any pts_per_block >= 256
 
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)

@@ -3,8 +3,7 @@
 #   gpurun --timeout 900 -- 'bash profiles/collect_profiles.sh r01'
 # 1. kernel trace + stats of the default bench command (the run bench.py's numbers are compared with);
 # 2. PMC passes (counters in their own runs, --kernel-trace only) on a BOUNDED configuration — 64 pairs, 20 fixed
-#    iterations per level (22 linearisations: the tap cache of warp_residual is as warm as in the converge-mode bench), synthetic pairs rendered without a fork pool (the profiler initialises the GPU before python
-#    starts, forking afterwards hangs) — each under its own timeout.
+#    iterations per level (22 linearisations: the tap cache of warp_residual is as warm as in the converge-mode bench), synthetic pairs read from a cache rendered beforehand — each under its own timeout.
 # Raw output goes to gpurun_out/profiles_<tag>/; profiles/summarize.py turns it into the committed summaries.
 set -u
 TAG=${1:-r01}
@@ -12,8 +11,12 @@ R=$(pwd)
 O=$R/gpurun_out/profiles_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-# (--gen-workers 1: no fork pool under the profiler)
-timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 \
+# the synthetic inputs are rendered once, outside the profiler (a fork pool under rocprofv3 hangs: the profiler initialises
+# the GPU before python starts), and the profiled runs read them back from /tmp
+CACHE=/tmp/bpvo_bench_inputs
+timeout 300 python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_default.err"; echo "inputs rc=$?"
+timeout 300 python3 "$R/bench.py" --pairs-per-gpu 64 --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_pmc.err"; echo "pmc inputs rc=$?"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 --input-cache $CACHE \
     > "$O/trace_bench.json" 2> "$O/trace.err"; echo "trace rc=$?"
 export BPVO_HIP_LANES=1
 i=0
@@ -25,7 +28,7 @@ for CNT in "FETCH_SIZE" "WRITE_SIZE" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 150 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc$i" -- python3 "$R/bench.py" --pairs-per-gpu 64 --fixed-iters 20 \
-      --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --gen-workers 1 > "$O/pmc$i.json" 2> "$O/pmc$i.err"
+      --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --gen-workers 1 --input-cache $CACHE > "$O/pmc$i.json" 2> "$O/pmc$i.err"
   echo "pmc$i ($CNT) rc=$?"
 done
 cd "$R" && python3 profiles/summarize.py "$O" "$TAG"
