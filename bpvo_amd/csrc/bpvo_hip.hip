@@ -115,7 +115,8 @@ struct bpvo_hip_ctx {
   unsigned long long* d_counters = nullptr;   // [4] points, linearisations, bracketed / full median selections
   // pinned staging
   FrameJob* h_fjobs = nullptr;
-  int* h_ints = nullptr;           // [max(n_frames*L, 16)]
+  int* h_ints = nullptr;           // [max(n_frames*kMaxLevels, 16)] pinned
+  int* d_ints = nullptr;           // same size, device
   int cap_max = 0;
   // VisualOdometry state (bpvo/vo.cc:45-52)
   int vo_ref = 0, vo_cur = 1, vo_prev = 2;
@@ -409,9 +410,8 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
     launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, p.withNormalization);
   }
   // one read-back of the point counts: the host needs them to size the template-build and GN grids
-  for(int i = 0; i < count; ++i)
-    HIP_CK(c, hipMemcpyAsync(c->h_ints + (size_t) i * kMaxLevels, c->frames[first + i * stride].n_dev, sizeof(int) * kMaxLevels,
-                             hipMemcpyDeviceToHost, c->stream));
+  launch_gather_counts(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, c->d_ints);
+  HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_ints, sizeof(int) * kMaxLevels * (size_t) count, hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   std::vector<int> max_n(c->L, 0);
   for(int i = 0; i < count; ++i) {
@@ -847,6 +847,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMemset(cp->d_counters, 0, 4 * sizeof(unsigned long long)));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
+  CREATE_CK(hipMalloc((void**) &cp->d_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
 #undef CREATE_CK
   cp->T_kf = m44_identity();
   cp->cloud_pose = m44_identity();
@@ -864,7 +865,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
-  (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints);
+  (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
     (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active);

@@ -16,6 +16,8 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes);
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border);
+void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level, int num_levels,
+                          int* out /*[nframes][kMaxLevels]*/);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
                           int num_levels, int with_normalization);
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);

@@ -479,20 +479,49 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   const float* __restrict__ D = j.desc;
   float pixv[C], Ix[C], Iy[C];
   const float NN = 1.0f / 18.0f;
-#pragma unroll
-  for(int c = 0; c < C; ++c) {
-    const float* cc = D + (size_t) ii * C + c;
-    float gx, gy;
+  if constexpr(C == 8) {
+    // a pixel's 8 channels are one 32-byte record: every neighbour is fetched with two 16-byte loads (one request per
+    // 128-byte line and record instead of eight dword requests that thrash the 16 KB L1 between them)
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(D) + (size_t) ii * 2;
+    const ptrdiff_t rs = (ptrdiff_t) W * 2;   // row stride in float4
+    auto load8 = [&](ptrdiff_t off, float (&v)[8]) {
+      const float4 a = rec[off], b = rec[off + 1];
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    };
+    float xp[8], xm[8], yp[8], ym[8];
+    load8(0, pixv);
+    load8(2, xp); load8(-2, xm); load8(rs, yp); load8(-rs, ym);
     if(!grad_cd5) {
-      gx = 0.5f * (cc[C] - cc[-C]);
-      gy = 0.5f * (cc[(size_t) W * C] - cc[-(ptrdiff_t) W * C]);
+#pragma unroll
+      for(int c = 0; c < 8; ++c) {
+        Ix[c] = fx * (0.5f * (xp[c] - xm[c]));
+        Iy[c] = fy * (0.5f * (yp[c] - ym[c]));
+      }
     } else {
-      gx = NN * (1.0f * cc[-2 * C] - 8.0f * cc[-C] + 8.0f * cc[C] - 1.0f * cc[2 * C]);
-      gy = NN * (1.0f * cc[-2 * (ptrdiff_t) W * C] - 8.0f * cc[-(ptrdiff_t) W * C] + 8.0f * cc[(ptrdiff_t) W * C] - 1.0f * cc[2 * (ptrdiff_t) W * C]);
+      float xp2[8], xm2[8], yp2[8], ym2[8];
+      load8(4, xp2); load8(-4, xm2); load8(2 * rs, yp2); load8(-2 * rs, ym2);
+#pragma unroll
+      for(int c = 0; c < 8; ++c) {
+        Ix[c] = fx * (NN * (1.0f * xm2[c] - 8.0f * xm[c] + 8.0f * xp[c] - 1.0f * xp2[c]));
+        Iy[c] = fy * (NN * (1.0f * ym2[c] - 8.0f * ym[c] + 8.0f * yp[c] - 1.0f * yp2[c]));
+      }
     }
-    pixv[c] = cc[0];
-    Ix[c] = fx * gx;      // Ix = _mm_mul_ps(FX, Ix) (rigid_body_warp.cc:103-104)
-    Iy[c] = fy * gy;
+  } else {
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+      const float* cc = D + (size_t) ii * C + c;
+      float gx, gy;
+      if(!grad_cd5) {
+        gx = 0.5f * (cc[C] - cc[-C]);
+        gy = 0.5f * (cc[(size_t) W * C] - cc[-(ptrdiff_t) W * C]);
+      } else {
+        gx = NN * (1.0f * cc[-2 * C] - 8.0f * cc[-C] + 8.0f * cc[C] - 1.0f * cc[2 * C]);
+        gy = NN * (1.0f * cc[-2 * (ptrdiff_t) W * C] - 8.0f * cc[-(ptrdiff_t) W * C] + 8.0f * cc[(ptrdiff_t) W * C] - 1.0f * cc[2 * (ptrdiff_t) W * C]);
+      }
+      pixv[c] = cc[0];
+      Ix[c] = fx * gx;      // Ix = _mm_mul_ps(FX, Ix) (rigid_body_warp.cc:103-104)
+      Iy[c] = fy * gy;
+    }
   }
   // tiled stores (types.h tile_index): consecutive lanes write consecutive vectors
   if constexpr(C == 8) {
@@ -508,6 +537,16 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
     j.pix[i] = pixv[0];
     reinterpret_cast<float2*>(j.grad)[i] = make_float2(Ix[0], Iy[0]);
   }
+}
+
+// point counts of every (frame, level) of a batch into one contiguous array, so that the host reads them back with a
+// single copy instead of one per frame
+__global__ void gather_counts_kernel(const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels, int* out /*[nframes][kMaxLevels]*/)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nframes * kMaxLevels) return;
+  const int i = t / kMaxLevels, l = t - i * kMaxLevels;
+  out[t] = (l >= first_level && l < num_levels) ? *jobs[(size_t) l * job_pitch + i].n_out : 0;
 }
 
 // Jacobians in the reference layout for the C ABI accessor (bpvo_hip_get_jacobians): J[(c*N + i)*6 + k]
@@ -590,6 +629,11 @@ void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, in
 {
   hipLaunchKernelGGL(normalization_kernel, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
                      with_normalization);
+}
+void launch_gather_counts(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels, int* out)
+{
+  hipLaunchKernelGGL(gather_counts_kernel, dim3((nframes * kMaxLevels + 255) / 256), dim3(256), 0, s, jobs, job_pitch, nframes, first_level,
+                     num_levels, out);
 }
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5)
 {

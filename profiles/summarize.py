@@ -14,14 +14,15 @@ out = []
 
 
 def db_of(sub):
-    fs = sorted(glob.glob(os.path.join(src, sub, "*", "*_results.db")))
+    # newest database: gpurun merges every run's output into the same local directory
+    fs = sorted(glob.glob(os.path.join(src, sub, "*", "*_results.db")), key=os.path.getmtime)
     return sqlite3.connect(fs[-1]) if fs else None
 
 
 db = db_of("trace")
 if db:
     rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1   (durations in us)",
+    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs   (durations in us)",
              "%-100s %8s %14s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
     for r in rows:
         lines.append("%-100s %8d %14.1f %10.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
@@ -61,7 +62,7 @@ open(os.path.join(src, f"{tag}_pmc_summary.txt"), "w").write("\n".join(lines) + 
 # HBM traffic of warp_residual per point (exact request sizes) for bench.py's roofline.traffic
 traffic = {}
 for k, cs in per.items():
-    if "warp_residual_kernel<8>" in k and "TCC_EA0_RDREQ_128B_sum" in cs:
+    if "warp_residual_kernel<8" in k and "TCC_EA0_RDREQ_128B_sum" in cs:
         rd = 128 * cs["TCC_EA0_RDREQ_128B_sum"]["avg"] + 64 * cs["TCC_EA0_RDREQ_64B_sum"]["avg"] + 32 * cs["TCC_EA0_RDREQ_32B_sum"]["avg"]
         wr64 = cs.get("TCC_EA0_WRREQ_64B_sum", {}).get("avg", 0.0)
         wr = cs.get("TCC_EA0_WRREQ_sum", {}).get("avg", 0.0)
@@ -74,7 +75,7 @@ for k, cs in per.items():
             traffic["write_size_kib_raw"] = cs["WRITE_SIZE"]["avg"]
 try:
     pj = json.loads(open(os.path.join(src, "pmc3.json")).read().strip().splitlines()[-1])
-    k6 = [k for k in per if "warp_residual_kernel<8>" in k][0]
+    k6 = [k for k in per if "warp_residual_kernel<8" in k][0]
     launches = per[k6]["TCC_EA0_RDREQ_128B_sum"]["launches"]
     pts_per_launch = pj["points_linearized_rank0"] / launches
     traffic["pmc_config"] = pj["config"]["workload"]
