@@ -50,27 +50,34 @@ __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const
 
 // ---- K0: cv::pyrDown u8 (reference call site: bpvo/image_pyramid.cc:49).  [1 4 6 4 1]^2 / 256 with (s + 128) >> 8,
 // BORDER_REFLECT_101, dst = ((W+1)/2, (R+1)/2).  Integer arithmetic: evaluation order is irrelevant.
+// Every thread produces PD_ROWS vertically adjacent outputs of one column: the horizontal [1 4 6 4 1] sums of the
+// 2*PD_ROWS + 3 source rows involved are formed once and shared between the outputs.
+constexpr int PD_ROWS = 4;
 __global__ __launch_bounds__(256) void pyrdown_u8_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
 {
   const FrameJob& sj = src_jobs[blockIdx.z];
   const FrameJob& dj = dst_jobs[blockIdx.z];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if(x >= dj.cols || y >= dj.rows) return;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
+  if(x >= dj.cols || y0 >= dj.rows) return;
   const int sw = sj.cols, sh = sj.rows;
   const uint8_t* __restrict__ s = sj.img;
   int xs[5];
 #pragma unroll
   for(int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, sw);
-  int acc = 0;
-  const int wgt[5] = {1, 4, 6, 4, 1};
+  int h[2 * PD_ROWS + 3];
 #pragma unroll
-  for(int k = 0; k < 5; ++k) {
-    const uint8_t* row = s + (size_t) reflect101(2 * y - 2 + k, sh) * sw;
-    const int h = row[xs[2]] * 6 + (row[xs[1]] + row[xs[3]]) * 4 + row[xs[0]] + row[xs[4]];
-    acc += wgt[k] * h;
+  for(int k = 0; k < 2 * PD_ROWS + 3; ++k) {
+    const uint8_t* row = s + (size_t) reflect101(min(2 * y0 - 2 + k, sh + 1), sh) * sw;
+    h[k] = row[xs[2]] * 6 + (row[xs[1]] + row[xs[3]]) * 4 + row[xs[0]] + row[xs[4]];
   }
-  ((uint8_t*) dj.img)[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
+#pragma unroll
+  for(int r = 0; r < PD_ROWS; ++r) {
+    const int y = y0 + r;
+    if(y >= dj.rows) break;
+    const int acc = h[2 * r] + 4 * h[2 * r + 1] + 6 * h[2 * r + 2] + 4 * h[2 * r + 3] + h[2 * r + 4];
+    ((uint8_t*) dj.img)[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
+  }
 }
 
 // ---- IntensityDescriptor::compute: u8 -> f32 (reference: bpvo/intensity_descriptor.cc:31-43)
@@ -90,21 +97,40 @@ __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
 
 // ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
 // bit k = [neighbour_k >= centre], neighbours (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); 1-px border = 0.
+// Workgroups of 64 x 16 pixels: every thread walks 4 rows of one column with a sliding 3 x 3 window (6 rows x 3 bytes loaded
+// for 4 outputs).  Tiny one-pixel-per-thread workgroups were bound by the workgroup dispatch rate (~1.15 WG/ns), not by HBM.
+constexpr int ROWS_PER_THREAD = 4;
 __global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS_PER_THREAD;
   const int W = j.cols, R = j.rows;
-  if(x >= W || y >= R) return;
-  uint8_t out = 0;
-  if(x > 0 && x < W - 1 && y > 0 && y < R - 1) {
-    const uint8_t* p = j.img + (size_t) y * W + x;
-    const uint8_t c = p[0];
-    out = (uint8_t) (((p[-W - 1] >= c) << 0) | ((p[-W] >= c) << 1) | ((p[-W + 1] >= c) << 2) | ((p[-1] >= c) << 3) |
-                     ((p[1] >= c) << 4) | ((p[W - 1] >= c) << 5) | ((p[W] >= c) << 6) | ((p[W + 1] >= c) << 7));
+  if(x >= W || y0 >= R) return;
+  const bool xin = x > 0 && x < W - 1;
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+  uint8_t a[3], b[3], c[3];   // rows y-1, y, y+1; columns x-1, x, x+1
+  auto load = [&](int y, uint8_t (&v)[3]) {
+    const uint8_t* p = j.img + (size_t) min(max(y, 0), R - 1) * W;
+    v[0] = p[xm]; v[1] = p[x]; v[2] = p[xp];
+  };
+  load(y0 - 1, a);
+  load(y0, b);
+#pragma unroll
+  for(int k = 0; k < ROWS_PER_THREAD; ++k) {
+    const int y = y0 + k;
+    if(y >= R) break;
+    load(y + 1, c);
+    uint8_t out = 0;
+    if(xin && y > 0 && y < R - 1) {
+      const uint8_t ctr = b[1];
+      out = (uint8_t) (((a[0] >= ctr) << 0) | ((a[1] >= ctr) << 1) | ((a[2] >= ctr) << 2) | ((b[0] >= ctr) << 3) |
+                       ((b[2] >= ctr) << 4) | ((c[0] >= ctr) << 5) | ((c[1] >= ctr) << 6) | ((c[2] >= ctr) << 7));
+    }
+    j.cen[(size_t) y * W + x] = out;
+#pragma unroll
+    for(int m = 0; m < 3; ++m) { a[m] = b[m]; b[m] = c[m]; }
   }
-  j.cen[(size_t) y * W + x] = out;
 }
 
 // ---- K1a': census of the 3x3-smoothed image, sigmaPriorToCensusTransform > 0 (reference: bpvo/census.cc:63-66 ->
@@ -268,25 +294,30 @@ __global__ __launch_bounds__(256) void saliency_kernel(const FrameJob* jobs)
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if(x >= W || y >= R) return;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS_PER_THREAD;
+  if(x >= W || y0 >= R) return;
   const float* __restrict__ I = j.desc;
   const int n = W & ~3;
-  float S = 0.0f;
-  if(y >= 1 && y <= R - 2 && x != W - 1) {
-    const size_t row = (size_t) y * W;
-    if(x >= n) {
-      S = grad_tail<C>(I, row + x, W, 0);
-      for(int c = 1; c < C; ++c) S += grad_tail<C>(I, row + x, W, c);
-    } else if(C == 1 || x >= 4) {
-      S = grad_abs<C>(I, row + x, W, 0);
-    } else {
-      const int xs = n - 4 + x;
-      const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
-      S = S0 + grad_abs<C>(I, row + xs, W, C - 1);
+#pragma unroll
+  for(int k = 0; k < ROWS_PER_THREAD; ++k) {
+    const int y = y0 + k;
+    if(y >= R) break;
+    float S = 0.0f;
+    if(y >= 1 && y <= R - 2 && x != W - 1) {
+      const size_t row = (size_t) y * W;
+      if(x >= n) {
+        S = grad_tail<C>(I, row + x, W, 0);
+        for(int c = 1; c < C; ++c) S += grad_tail<C>(I, row + x, W, c);
+      } else if(C == 1 || x >= 4) {
+        S = grad_abs<C>(I, row + x, W, 0);
+      } else {
+        const int xs = n - 4 + x;
+        const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
+        S = S0 + grad_abs<C>(I, row + xs, W, C - 1);
+      }
     }
+    j.sal[(size_t) y * W + x] = S;
   }
-  j.sal[(size_t) y * W + x] = S;
 }
 
 // ---- K4: pixel selection (reference: bpvo/template_data.cc:43-89, bpvo/imgproc.h:117-160).
@@ -300,11 +331,15 @@ __device__ __forceinline__ bool is_local_max(const float* __restrict__ S, int W,
   const float* p = S + (size_t) y * W + x;
   const float v = p[0];
   if(radius == 1) {   // WITH_SIMD form: 3 rows x 4 cols (cols -1..+2), strict > (Q8)
+    // all 11 neighbours are loaded before any comparison (no short-circuit: that would serialise 11 memory latencies)
+    float a[4], b[4], c[4];
+#pragma unroll
+    for(int k = 0; k < 4; ++k) { a[k] = p[k - 1 - W]; b[k] = p[k - 1]; c[k] = p[k - 1 + W]; }
     bool ok = true;
 #pragma unroll
-    for(int k = -1; k <= 2; ++k) {
-      if(k != 0) ok = ok && (v > p[k]);
-      ok = ok && (v > p[k - W]) && (v > p[k + W]);
+    for(int k = 0; k < 4; ++k) {
+      if(k != 1) ok = ok & (v > b[k]);
+      ok = ok & (v > a[k]) & (v > c[k]);
     }
     return ok;
   }
@@ -314,29 +349,37 @@ __device__ __forceinline__ bool is_local_max(const float* __restrict__ S, int W,
   return true;
 }
 
+constexpr int SEL_CHUNKS = 4;   // 256-pixel chunks per workgroup (the chunk stays the unit of the order-preserving scan)
 __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, float min_saliency, float min_disp,
                                                           float max_disp, int border)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
-  const int p = blockIdx.x * 256 + threadIdx.x;
   const int npix = W * R;
-  bool f = false;
-  if(p < npix) {
-    const int y = p / W, x = p - y * W;
-    if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1) {
-      if(j.sal[p] >= min_saliency && is_local_max(j.sal, W, j.nms_radius, y, x)) {
-        const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
-        f = (d >= min_disp && d <= max_disp);
+  __shared__ int s_cnt[SEL_CHUNKS][4];
+#pragma unroll
+  for(int k = 0; k < SEL_CHUNKS; ++k) {
+    const int chunk = blockIdx.x * SEL_CHUNKS + k;
+    const int p = chunk * 256 + threadIdx.x;
+    bool f = false;
+    if(p < npix) {
+      const int y = p / W, x = p - y * W;
+      if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1) {
+        if(j.sal[p] >= min_saliency && is_local_max(j.sal, W, j.nms_radius, y, x)) {
+          const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+          f = (d >= min_disp && d <= max_disp);
+        }
       }
+      j.flag[p] = f ? 1 : 0;
     }
-    j.flag[p] = f ? 1 : 0;
+    const unsigned long long m = __ballot(f);
+    if((threadIdx.x & 63) == 0) s_cnt[k][threadIdx.x >> 6] = __popcll(m);
   }
-  __shared__ int s_cnt[4];
-  const unsigned long long m = __ballot(f);
-  if((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
-  if(threadIdx.x == 0 && blockIdx.x * 256 < npix) j.blk_count[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if(threadIdx.x < SEL_CHUNKS) {
+    const int chunk = blockIdx.x * SEL_CHUNKS + threadIdx.x;
+    if(chunk * 256 < npix) j.blk_count[chunk] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
+  }
 }
 
 __global__ __launch_bounds__(1024) void select_scan_kernel(const FrameJob* jobs)
@@ -378,29 +421,38 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols;
-  const int p = blockIdx.x * 256 + threadIdx.x;
   const int npix = W * j.rows;
-  if(blockIdx.x * 256 >= npix) return;
-  const bool f = (p < npix) && j.flag[p];
-  __shared__ int s_cnt[4];
-  const unsigned long long m = __ballot(f);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if(lane == 0) s_cnt[wave] = __popcll(m);
-  __syncthreads();
-  if(!f) return;
-  int rank = j.blk_count[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
-  for(int w = 0; w < wave; ++w) rank += s_cnt[w];
   const int N = *j.n_out;
-  if(rank >= N) return;
-  const int y = p / W, x = p - y * W;
-  const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
-  const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
-  const float Bf = j.b * fx;
-  const float Z = (float) ((double) Bf * (1.0 / (double) d));
-  const float X = ((float) x - cx) * Z * (1.0f / fx);
-  const float Y = ((float) y - cy) * Z * (1.0f / fy);
-  j.pts[rank] = make_float4(X, Y, Z, 1.0f);
-  j.inds[rank] = p;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_cnt[SEL_CHUNKS][4];
+  bool f[SEL_CHUNKS];
+  unsigned long long m[SEL_CHUNKS];
+#pragma unroll
+  for(int k = 0; k < SEL_CHUNKS; ++k) {
+    const int p = (blockIdx.x * SEL_CHUNKS + k) * 256 + threadIdx.x;
+    f[k] = (p < npix) && j.flag[p];
+    m[k] = __ballot(f[k]);
+    if(lane == 0) s_cnt[k][wave] = __popcll(m[k]);
+  }
+  __syncthreads();
+#pragma unroll
+  for(int k = 0; k < SEL_CHUNKS; ++k) {
+    if(!f[k]) continue;
+    const int chunk = blockIdx.x * SEL_CHUNKS + k;
+    const int p = chunk * 256 + threadIdx.x;
+    int rank = j.blk_count[chunk] + __popcll(m[k] & ((1ull << lane) - 1ull));
+    for(int w = 0; w < wave; ++w) rank += s_cnt[k][w];
+    if(rank >= N) continue;
+    const int y = p / W, x = p - y * W;
+    const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+    const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
+    const float Bf = j.b * fx;
+    const float Z = (float) ((double) Bf * (1.0 / (double) d));
+    const float X = ((float) x - cx) * Z * (1.0f / fx);
+    const float Y = ((float) y - cy) * Z * (1.0f / fy);
+    j.pts[rank] = make_float4(X, Y, Z, 1.0f);
+    j.inds[rank] = p;
+  }
 }
 
 // ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
@@ -581,6 +633,7 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 
 // ---- host-callable launchers ------------------------------------------------------------------------------------
 static inline dim3 grid2d(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 3) / 4, nz); }
+static inline dim3 grid2d_rows(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 4 * ROWS_PER_THREAD - 1) / (4 * ROWS_PER_THREAD), nz); }
 
 void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes)
 {
@@ -589,7 +642,7 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 }
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {
-  hipLaunchKernelGGL(pyrdown_u8_kernel, grid2d(dW, dR, nframes), dim3(256), 0, s, src, dst);
+  hipLaunchKernelGGL(pyrdown_u8_kernel, dim3((dW + 63) / 64, (dR + 4 * PD_ROWS - 1) / (4 * PD_ROWS), nframes), dim3(256), 0, s, src, dst);
 }
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {
@@ -601,7 +654,7 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
     hipLaunchKernelGGL(census_blur_kernel, dim3((W + CB_TW - 1) / CB_TW, (R + CB_TH - 1) / CB_TH, nframes), dim3(256), 0, s,
                        jobs, blur_taps[0], blur_taps[1]);
   else
-    hipLaunchKernelGGL(census_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(census_kernel, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
 }
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
 {
@@ -613,13 +666,13 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 }
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes)
 {
-  if(C == 1) hipLaunchKernelGGL(saliency_kernel<1>, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
-  else hipLaunchKernelGGL(saliency_kernel<8>, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+  if(C == 1) hipLaunchKernelGGL(saliency_kernel<1>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
+  else hipLaunchKernelGGL(saliency_kernel<8>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
 }
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border)
 {
-  const int nblk = (W * R + 255) / 256;
+  const int nblk = ((W * R + 255) / 256 + SEL_CHUNKS - 1) / SEL_CHUNKS;
   hipLaunchKernelGGL(select_flag_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs, min_saliency, min_disp, max_disp, border);
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
   hipLaunchKernelGGL(select_write_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs);
