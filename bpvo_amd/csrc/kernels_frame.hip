@@ -192,64 +192,100 @@ __global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, 
 // Arithmetic per plane, f32, no fusing, exactly OpenCV's symmetric 5-tap filters:
 //   row: t = S0*k0 + (S-1 + S+1)*k1 + (S-2 + S+2)*k2        column: s = k0*T0; s += k1*(T+1 + T-1); s += k2*(T+2 + T-2)
 constexpr int BP_TW = 64, BP_TH = 8, BP_HALO = 2;
+constexpr int BP_STACK = 4;   // vertically adjacent tiles per workgroup
+// The workgroup walks BP_STACK vertically adjacent tiles; the census bytes of the next tile are fetched into registers
+// before the current tile's passes run, so the global-load latency is hidden behind the LDS/VALU work instead of being
+// exposed once per (short-lived) workgroup.
 __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2)
 {
-  __shared__ uint8_t s_cen[(BP_TH + 2 * BP_HALO) * (BP_TW + 2 * BP_HALO + 4)];
-  __shared__ float s_row[(BP_TH + 2 * BP_HALO) * BP_TW * 8];
-  constexpr int CW = BP_TW + 2 * BP_HALO + 4;   // padded LDS row pitch of the census tile
+  constexpr int CR = BP_TH + 2 * BP_HALO, CC = BP_TW + 2 * BP_HALO;   // staged census rows / columns
+  constexpr int CW = CC + 4;                                             // padded LDS row pitch of the census tile
+  constexpr int NPRE = (CR * CC + 255) / 256;                            // census bytes per thread
+  __shared__ uint8_t s_cen[CR * CW];
+  __shared__ float s_row[CR * BP_TW * 8];
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
-  const int x0 = blockIdx.x * BP_TW, y0 = blockIdx.y * BP_TH;
+  const int x0 = blockIdx.x * BP_TW;
   const int tid = threadIdx.x;
+  const uint8_t* __restrict__ cen = j.cen;
 
-  for(int i = tid; i < (BP_TH + 2 * BP_HALO) * (BP_TW + 2 * BP_HALO); i += 256) {
-    const int ly = i / (BP_TW + 2 * BP_HALO), lx = i - ly * (BP_TW + 2 * BP_HALO);
-    const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
-    s_cen[ly * CW + lx] = j.cen[(size_t) gy * W + gx];
-  }
-  __syncthreads();
-
-  // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
-  for(int i = tid; i < (BP_TH + 2 * BP_HALO) * BP_TW; i += 256) {
-    const int ly = i / BP_TW, lx = i - ly * BP_TW;
-    const uint8_t* c = s_cen + ly * CW + lx;   // c[0..4] = columns x-2..x+2
-    const unsigned cm2 = c[0], cm1 = c[1], c0 = c[2], cp1 = c[3], cp2 = c[4];
-    float t[8];
+  uint8_t pre[NPRE];
+  auto prefetch = [&](int y0) {
 #pragma unroll
-    for(int b = 0; b < 8; ++b) {
-      const float S0 = (float) ((c0 >> b) & 1u), Sm1 = (float) ((cm1 >> b) & 1u), Sp1 = (float) ((cp1 >> b) & 1u),
-                  Sm2 = (float) ((cm2 >> b) & 1u), Sp2 = (float) ((cp2 >> b) & 1u);
-      t[b] = S0 * k0 + (Sm1 + Sp1) * k1 + (Sm2 + Sp2) * k2;
+    for(int k = 0; k < NPRE; ++k) {
+      const int i = tid + k * 256;
+      const int ly = i / CC, lx = i - ly * CC;
+      const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
+      pre[k] = (i < CR * CC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
     }
-    float4* o = reinterpret_cast<float4*>(s_row + (size_t) i * 8);
-    o[0] = make_float4(t[0], t[1], t[2], t[3]);
-    o[1] = make_float4(t[4], t[5], t[6], t[7]);
-  }
-  __syncthreads();
-
-  // vertical pass: 4 pixels per thread, consecutive threads -> consecutive pixels (2 KB contiguous per wave store)
-  for(int i = tid; i < BP_TH * BP_TW; i += 256) {
-    const int ly = i / BP_TW, lx = i - ly * BP_TW;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if(gx >= W || gy >= R) continue;
-    const float4* T = reinterpret_cast<const float4*>(s_row);
-    const int base = (ly * BP_TW + lx) * 2;         // row ly of s_row is image row gy-2
-    const int pitch = BP_TW * 2;
-    float4 out[2];
+  };
+  const int ybase = blockIdx.y * BP_TH * BP_STACK;
+  prefetch(ybase);
+  for(int t = 0; t < BP_STACK; ++t) {
+    const int y0 = ybase + t * BP_TH;
+    if(y0 >= R) break;
 #pragma unroll
-    for(int h = 0; h < 2; ++h) {
-      const float4 Tm2 = T[base + h], Tm1 = T[base + pitch + h], T0 = T[base + 2 * pitch + h], Tp1 = T[base + 3 * pitch + h],
-                   Tp2 = T[base + 4 * pitch + h];
-      float4 s;
-      s.x = k0 * T0.x; s.x += k1 * (Tp1.x + Tm1.x); s.x += k2 * (Tp2.x + Tm2.x);
-      s.y = k0 * T0.y; s.y += k1 * (Tp1.y + Tm1.y); s.y += k2 * (Tp2.y + Tm2.y);
-      s.z = k0 * T0.z; s.z += k1 * (Tp1.z + Tm1.z); s.z += k2 * (Tp2.z + Tm2.z);
-      s.w = k0 * T0.w; s.w += k1 * (Tp1.w + Tm1.w); s.w += k2 * (Tp2.w + Tm2.w);
-      out[h] = s;
+    for(int k = 0; k < NPRE; ++k) {
+      const int i = tid + k * 256;
+      if(i < CR * CC) { const int ly = i / CC, lx = i - ly * CC; s_cen[ly * CW + lx] = pre[k]; }
     }
-    float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
-    d[0] = out[0];
-    d[1] = out[1];
+    __syncthreads();
+    if(t + 1 < BP_STACK && y0 + BP_TH < R) prefetch(y0 + BP_TH);
+
+    // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
+    for(int i = tid; i < CR * BP_TW; i += 256) {
+      const int ly = i / BP_TW, lx = i - ly * BP_TW;
+      const uint8_t* c = s_cen + ly * CW + lx;   // c[0..4] = columns x-2..x+2
+      const unsigned cm2 = c[0], cm1 = c[1], c0 = c[2], cp1 = c[3], cp2 = c[4];
+      float tt[8];
+#ifdef EXP_NOROWPASS
+#pragma unroll
+      for(int b = 0; b < 8; ++b) tt[b] = (float) (c0 + cm1 + cp1 + cm2 + cp2) * k0;
+#else
+#pragma unroll
+      for(int b = 0; b < 8; ++b) {
+        const float S0 = (float) ((c0 >> b) & 1u), Sm1 = (float) ((cm1 >> b) & 1u), Sp1 = (float) ((cp1 >> b) & 1u),
+                    Sm2 = (float) ((cm2 >> b) & 1u), Sp2 = (float) ((cp2 >> b) & 1u);
+        tt[b] = S0 * k0 + (Sm1 + Sp1) * k1 + (Sm2 + Sp2) * k2;
+      }
+#endif
+      // two planes of 4 channels each: consecutive lanes are 16 bytes apart in either plane, so the 16-byte LDS accesses of
+      // both passes are bank-conflict free (one [8]-float record per pixel would put lanes 32 bytes apart: 2-way conflicts)
+      float4* o = reinterpret_cast<float4*>(s_row);
+      o[i] = make_float4(tt[0], tt[1], tt[2], tt[3]);
+      o[CR * BP_TW + i] = make_float4(tt[4], tt[5], tt[6], tt[7]);
+    }
+    __syncthreads();
+
+    // vertical pass: consecutive threads -> consecutive pixels (2 KB contiguous per wave store)
+    for(int i = tid; i < BP_TH * BP_TW; i += 256) {
+      const int ly = i / BP_TW, lx = i - ly * BP_TW;
+      const int gx = x0 + lx, gy = y0 + ly;
+      if(gx >= W || gy >= R) continue;
+      const float4* T = reinterpret_cast<const float4*>(s_row);
+      const int base = ly * BP_TW + lx;               // row ly of s_row is image row gy-2
+      const int pitch = BP_TW, plane = CR * BP_TW;
+      float4 out[2];
+#ifdef EXP_NOCOLPASS
+      out[0] = T[base + 2 * pitch]; out[1] = T[plane + base + 2 * pitch];
+#else
+#pragma unroll
+      for(int h = 0; h < 2; ++h) {
+        const float4* Th = T + h * plane + base;
+        const float4 Tm2 = Th[0], Tm1 = Th[pitch], T0 = Th[2 * pitch], Tp1 = Th[3 * pitch], Tp2 = Th[4 * pitch];
+        float4 s;
+        s.x = k0 * T0.x; s.x += k1 * (Tp1.x + Tm1.x); s.x += k2 * (Tp2.x + Tm2.x);
+        s.y = k0 * T0.y; s.y += k1 * (Tp1.y + Tm1.y); s.y += k2 * (Tp2.y + Tm2.y);
+        s.z = k0 * T0.z; s.z += k1 * (Tp1.z + Tm1.z); s.z += k2 * (Tp2.z + Tm2.z);
+        s.w = k0 * T0.w; s.w += k1 * (Tp1.w + Tm1.w); s.w += k2 * (Tp2.w + Tm2.w);
+        out[h] = s;
+      }
+#endif
+      float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
+      d[0] = out[0];
+      d[1] = out[1];
+    }
+    __syncthreads();   // s_cen / s_row are rewritten by the next tile
   }
 }
 
@@ -659,7 +695,7 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
 {
   if(sigma > 0.0f)
-    hipLaunchKernelGGL(bitplanes_blur_kernel, dim3((W + BP_TW - 1) / BP_TW, (R + BP_TH - 1) / BP_TH, nframes), dim3(256), 0, s,
+    hipLaunchKernelGGL(bitplanes_blur_kernel, dim3((W + BP_TW - 1) / BP_TW, (R + BP_TH * BP_STACK - 1) / (BP_TH * BP_STACK), nframes), dim3(256), 0, s,
                        jobs, k[0], k[1], k[2]);
   else
     hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
