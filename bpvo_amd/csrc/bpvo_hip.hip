@@ -274,6 +274,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
+  j.cnt = c->d_counters + 4 * (size_t) ws;
   return j;
 }
 
@@ -503,16 +504,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
         { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
         if(c->profile_all) {
-          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g, c->d_counters); }
+          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
           { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
             launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                           p.gradientTolerance, ln->d_active, parity, c->d_counters); }
+                           p.gradientTolerance, ln->d_active, parity); }
         } else {
-          launch_median(ln->stream, g, c->d_counters);
+          launch_median(ln->stream, g);
           launch_irls_reduce(ln->stream, g);
           launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                         p.gradientTolerance, ln->d_active, parity, c->d_counters);
+                         p.gradientTolerance, ln->d_active, parity);
         }
       }
       LANE_CK(ln, hipMemcpyAsync(ln->h_active, ln->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
@@ -591,8 +592,12 @@ size_t tiled_floats(int n, int floats_per_point) { return (size_t) ((n + kTile -
 
 int refresh_counters(bpvo_hip_ctx* c)
 {
+  // per-workspace counters (PairJob::cnt), summed here
+  std::vector<unsigned long long> all(4 * (size_t) c->n_pairs);
+  HIP_CK(c, hipMemcpy(all.data(), c->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   unsigned long long h[4] = {0, 0, 0, 0};
-  HIP_CK(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  for(int w = 0; w < c->n_pairs; ++w)
+    for(int k = 0; k < 4; ++k) h[k] += all[4 * (size_t) w + k];
   c->median_bracketed = h[2];
   c->median_full = h[3];
   c->total_lin = h[1];
@@ -843,8 +848,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
-  CREATE_CK(hipMalloc((void**) &cp->d_counters, 4 * sizeof(unsigned long long)));
-  CREATE_CK(hipMemset(cp->d_counters, 0, 4 * sizeof(unsigned long long)));
+  CREATE_CK(hipMalloc((void**) &cp->d_counters, 4 * sizeof(unsigned long long) * n_pairs));
+  CREATE_CK(hipMemset(cp->d_counters, 0, 4 * sizeof(unsigned long long) * n_pairs));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
   CREATE_CK(hipMalloc((void**) &cp->d_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
@@ -1069,9 +1074,9 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   g.interp = c->params.interp;
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g, c->d_counters); }
+  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
   { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0, c->d_counters); }
+  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0); }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   HIP_CK(c, hipGetLastError());
@@ -1386,7 +1391,7 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   c->profiling = enable != 0;
   c->profile_all = enable >= 2;
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
-  HIP_CK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long)));
+  HIP_CK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long) * c->n_pairs));
   c->total_lin = 0;
   for(auto& ln : c->lanes) ln.k6_seq = 0;
   return BPVO_OK;

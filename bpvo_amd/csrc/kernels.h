@@ -38,12 +38,11 @@ void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*d
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 void launch_warp_residual(hipStream_t s, const GNLaunch& g);
-void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters /*device [4] or null*/);
+void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
-                    float f_tol, float g_tol, int* active_counter /*device [2]*/, int parity,
-                    unsigned long long* counters /*device [2]: points, linearisations; may be null*/);
+                    float f_tol, float g_tol, int* active_counter /*device [2]*/, int parity);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
 int  gn_pts_per_block(int npairs);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);

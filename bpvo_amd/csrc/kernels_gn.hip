@@ -539,7 +539,7 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
 template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, unsigned long long* counters)
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs)
 {
   const PairJob& j = jobs[blockIdx.x];
   GNState* st = j.st;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   }
 
   if(tid == 0) {
-    if(counters) atomicAdd(&counters[done ? 2 : 3], 1ull);                  // measurement: bracketed vs full selections
+    j.cnt[done ? 2 : 3] += 1ull;                                            // measurement: bracketed vs full selections
     const unsigned long long nm6 = (unsigned long long) n_total - 6ull;     // size_t wrap for n < 6 (Q5)
     float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
     if((double) s < 1e-6) s = 1.0f;
@@ -979,8 +979,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 
 __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
                                                      int max_iterations, int max_fun_evals, float p_tol, float f_tol,
-                                                     float g_tol_param, int* active_counter, int parity,
-                                                     unsigned long long* counters)
+                                                     float g_tol_param, int* active_counter, int parity)
 {
   const PairJob& j = jobs[blockIdx.x];
   GNState* gst = j.st;
@@ -1011,11 +1010,11 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   if(threadIdx.x == 0) {
     GNState* st = reinterpret_cast<GNState*>(s_state);
     const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
-    if(again && mode == 0 && active_counter) atomicAdd(&active_counter[parity], 1);
-    if(counters) {     // measurement: points and linearisations processed (bench.py roofline)
-      atomicAdd(&counters[0], (unsigned long long) j.n);
-      atomicAdd(&counters[1], 1ull);
-    }
+    // "some workspace still active": every writer stores the same value — a same-address atomicAdd from every block of a
+    // 1024-pair batch serialises into tens of microseconds
+    if(again && mode == 0 && active_counter) active_counter[parity] = 1;
+    j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
+    j.cnt[1] += 1ull;
   }
   __syncthreads();
   for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
@@ -1178,7 +1177,7 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   }
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
-void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counters)
+void launch_median(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   static bool attr_set = false;
@@ -1187,8 +1186,8 @@ void launch_median(hipStream_t s, const GNLaunch& g, unsigned long long* counter
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     attr_set = true;
   }
-  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
-  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, counters);
+  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
+  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
 }
 
 template <int C>
@@ -1209,11 +1208,11 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
   else launch_irls_c<8>(s, g, ppb);
 }
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
-                    float f_tol, float g_tol, int* active_counter, int parity, unsigned long long* counters)
+                    float f_tol, float g_tol, int* active_counter, int parity)
 {
   const int ppb = gn_pts_per_block(g.npairs);
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
-                     f_tol, g_tol, active_counter, parity, counters);
+                     f_tol, g_tol, active_counter, parity);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {

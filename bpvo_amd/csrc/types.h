@@ -103,6 +103,8 @@ struct PairJob {
   uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, -} of the bracket pass
   float*        partials; // [nblocks][kPartialStride]
+  unsigned long long* cnt; // [4] per-workspace measurement counters: points linearised, linearisations, bracketed / full
+                           // median selections (per workspace, written by one thread: no same-address atomics)
   GNState*      st;
 };
 
