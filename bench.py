@@ -49,6 +49,9 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events at all")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel (diagnostics, slower)")
     ap.add_argument("--gen-workers", type=int, default=0)
+    ap.add_argument("--other-configs", type=int, default=256,
+                    help="pairs per batch for the extra lines of BASELINE.json's other single-GPU configs (640x480 intensity/Huber, "
+                         "640x480 bit-planes/Tukey) and the B = 1 latency of the headline config; 0 = skip; N = 1 only")
     ap.add_argument("--input-cache", default="", help="directory holding the rendered synthetic inputs of this exact shard; "
                     "written on first use (lets the rocprofv3 runs skip the CPU rendering, which must not fork under the profiler)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -106,6 +109,42 @@ def cpu_baseline(args, batch, n_sample):
     }
 
 
+def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, levels, loss, steps=3, warmup=1):
+    """GN iterations/s of one more configuration (same step definition as the headline, inputs resident in HBM)."""
+    from types import SimpleNamespace
+    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0))
+    ctx = hip.create(batch["K"], batch["b"], rows, cols, p, device=dev_index, n_frames=2 * n, n_pairs=n)
+    d_i = torch.from_numpy(batch["images"][: 2 * n]).to(dev)
+    d_d = torch.from_numpy(batch["disparities"][: 2 * n]).to(dev)
+    for _ in range(warmup):
+        ctx.batch_run_device(n, d_i.data_ptr(), d_d.data_ptr())
+    ctx.profiling(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        poses, stats = ctx.batch_run_device(n, d_i.data_ptr(), d_d.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gn = ctx.total_linearizations()
+    dT = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - batch["T_gt"][:n, :3, 3], axis=1)
+    ctx.close()
+    return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "frames_per_s": 2.0 * n * steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "gn_iterations_per_pair": gn / (steps * n), "median_trans_err_vs_gt_m": float(np.median(dT))}
+
+
+def other_configs(hip, torch, dev, dev_index, args, batch, other_batch):
+    """BASELINE.json configs[1], [2] (640x480) as batches, and configs[3] (one KITTI-shaped pair at a time: the latency-bound
+    B = 1 case the roofline section of SURVEY.md asks to report next to the batched one)."""
+    n = args.other_configs
+    out = {
+        "640x480 intensity, 4 levels, huber": timed_batch(hip, torch, dev, dev_index, other_batch, 480, 640, n, "intensity", 4, "huber"),
+        "640x480 bitplanes, 4 levels, tukey": timed_batch(hip, torch, dev, dev_index, other_batch, 480, 640, n, "bitplanes", 4, "tukey"),
+        "1241x376 bitplanes, 4 levels, tukey, one pair per call (B = 1)":
+            timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1, args.descriptor, args.levels, args.loss, steps=5, warmup=2),
+    }
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +170,10 @@ def main():
             np.save(cache + "_img.npy", batch["images"]); np.save(cache + "_disp.npy", batch["disparities"]); np.save(cache + "_gt.npy", batch["T_gt"])
             open(cache + ".ok", "w").close()
     t_gen = time.perf_counter() - t0
+    # inputs of the extra configs are rendered now as well: the fork pool must not run after the GPU is initialised
+    other_batch = None
+    if world == 1 and args.other_configs > 0 and (args.rows, args.cols) == (376, 1241):
+        other_batch = synth.make_batch(480, 640, args.other_configs, first_index=0, workers=workers)
 
     import torch
     import torch.distributed as dist
@@ -237,6 +280,10 @@ def main():
         if args.cpu_pairs > 0:
             cpu = cpu_baseline(args, batch, args.cpu_pairs)
 
+        others = None
+        if other_batch is not None:
+            others = other_configs(hip, torch, dev, dev_index, args, batch, other_batch)
+
         iters = stats["numIterations"].astype(np.float64)
         out = {
             "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS)"
@@ -260,6 +307,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,
+            "other_configs": others,
             "setup": {"synth_seconds": t_gen, "gen_workers": workers},
         }
         print(json.dumps(out))
