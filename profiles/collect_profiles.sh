@@ -8,15 +8,16 @@
 set -u
 TAG=${1:-r01}
 R=$(pwd)
-O=$R/gpurun_out/profiles_$TAG
-rm -rf "$O"; mkdir -p "$O"
+# raw rocprofv3 databases stay on the box (gpurun merges at most 64 MiB back); only the summaries are copied out
+O=/tmp/bpvo_profiles_$TAG
+rm -rf "$O"; mkdir -p "$O"; mkdir -p "$R/gpurun_out/profiles_$TAG"
 cd /tmp && export TMPDIR=/tmp
 # the synthetic inputs are rendered once, outside the profiler (a fork pool under rocprofv3 hangs: the profiler initialises
 # the GPU before python starts), and the profiled runs read them back from /tmp
 CACHE=/tmp/bpvo_bench_inputs
-timeout 300 python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_default.err"; echo "inputs rc=$?"
-timeout 300 python3 "$R/bench.py" --pairs-per-gpu 64 --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_pmc.err"; echo "pmc inputs rc=$?"
-timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 --input-cache $CACHE \
+timeout 300 python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_default.err"; echo "inputs rc=$?"
+timeout 300 python3 "$R/bench.py" --pairs-per-gpu 64 --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_pmc.err"; echo "pmc inputs rc=$?"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache $CACHE \
     > "$O/trace_bench.json" 2> "$O/trace.err"; echo "trace rc=$?"
 export BPVO_HIP_LANES=1
 i=0
@@ -28,7 +29,7 @@ for CNT in "FETCH_SIZE" "WRITE_SIZE" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout 150 rocprofv3 --pmc $CNT --kernel-trace -d "$O/pmc$i" -- python3 "$R/bench.py" --pairs-per-gpu 64 --fixed-iters 20 \
-      --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --gen-workers 1 --input-cache $CACHE > "$O/pmc$i.json" 2> "$O/pmc$i.err"
+      --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --gen-workers 1 --input-cache $CACHE > "$O/pmc$i.json" 2> "$O/pmc$i.err"
   echo "pmc$i ($CNT) rc=$?"
 done
-cd "$R" && python3 profiles/summarize.py "$O" "$TAG"
+cd "$R" && python3 profiles/summarize.py "$O" "$TAG" && cp "$O"/${TAG}_* "$O"/trace_bench.json "$O"/*.err "$R/gpurun_out/profiles_$TAG/"

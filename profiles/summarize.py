@@ -22,7 +22,7 @@ def db_of(sub):
 db = db_of("trace")
 if db:
     rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs   (durations in us)",
+    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs   (durations in us)",
              "%-100s %8s %14s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
     for r in rows:
         lines.append("%-100s %8d %14.1f %10.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
