@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       }
 #endif
       float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
-      d[0] = out[0];
-      d[1] = out[1];
+      store_stream(d, out[0]);
+      store_stream(d + 1, out[1]);
     }
     __syncthreads();   // s_cen / s_row are rewritten by the next tile
   }
@@ -614,13 +614,13 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   // tiled stores (types.h tile_index): consecutive lanes write consecutive vectors
   if constexpr(C == 8) {
     float4* pv = reinterpret_cast<float4*>(j.pix);
-    pv[tile_index<2>(i, 0)] = make_float4(pixv[0], pixv[1], pixv[2], pixv[3]);
-    pv[tile_index<2>(i, 1)] = make_float4(pixv[4], pixv[5], pixv[6], pixv[7]);
+    store_stream(pv + tile_index<2>(i, 0), make_float4(pixv[0], pixv[1], pixv[2], pixv[3]));
+    store_stream(pv + tile_index<2>(i, 1), make_float4(pixv[4], pixv[5], pixv[6], pixv[7]));
     float4* gv = reinterpret_cast<float4*>(j.grad);
-    gv[tile_index<4>(i, 0)] = make_float4(Ix[0], Ix[1], Ix[2], Ix[3]);
-    gv[tile_index<4>(i, 1)] = make_float4(Ix[4], Ix[5], Ix[6], Ix[7]);
-    gv[tile_index<4>(i, 2)] = make_float4(Iy[0], Iy[1], Iy[2], Iy[3]);
-    gv[tile_index<4>(i, 3)] = make_float4(Iy[4], Iy[5], Iy[6], Iy[7]);
+    store_stream(gv + tile_index<4>(i, 0), make_float4(Ix[0], Ix[1], Ix[2], Ix[3]));
+    store_stream(gv + tile_index<4>(i, 1), make_float4(Ix[4], Ix[5], Ix[6], Ix[7]));
+    store_stream(gv + tile_index<4>(i, 2), make_float4(Iy[0], Iy[1], Iy[2], Iy[3]));
+    store_stream(gv + tile_index<4>(i, 3), make_float4(Iy[4], Iy[5], Iy[6], Iy[7]));
   } else {
     j.pix[i] = pixv[0];
     reinterpret_cast<float2*>(j.grad)[i] = make_float2(Ix[0], Iy[0]);

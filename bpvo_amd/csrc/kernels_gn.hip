@@ -112,7 +112,7 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
   const bool in_block = i_raw < n;
   const int i = in_block ? i_raw : n - 1;
   const int W = j.cols, R = j.rows;
-  const float4 X = j.pts[i];
+  const float4 X = load_stream(j.pts + i);
   int xi = 0, yi = 0;
   bool valid;
   double xf = 0.0, yf = 0.0;       // fractional parts (standard formulation)
@@ -177,21 +177,25 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
       float4 a0, a1, a2, a3, b0, b1, b2, b3;
       float4* tc = reinterpret_cast<float4*>(j.tapcache);
       if(hit) {
-        a0 = tc[tile_index<8>(i, 0)]; a1 = tc[tile_index<8>(i, 1)]; a2 = tc[tile_index<8>(i, 2)]; a3 = tc[tile_index<8>(i, 3)];
-        b0 = tc[tile_index<8>(i, 4)]; b1 = tc[tile_index<8>(i, 5)]; b2 = tc[tile_index<8>(i, 6)]; b3 = tc[tile_index<8>(i, 7)];
+        a0 = load_stream(tc + tile_index<8>(i, 0)); a1 = load_stream(tc + tile_index<8>(i, 1));
+        a2 = load_stream(tc + tile_index<8>(i, 2)); a3 = load_stream(tc + tile_index<8>(i, 3));
+        b0 = load_stream(tc + tile_index<8>(i, 4)); b1 = load_stream(tc + tile_index<8>(i, 5));
+        b2 = load_stream(tc + tile_index<8>(i, 6)); b3 = load_stream(tc + tile_index<8>(i, 7));
       } else {
         const float4* q0 = reinterpret_cast<const float4*>(d0);
         const float4* q1 = reinterpret_cast<const float4*>(d1);
         a0 = q0[0]; a1 = q0[1]; a2 = q0[2]; a3 = q0[3];
         b0 = q1[0]; b1 = q1[1]; b2 = q1[2]; b3 = q1[3];
         if(in_block) {
-          tc[tile_index<8>(i, 0)] = a0; tc[tile_index<8>(i, 1)] = a1; tc[tile_index<8>(i, 2)] = a2; tc[tile_index<8>(i, 3)] = a3;
-          tc[tile_index<8>(i, 4)] = b0; tc[tile_index<8>(i, 5)] = b1; tc[tile_index<8>(i, 6)] = b2; tc[tile_index<8>(i, 7)] = b3;
+          store_stream(tc + tile_index<8>(i, 0), a0); store_stream(tc + tile_index<8>(i, 1), a1);
+          store_stream(tc + tile_index<8>(i, 2), a2); store_stream(tc + tile_index<8>(i, 3), a3);
+          store_stream(tc + tile_index<8>(i, 4), b0); store_stream(tc + tile_index<8>(i, 5), b1);
+          store_stream(tc + tile_index<8>(i, 6), b2); store_stream(tc + tile_index<8>(i, 7), b3);
           j.tapkey[i] = key;
         }
       }
       const float4* p0 = reinterpret_cast<const float4*>(j.pix);
-      const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
+      const float4 t0 = load_stream(p0 + tile_index<2>(i, 0)), t1 = load_stream(p0 + tile_index<2>(i, 1));
       I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
       I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
       I10[0] = b0.x; I10[1] = b0.y; I10[2] = b0.z; I10[3] = b0.w; I10[4] = b1.x; I10[5] = b1.y; I10[6] = b1.z; I10[7] = b1.w;
@@ -232,8 +236,8 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
   if(in_block) {
     if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
       float4* o = reinterpret_cast<float4*>(j.r);
-      o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
-      o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
+      store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
+      store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
     } else {
       j.r[i] = res[0];
     }
@@ -788,13 +792,14 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
     // Per (point, channel) that is 6 multiply-adds instead of the 27 of the reference's rankUpdatePoint; the 6x6 outer
     // products are formed once per point.  Algebraically identical, rounding differs at the 1e-7 level like any other
     // summation order (H, G are tolerance-compared).
-    const float4 P = j.pts[i];
+    const float4 P = load_stream(j.pts + i);
     float rr[C], Ix[C], Iy[C];
     if constexpr(C == 8) {
       const float4* qr = reinterpret_cast<const float4*>(j.r);
       const float4* qg = reinterpret_cast<const float4*>(j.grad);
-      const float4 r0 = qr[tile_index<2>(i, 0)], r1 = qr[tile_index<2>(i, 1)];
-      const float4 gx0 = qg[tile_index<4>(i, 0)], gx1 = qg[tile_index<4>(i, 1)], gy0 = qg[tile_index<4>(i, 2)], gy1 = qg[tile_index<4>(i, 3)];
+      const float4 r0 = load_stream(qr + tile_index<2>(i, 0)), r1 = load_stream(qr + tile_index<2>(i, 1));
+      const float4 gx0 = load_stream(qg + tile_index<4>(i, 0)), gx1 = load_stream(qg + tile_index<4>(i, 1)),
+                   gy0 = load_stream(qg + tile_index<4>(i, 2)), gy1 = load_stream(qg + tile_index<4>(i, 3));
       rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
       Ix[0] = gx0.x; Ix[1] = gx0.y; Ix[2] = gx0.z; Ix[3] = gx0.w; Ix[4] = gx1.x; Ix[5] = gx1.y; Ix[6] = gx1.z; Ix[7] = gx1.w;
       Iy[0] = gy0.x; Iy[1] = gy0.y; Iy[2] = gy0.z; Iy[3] = gy0.w; Iy[4] = gy1.x; Iy[5] = gy1.y; Iy[6] = gy1.z; Iy[7] = gy1.w;

@@ -64,6 +64,37 @@ __global__ __launch_bounds__(256) void kB(const float4* rec, float4* r, unsigned
   valid[i] = (unsigned char) (((int) kk.x) & 1);
 }
 
+// E: like A with configurable tile size (points per tile) and threads per block, optional nontemporal loads
+template <int TILE, int NT>
+__device__ __forceinline__ size_t tidx(int pieces, size_t i, int piece) { return ((i / TILE) * pieces + piece) * TILE + (i % TILE); }
+template <int TILE, int NT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void kE(const float4* pts, const unsigned* key, const float4* pix, const float4* taps, float4* r, unsigned char* valid, size_t n)
+{
+  const size_t i = (size_t) blockIdx.x * BLOCK + threadIdx.x;
+  if(i >= n) return;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  auto ld = [&](const float4* p) {
+    if(NT) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *p;
+  };
+  float4 acc = ld(pts + i);
+  const unsigned k = key[i];
+  const float4 p0 = ld(pix + tidx<TILE, NT>(2, i, 0)), p1 = ld(pix + tidx<TILE, NT>(2, i, 1));
+  float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for(int q = 0; q < 8; ++q) { const float4 t = ld(taps + tidx<TILE, NT>(8, i, q)); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+  const float4 o0 = make_float4(s.x - p0.x + acc.x, s.y - p0.y, s.z - p0.z, s.w - p0.w);
+  const float4 o1 = make_float4(s.x - p1.x, s.y - p1.y + acc.y, s.z - p1.z, s.w - p1.w + (float) k);
+  if(NT) {
+    v4f a; a.x = o0.x; a.y = o0.y; a.z = o0.z; a.w = o0.w;
+    v4f b; b.x = o1.x; b.y = o1.y; b.z = o1.z; b.w = o1.w;
+    __builtin_nontemporal_store(a, reinterpret_cast<v4f*>(r + tidx<TILE, NT>(2, i, 0)));
+    __builtin_nontemporal_store(b, reinterpret_cast<v4f*>(r + tidx<TILE, NT>(2, i, 1)));
+  }
+  else { r[tidx<TILE, NT>(2, i, 0)] = o0; r[tidx<TILE, NT>(2, i, 1)] = o1; }
+  valid[i] = (unsigned char) (k & 1);
+}
+
 __global__ __launch_bounds__(256) void kC(const float4* a, float4* b, size_t n4)
 {
   const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -102,6 +133,11 @@ int main()
   time("A2: no key load (209 B)", n * 209.0, [&] { hipLaunchKernelGGL(kA<2>, dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("A3: neither (208 B)", n * 208.0, [&] { hipLaunchKernelGGL(kA<3>, dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("A5: 2 points per thread (213 B)", n * 213.0, [&] { hipLaunchKernelGGL(kA2, dim3(grid / 2), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E1: tile 256, block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<256, 0, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E2: tile 64, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 0, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E3: tile 1024, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<1024, 0, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4: tile 64, block 256, nontemporal", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 1, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E5: tile 64, block 64", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 0, 64>), dim3(grid * 4), dim3(64), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("B: 1 merged read (192 B) + writes", n * 225.0, [&] { hipLaunchKernelGGL(kB, dim3(grid), dim3(256), 0, 0, rec, r, valid, n); });
   const size_t n4 = n * 8;   // 128 B/point worth of float4
   time("C: float4 copy (r+w)", n4 * 32.0, [&] { hipLaunchKernelGGL(kC, dim3((int) ((n4 + 255) / 256)), dim3(256), 0, 0, taps, rec, n4); });
