@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const
   if(f4) {
     const float4* s4 = reinterpret_cast<const float4*>(sd);
     float4* d4 = reinterpret_cast<float4*>(dd);
-    for(size_t k = t; k < npix / 4; k += stride) d4[k] = s4[k];
+    for(size_t k = t; k < npix / 4; k += stride) d4[k] = load_stream(s4 + k);   // the packed input is read once
   } else {
     for(size_t k = t; k < npix; k += stride) dd[k] = sd[k];
   }

@@ -469,8 +469,8 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
         const int pt = base + u * MED_THREADS;
         const bool in = pt < n;
         v[u] = in ? j.valid[pt] : (unsigned char) 0;
-        a[u] = in ? q[tile_index<2>(pt, 0)] : make_float4(0, 0, 0, 0);
-        b[u] = in ? q[tile_index<2>(pt, 1)] : make_float4(0, 0, 0, 0);
+        a[u] = in ? load_stream(q + tile_index<2>(pt, 0)) : make_float4(0, 0, 0, 0);
+        b[u] = in ? load_stream(q + tile_index<2>(pt, 1)) : make_float4(0, 0, 0, 0);
       }
 #pragma unroll
       for(int u = 0; u < U; ++u) {
