@@ -226,6 +226,7 @@ def main():
 
     gn_local = ctx.total_linearizations()
     med_paths = ctx.median_path_counts()
+    fused_pts = ctx.fused_point_counts()
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
     points_linearized = all_kstats["irls_reduce"]["units"]     # device-side count: sum over linearisations of N
     kstats = all_kstats if not args.no_profile else {}
@@ -304,6 +305,8 @@ def main():
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,
             "median_selections": {"bracketed": med_paths[0], "full": med_paths[1]},
+            "fused_path": {"points": fused_pts[0], "of": fused_pts[1],
+                           "note": "linearisations with a frozen robust scale: residuals recomputed inside irls_reduce, warp_residual skips them"},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

@@ -374,6 +374,12 @@ class Context:
         self.call("median_path_counts", C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def fused_point_counts(self):
+        """(fused, total) points linearised since the last counter reset (HIP library only)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.call("fused_point_counts", C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def total_linearizations(self):
         n = C.c_uint64()
         self.call("total_linearizations", C.byref(n))

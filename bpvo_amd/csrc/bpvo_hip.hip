@@ -125,7 +125,9 @@ struct bpvo_hip_ctx {
   std::vector<bpvo_hip_point_with_info> cloud;
   M44 cloud_pose;
   // measurement
+  double points_fused = 0;     // points linearised through the fused path since the last counter reset
   int fast_warp = 0;           // bpvo_hip_set_warp_formulation
+  int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (BPVO_HIP_FUSE_FROZEN=0 disables)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
@@ -274,7 +276,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
-  j.cnt = c->d_counters + 4 * (size_t) ws;
+  j.cnt = c->d_counters + kWsCounters * (size_t) ws;
   return j;
 }
 
@@ -484,6 +486,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.loss = p.lossFunction;
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
+    g.fuse_frozen = c->fuse_frozen;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
@@ -593,11 +596,11 @@ size_t tiled_floats(int n, int floats_per_point) { return (size_t) ((n + kTile -
 int refresh_counters(bpvo_hip_ctx* c)
 {
   // per-workspace counters (PairJob::cnt), summed here
-  std::vector<unsigned long long> all(4 * (size_t) c->n_pairs);
+  std::vector<unsigned long long> all(kWsCounters * (size_t) c->n_pairs);
   HIP_CK(c, hipMemcpy(all.data(), c->d_counters, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  unsigned long long h[4] = {0, 0, 0, 0};
+  unsigned long long h[kWsCounters] = {};
   for(int w = 0; w < c->n_pairs; ++w)
-    for(int k = 0; k < 4; ++k) h[k] += all[4 * (size_t) w + k];
+    for(int k = 0; k < kWsCounters; ++k) h[k] += all[kWsCounters * (size_t) w + k];
   c->median_bracketed = h[2];
   c->median_full = h[3];
   c->total_lin = h[1];
@@ -607,7 +610,9 @@ int refresh_counters(bpvo_hip_ctx* c)
   double all_k6 = 0;
   for(const auto& ln : c->lanes) all_k6 += ln.k6_seq;
   const bool sampled = c->profiling && !c->profile_all && all_k6 > 0;
-  c->kc_units[KC_WARP_RESIDUAL] = sampled ? (double) h[0] * (double) c->kc_launches[KC_WARP_RESIDUAL] / all_k6 : (double) h[0];
+  // (h[4]: the points warp_residual itself processed; workspaces with a frozen scale go through irls_reduce's fused path)
+  c->kc_units[KC_WARP_RESIDUAL] = sampled ? (double) h[4] * (double) c->kc_launches[KC_WARP_RESIDUAL] / all_k6 : (double) h[4];
+  c->points_fused = (double) h[0] - (double) h[4];
   c->kc_units[KC_IRLS_REDUCE] = (double) h[0];
   c->kc_units[KC_MEDIAN] = (double) h[0];
   c->kc_units[KC_GN_STEP] = (double) h[1];
@@ -637,12 +642,28 @@ void trajectory_push(bpvo_hip_ctx* c, const M44& T)   // Trajectory::push_back +
   else c->trajectory.push_back(Ti);
 }
 
+// Fused path of the estimate loops: the residual / valid buffers of a workspace may lag behind its last linearisation
+// (GNState::r_stale).  Everything that reads them goes through here first; the check itself happens on the device.
+int ensure_residuals(bpvo_hip_ctx* c, int ws)
+{
+  Workspace& w = c->ws[ws];
+  if(w.last_ref < 0 || c->C != 8) return BPVO_OK;
+  int rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
+  if(rc) return rc;
+  GNLaunch g;
+  g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[w.last_ref].n_host[w.last_level]; g.C = c->C;
+  launch_refresh_residuals(c->stream, g);
+  return BPVO_OK;
+}
+
 int fraction_good(bpvo_hip_ctx* c, int ws, float thr, float* frac)
 {
   Workspace& w = c->ws[ws];
   if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
   const int n = c->frames[w.last_ref].n_host[w.last_level];
-  int rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
+  int rc = ensure_residuals(c, ws);
+  if(rc) return rc;
+  rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
   if(rc) return rc;
   HIP_CK(c, hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), c->stream));
   launch_count_good(c->stream, c->d_job1, n, c->C, c->params.lossFunction, thr, c->d_count);
@@ -660,7 +681,9 @@ int get_weights_host(bpvo_hip_ctx* c, int ws, std::vector<float>& w_cm, int* n_o
   if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
   const int n = c->frames[w.last_ref].n_host[w.last_level];
   const int C = c->C;
-  int rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
+  int rc = ensure_residuals(c, ws);
+  if(rc) return rc;
+  rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
   if(rc) return rc;
   launch_weights(c->stream, c->d_job1, n, C, c->params.lossFunction, c->d_wtmp);
   std::vector<float> pm((size_t) n * C);
@@ -831,6 +854,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   {
     int max_lanes = kDefaultLanes;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
   for(size_t k = 0; k < cp->lanes.size(); ++k) {
@@ -848,8 +872,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
-  CREATE_CK(hipMalloc((void**) &cp->d_counters, 4 * sizeof(unsigned long long) * n_pairs));
-  CREATE_CK(hipMemset(cp->d_counters, 0, 4 * sizeof(unsigned long long) * n_pairs));
+  CREATE_CK(hipMalloc((void**) &cp->d_counters, kWsCounters * sizeof(unsigned long long) * n_pairs));
+  CREATE_CK(hipMemset(cp->d_counters, 0, kWsCounters * sizeof(unsigned long long) * n_pairs));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
   CREATE_CK(hipMalloc((void**) &cp->d_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
@@ -1100,6 +1124,7 @@ int bpvo_hip_get_residuals(bpvo_hip_ctx* c, int ws, float* r, size_t* n_out)
   if(n_out) *n_out = (size_t) n * C;
   if(!r) return BPVO_OK;
   (void) hipSetDevice(c->device);
+  { int rc = ensure_residuals(c, ws); if(rc) return rc; }
   std::vector<float> t(tiled_floats(n, C));
   if(n) HIP_CK(c, hipMemcpyAsync(t.data(), w.r, t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
@@ -1115,6 +1140,7 @@ int bpvo_hip_get_valid(bpvo_hip_ctx* c, int ws, uint16_t* v, size_t* n_out)
   if(n_out) *n_out = (size_t) n;
   if(!v) return BPVO_OK;
   (void) hipSetDevice(c->device);
+  { int rc = ensure_residuals(c, ws); if(rc) return rc; }
   std::vector<uint8_t> b((size_t) n);
   HIP_CK(c, hipMemcpyAsync(b.data(), w.valid, b.size(), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
@@ -1391,7 +1417,7 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   c->profiling = enable != 0;
   c->profile_all = enable >= 2;
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
-  HIP_CK(c, hipMemset(c->d_counters, 0, 4 * sizeof(unsigned long long) * c->n_pairs));
+  HIP_CK(c, hipMemset(c->d_counters, 0, kWsCounters * sizeof(unsigned long long) * c->n_pairs));
   c->total_lin = 0;
   for(auto& ln : c->lanes) ln.k6_seq = 0;
   return BPVO_OK;
@@ -1416,8 +1442,21 @@ int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* c, bpvo_hip_kernel_stat* out, int ma
     out[n].total_ms = c->kc_ms[k];
     out[n].units = c->kc_units[k];
     out[n].bytes_per_unit = bpu[k];
+    if(k == KC_IRLS_REDUCE && c->kc_units[k] > 0)   // fused points carry warp_residual's bytes as well
+      out[n].bytes_per_unit = bpu[k] + bpu[KC_WARP_RESIDUAL] * c->points_fused / c->kc_units[k];
   }
   *n_out = n;
+  return BPVO_OK;
+}
+int bpvo_hip_fused_point_counts(bpvo_hip_ctx* c, uint64_t* fused, uint64_t* total)
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  int rc = refresh_counters(c);
+  if(rc) return rc;
+  *fused = (uint64_t) c->points_fused;
+  *total = (uint64_t) c->kc_units[KC_IRLS_REDUCE];
   return BPVO_OK;
 }
 int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* full)

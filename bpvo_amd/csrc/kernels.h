@@ -31,6 +31,8 @@ struct GNLaunch {
   int C;
   int loss;
   int interp = 0;        // BPVO_INTERP_* (kLinear uses the tap-cached kernel, the others warp_residual_interp_kernel)
+  int fuse_frozen = 0;   // estimate loops, C = 8, kLinear, f64 formulation: once a workspace's scale is frozen, irls_reduce
+                         // recomputes the residuals itself and warp_residual skips the workspace
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
 };
 int  gn_num_blocks(int max_points);
@@ -38,6 +40,7 @@ void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*d
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 void launch_warp_residual(hipStream_t s, const GNLaunch& g);
+void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
 void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)

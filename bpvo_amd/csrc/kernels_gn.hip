@@ -86,31 +86,27 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
 // PhotoError::Impl::operator() / run of that branch (bpvo/photo_error.cc:118-214; same arithmetic as BilinearInterp,
 // bpvo/interp_util.h:49-71,93-96,184-203): Iw = dp_ps(C, [I00, I01, I10, I11]) = (C0*I00 + C1*I01) + (C2*I10 + C3*I11),
 // r = Iw - I0, and for an invalid point Iw = 0, i.e. r = -I0.
-template <int C, bool FAST>
-__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs)
+// P = K * T[0:3,:] in f32, index-order sums (RigidBodyWarp::setPose, bpvo/rigid_body_warp.h:111-114)
+__device__ __forceinline__ void projection_matrix(const PairJob& j, const float* __restrict__ T, float (&P)[12])
 {
-  const PairJob& j = jobs[blockIdx.y];
-  const GNState* __restrict__ st = j.st;
-  if(!st->active) return;
-  const int n = j.n;
-  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
-
-  float P[12];
 #pragma unroll
   for(int r = 0; r < 3; ++r)
 #pragma unroll
     for(int c = 0; c < 4; ++c) {
-      float s = j.K[r * 3 + 0] * st->T[0 * 4 + c];
-      s += j.K[r * 3 + 1] * st->T[1 * 4 + c];
-      s += j.K[r * 3 + 2] * st->T[2 * 4 + c];
+      float s = j.K[r * 3 + 0] * T[0 * 4 + c];
+      s += j.K[r * 3 + 1] * T[1 * 4 + c];
+      s += j.K[r * 3 + 2] * T[2 * 4 + c];
       P[r * 4 + c] = s;
     }
+}
 
-  // lanes past the end of the last block redo the last point (loads only) so that the whole block reaches the
-  // block-level bracket step below; their stores are masked
-  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
-  const bool in_block = i_raw < n;
-  const int i = in_block ? i_raw : n - 1;
+// One template point of warp_residual: projection, validity, (cached) bilinear taps, residuals of all C channels.
+// `in_block` gates the tap-cache update (lanes past the end of a block redo the last point, loads only).  Returns valid.
+// HALF (C = 8, f64 formulation): the taps are fetched and consumed in two groups of four channels, which halves the
+// registers they occupy — for the fused path of irls_reduce, where the 29 accumulators are live as well.
+template <int C, bool FAST, bool HALF = false>
+__device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12], int i, bool in_block, float (&res)[C])
+{
   const int W = j.cols, R = j.rows;
   const float4 X = load_stream(j.pts + i);
   int xi = 0, yi = 0;
@@ -159,9 +155,47 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     const float xfyf = fx * fy;
     cf[0] = xfyf - fy - fx + 1.0f; cf[1] = fx - xfyf; cf[2] = fy - xfyf; cf[3] = xfyf;
   }
-  if(in_block) j.valid[i] = valid ? 1 : 0;
 
-  float res[C];
+  if constexpr(HALF && C == 8 && !FAST) {
+    if(valid) {
+      const double wx = 1.0 - xf, wy = 1.0 - yf;
+      const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
+      const float4* q1 = q0 + (size_t) W * 2;
+      const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+      const bool hit = j.tapkey[i] == key;
+      float4* tc = reinterpret_cast<float4*>(j.tapcache);
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+#pragma unroll
+      for(int h = 0; h < 2; ++h) {
+        float4 a, b, c, d;      // I00, I01, I10, I11 of channels 4h .. 4h+3
+        if(hit) {
+          a = load_stream(tc + tile_index<8>(i, h)); b = load_stream(tc + tile_index<8>(i, 2 + h));
+          c = load_stream(tc + tile_index<8>(i, 4 + h)); d = load_stream(tc + tile_index<8>(i, 6 + h));
+        } else {
+          a = q0[h]; b = q0[2 + h]; c = q1[h]; d = q1[2 + h];
+          if(in_block) {
+            store_stream(tc + tile_index<8>(i, h), a); store_stream(tc + tile_index<8>(i, 2 + h), b);
+            store_stream(tc + tile_index<8>(i, 4 + h), c); store_stream(tc + tile_index<8>(i, 6 + h), d);
+          }
+        }
+        const float4 t = load_stream(p0 + tile_index<2>(i, h));
+        const float i00[4] = {a.x, a.y, a.z, a.w}, i01[4] = {b.x, b.y, b.z, b.w}, i10[4] = {c.x, c.y, c.z, c.w},
+                    i11[4] = {d.x, d.y, d.z, d.w}, i0[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for(int k = 0; k < 4; ++k) {
+          const double Iw = wy * ((double) i00[k] * wx + (double) i01[k] * xf) + yf * ((double) i10[k] * wx + (double) i11[k] * xf);
+          res[4 * h + k] = (float) (Iw - (double) i0[k]);
+        }
+        if(h == 0) __builtin_amdgcn_sched_barrier(0);   // keep the second group's loads behind the first group's arithmetic
+      }
+      if(!hit && in_block) j.tapkey[i] = key;
+    } else {
+#pragma unroll
+      for(int c = 0; c < 8; ++c) res[c] = 0.0f;
+    }
+    return valid;
+  }
+
   if(valid) {
     const double wx = 1.0 - xf, wy = 1.0 - yf;
     const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
@@ -233,6 +267,38 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
       }
     }
   }
+  return valid;
+}
+
+template <int C, bool FAST>
+__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, int mode)
+{
+  // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
+  // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
+  // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
+  const PairJob& j = jobs[blockIdx.y];
+  const GNState* __restrict__ st = j.st;
+  if(mode == 2) { if(!st->r_stale) return; }
+  else {
+    if(!st->active) return;
+    if(mode == 1 && !(st->delta_scale > 1e-6f)) return;
+  }
+  const int n = j.n;
+  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+
+  if(mode != 2 && blockIdx.x == 0 && threadIdx.x == 0) j.cnt[4] += (unsigned long long) n;   // points this kernel processes
+
+  float P[12];
+  projection_matrix(j, mode == 2 ? st->T_lin : st->T, P);
+
+  // lanes past the end of the last block redo the last point (loads only) so that the whole block reaches the
+  // block-level bracket step below; their stores are masked
+  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const bool in_block = i_raw < n;
+  const int i = in_block ? i_raw : n - 1;
+  float res[C];
+  const bool valid = warp_point<C, FAST>(j, P, i, in_block, res);
+  if(in_block) j.valid[i] = valid ? 1 : 0;
   if(in_block) {
     if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
       float4* o = reinterpret_cast<float4*>(j.r);
@@ -243,7 +309,14 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     }
   }
   // bracket pass of the exact median (see bracket_block) while the residuals are in registers
-  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
+  if(mode != 2 && (st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
+}
+
+// clears r_stale after a refresh launch (one thread per workspace)
+__global__ void clear_stale_kernel(const PairJob* jobs, int n)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if(p < n) jobs[p].st->r_stale = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -762,12 +835,27 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
   return 1.0f;
 }
 
-template <int C, int LOSS>
-__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, int pts_per_block)
+template <int C, int LOSS, bool FUSED>
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int fuse_frozen)
 {
   const PairJob& j = jobs[blockIdx.y];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
+  // two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves,
+  // FUSED = true (137 VGPRs instead of 125: kept out of the plain kernel's register budget) the frozen ones
+  if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
+  // Fused path (C = 8): the robust scale is frozen for the rest of the level, so nothing separates the residuals from
+  // their weights any more — they are recomputed here exactly as warp_residual does (same warp_point, same tap cache) and
+  // never written: the r write + read, the second point read and the valid byte (82 of 341 B per point and iteration)
+  // disappear.  Same values, same accumulation order as the two-kernel form.
+  constexpr bool fused = FUSED && (C == 8);
+  float P[12];
+  if constexpr(fused) {
+    projection_matrix(j, st->T, P);
+    // uniform over the workgroup: pin the 12 values to scalar registers (the vector budget decides the occupancy here)
+#pragma unroll
+    for(int k = 0; k < 12; ++k) P[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(P[k])));
+  }
   const int n = j.n;
   const int p_begin = blockIdx.x * pts_per_block;
   if(p_begin >= n) return;
@@ -780,7 +868,10 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   for(int k = 0; k < kNumAcc; ++k) acc[k] = 0.0f;
 
   for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
-    const float v = (float) j.valid[i];
+    float rr[C], Ix[C], Iy[C];
+    float v;
+    if constexpr(fused) v = warp_point<8, false, true>(j, P, i, true, rr) ? 1.0f : 0.0f;
+    else v = (float) j.valid[i];
     acc[28] += v;
     // per point: 16 B point + 2*C gradient floats + C residuals (all tiled / coalesced), ALL issued before the first use
     // (7 independent 16-byte loads in flight per lane for C = 8).
@@ -792,15 +883,16 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
     // Per (point, channel) that is 6 multiply-adds instead of the 27 of the reference's rankUpdatePoint; the 6x6 outer
     // products are formed once per point.  Algebraically identical, rounding differs at the 1e-7 level like any other
     // summation order (H, G are tolerance-compared).
-    const float4 P = load_stream(j.pts + i);
-    float rr[C], Ix[C], Iy[C];
+    const float4 Pt = load_stream(j.pts + i);
     if constexpr(C == 8) {
       const float4* qr = reinterpret_cast<const float4*>(j.r);
       const float4* qg = reinterpret_cast<const float4*>(j.grad);
-      const float4 r0 = load_stream(qr + tile_index<2>(i, 0)), r1 = load_stream(qr + tile_index<2>(i, 1));
+      if constexpr(!fused) {
+        const float4 r0 = load_stream(qr + tile_index<2>(i, 0)), r1 = load_stream(qr + tile_index<2>(i, 1));
+        rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+      }
       const float4 gx0 = load_stream(qg + tile_index<4>(i, 0)), gx1 = load_stream(qg + tile_index<4>(i, 1)),
                    gy0 = load_stream(qg + tile_index<4>(i, 2)), gy1 = load_stream(qg + tile_index<4>(i, 3));
-      rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
       Ix[0] = gx0.x; Ix[1] = gx0.y; Ix[2] = gx0.z; Ix[3] = gx0.w; Ix[4] = gx1.x; Ix[5] = gx1.y; Ix[6] = gx1.z; Ix[7] = gx1.w;
       Iy[0] = gy0.x; Iy[1] = gy0.y; Iy[2] = gy0.z; Iy[3] = gy0.w; Iy[4] = gy1.x; Iy[5] = gy1.y; Iy[6] = gy1.z; Iy[7] = gy1.w;
     } else {
@@ -821,7 +913,7 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
       Gy += wy * r;
       acc[27] += (w * r) * r;
     }
-    const JacPoint jp = jac_point(P.x, P.y, P.z, s_nrm);
+    const JacPoint jp = jac_point(Pt.x, Pt.y, Pt.z, s_nrm);
     const float t_xz2 = jp.x * jp.rz2, t_yz2 = jp.y * jp.rz2;
     const float A[6] = {-(t_xz2 * jp.yc2), jp.zc3 * jp.rz + t_xz2 * jp.xc1, -(jp.yc2 * jp.rz), jp.rzs, 0.0f, -(jp.s_i * t_xz2)};
     const float B[6] = {-(jp.zc3 * jp.rz) - t_yz2 * jp.yc2, t_yz2 * jp.xc1, jp.xc1 * jp.rz, 0.0f, jp.rzs, -(jp.s_i * t_yz2)};
@@ -984,7 +1076,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 
 __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
                                                      int max_iterations, int max_fun_evals, float p_tol, float f_tol,
-                                                     float g_tol_param, int* active_counter, int parity)
+                                                     float g_tol_param, int* active_counter, int parity, int fuse_frozen)
 {
   const PairJob& j = jobs[blockIdx.x];
   GNState* gst = j.st;
@@ -1014,6 +1106,9 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
 
   if(threadIdx.x == 0) {
     GNState* st = reinterpret_cast<GNState*>(s_state);
+    // the linearisation consumed here was taken at st->T; with the fused path its residuals were never written
+    for(int i = 0; i < 16; ++i) st->T_lin[i] = st->T[i];
+    st->r_stale = (fuse_frozen && !(st->delta_scale > 1e-6f)) ? 1 : 0;
     const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
     // "some workspace still active": every writer stores the same value — a same-address atomicAdd from every block of a
     // 1024-pair batch serialises into tens of microseconds
@@ -1174,12 +1269,20 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
     return;
   }
   if(g.fast_warp) {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
   } else {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.fuse_frozen ? 1 : 0);
   }
+}
+// refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
+void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
+{
+  if(g.max_points <= 0 || g.C != 8) return;
+  const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 2);
+  hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
 void launch_median(hipStream_t s, const GNLaunch& g)
@@ -1199,10 +1302,19 @@ template <int C>
 static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 {
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
+  const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   switch(g.loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
-    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb); break;
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+  }
+  if constexpr(C == 8) {
+    if(!fuse) return;
+    switch(g.loss) {
+      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+    }
   }
 }
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
@@ -1216,8 +1328,9 @@ void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iteratio
                     float f_tol, float g_tol, int* active_counter, int parity)
 {
   const int ppb = gn_pts_per_block(g.npairs);
+  const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
-                     f_tol, g_tol, active_counter, parity);
+                     f_tol, g_tol, active_counter, parity, fuse);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {

@@ -12,6 +12,7 @@ constexpr int kMaxLevels = BPVO_HIP_MAX_LEVELS;
 constexpr int kHistBins1 = 2048;   // radix-select pass 1: |r| bits [30:20]
 constexpr int kReduceVals = 28;    // 21 upper-triangular H + 6 G + sum w r^2
 constexpr int kPartialStride = 32;
+constexpr int kWsCounters = 8;
 constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hip_batch_result_records_device)
 
 // TILED per-point layout.  Template pixels, Jacobians and residuals are records of W floats per point
@@ -81,6 +82,11 @@ struct GNState {
   int   median_valid;
   bpvo_hip_stats stats[kMaxLevels];
   float T_out[16];                           // pose handed back (T in/out of run())
+  // Fused path for frozen scales (irls_reduce recomputes the residuals, warp_residual skips the workspace): the
+  // residual / valid buffers are then NOT those of the last linearisation.  T_lin is the pose of the last linearisation
+  // and r_stale says that the buffers have to be refreshed from it before anything reads them (done on demand).
+  float T_lin[16];
+  int   r_stale;
 };
 
 // Streaming (non-temporal) 16-byte accesses for data that is read or written exactly once per launch and is far larger
@@ -120,8 +126,9 @@ struct PairJob {
   uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, -} of the bracket pass
   float*        partials; // [nblocks][kPartialStride]
-  unsigned long long* cnt; // [4] per-workspace measurement counters: points linearised, linearisations, bracketed / full
-                           // median selections (per workspace, written by one thread: no same-address atomics)
+  unsigned long long* cnt; // [kWsCounters] per-workspace measurement counters: [0] points linearised, [1] linearisations,
+                           // [2] bracketed / [3] full median selections, [4] points processed by warp_residual (the rest
+                           // went through the fused path of irls_reduce); written by one thread each: no atomics
   GNState*      st;
 };
 

@@ -234,6 +234,9 @@ int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int 
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */
 /* exact median selections served by the bracketed path / by the full 3-pass path since the last counter reset */
 int bpvo_hip_median_path_counts(bpvo_hip_ctx* ctx, uint64_t* bracketed, uint64_t* full);
+/* points linearised since the last counter reset: `fused` of `total` went through the fused residual + reduction path that
+ * irls_reduce takes once a workspace's robust scale is frozen for the level (warp_residual skips those workspaces) */
+int bpvo_hip_fused_point_counts(bpvo_hip_ctx* ctx, uint64_t* fused, uint64_t* total);
 
 #ifdef __cplusplus
 }

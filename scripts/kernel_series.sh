@@ -2,8 +2,8 @@
 P=${1:-128}; PAT=${2:-median_finish}
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-timeout 300 python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache /tmp/bpvo_bench_inputs > /dev/null 2>&1
-rm -rf /tmp/trs; timeout 400 rocprofv3 --kernel-trace -d /tmp/trs -- python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 1 --cpu-pairs 0 --no-profile --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs > /tmp/trs.json 2>/tmp/trs.err
+timeout 300 python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache /tmp/bpvo_bench_inputs > /dev/null 2>&1
+rm -rf /tmp/trs; timeout 400 rocprofv3 --kernel-trace -d /tmp/trs -- python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 1 --cpu-pairs 0 --other-configs 0 --no-profile --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs > /tmp/trs.json 2>/tmp/trs.err
 python3 - <<PY
 import glob, sqlite3, os
 fs = sorted(glob.glob("/tmp/trs/*/*_results.db"), key=os.path.getmtime)

@@ -2,8 +2,8 @@
 P=${1:-256}
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-timeout 300 python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 0 --cpu-pairs 0 --no-profile --input-cache /tmp/bpvo_bench_inputs > /dev/null 2>&1
-rm -rf /tmp/trk; timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/trk -- python3 $R/bench.py --pairs-per-gpu $P --steps 3 --warmup 1 --cpu-pairs 0 --no-profile --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs > /tmp/trk.json 2>/tmp/trk.err
+timeout 300 python3 $R/bench.py --pairs-per-gpu $P --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache /tmp/bpvo_bench_inputs > /dev/null 2>&1
+rm -rf /tmp/trk; timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/trk -- python3 $R/bench.py --pairs-per-gpu $P --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --no-profile --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs > /tmp/trk.json 2>/tmp/trk.err
 python3 - <<PY
 import glob, sqlite3, os
 fs = sorted(glob.glob("/tmp/trk/*/*_results.db"), key=os.path.getmtime)

@@ -484,3 +484,35 @@ def test_census_of_smoothed_image_bit_exact(hip, orc, rows, cols, levels, sigma_
     To, _ = co.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("loss", ["tukey", "huber"])
+def test_fused_frozen_scale_path_is_bit_identical(hip, rows, cols, levels, loss, monkeypatch):
+    """Once a workspace's robust scale is frozen for a level (mestimator.cc:467-490), irls_reduce recomputes the residuals
+    itself and warp_residual skips the workspace; the residual / valid buffers are refreshed on demand from the pose of the
+    last linearisation.  Everything observable must equal the two-kernel form bit for bit."""
+    out = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("BPVO_HIP_FUSE_FROZEN", fuse)
+        ctx, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss=loss)
+        T, st = ctx.estimate_pose(0, 0, 1)
+        rec = dict(T=T, st=st, frac=ctx.fraction_good(0, 0.85), r=ctx.get_residuals(0), v=ctx.get_valid(0), w=ctx.get_weights(0),
+                   fused=ctx.fused_point_counts())
+        # and again through the batch entry point
+        b = synth.make_batch(rows, cols, 3, first_index=5)
+        bctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss=loss, levels=levels), n_frames=6, n_pairs=3)
+        poses, stats = bctx.batch_run(b["images"], b["disparities"])
+        rec["bposes"] = poses
+        rec["bstats"] = stats
+        rec["br"] = bctx.get_residuals(2)
+        rec["bw"] = bctx.get_weights(2)
+        out.append(rec)
+    a, b = out
+    assert a["fused"][0] == 0 and b["fused"][0] > 0 and a["fused"][1] == b["fused"][1]
+    assert bits_equal(a["T"], b["T"]) and bits_equal(a["bposes"], b["bposes"])
+    assert a["st"] == b["st"]
+    assert a["bstats"].tobytes() == b["bstats"].tobytes()
+    assert a["frac"] == b["frac"]
+    assert np.array_equal(a["v"], b["v"]) and bits_equal(a["r"], b["r"]) and bits_equal(a["w"], b["w"])
+    assert bits_equal(a["br"], b["br"]) and bits_equal(a["bw"], b["bw"])
