@@ -39,6 +39,7 @@ struct FrameSlot {
   void* tmpl_slab = nullptr;
   uint8_t* img[kMaxLevels] = {};
   uint8_t* cen[kMaxLevels] = {};
+  float* ch0[kMaxLevels] = {};
   float* desc[kMaxLevels] = {};
   float* disp = nullptr;
   float* sal[kMaxLevels] = {};
@@ -194,6 +195,7 @@ void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
   f.disp = cv.take<float>(c->geom[0].npix);
   for(int l = 0; l < c->L; ++l) f.desc[l] = cv.take<float>(c->geom[l].npix * c->C);
   for(int l = 0; l < c->L; ++l) f.cen[l] = (c->C == 8) ? cv.take<uint8_t>(c->geom[l].npix) : nullptr;
+  for(int l = 0; l < c->L; ++l) f.ch0[l] = (c->C == 8) ? cv.take<float>(c->geom[l].npix) : nullptr;
   if(total) *total = cv.off;
 }
 
@@ -234,6 +236,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   std::memset(&j, 0, sizeof(j));
   j.img = f.img[l];
   j.cen = f.cen[l];
+  j.ch0 = f.ch0[l];
   j.desc = f.desc[l];
   j.sal = f.sal[l];
   j.flag = f.flag[l];

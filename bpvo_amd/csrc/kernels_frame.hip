@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
       store_stream(d, out[0]);
       store_stream(d + 1, out[1]);
+      j.ch0[(size_t) gy * W + gx] = out[0].x;
     }
     __syncthreads();   // s_cen / s_row are rewritten by the next tile
   }
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256) void bitplanes_noblur_kernel(const FrameJob* j
   if(i >= n) return;
   const unsigned c = j.cen[i];
   float4* d = reinterpret_cast<float4*>(j.desc + (size_t) i * 8);
+  j.ch0[i] = (float) (c & 1u);
   d[0] = make_float4((float) (c & 1u), (float) ((c >> 1) & 1u), (float) ((c >> 2) & 1u), (float) ((c >> 3) & 1u));
   d[1] = make_float4((float) ((c >> 4) & 1u), (float) ((c >> 5) & 1u), (float) ((c >> 6) & 1u), (float) ((c >> 7) & 1u));
 }
@@ -344,8 +346,10 @@ __global__ __launch_bounds__(256) void saliency_kernel(const FrameJob* jobs)
       if(x >= n) {
         S = grad_tail<C>(I, row + x, W, 0);
         for(int c = 1; c < C; ++c) S += grad_tail<C>(I, row + x, W, c);
-      } else if(C == 1 || x >= 4) {
+      } else if(C == 1) {
         S = grad_abs<C>(I, row + x, W, 0);
+      } else if(x >= 4) {
+        S = grad_abs<1>(j.ch0, row + x, W, 0);     // channel 0 from its compact plane
       } else {
         const int xs = n - 4 + x;
         const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
