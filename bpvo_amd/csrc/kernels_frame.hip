@@ -238,17 +238,12 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       const uint8_t* c = s_cen + ly * CW + lx;   // c[0..4] = columns x-2..x+2
       const unsigned cm2 = c[0], cm1 = c[1], c0 = c[2], cp1 = c[3], cp2 = c[4];
       float tt[8];
-#ifdef EXP_NOROWPASS
-#pragma unroll
-      for(int b = 0; b < 8; ++b) tt[b] = (float) (c0 + cm1 + cp1 + cm2 + cp2) * k0;
-#else
 #pragma unroll
       for(int b = 0; b < 8; ++b) {
         const float S0 = (float) ((c0 >> b) & 1u), Sm1 = (float) ((cm1 >> b) & 1u), Sp1 = (float) ((cp1 >> b) & 1u),
                     Sm2 = (float) ((cm2 >> b) & 1u), Sp2 = (float) ((cp2 >> b) & 1u);
         tt[b] = S0 * k0 + (Sm1 + Sp1) * k1 + (Sm2 + Sp2) * k2;
       }
-#endif
       // two planes of 4 channels each: consecutive lanes are 16 bytes apart in either plane, so the 16-byte LDS accesses of
       // both passes are bank-conflict free (one [8]-float record per pixel would put lanes 32 bytes apart: 2-way conflicts)
       float4* o = reinterpret_cast<float4*>(s_row);
@@ -266,9 +261,6 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       const int base = ly * BP_TW + lx;               // row ly of s_row is image row gy-2
       const int pitch = BP_TW, plane = CR * BP_TW;
       float4 out[2];
-#ifdef EXP_NOCOLPASS
-      out[0] = T[base + 2 * pitch]; out[1] = T[plane + base + 2 * pitch];
-#else
 #pragma unroll
       for(int h = 0; h < 2; ++h) {
         const float4* Th = T + h * plane + base;
@@ -280,7 +272,6 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
         s.w = k0 * T0.w; s.w += k1 * (Tp1.w + Tm1.w); s.w += k2 * (Tp2.w + Tm2.w);
         out[h] = s;
       }
-#endif
       float4* d = reinterpret_cast<float4*>(j.desc + ((size_t) gy * W + gx) * 8);
       store_stream(d, out[0]);
       store_stream(d + 1, out[1]);
