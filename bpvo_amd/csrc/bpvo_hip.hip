@@ -128,7 +128,8 @@ struct bpvo_hip_ctx {
   // measurement
   double points_fused = 0;     // points linearised through the fused path since the last counter reset
   int fast_warp = 0;           // bpvo_hip_set_warp_formulation
-  int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (BPVO_HIP_FUSE_FROZEN=0 disables)
+  int fuse_frozen = 0;         // estimate loops: fused residual + reduction once a workspace's scale is frozen; opt-in with
+                               // BPVO_HIP_FUSE_FROZEN=1 (+2 % GN iterations/s)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)

@@ -32,4 +32,4 @@ for CNT in "FETCH_SIZE" "WRITE_SIZE" \
       --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --gen-workers 1 --input-cache $CACHE > "$O/pmc$i.json" 2> "$O/pmc$i.err"
   echo "pmc$i ($CNT) rc=$?"
 done
-cd "$R" && python3 profiles/summarize.py "$O" "$TAG" && cp "$O"/${TAG}_* "$O"/trace_bench.json "$O"/*.err "$R/gpurun_out/profiles_$TAG/"
+cd "$R" && python3 profiles/summarize.py "$O" "$TAG" && cp "$O"/${TAG}_* "$O"/trace_bench.json "$O"/pmc*.json "$O"/*.err "$R/gpurun_out/profiles_$TAG/"

@@ -77,7 +77,10 @@ try:
     pj = json.loads(open(os.path.join(src, "pmc3.json")).read().strip().splitlines()[-1])
     k6 = [k for k in per if "warp_residual_kernel<8" in k][0]
     launches = per[k6]["TCC_EA0_RDREQ_128B_sum"]["launches"]
-    pts_per_launch = pj["points_linearized_rank0"] / launches
+    # points warp_residual itself processed (linearisations with a frozen scale go through irls_reduce's fused path)
+    fp = pj.get("fused_path") or {"points": 0, "of": pj["points_linearized_rank0"]}
+    pts_per_launch = (fp["of"] - fp["points"]) / launches
+    traffic["fused_fraction_in_pmc_run"] = fp["points"] / max(1, fp["of"])
     traffic["pmc_config"] = pj["config"]["workload"]
     traffic["points_per_launch"] = pts_per_launch
     traffic["warp_residual_hbm_bytes_per_point"] = (traffic["warp_residual_read_bytes_per_launch"]
