@@ -15,6 +15,7 @@
 #include <cctype>
 #include <fstream>
 #include <map>
+#include <ostream>
 #include <sstream>
 #include <string>
 #include <strings.h>
@@ -170,6 +171,120 @@ inline AlgorithmParameters AlgorithmParametersFromFile(const std::string& filena
   p.maxTestLevel = cf.get<int>("maxTestLevel", 0);
   p.withNormalization = cf.get<int>("withNormalization", 1);
   return p;
+}
+
+/* ToString (reference: bpvo/types.cc:109-264) — the strings the apps print, spelling included ("CenteralDifference") */
+inline std::string ToString(LossFunctionType t)
+{
+  switch(t) { case kHuber: return "Huber"; case kTukey: return "Tukey"; case kL2: return "L2"; }
+  return "Unknown";
+}
+inline std::string ToString(VerbosityType v)
+{
+  switch(v) { case kIteration: return "Iteration"; case kFinal: return "Final"; case kSilent: return "Silent"; case kDebug: return "Debug"; }
+  return "Unknown";
+}
+inline std::string ToString(PoseEstimationStatus s)
+{
+  switch(s) {
+    case kParameterTolReached: return "ParameterTolReached";
+    case kFunctionTolReached: return "FunctionTolReached";
+    case kGradientTolReached: return "GradientTolReached";
+    case kMaxIterations: return "MaxIterations";
+    case kSolverError: return "SolverError";
+  }
+  return "Unknown";
+}
+inline std::string ToString(KeyFramingReason r)
+{
+  switch(r) {
+    case kLargeTranslation: return "LargeTranslation";
+    case kLargeRotation: return "LargeRotation";
+    case kSmallFracOfGoodPoints: return "SmallFracOfGoodPoints";
+    case kNoKeyFraming: return "NoKeyFraming";
+    case kFirstFrame: return "FirstFrame";
+  }
+  return "Unknown";
+}
+inline std::string ToString(DescriptorType t)
+{
+  switch(t) {
+    case kIntensity: return "Intensity";
+    case kIntensityAndGradient: return "IntensityAndGradient";
+    case kDescriptorFieldsFirstOrder: return "DescriptorFields";
+    case kDescriptorFieldsSecondOrder: return "DescriptorFields2ndOrder";
+    case kBitPlanes: return "BitPlanes";
+    case kLatch: return "Latch";
+    case kCentralDifference: return "CenteralDifference";
+    case kLaplacian: return "Laplacian";
+  }
+  return "Unknown";
+}
+inline std::string ToString(GradientEstimationType t)
+{
+  switch(t) { case kCentralDifference_3: return "CentralDifference_3"; case kCentralDifference_5: return "CentralDifference_5"; }
+  return "Unknown";
+}
+inline std::string ToString(InterpolationType t)
+{
+  switch(t) { case kLinear: return "Linear"; case kCosine: return "Cosine"; case kCubic: return "Cubic"; case kCubicHermite: return "CubicHermite"; }
+  return "Unknown";
+}
+
+/* stream output (reference: bpvo/types.cc:267-303,312-320,349-364), same labels and order */
+inline std::ostream& operator<<(std::ostream& os, const AlgorithmParameters& p)
+{
+  os << "numPyramidLevels = " << p.numPyramidLevels << "\n";
+  os << "minImageDimensionForPyramid = " << p.minImageDimensionForPyramid << "\n";
+  os << "sigmaPriorToCensusTransform = " << p.sigmaPriorToCensusTransform << "\n";
+  os << "sigmaBitPlanes = " << p.sigmaBitPlanes << "\n";
+  os << "dfSigma1 = " << p.dfSigma1 << "\n";
+  os << "dfSigma2 = " << p.dfSigma2 << "\n";
+  os << "latchNumBytes = " << p.latchNumBytes << "\n";
+  os << "latchRotationInvariance = " << p.latchRotationInvariance << "\n";
+  os << "latchHalfSsdSize = " << p.latchHalfSsdSize << "\n";
+  os << "centralDifferenceRadius = " << p.centralDifferenceRadius << "\n";
+  os << "centralDifferenceSigmaBefore = " << p.centralDifferenceSigmaBefore << "\n";
+  os << "centralDifferenceSigmaAfter = " << p.centralDifferenceSigmaAfter << "\n";
+  os << "laplacianKernelSize = " << p.laplacianKernelSize << "\n";
+  os << "maxIterations = " << p.maxIterations << "\n";
+  os << "parameterTolerance = " << p.parameterTolerance << "\n";
+  os << "functionTolerance = " << p.functionTolerance << "\n";
+  os << "gradientTolerance = " << p.gradientTolerance << "\n";
+  os << "relaxTolerancesForCoarseLevel = " << p.relaxTolerancesForCoarseLevels << "\n";
+  os << "gradienEstimation: " << ToString(static_cast<GradientEstimationType>(p.gradientEstimation)) << "\n";
+  os << "InterpolationType: " << ToString(static_cast<InterpolationType>(p.interp)) << "\n";
+  os << "lossFunction = " << ToString(static_cast<LossFunctionType>(p.lossFunction)) << "\n";
+  os << "verbosity = " << ToString(static_cast<VerbosityType>(p.verbosity)) << "\n";
+  os << "minTranslationMagToKeyFrame = " << p.minTranslationMagToKeyFrame << "\n";
+  os << "minRotationMagToKeyFrame = " << p.minRotationMagToKeyFrame << "\n";
+  os << "maxFractionOfGoodPointsToKeyFrame = " << p.maxFractionOfGoodPointsToKeyFrame << "\n";
+  os << "goodPointThreshold = " << p.goodPointThreshold << "\n";
+  os << "minNumPixelsForNonMaximaSuppression = " << p.minNumPixelsForNonMaximaSuppression << "\n";
+  os << "minNumPixelsToWork = " << p.minNumPixelsToWork << "\n";
+  os << "minSaliency = " << p.minSaliency << "\n";
+  os << "minValidDisparity = " << p.minValidDisparity << "\n";
+  os << "maxValidDisparity = " << p.maxValidDisparity << "\n";
+  os << "withNormalization = " << p.withNormalization << "\n";
+  os << "maxTestLevel = " << p.maxTestLevel;
+  return os;
+}
+inline std::ostream& operator<<(std::ostream& os, const OptimizerStatistics& s)
+{
+  os << "numIterations: " << s.numIterations << "\n"
+     << "finalError: " << s.finalError << "\n"
+     << "firstOrderOptimality: " << s.firstOrderOptimality << "\n"
+     << "status: " << ToString(s.status);
+  return os;
+}
+inline std::ostream& operator<<(std::ostream& os, const ImageSize& s) { return os << "[" << s.rows << "," << s.cols << "]"; }
+/* the pose prints as four rows of four values (the reference streams an Eigen::Matrix4f: same row layout, Eigen pads columns) */
+inline std::ostream& operator<<(std::ostream& os, const Result& r)
+{
+  for(int i = 0; i < 4; ++i) os << r.pose[4 * i] << " " << r.pose[4 * i + 1] << " " << r.pose[4 * i + 2] << " " << r.pose[4 * i + 3] << "\n";
+  os << "isKeyFrame: " << std::boolalpha << r.isKeyFrame << std::noboolalpha << "\n";
+  if(!r.optimizerStatistics.empty()) os << r.optimizerStatistics.front();
+  return os;
 }
 
 /* WriteTrajectoryKittiFormat (reference: apps/eval_kitti.cc:43-59): the 3x4 of every pose, row-major, "%lf" */

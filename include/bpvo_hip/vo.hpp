@@ -43,7 +43,10 @@ typedef std::vector<float> WeightsVector;
 
 enum LossFunctionType { kHuber = BPVO_LOSS_HUBER, kTukey = BPVO_LOSS_TUKEY, kL2 = BPVO_LOSS_L2 };
 enum VerbosityType { kIteration = BPVO_VERB_ITERATION, kFinal, kSilent, kDebug };
-enum DescriptorType { kIntensity = BPVO_DESC_INTENSITY, kBitPlanes = BPVO_DESC_BITPLANES };
+/* all eight values of the reference (bpvo/types.h:142-152); only kIntensity and kBitPlanes are on the device path */
+enum DescriptorType { kIntensity = BPVO_DESC_INTENSITY, kIntensityAndGradient, kDescriptorFieldsFirstOrder, kDescriptorFieldsSecondOrder,
+                      kLatch, kCentralDifference, kLaplacian, kBitPlanes = BPVO_DESC_BITPLANES };
+static_assert(kLaplacian + 1 == kBitPlanes, "DescriptorType numbering follows the reference");
 enum GradientEstimationType { kCentralDifference_3 = BPVO_GRAD_CD3, kCentralDifference_5 = BPVO_GRAD_CD5 };
 enum InterpolationType { kLinear = BPVO_INTERP_LINEAR, kCosine, kCubic, kCubicHermite };
 enum PoseEstimationStatus { kParameterTolReached = BPVO_STATUS_PARAMETER_TOL, kFunctionTolReached, kGradientTolReached,

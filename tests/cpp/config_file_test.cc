@@ -2,6 +2,8 @@
 // (no GPU needed: only bpvo_hip_default_params is called).
 #include <bpvo_hip/config_file.hpp>
 #include <cstdio>
+#include <iostream>
+#include <sstream>
 
 int main(int argc, char** argv)
 {
@@ -16,6 +18,16 @@ int main(int argc, char** argv)
                 p.functionTolerance, p.gradientTolerance, p.gradientEstimation, p.interp, p.lossFunction, p.descriptor, p.verbosity,
                 p.minTranslationMagToKeyFrame, p.minRotationMagToKeyFrame, p.goodPointThreshold, p.minSaliency, p.minValidDisparity,
                 p.maxTestLevel, p.withNormalization, p.centralDifferenceSigmaAfter);
+    if(argc > 2) {   // printing helpers (bpvo/types.cc:109-364)
+      std::ostringstream ss;
+      ss << p << "\n--\n" << bpvo::OptimizerStatistics() << "\n--\n" << bpvo::ImageSize(3, 4) << "\n--\n";
+      bpvo::Result r;
+      r.pose.fill(0.0f); r.pose[0] = r.pose[5] = r.pose[10] = r.pose[15] = 1.0f;
+      r.optimizerStatistics.push_back(bpvo::OptimizerStatistics());
+      ss << r << "\n--\n" << bpvo::ToString(bpvo::kSmallFracOfGoodPoints) << " " << bpvo::ToString(bpvo::kCentralDifference) << " "
+         << bpvo::ToString(bpvo::kBitPlanes) << " " << bpvo::ToString(bpvo::kFunctionTolReached) << " " << bpvo::ToString(bpvo::kCubicHermite);
+      std::cout << "PRINT\n" << ss.str() << std::endl;
+    }
   } catch(const bpvo::Error& e) {
     std::printf("ERROR %s\n", e.what());
     return 1;

@@ -128,6 +128,18 @@ def test_config_file_reader_matches_reference_semantics(tmp_path):
     # file defaults, not constructor defaults (bpvo/types.cc:68-107): CD5, gradientTolerance 1e-6, minValidDisparity 1
     assert kv["gradientEstimation"] == str(capi.GRAD_CD5) and float(kv["gradientTolerance"]) == pytest.approx(1e-6)
     assert float(kv["minValidDisparity"]) == 1.0 and float(kv["goodPointThreshold"]) == 0.75
+    # printing helpers: labels, order and spelling of bpvo/types.cc:109-364
+    out2 = subprocess.run([exe, str(cfg), "print"], capture_output=True, text=True)
+    assert out2.returncode == 0, out2.stdout
+    txt = out2.stdout.split("PRINT\n", 1)[1]
+    blocks = txt.strip().split("\n--\n")
+    assert blocks[0].splitlines()[0] == "numPyramidLevels = 3" and blocks[0].splitlines()[-1] == "maxTestLevel = 0"
+    assert "gradienEstimation: CentralDifference_5" in blocks[0] and "InterpolationType: Linear" in blocks[0] and "lossFunction = L2" in blocks[0]
+    assert "relaxTolerancesForCoarseLevel = 1" in blocks[0] and len(blocks[0].splitlines()) == 33
+    assert blocks[1] == "numIterations: 0\nfinalError: -1\nfirstOrderOptimality: -1\nstatus: SolverError"
+    assert blocks[2] == "[3,4]"
+    assert blocks[3].splitlines()[0] == "1 0 0 0" and "isKeyFrame: false" in blocks[3] and blocks[3].endswith("status: SolverError")
+    assert blocks[4] == "SmallFracOfGoodPoints CenteralDifference BitPlanes FunctionTolReached CubicHermite"
     bad = tmp_path / "bad.cfg"
     bad.write_text("numPyramidLevels 3\n")
     out = subprocess.run([exe, str(bad)], capture_output=True, text=True)
