@@ -173,6 +173,46 @@ class VisualOdometryFrame {
   bool hasTemplate() const { int d = 0, t = 0; _dev->check(bpvo_hip_frame_state(_dev->ctx(), _slot, &d, &t)); return t != 0; }
   int numLevels() const { return bpvo_hip_num_levels(_dev->ctx()); }
   int numPointsAtLevel(int level) const { int n = 0; _dev->check(bpvo_hip_num_points(_dev->ctx(), _slot, level, &n)); return n; }
+  /* The frame lives in device memory; what the reference hands out as references to host containers
+   * (imagePointer, getDenseDescriptorAtLevel()->getChannel, getTemplateDataAtLevel()->{points, pixels, jacobians},
+   * bpvo/vo_frame.h:62-80, bpvo/template_data.h:68-75) is copied out on request. */
+  ImageSize levelSize(int level) const
+  {
+    int r = 0, c = 0;
+    _dev->check(bpvo_hip_level_size(_dev->ctx(), level, &r, &c));
+    return ImageSize(r, c);
+  }
+  int numChannels() const { return bpvo_hip_num_channels(_dev->ctx()); }
+  std::vector<uint8_t> image(int level = 0) const
+  {
+    std::vector<uint8_t> v((size_t) levelSize(level).numel());
+    _dev->check(bpvo_hip_get_image(_dev->ctx(), _slot, level, v.data()));
+    return v;
+  }
+  std::vector<float> descriptorChannel(int level, int channel) const
+  {
+    std::vector<float> v((size_t) levelSize(level).numel());
+    _dev->check(bpvo_hip_get_descriptor_channel(_dev->ctx(), _slot, level, channel, v.data()));
+    return v;
+  }
+  PointVector points(int level) const
+  {
+    PointVector v((size_t) numPointsAtLevel(level));
+    if(!v.empty()) _dev->check(bpvo_hip_get_points(_dev->ctx(), _slot, level, v[0].data()));
+    return v;
+  }
+  std::vector<float> pixels(int level) const           // [channel][point], TemplateData::pixels()
+  {
+    std::vector<float> v((size_t) numPointsAtLevel(level) * numChannels());
+    if(!v.empty()) _dev->check(bpvo_hip_get_pixels(_dev->ctx(), _slot, level, v.data()));
+    return v;
+  }
+  std::vector<float> jacobians(int level) const        // [channel][point][6], TemplateData::jacobians()
+  {
+    std::vector<float> v((size_t) numPointsAtLevel(level) * numChannels() * 6);
+    if(!v.empty()) _dev->check(bpvo_hip_get_jacobians(_dev->ctx(), _slot, level, v.data()));
+    return v;
+  }
   int slot() const { return _slot; }
   const std::shared_ptr<detail::Device>& device() const { return _dev; }
  private:

@@ -16,6 +16,8 @@ int facade_surface()
   auto dev = std::make_shared<bpvo::detail::Device>(K, 0.1f, bpvo::ImageSize(64, 64), p, 2, 1);
   bpvo::VisualOdometryFrame ref(dev, 0), cur(dev, 1);
   ref.setData(nullptr, nullptr); ref.setTemplate(); (void) ref.hasTemplate(); (void) cur.empty(); cur.clear(); (void) ref.numLevels();
+  (void) ref.levelSize(1).numel(); (void) ref.numChannels(); (void) ref.image(0).size(); (void) ref.descriptorChannel(0, 0).size();
+  (void) ref.points(0).size(); (void) ref.pixels(0).size(); (void) ref.jacobians(0).size();
   bpvo::VisualOdometryPoseEstimator est(dev);
   bpvo::Matrix44 T0, T1;
   T0.fill(0.f);
