@@ -755,6 +755,12 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     g_create_error = "invalid argument";
     return BPVO_ERR_INVALID_ARG;
   }
+  // pixel coordinates travel as 16-bit values (selection lists are uint16_t in the reference as well, Q9; the tap-cache key
+  // packs (yi << 16 | xi)), and linear pixel indices as int
+  if(rows > 65535 || cols > 65535 || (long long) rows * cols * 8 > 0x7fffffffLL) {
+    g_create_error = "image too large (at most 65535 x 65535 and 2^28 pixels)";
+    return BPVO_ERR_INVALID_ARG;
+  }
   int ndev = 0;
   if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_create_error = "no HIP device: libbpvo_hip has no CPU fallback";
