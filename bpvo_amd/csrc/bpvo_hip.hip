@@ -832,6 +832,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   bpvo_hip_ctx* cp = c.get();
   auto dev_fail = [&](hipError_t e, const char* what) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+    bpvo_hip_destroy(c.release());   // frees whatever was allocated so far (a failed create must not leak device memory)
     return BPVO_ERR_DEVICE;
   };
 #define CREATE_CK(expr) do { hipError_t e_ = (expr); if(e_ != hipSuccess) return dev_fail(e_, #expr); } while(0)
