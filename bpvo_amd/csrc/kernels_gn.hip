@@ -1288,7 +1288,10 @@ static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 
 void launch_median(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};   // the attribute is per device: a process may hold contexts on several
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  bool& attr_set = attr_set_dev[dev & 63];
   if(!attr_set) {
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
