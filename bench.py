@@ -92,9 +92,9 @@ def cpu_baseline(args, batch, n_sample):
         ctx = orc.create(batch["K"], batch["b"], args.rows, args.cols, p, n_frames=2 * n, n_pairs=n)
         ctx.call("set_num_threads", threads)
         t0 = time.perf_counter()
-        ctx.batch_run(batch["images"][: 2 * n], batch["disparities"][: 2 * n])
+        cpu_poses, _ = ctx.batch_run(batch["images"][: 2 * n], batch["disparities"][: 2 * n])
         dt = time.perf_counter() - t0
-        out[label] = dict(gn_iters=ctx.total_linearizations(), seconds=dt, threads=threads)
+        out[label] = dict(gn_iters=ctx.total_linearizations(), seconds=dt, threads=threads, poses=cpu_poses)
         ctx.close()
     one = out["1"]
     allc = out["all"]
@@ -103,6 +103,7 @@ def cpu_baseline(args, batch, n_sample):
         "sample": f"{n} pairs of the same workload (seeds 1000..{999 + n}), oracle/ C++ restatement single-threaded "
                   f"(= the reference's default build, WITH_TBB OFF): {one['gn_iters']} GN iterations in {one['seconds']:.2f} s",
         "frames_per_s": n / one["seconds"],
+        "_poses": one["poses"],
         "all_cores": {"value": allc["gn_iters"] / allc["seconds"], "cores": allc["threads"], "seconds": allc["seconds"],
                       "host_cores": os.cpu_count(),
                       "note": "OpenMP over the 8 channels / range-split reduction = the reference's TBB decomposition (max 8-way)"},
@@ -278,8 +279,19 @@ def main():
                         "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"]}
 
         cpu = None
+        pose_vs_cpu = None
         if args.cpu_pairs > 0:
             cpu = cpu_baseline(args, batch, args.cpu_pairs)
+            # pose agreement of the GPU path with the CPU path on the pairs both ran (BASELINE.json: "pose RMSE vs ref")
+            cp = cpu.pop("_poses").astype(np.float64)
+            gp = poses[: cp.shape[0]].astype(np.float64)
+            E = np.einsum("nji,njk->nik", cp[:, :3, :3], gp[:, :3, :3])                    # R_cpu^T R_gpu
+            w = 0.5 * np.stack([E[:, 2, 1] - E[:, 1, 2], E[:, 0, 2] - E[:, 2, 0], E[:, 1, 0] - E[:, 0, 1]], axis=1)
+            rot = np.arcsin(np.minimum(1.0, np.linalg.norm(w, axis=1)))
+            tr = np.linalg.norm(cp[:, :3, 3] - gp[:, :3, 3], axis=1)
+            pose_vs_cpu = {"pairs": int(cp.shape[0]), "rot_rmse_rad": float(np.sqrt(np.mean(rot ** 2))), "rot_max_rad": float(rot.max()),
+                           "trans_rmse_m": float(np.sqrt(np.mean(tr ** 2))), "trans_max_m": float(tr.max()),
+                           "tolerance": "1e-4 rad / 1e-3 m (BASELINE.json north_star)"}
 
         others = None
         if other_batch is not None:
@@ -304,6 +316,7 @@ def main():
             "points_linearized_rank0": points_linearized,
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,
+            "pose_vs_cpu": pose_vs_cpu,
             "median_selections": {"bracketed": med_paths[0], "full": med_paths[1]},
             "fused_path": {"points": fused_pts[0], "of": fused_pts[1],
                            "note": "linearisations with a frozen robust scale: residuals recomputed inside irls_reduce, warp_residual skips them"},
