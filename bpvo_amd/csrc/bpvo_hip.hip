@@ -82,7 +82,8 @@ struct Lane {
   PairJob* d_pjobs = nullptr;      // [L][n_pairs]
   float* h_T = nullptr;            // pinned [n_pairs][16]
   float* d_Tinit = nullptr;
-  int* d_active = nullptr;         // [2]
+  int* d_active = nullptr;         // [2] ([0]: count of the active list)
+  int* d_list = nullptr;           // [2][n_pairs] active-workspace lists of alternating host rounds (ActiveSet)
   int* h_active = nullptr;         // pinned [4]
   GNState* h_states = nullptr;     // pinned [n_pairs]
   std::vector<EventPair> ev_pending;
@@ -494,18 +495,19 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
-    LANE_CK(ln, hipMemsetAsync(ln->d_active, 0, 2 * sizeof(int), ln->stream));
-    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues
-    // kItersPerSync iterations back to back and only then reads the "workspaces still active" counter: blocks of
-    // finished workspaces exit on their first load, so a few speculative launches cost less than a round trip per
-    // iteration.
+    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues a round of
+    // kItersPerSync iterations back to back; the round ends with a compaction of the list of still-active workspaces
+    // (ActiveSet, kernels.h) whose count the host reads: it is the workspace dimension of the next round's grids, so
+    // finished workspaces cost nothing from then on (inside a round their workgroups exit on the first load).
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
     constexpr int kItersPerSync = 4;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
-    for(int it = 0; it < max_lin;) {
-      int parity = 0;
+    int* const lists[2] = {ln->d_list, ln->d_list + NP};
+    int round = 0, n_active = n;
+    g.active.list = nullptr;                // first round: every workspace of the group, in order
+    for(int it = 0; it < max_lin; ++round) {
+      g.npairs = n_active;
       for(int k = 0; k < kItersPerSync && it < max_lin; ++k, ++it) {
-        parity = it & 1;
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
@@ -515,17 +517,21 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
           { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
             launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                           p.gradientTolerance, ln->d_active, parity); }
+                           p.gradientTolerance); }
         } else {
           launch_median(ln->stream, g);
           launch_irls_reduce(ln->stream, g);
           launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                         p.gradientTolerance, ln->d_active, parity);
+                         p.gradientTolerance);
         }
       }
-      LANE_CK(ln, hipMemcpyAsync(ln->h_active, ln->d_active + parity, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
+      int* const next = lists[round & 1];
+      launch_compact_active(ln->stream, g.jobs, g.active, n_active, next, ln->d_active);
+      LANE_CK(ln, hipMemcpyAsync(ln->h_active, ln->d_active, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
       LANE_CK(ln, hipStreamSynchronize(ln->stream));
-      if(ln->h_active[0] == 0) break;
+      n_active = ln->h_active[0];
+      if(n_active <= 0) break;
+      g.active.list = next;
     }
   }
   launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
@@ -875,6 +881,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_active, 2 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_list, 2 * sizeof(int) * (size_t) n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
@@ -908,7 +915,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
-    (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active);
+    (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active); (void) hipFree(ln.d_list);
     (void) hipHostFree(ln.h_pjobs); (void) hipHostFree(ln.h_T); (void) hipHostFree(ln.h_active); (void) hipHostFree(ln.h_states);
     for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
     for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
@@ -1111,7 +1118,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
   { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0, nullptr, 0); }
+  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0); }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   HIP_CK(c, hipGetLastError());

@@ -24,9 +24,19 @@ void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one jo
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
 
 // Gauss-Newton stage (batched over workspaces / pairs)
+// Compacted list of the workspaces of a launch that are still iterating (estimate loops).  The host rebuilds it (on the
+// device) once per round of kItersPerSync iterations, together with the read-back of the count, and sizes the workspace
+// dimension of the next round's grids with that count; entry k of the list names the k-th active workspace.  Without it
+// every launch dispatches the workgroups of the finished workspaces as well: ~0.9 ns each, ~150 µs per launch in the tail
+// of a level at 1024 pairs.  list == nullptr: every workspace of the launch, in order.
+struct ActiveSet {
+  const int* list = nullptr;   // device [npairs]
+};
+
 struct GNLaunch {
   const PairJob* jobs;   // device, [npairs] for the level
-  int npairs;
+  int npairs;            // grid size in workspaces (= number of list entries when an ActiveSet is given)
+  ActiveSet active;
   int max_points;        // max n over the pairs (grid sizing)
   int C;
   int loss;
@@ -39,13 +49,15 @@ int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
+// out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
+void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);
 void launch_warp_residual(hipStream_t s, const GNLaunch& g);
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
 void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
-                    float f_tol, float g_tol, int* active_counter /*device [2]*/, int parity);
+                    float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
 int  gn_pts_per_block(int npairs);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);

@@ -17,6 +17,9 @@ namespace bpvo_hip {
 
 constexpr int GN_BLOCK = 256;
 
+// workspace of a workgroup: k-th entry of the active list, or k itself without a list
+__device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
+
 // K7a (fused into warp_residual): bracket counting + candidate compaction for the exact median of the NEXT kernel.
 // The median moves little between GN iterations, so while the residuals are still in registers every block counts its
 // keys (bit patterns of |r| of valid points) below the bracket [lo, hi) around the previous median and compacts the keys
@@ -271,12 +274,12 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
 }
 
 template <int C, bool FAST>
-__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, int mode)
+__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
 {
   // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
   // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
   // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
-  const PairJob& j = jobs[blockIdx.y];
+  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(mode == 2) { if(!st->r_stale) return; }
   else {
@@ -361,9 +364,9 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
 }
 
 template <int C>
-__global__ __launch_bounds__(GN_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, int interp)
+__global__ __launch_bounds__(GN_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp)
 {
-  const PairJob& j = jobs[blockIdx.y];
+  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
   const int n = j.n;
@@ -616,9 +619,9 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
 template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs)
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
 {
-  const PairJob& j = jobs[blockIdx.x];
+  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
@@ -836,9 +839,9 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
 }
 
 template <int C, int LOSS, bool FUSED>
-__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int fuse_frozen)
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen)
 {
-  const PairJob& j = jobs[blockIdx.y];
+  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
   // two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves,
@@ -1076,11 +1079,10 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 
 __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
                                                      int max_iterations, int max_fun_evals, float p_tol, float f_tol,
-                                                     float g_tol_param, int* active_counter, int parity, int fuse_frozen)
+                                                     float g_tol_param, ActiveSet act, int fuse_frozen)
 {
-  const PairJob& j = jobs[blockIdx.x];
+  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* gst = j.st;
-  if(active_counter && blockIdx.x == 0 && threadIdx.x == 0) active_counter[parity ^ 1] = 0;
   if(!gst->active) return;
 
   // the state lives in HBM between launches; the serial bookkeeping runs on an LDS copy (global-memory round trips
@@ -1110,14 +1112,40 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
     for(int i = 0; i < 16; ++i) st->T_lin[i] = st->T[i];
     st->r_stale = (fuse_frozen && !(st->delta_scale > 1e-6f)) ? 1 : 0;
     const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
-    // "some workspace still active": every writer stores the same value — a same-address atomicAdd from every block of a
-    // 1024-pair batch serialises into tens of microseconds
-    if(again && mode == 0 && active_counter) active_counter[parity] = 1;
+    (void) again;   // who is still active is read from st->active by compact_active_kernel once per host round
     j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
     j.cnt[1] += 1ull;
   }
   __syncthreads();
   for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Active list of the next host round: the still-active workspaces of the current list, in order (one 1024-thread
+// workgroup, block scan per chunk of 1024 entries; no atomics, deterministic order).
+__global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __restrict__ jobs, ActiveSet in, int n_in,
+                                                              int* __restrict__ out_list, int* __restrict__ out_count)
+{
+  __shared__ unsigned s_wave[16];
+  __shared__ unsigned s_base;
+  if(threadIdx.x == 0) s_base = 0;
+  __syncthreads();
+  for(int base = 0; base < n_in; base += 1024) {
+    const int k = base + threadIdx.x;
+    int ws = -1;
+    if(k < n_in) {
+      ws = in.list ? in.list[k] : k;
+      if(!jobs[ws].st->active) ws = -1;
+    }
+    unsigned total;
+    const unsigned off = block_excl_scan_1024(ws >= 0 ? 1u : 0u, s_wave, total);
+    const unsigned b = s_base;
+    if(ws >= 0) out_list[b + off] = ws;
+    __syncthreads();
+    if(threadIdx.x == 0) s_base = b + total;
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) *out_count = (int) s_base;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1264,16 +1292,16 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   if(g.max_points <= 0) return;
   const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
-    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.interp);
-    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.interp);
+    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.interp);
     return;
   }
   if(g.fast_warp) {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
   } else {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.fuse_frozen ? 1 : 0);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.fuse_frozen ? 1 : 0);
   }
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
@@ -1281,7 +1309,7 @@ void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0 || g.C != 8) return;
   const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
-  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, 2);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
@@ -1297,8 +1325,8 @@ void launch_median(hipStream_t s, const GNLaunch& g)
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     attr_set = true;
   }
-  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
-  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs);
+  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
 }
 
 template <int C>
@@ -1307,16 +1335,16 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
   const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   switch(g.loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
-    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
   }
   if constexpr(C == 8) {
     if(!fuse) return;
     switch(g.loss) {
-      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
-      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
-      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ppb, fuse); break;
+      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
     }
   }
 }
@@ -1327,13 +1355,17 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
   if(g.C == 1) launch_irls_c<1>(s, g, ppb);
   else launch_irls_c<8>(s, g, ppb);
 }
+void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count)
+{
+  hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, s, jobs, in, n_in, out_list, out_count);
+}
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
-                    float f_tol, float g_tol, int* active_counter, int parity)
+                    float f_tol, float g_tol)
 {
   const int ppb = gn_pts_per_block(g.npairs);
   const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
-                     f_tol, g_tol, active_counter, parity, fuse);
+                     f_tol, g_tol, g.active, fuse);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {
