@@ -59,7 +59,7 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
-int  gn_pts_per_block(int npairs);
+int  gn_pts_per_block(int C);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records);

@@ -1271,7 +1271,9 @@ __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* re
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
 // fixed, so that a pair's block partials (and hence its rounding) do not depend on the size of the batch it is in
-int gn_pts_per_block(int /*npairs*/) { return 512; }   // 1024 / 2048 measured within 3 % of this
+// (a function of C only, never of the batch).  C = 8: 512 (1024 / 2048 measured within 3 % of it).  C = 1: the per-point
+// work is an eighth, so the 29-accumulator reduction tail of a workgroup dominates — 8 points per thread instead of 2.
+int gn_pts_per_block(int C) { return C == 8 ? 512 : 2048; }
 int gn_num_blocks(int max_points) { return (max_points + 255) / 256; }   // upper bound for any pts_per_block >= 256
 
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)
@@ -1351,7 +1353,7 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
-  const int ppb = gn_pts_per_block(g.npairs);
+  const int ppb = gn_pts_per_block(g.C);
   if(g.C == 1) launch_irls_c<1>(s, g, ppb);
   else launch_irls_c<8>(s, g, ppb);
 }
@@ -1362,7 +1364,7 @@ void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol)
 {
-  const int ppb = gn_pts_per_block(g.npairs);
+  const int ppb = gn_pts_per_block(g.C);
   const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
                      f_tol, g_tol, g.active, fuse);
