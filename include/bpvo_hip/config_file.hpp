@@ -18,6 +18,7 @@
 #include <ostream>
 #include <sstream>
 #include <string>
+#include <vector>
 #include <strings.h>
 
 #include "vo.hpp"
@@ -71,11 +72,16 @@ class ConfigFile {
       if(line.empty()) continue;
       if(line.front() == '#' || line.front() == '%') continue;
       line.erase(std::remove_if(line.begin(), line.end(), [](char c) { return std::isspace((unsigned char) c); }), line.end());
-      if(line.empty()) continue;
-      const size_t eq = line.find('=');
-      if(eq == std::string::npos || line.find('=', eq + 1) != std::string::npos || eq == 0 || eq + 1 == line.size())
-        throw Error("Malformed ConfigFile line " + line);
-      _data[line.substr(0, eq)] = line.substr(eq + 1);
+      // splitstr(line, '=') (bpvo/utils.cc:96-105: std::getline tokens, so "=3" has an empty key and is accepted, "a=" and
+      // a whitespace-only line are malformed) — pinned against the reference's reader in tests/test_reference_pins_cpu.py
+      std::vector<std::string> tokens;
+      {
+        std::stringstream ss(line);
+        std::string token;
+        while(std::getline(ss, token, '=')) tokens.push_back(token);
+      }
+      if(tokens.size() != 2) throw Error("Malformed ConfigFile line " + line);
+      _data[tokens[0]] = tokens[1];
     }
   }
   std::map<std::string, std::string, CaseInsenstiveComparator> _data;

@@ -1,5 +1,5 @@
 /*
- * ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/src/orc.h for the full notice; PARITY UNPINNED).
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/src/orc.h for the full notice; PARITY UNPINNED but for median / census operators / ConfigFile).
  *
  * C ABI of the CPU restatement, deliberately the same shape as include/bpvo_hip/c_api.h so that one Python
  * wrapper can drive both and compare them call by call.  Only tests/, __graft_entry__.smoke() and bench.py's

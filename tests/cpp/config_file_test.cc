@@ -2,12 +2,23 @@
 // (no GPU needed: only bpvo_hip_default_params is called).
 #include <bpvo_hip/config_file.hpp>
 #include <cstdio>
+#include <string>
 #include <iostream>
 #include <sstream>
 
 int main(int argc, char** argv)
 {
   if(argc < 2) return 2;
+  if(argc >= 5 && std::string(argv[2]) == "get") {    // raw lookup: config_file_test <file> get <key> <default>
+    try {
+      bpvo::ConfigFile cf{std::string(argv[1])};
+      std::printf("%s\n", cf.get<std::string>(argv[3], std::string(argv[4])).c_str());
+      return 0;
+    } catch(const bpvo::Error& e) {
+      std::printf("ERROR %s\n", e.what());
+      return 1;
+    }
+  }
   try {
     const bpvo::AlgorithmParameters p = bpvo::AlgorithmParametersFromFile(argv[1]);
     std::printf("numPyramidLevels %d\nsigmaPriorToCensusTransform %g\nsigmaBitPlanes %g\nmaxIterations %d\nparameterTolerance %g\n"
