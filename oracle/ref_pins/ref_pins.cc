@@ -3,10 +3,12 @@
 //   bpvo::median              bpvo/utils.h:224-252   (the selection rule of the robust scale)
 //   v128 operators            bpvo/v128.h:36-130     (the byte comparisons of the census transform, bpvo/census.cc:42-57)
 //   bpvo::ConfigFile, icompare bpvo/config_file.{h,cc}, bpvo/utils.{h,cc}   (the conf/*.cfg reader)
+//   simd::dot, simd::abs      bpvo/simd.h:60-80      (4-float dot product of the projectPoints formulation, |x| of the saliency map)
 // The reference sources are compiled where they lie under /root/reference (oracle/Makefile, target `ref`); nothing is
 // copied.  The wrappers only marshal arguments; census_bytes() composes the reference's operators in the order
 // censusOp (bpvo/census.cc:42-57) does, because that function itself sits in a translation unit that needs OpenCV.
 #include <bpvo/config_file.h>
+#include <bpvo/simd.h>
 #include <bpvo/utils.h>
 #include <bpvo/v128.h>
 
@@ -38,6 +40,9 @@ void ref_census_bytes(const uint8_t nbr[8][16], const uint8_t c16[16], uint8_t o
   for(int k = 1; k < 8; ++k) r = r | ((v128(nbr[k]) >= c) & K[k]);
   _mm_storeu_si128((__m128i*) out, r);
 }
+
+float ref_simd_dot(const float a[4], const float b[4]) { return bpvo::simd::dot(_mm_loadu_ps(a), _mm_loadu_ps(b)); }
+void ref_simd_abs(const float a[4], float out[4]) { _mm_storeu_ps(out, bpvo::simd::abs(_mm_loadu_ps(a))); }
 
 int ref_icompare(const char* a, const char* b) { return bpvo::icompare(a, b) ? 1 : 0; }
 

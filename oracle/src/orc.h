@@ -11,8 +11,8 @@
  * test/ directory holds no assertion, golden value or fixture.
  * Pinned against the reference's own code, compiled from its tree into oracle/_ref (make ref;
  * tests/test_reference_pins_cpu.py): bpvo::median (the selection rule of the robust scale), the
- * v128 byte operators the census is composed of, and the ConfigFile reader — the only parts on
- * or next to the path that compile without Eigen / OpenCV.  The oracle therefore restates the
+ * v128 byte operators the census is composed of, simd::dot / simd::abs, and the ConfigFile reader
+ * — the only parts on or next to the path that compile without Eigen / OpenCV.  The oracle therefore restates the
  * reference's sources line by line (citations on every function, paths relative to the
  * reference checkout) and restates the published semantics of the third-party calls on the
  * path (OpenCV 2.4.x pyrDown / GaussianBlur / convertTo, Eigen 3.2.x LDLT / isApprox /

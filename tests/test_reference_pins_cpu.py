@@ -123,3 +123,21 @@ def test_config_file_reader_matches_the_reference(ref, tmp_path):
         frc, fval = _facade_get(exe, str(p), "a", "D")
         assert (rc == 2) == (frc != 0), (bad, rc, buf.value, frc, fval)
     assert ref.ref_icompare(b"BitPlanes", b"bitplanes") == 1 and ref.ref_icompare(b"Bit", b"Bits") == 0
+
+
+def test_simd_dot_and_abs_match_the_restated_forms(ref):
+    """simd::dot (bpvo/simd.h:69-80, _mm_dp_ps under SSE4.1) = (a0 b0 + a1 b1) + (a2 b2 + a3 b3) in f32 — the summation order
+    the projectPoints / BilinearInterp formulation is restated with; simd::abs clears the sign bit (-0.0 -> +0.0, NaN kept)."""
+    ref.ref_simd_dot.restype = C.c_float
+    rng = np.random.default_rng(13)
+    for _ in range(2000):
+        a = (rng.standard_normal(4) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
+        b = rng.random(4).astype(np.float32)
+        got = np.float32(ref.ref_simd_dot(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+        p = a * b
+        want = np.float32(np.float32(p[0] + p[1]) + np.float32(p[2] + p[3]))
+        assert got.tobytes() == want.tobytes(), (a, b, got, want)
+    x = np.array([-0.0, -1.5, 2.25, -np.inf], np.float32)
+    out = np.empty(4, np.float32)
+    ref.ref_simd_abs(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert out.tobytes() == np.array([0.0, 1.5, 2.25, np.inf], np.float32).tobytes()
