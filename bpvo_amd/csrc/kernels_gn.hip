@@ -16,6 +16,14 @@
 namespace bpvo_hip {
 
 constexpr int GN_BLOCK = 256;
+// workgroup size of the warp + residual kernels = chunk of the fused bracket step (candidate segments, med_blk entries).
+// 64-thread workgroups stream a little better (the bare access pattern: 6.48 against 6.24 TB/s, scripts/micro/streams.hip;
+// warp_residual: +1 %), but median_finish then walks four times as many candidate segments: 256 measured 3 % faster overall.
+#ifndef K6_BLOCK_VALUE
+#define K6_BLOCK_VALUE 256
+#endif
+constexpr int K6_BLOCK = K6_BLOCK_VALUE;
+constexpr int K6_WAVES = K6_BLOCK / 64;
 
 // workspace of a workgroup: k-th entry of the active list, or k itself without a list
 __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
@@ -52,22 +60,24 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     sum_below += __shfl_down(sum_below, o);
     sum_valid += __shfl_down(sum_valid, o);
   }
-  __shared__ unsigned s_in[4], s_below[4], s_valid[4];
-  if(lane == 63) s_in[wave] = incl;
-  if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
-  __syncthreads();
   unsigned woff = 0;
-  for(int w = 0; w < wave; ++w) woff += s_in[w];
-  if(threadIdx.x == 0) {
-    uint4 o;
-    o.x = s_below[0] + s_below[1] + s_below[2] + s_below[3];
-    o.y = s_in[0] + s_in[1] + s_in[2] + s_in[3];
-    o.z = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
-    o.w = 0;
-    reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
+  if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
+    const unsigned t_in = __shfl(incl, 63);
+    if(lane == 0) reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = make_uint4(sum_below, t_in, sum_valid, 0u);
+  } else {
+    __shared__ unsigned s_in[K6_WAVES], s_below[K6_WAVES], s_valid[K6_WAVES];
+    if(lane == 63) s_in[wave] = incl;
+    if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
+    __syncthreads();
+    for(int w = 0; w < wave; ++w) woff += s_in[w];
+    if(threadIdx.x == 0) {
+      uint4 o = make_uint4(0u, 0u, 0u, 0u);
+      for(int w = 0; w < K6_WAVES; ++w) { o.x += s_below[w]; o.y += s_in[w]; o.z += s_valid[w]; }
+      reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
+    }
   }
   if(cnt) {
-    unsigned* seg = j.cand + (size_t) blockIdx.x * GN_BLOCK * C;
+    unsigned* seg = j.cand + (size_t) blockIdx.x * K6_BLOCK * C;
     unsigned pos = woff + incl - cnt;
 #pragma unroll
     for(int c = 0; c < C; ++c)
@@ -274,7 +284,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
 }
 
 template <int C, bool FAST>
-__global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
 {
   // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
   // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
     if(mode == 1 && !(st->delta_scale > 1e-6f)) return;
   }
   const int n = j.n;
-  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+  if((int) (blockIdx.x * K6_BLOCK) >= n) return;
 
   if(mode != 2 && blockIdx.x == 0 && threadIdx.x == 0) j.cnt[4] += (unsigned long long) n;   // points this kernel processes
 
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_kernel(const PairJob* 
 
   // lanes past the end of the last block redo the last point (loads only) so that the whole block reaches the
   // block-level bracket step below; their stores are masked
-  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const int i_raw = blockIdx.x * K6_BLOCK + threadIdx.x;
   const bool in_block = i_raw < n;
   const int i = in_block ? i_raw : n - 1;
   float res[C];
@@ -364,13 +374,13 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
 }
 
 template <int C>
-__global__ __launch_bounds__(GN_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp)
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
   const int n = j.n;
-  if((int) (blockIdx.x * GN_BLOCK) >= n) return;
+  if((int) (blockIdx.x * K6_BLOCK) >= n) return;
 
   float P[12];
 #pragma unroll
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(GN_BLOCK) void warp_residual_interp_kernel(const Pa
       P[r * 4 + c] = s;
     }
 
-  const int i_raw = blockIdx.x * GN_BLOCK + threadIdx.x;
+  const int i_raw = blockIdx.x * K6_BLOCK + threadIdx.x;
   const bool in_block = i_raw < n;
   const int i = in_block ? i_raw : n - 1;
   const int W = j.cols, R = j.rows;
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   // ---- bracketed path
   if(st->median_valid) {
     // totals of the per-block counters written by the bracket step of warp_residual (bracket_block)
-    const int nblk = (j.n + GN_BLOCK - 1) / GN_BLOCK;
+    const int nblk = (j.n + K6_BLOCK - 1) / K6_BLOCK;
     unsigned c_below = 0, c_in = 0, c_valid = 0;
     for(int b = tid; b < nblk; b += MED_THREADS) {
       const uint4 o = reinterpret_cast<const uint4*>(j.med_blk)[b];
@@ -676,7 +686,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
         const int lane = tid & 63, wave = tid >> 6;
         for(int b = wave; b < nblk; b += MED_THREADS / 64) {
           const unsigned mb = reinterpret_cast<const uint4*>(j.med_blk)[b].y;
-          const unsigned* seg = j.cand + (size_t) b * GN_BLOCK * C;
+          const unsigned* seg = j.cand + (size_t) b * K6_BLOCK * C;
           for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
         }
       };
@@ -1274,7 +1284,8 @@ __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* re
 // (a function of C only, never of the batch).  C = 8: 512 (1024 / 2048 measured within 3 % of it).  C = 1: the per-point
 // work is an eighth, so the 29-accumulator reduction tail of a workgroup dominates — 8 points per thread instead of 2.
 int gn_pts_per_block(int C) { return C == 8 ? 512 : 2048; }
-int gn_num_blocks(int max_points) { return (max_points + 255) / 256; }   // upper bound for any pts_per_block >= 256
+// upper bound of the block-indexed buffers: bracket chunks of warp_residual (K6_BLOCK points) and reduction partials
+int gn_num_blocks(int max_points) { return (max_points + K6_BLOCK - 1) / K6_BLOCK; }
 
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)
 {
@@ -1292,26 +1303,26 @@ void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
 void launch_warp_residual(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
-  const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
+  const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
-    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.interp);
-    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
     return;
   }
   if(g.fast_warp) {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
   } else {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, g.fuse_frozen ? 1 : 0);
+    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.fuse_frozen ? 1 : 0);
   }
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0 || g.C != 8) return;
-  const dim3 grid((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs);
-  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
+  const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BLOCK) void kE(const float4* pts, const unsigned* k
   if(i >= n) return;
   typedef float v4f __attribute__((ext_vector_type(4)));
   auto ld = [&](const float4* p) {
-    if(NT) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    if(NT & 1) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
     return *p;
   };
   float4 acc = ld(pts + i);
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void kE(const float4* pts, const unsigned* k
   for(int q = 0; q < 8; ++q) { const float4 t = ld(taps + tidx<TILE, NT>(8, i, q)); s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
   const float4 o0 = make_float4(s.x - p0.x + acc.x, s.y - p0.y, s.z - p0.z, s.w - p0.w);
   const float4 o1 = make_float4(s.x - p1.x, s.y - p1.y + acc.y, s.z - p1.z, s.w - p1.w + (float) k);
-  if(NT) {
+  if(NT & 2) {
     v4f a; a.x = o0.x; a.y = o0.y; a.z = o0.z; a.w = o0.w;
     v4f b; b.x = o1.x; b.y = o1.y; b.z = o1.z; b.w = o1.w;
     __builtin_nontemporal_store(a, reinterpret_cast<v4f*>(r + tidx<TILE, NT>(2, i, 0)));
@@ -136,7 +136,12 @@ int main()
   time("E1: tile 256, block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<256, 0, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E2: tile 64, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 0, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E3: tile 1024, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<1024, 0, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
-  time("E4: tile 64, block 256, nontemporal", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 1, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4: tile 64, block 256, NT loads+stores", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4a: NT loads only", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 1, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4b: NT stores only", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 2, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4c: NT, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 3, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4d: NT, block 64", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 3, 64>), dim3(grid * 4), dim3(64), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4e: NT, tile 1024 block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<1024, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E5: tile 64, block 64", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 0, 64>), dim3(grid * 4), dim3(64), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("B: 1 merged read (192 B) + writes", n * 225.0, [&] { hipLaunchKernelGGL(kB, dim3(grid), dim3(256), 0, 0, rec, r, valid, n); });
   const size_t n4 = n * 8;   // 128 B/point worth of float4
