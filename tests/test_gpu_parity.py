@@ -579,3 +579,22 @@ def test_random_odd_sizes_and_parameters_pipeline_parity(hip, orc, seed):
         rot, trans = pose_error(Th, To)
         # random textures can leave the problem ill-conditioned: the bar scales with the conditioning seen by both sides
         assert rot <= 20 * ROT_TOL and trans <= 20 * trans_tol(K), (rows, cols, kw, rot, trans, sh, so)
+
+
+def test_full_hd_auto_pyramid_parity(hip, orc):
+    """1920x1080, numPyramidLevels = -1 (auto: 1 + round(log2(1080 / 40)) = 6 levels, bpvo/vo.cc:101-105), bit-planes / Tukey:
+    the largest size in the tests — selection lists, robust scales and the final pose against the CPU path."""
+    rows, cols = 1080, 1920
+    ch, co, d = both(hip, orc, rows, cols, -1, descriptor="bitplanes", loss="tukey")
+    assert ch.L == co.L == 6
+    for l in range(ch.L):
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l)), l
+    T = _perturbed_pose(1.0)
+    for l in (0, 3, 5):
+        a, b = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+        assert np.array_equal(ch.get_valid(0), co.get_valid(0)) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+        assert a["sigma"] == b["sigma"] and a["num_valid"] == b["num_valid"]
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
