@@ -596,7 +596,7 @@ void detile_to_channel_major(const float* src, int n, int C, int E, int V, float
   for(int i = 0; i < n; ++i)
     for(int w = 0; w < W; ++w) {
       const int piece = w / V, within = w - piece * V;
-      const float v = src[(((size_t) (i >> 6) * pieces + piece) * 64 + (size_t) (i & 63)) * V + within];
+      const float v = src[(((size_t) (i / kTile) * pieces + piece) * kTile + (size_t) (i % kTile)) * V + within];
       const int ch = w / E, e = w - ch * E;
       out[((size_t) ch * n + i) * E + e] = v;
     }
