@@ -21,10 +21,11 @@ constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hi
 //     vec[((i / kTile) * PIECES + piece) * kTile + (i % kTile)]
 // so that lane l of a wave reading piece k of its point touches one contiguous 64*V*4-byte segment: every wave-level
 // load/store of these arrays is fully coalesced (a plain point-major record layout makes each 16-byte load of a
-// wave hit 64 different cache lines).  With kTile = 1024 a 256-thread workgroup reads 4 KiB runs per piece and a piece
-// is a 16 KiB run: measured +3 % GN iterations/s over 64-point tiles (the bare access pattern: 6.06 -> 6.23 TB/s).
+// wave hit 64 different cache lines).  Tile size, measured on the 1024-pair bench (warp_residual, algorithmic TB/s):
+// 64: 5.25, 256: 5.27, 1024: 5.40, 2048: 5.66, 4096: 5.66, 8192: 5.27, 16384: 5.26, 65536: 5.13 — HBM likes long runs
+// per stream (a piece of a 2048-point tile is a 32 KiB run) as long as the pieces of one point stay within ~0.5 MiB.
 #ifndef BPVO_TILE_VALUE
-#define BPVO_TILE_VALUE 1024
+#define BPVO_TILE_VALUE 2048
 #endif
 constexpr int kTile = BPVO_TILE_VALUE;   // points per tile (a power of two, multiple of the wavefront size)
 template <int PIECES>
