@@ -142,6 +142,9 @@ int main()
   time("E4c: NT, block 1024", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 3, 1024>), dim3(grid / 4), dim3(1024), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E4d: NT, block 64", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 3, 64>), dim3(grid * 4), dim3(64), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E4e: NT, tile 1024 block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<1024, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4f: NT, tile 2048 block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<2048, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4g: NT, tile 4096 block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<4096, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
+  time("E4h: NT, tile 16384 block 256", n * 213.0, [&] { hipLaunchKernelGGL((kE<16384, 3, 256>), dim3(grid), dim3(256), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("E5: tile 64, block 64", n * 213.0, [&] { hipLaunchKernelGGL((kE<64, 0, 64>), dim3(grid * 4), dim3(64), 0, 0, pts, key, pix, taps, r, valid, n); });
   time("B: 1 merged read (192 B) + writes", n * 225.0, [&] { hipLaunchKernelGGL(kB, dim3(grid), dim3(256), 0, 0, rec, r, valid, n); });
   const size_t n4 = n * 8;   // 128 B/point worth of float4
