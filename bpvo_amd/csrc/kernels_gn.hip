@@ -1281,9 +1281,12 @@ __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* re
 
 // ---- launchers ----------------------------------------------------------------------------------------------------
 // fixed, so that a pair's block partials (and hence its rounding) do not depend on the size of the batch it is in
-// (a function of C only, never of the batch).  C = 8: 512 (1024 / 2048 measured within 3 % of it).  C = 1: the per-point
+// (a function of C only, never of the batch).  C = 8: K8_PPB_VALUE.  C = 1: the per-point
 // work is an eighth, so the 29-accumulator reduction tail of a workgroup dominates — 8 points per thread instead of 2.
-int gn_pts_per_block(int C) { return C == 8 ? 512 : 2048; }
+#ifndef K8_PPB_VALUE
+#define K8_PPB_VALUE 1024   // with 2048-point tiles: 256 -> 401 us, 512 -> 239, 1024 -> 228, 2048 -> 228 per 12.2 M-point launch
+#endif
+int gn_pts_per_block(int C) { return C == 8 ? K8_PPB_VALUE : 2048; }
 // upper bound of the block-indexed buffers: bracket chunks of warp_residual (K6_BLOCK points) and reduction partials
 int gn_num_blocks(int max_points) { return (max_points + K6_BLOCK - 1) / K6_BLOCK; }
 
