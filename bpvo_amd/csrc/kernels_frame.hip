@@ -384,37 +384,72 @@ __device__ __forceinline__ bool is_local_max(const float* __restrict__ S, int W,
   return true;
 }
 
-constexpr int SEL_CHUNKS = 4;   // 256-pixel chunks per workgroup (the chunk stays the unit of the order-preserving scan)
+// A thread owns 4 consecutive pixels of the row-major scan, a wavefront therefore exactly one 256-pixel chunk (the unit
+// of the order-preserving scan): chunk counts and in-chunk ranks are wavefront operations, no LDS, no barrier.  The 3 x 4
+// NMS windows of the 4 pixels overlap (3 rows x 7 columns instead of 4 x 11 loads) when they lie in one row.
+constexpr int SEL_PX = 4;                       // pixels per thread
+constexpr int SEL_BLOCK_PX = 256 * SEL_PX;      // pixels per workgroup = 4 chunks
 __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, float min_saliency, float min_disp,
                                                           float max_disp, int border)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
   const int npix = W * R;
-  __shared__ int s_cnt[SEL_CHUNKS][4];
+  const int p0 = blockIdx.x * SEL_BLOCK_PX + threadIdx.x * SEL_PX;
+  const float* __restrict__ S = j.sal;
+  bool f[SEL_PX] = {false, false, false, false};
+  if(p0 < npix) {
+    const int y0 = p0 / W, x0 = p0 - y0 * W;
+    const bool one_row = x0 + SEL_PX <= W && p0 + SEL_PX <= npix;
+    const bool inner = one_row && j.nms_radius == 1 && y0 >= border && y0 < R - border - 1 && x0 >= border && x0 + SEL_PX - 1 < W - border - 1;
+    if(inner) {
+      // shared window: rows y0-1..y0+1, columns x0-1..x0+5
+      float a[7], b[7], c[7];
+      const float* q = S + (size_t) y0 * W + x0 - 1;
 #pragma unroll
-  for(int k = 0; k < SEL_CHUNKS; ++k) {
-    const int chunk = blockIdx.x * SEL_CHUNKS + k;
-    const int p = chunk * 256 + threadIdx.x;
-    bool f = false;
-    if(p < npix) {
-      const int y = p / W, x = p - y * W;
-      if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1) {
-        if(j.sal[p] >= min_saliency && is_local_max(j.sal, W, j.nms_radius, y, x)) {
-          const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
-          f = (d >= min_disp && d <= max_disp);
+      for(int k = 0; k < 7; ++k) { a[k] = q[k - W]; b[k] = q[k]; c[k] = q[k + W]; }
+#pragma unroll
+      for(int e = 0; e < SEL_PX; ++e) {
+        const float v = b[e + 1];
+        bool ok = v >= min_saliency;
+#pragma unroll
+        for(int k = 0; k < 4; ++k) {      // columns x-1 .. x+2 of pixel e = window entries e .. e+3, strict > (Q8)
+          if(k != 1) ok = ok & (v > b[e + k]);
+          ok = ok & (v > a[e + k]) & (v > c[e + k]);
         }
+        f[e] = ok;
       }
-      j.flag[p] = f ? 1 : 0;
+    } else {
+#pragma unroll
+      for(int e = 0; e < SEL_PX; ++e) {
+        const int p = p0 + e;
+        if(p >= npix) break;
+        const int y = p / W, x = p - y * W;
+        if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1)
+          f[e] = S[p] >= min_saliency && is_local_max(S, W, j.nms_radius, y, x);
+      }
     }
-    const unsigned long long m = __ballot(f);
-    if((threadIdx.x & 63) == 0) s_cnt[k][threadIdx.x >> 6] = __popcll(m);
+    // disparity gate for the survivors (full-resolution map, template_data.cc:73-83)
+#pragma unroll
+    for(int e = 0; e < SEL_PX; ++e) {
+      if(!f[e]) continue;
+      const int p = p0 + e;
+      const int y = p / W, x = p - y * W;
+      const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+      f[e] = (d >= min_disp && d <= max_disp);
+    }
+    if(p0 + SEL_PX <= npix) {
+      *reinterpret_cast<uchar4*>(j.flag + p0) = make_uchar4(f[0], f[1], f[2], f[3]);
+    } else {
+      for(int e = 0; e < SEL_PX && p0 + e < npix; ++e) j.flag[p0 + e] = f[e] ? 1 : 0;
+    }
   }
-  __syncthreads();
-  if(threadIdx.x < SEL_CHUNKS) {
-    const int chunk = blockIdx.x * SEL_CHUNKS + threadIdx.x;
-    if(chunk * 256 < npix) j.blk_count[chunk] = s_cnt[threadIdx.x][0] + s_cnt[threadIdx.x][1] + s_cnt[threadIdx.x][2] + s_cnt[threadIdx.x][3];
-  }
+  // chunk count = wavefront sum
+  int cnt = (int) f[0] + (int) f[1] + (int) f[2] + (int) f[3];
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) cnt += __shfl_down(cnt, o);
+  const int chunk = blockIdx.x * (SEL_BLOCK_PX / 256) + (threadIdx.x >> 6);
+  if((threadIdx.x & 63) == 0 && chunk * 256 < npix) j.blk_count[chunk] = cnt;
 }
 
 __global__ __launch_bounds__(1024) void select_scan_kernel(const FrameJob* jobs)
@@ -457,36 +492,40 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols;
   const int npix = W * j.rows;
-  const int N = *j.n_out;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __shared__ int s_cnt[SEL_CHUNKS][4];
-  bool f[SEL_CHUNKS];
-  unsigned long long m[SEL_CHUNKS];
+  const int p0 = blockIdx.x * SEL_BLOCK_PX + threadIdx.x * SEL_PX;
+  const int chunk = blockIdx.x * (SEL_BLOCK_PX / 256) + (threadIdx.x >> 6);
+  if(chunk * 256 >= npix) return;             // whole wavefront past the image
+  uchar4 fl = make_uchar4(0, 0, 0, 0);
+  if(p0 + SEL_PX <= npix) fl = *reinterpret_cast<const uchar4*>(j.flag + p0);
+  else for(int e = 0; e < SEL_PX && p0 + e < npix; ++e) reinterpret_cast<unsigned char*>(&fl)[e] = j.flag[p0 + e];
+  const int mine = (int) fl.x + (int) fl.y + (int) fl.z + (int) fl.w;
+  // exclusive prefix over the wavefront = rank inside the chunk
+  const int lane = threadIdx.x & 63;
+  int incl = mine;
 #pragma unroll
-  for(int k = 0; k < SEL_CHUNKS; ++k) {
-    const int p = (blockIdx.x * SEL_CHUNKS + k) * 256 + threadIdx.x;
-    f[k] = (p < npix) && j.flag[p];
-    m[k] = __ballot(f[k]);
-    if(lane == 0) s_cnt[k][wave] = __popcll(m[k]);
+  for(int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if(lane >= o) incl += t;
   }
-  __syncthreads();
+  if(!mine) return;
+  int rank = j.blk_count[chunk] + incl - mine;
+  const int N = *j.n_out;
+  const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
+  const float Bf = j.b * fx;
+  const unsigned char fe[SEL_PX] = {fl.x, fl.y, fl.z, fl.w};
 #pragma unroll
-  for(int k = 0; k < SEL_CHUNKS; ++k) {
-    if(!f[k]) continue;
-    const int chunk = blockIdx.x * SEL_CHUNKS + k;
-    const int p = chunk * 256 + threadIdx.x;
-    int rank = j.blk_count[chunk] + __popcll(m[k] & ((1ull << lane) - 1ull));
-    for(int w = 0; w < wave; ++w) rank += s_cnt[k][w];
-    if(rank >= N) continue;
+  for(int e = 0; e < SEL_PX; ++e) {
+    if(!fe[e]) continue;
+    const int r = rank++;
+    if(r >= N) break;
+    const int p = p0 + e;
     const int y = p / W, x = p - y * W;
     const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
-    const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
-    const float Bf = j.b * fx;
     const float Z = (float) ((double) Bf * (1.0 / (double) d));
     const float X = ((float) x - cx) * Z * (1.0f / fx);
     const float Y = ((float) y - cy) * Z * (1.0f / fy);
-    j.pts[rank] = make_float4(X, Y, Z, 1.0f);
-    j.inds[rank] = p;
+    j.pts[r] = make_float4(X, Y, Z, 1.0f);
+    j.inds[r] = p;
   }
 }
 
@@ -707,7 +746,7 @@ void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, i
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border)
 {
-  const int nblk = ((W * R + 255) / 256 + SEL_CHUNKS - 1) / SEL_CHUNKS;
+  const int nblk = (W * R + SEL_BLOCK_PX - 1) / SEL_BLOCK_PX;
   hipLaunchKernelGGL(select_flag_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs, min_saliency, min_disp, max_disp, border);
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
   hipLaunchKernelGGL(select_write_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs);
