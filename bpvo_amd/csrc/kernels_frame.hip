@@ -100,25 +100,26 @@ __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
 // Workgroups of 64 x 16 pixels: every thread walks 4 rows of one column with a sliding 3 x 3 window (6 rows x 3 bytes loaded
 // for 4 outputs).  Tiny one-pixel-per-thread workgroups were bound by the workgroup dispatch rate (~1.15 WG/ns), not by HBM.
 constexpr int ROWS_PER_THREAD = 4;
+constexpr int CENSUS_ROWS = 8;   // rows per thread (4: 166, 8: 149, 16: 178 us per launch at 256 pairs)
 __global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS_PER_THREAD;
+  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CENSUS_ROWS;
   const int W = j.cols, R = j.rows;
   if(x >= W || y0 >= R) return;
   const bool xin = x > 0 && x < W - 1;
   const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
-  // all (ROWS_PER_THREAD + 2) x 3 bytes are loaded before the first use: a rolling window issued one row per iteration
+  // all (CENSUS_ROWS + 2) x 3 bytes are loaded before the first use: a rolling window issued one row per iteration
   // and every iteration waited for its own loads (PMC: 81 % of the wave cycles waiting, 1.6 waves per SIMD in flight)
-  uint8_t w[ROWS_PER_THREAD + 2][3];
+  uint8_t w[CENSUS_ROWS + 2][3];
 #pragma unroll
-  for(int k = 0; k < ROWS_PER_THREAD + 2; ++k) {
+  for(int k = 0; k < CENSUS_ROWS + 2; ++k) {
     const uint8_t* p = j.img + (size_t) min(max(y0 - 1 + k, 0), R - 1) * W;
     w[k][0] = p[xm]; w[k][1] = p[x]; w[k][2] = p[xp];
   }
 #pragma unroll
-  for(int k = 0; k < ROWS_PER_THREAD; ++k) {
+  for(int k = 0; k < CENSUS_ROWS; ++k) {
     const int y = y0 + k;
     if(y < R) {
       uint8_t out = 0;
@@ -728,7 +729,7 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
     hipLaunchKernelGGL(census_blur_kernel, dim3((W + CB_TW - 1) / CB_TW, (R + CB_TH - 1) / CB_TH, nframes), dim3(256), 0, s,
                        jobs, blur_taps[0], blur_taps[1]);
   else
-    hipLaunchKernelGGL(census_kernel, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(census_kernel, dim3((W + 63) / 64, (R + 4 * CENSUS_ROWS - 1) / (4 * CENSUS_ROWS), nframes), dim3(256), 0, s, jobs);
 }
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
 {
