@@ -388,8 +388,12 @@ __device__ __forceinline__ bool is_local_max(const float* __restrict__ S, int W,
 // A thread owns 4 consecutive pixels of the row-major scan, a wavefront therefore exactly one 256-pixel chunk (the unit
 // of the order-preserving scan): chunk counts and in-chunk ranks are wavefront operations, no LDS, no barrier.  The 3 x 4
 // NMS windows of the 4 pixels overlap (3 rows x 7 columns instead of 4 x 11 loads) when they lie in one row.
-constexpr int SEL_PX = 4;                       // pixels per thread
-constexpr int SEL_BLOCK_PX = 256 * SEL_PX;      // pixels per workgroup = 4 chunks
+#ifndef SEL_PX_VALUE
+#define SEL_PX_VALUE 4
+#endif
+constexpr int SEL_PX = SEL_PX_VALUE;            // pixels per thread (4, 8 or 16; measured: 8 is 3-7 % slower, 16 12-24 %)
+constexpr int SEL_BLOCK_PX = 256 * SEL_PX;      // pixels per workgroup
+constexpr int SEL_GROUP = 256 / SEL_PX;         // lanes that share one 256-pixel chunk (64, 32 or 16)
 __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, float min_saliency, float min_disp,
                                                           float max_disp, int border)
 {
@@ -398,17 +402,19 @@ __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, 
   const int npix = W * R;
   const int p0 = blockIdx.x * SEL_BLOCK_PX + threadIdx.x * SEL_PX;
   const float* __restrict__ S = j.sal;
-  bool f[SEL_PX] = {false, false, false, false};
+  bool f[SEL_PX];
+#pragma unroll
+  for(int e = 0; e < SEL_PX; ++e) f[e] = false;
   if(p0 < npix) {
     const int y0 = p0 / W, x0 = p0 - y0 * W;
     const bool one_row = x0 + SEL_PX <= W && p0 + SEL_PX <= npix;
     const bool inner = one_row && j.nms_radius == 1 && y0 >= border && y0 < R - border - 1 && x0 >= border && x0 + SEL_PX - 1 < W - border - 1;
     if(inner) {
-      // shared window: rows y0-1..y0+1, columns x0-1..x0+5
-      float a[7], b[7], c[7];
+      // shared window: rows y0-1..y0+1, columns x0-1..x0+SEL_PX+1, all loaded before the first comparison
+      float a[SEL_PX + 3], b[SEL_PX + 3], c[SEL_PX + 3];
       const float* q = S + (size_t) y0 * W + x0 - 1;
 #pragma unroll
-      for(int k = 0; k < 7; ++k) { a[k] = q[k - W]; b[k] = q[k]; c[k] = q[k + W]; }
+      for(int k = 0; k < SEL_PX + 3; ++k) { a[k] = q[k - W]; b[k] = q[k]; c[k] = q[k + W]; }
 #pragma unroll
       for(int e = 0; e < SEL_PX; ++e) {
         const float v = b[e + 1];
@@ -424,10 +430,11 @@ __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, 
 #pragma unroll
       for(int e = 0; e < SEL_PX; ++e) {
         const int p = p0 + e;
-        if(p >= npix) break;
-        const int y = p / W, x = p - y * W;
-        if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1)
-          f[e] = S[p] >= min_saliency && is_local_max(S, W, j.nms_radius, y, x);
+        if(p < npix) {
+          const int y = p / W, x = p - y * W;
+          if(y >= border && y < R - border - 1 && x >= border && x < W - border - 1)
+            f[e] = S[p] >= min_saliency && is_local_max(S, W, j.nms_radius, y, x);
+        }
       }
     }
     // disparity gate for the survivors (full-resolution map, template_data.cc:73-83)
@@ -440,17 +447,21 @@ __global__ __launch_bounds__(256) void select_flag_kernel(const FrameJob* jobs, 
       f[e] = (d >= min_disp && d <= max_disp);
     }
     if(p0 + SEL_PX <= npix) {
-      *reinterpret_cast<uchar4*>(j.flag + p0) = make_uchar4(f[0], f[1], f[2], f[3]);
+#pragma unroll
+      for(int e = 0; e < SEL_PX; e += 4)
+        *reinterpret_cast<uchar4*>(j.flag + p0 + e) = make_uchar4(f[e], f[e + 1], f[e + 2], f[e + 3]);
     } else {
       for(int e = 0; e < SEL_PX && p0 + e < npix; ++e) j.flag[p0 + e] = f[e] ? 1 : 0;
     }
   }
-  // chunk count = wavefront sum
-  int cnt = (int) f[0] + (int) f[1] + (int) f[2] + (int) f[3];
+  // chunk count = sum over the SEL_GROUP lanes of the chunk
+  int cnt = 0;
 #pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) cnt += __shfl_down(cnt, o);
-  const int chunk = blockIdx.x * (SEL_BLOCK_PX / 256) + (threadIdx.x >> 6);
-  if((threadIdx.x & 63) == 0 && chunk * 256 < npix) j.blk_count[chunk] = cnt;
+  for(int e = 0; e < SEL_PX; ++e) cnt += (int) f[e];
+#pragma unroll
+  for(int o = SEL_GROUP / 2; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+  const int chunk = p0 / 256;
+  if((threadIdx.x & (SEL_GROUP - 1)) == 0 && chunk * 256 < npix) j.blk_count[chunk] = cnt;
 }
 
 __global__ __launch_bounds__(1024) void select_scan_kernel(const FrameJob* jobs)
@@ -494,26 +505,37 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
   const int W = j.cols;
   const int npix = W * j.rows;
   const int p0 = blockIdx.x * SEL_BLOCK_PX + threadIdx.x * SEL_PX;
-  const int chunk = blockIdx.x * (SEL_BLOCK_PX / 256) + (threadIdx.x >> 6);
-  if(chunk * 256 >= npix) return;             // whole wavefront past the image
-  uchar4 fl = make_uchar4(0, 0, 0, 0);
-  if(p0 + SEL_PX <= npix) fl = *reinterpret_cast<const uchar4*>(j.flag + p0);
-  else for(int e = 0; e < SEL_PX && p0 + e < npix; ++e) reinterpret_cast<unsigned char*>(&fl)[e] = j.flag[p0 + e];
-  const int mine = (int) fl.x + (int) fl.y + (int) fl.z + (int) fl.w;
-  // exclusive prefix over the wavefront = rank inside the chunk
-  const int lane = threadIdx.x & 63;
+  const int wave_p0 = blockIdx.x * SEL_BLOCK_PX + (threadIdx.x & ~63) * SEL_PX;
+  if(wave_p0 >= npix) return;                 // whole wavefront past the image
+  const int chunk = p0 / 256;
+  unsigned char fe[SEL_PX];
+#pragma unroll
+  for(int e = 0; e < SEL_PX; ++e) fe[e] = 0;
+  if(p0 + SEL_PX <= npix) {
+#pragma unroll
+    for(int e = 0; e < SEL_PX; e += 4) {
+      const uchar4 v = *reinterpret_cast<const uchar4*>(j.flag + p0 + e);
+      fe[e] = v.x; fe[e + 1] = v.y; fe[e + 2] = v.z; fe[e + 3] = v.w;
+    }
+  } else {
+    for(int e = 0; e < SEL_PX && p0 + e < npix; ++e) fe[e] = j.flag[p0 + e];
+  }
+  int mine = 0;
+#pragma unroll
+  for(int e = 0; e < SEL_PX; ++e) mine += (int) fe[e];
+  // exclusive prefix over the SEL_GROUP lanes of the chunk = rank inside the chunk
+  const int gl = threadIdx.x & (SEL_GROUP - 1);
   int incl = mine;
 #pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
+  for(int o = 1; o < SEL_GROUP; o <<= 1) {
     const int t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
+    if(gl >= o) incl += t;
   }
   if(!mine) return;
   int rank = j.blk_count[chunk] + incl - mine;
   const int N = *j.n_out;
   const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
   const float Bf = j.b * fx;
-  const unsigned char fe[SEL_PX] = {fl.x, fl.y, fl.z, fl.w};
 #pragma unroll
   for(int e = 0; e < SEL_PX; ++e) {
     if(!fe[e]) continue;
