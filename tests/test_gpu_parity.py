@@ -598,3 +598,33 @@ def test_full_hd_auto_pyramid_parity(hip, orc):
     To, _ = co.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+@pytest.mark.parametrize("which", ["perf_bitplanes", "perf_intensity"])
+def test_reference_timing_configurations_sequence(hip, orc, which):
+    """The reference's own timing set-ups (conf/perf_bitplanes.cfg, conf/perf_intensity.cfg: the runs behind the figures quoted
+    in BASELINE.md §1) as AlgorithmParameters(filename) builds them — file defaults included (CD5 gradients, gradientTolerance
+    1e-6, minValidDisparity 1, goodPointThreshold 0.75; bpvo/types.cc:68-107) — on a 640x480 sequence through addFrame:
+    sigma_ct 0.75 + sigma_bp 1.6 + L2 for bit-planes, NMS radius 2 + minSaliency 2.5 + Huber for intensity."""
+    rows, cols = 480, 640
+    common = dict(levels=3, parameterTolerance=1e-6, functionTolerance=1e-4, gradientTolerance=1e-6, maxIterations=50,
+                  relaxTolerancesForCoarseLevels=1, gradientEstimation=capi.GRAD_CD5, minValidDisparity=1.0, goodPointThreshold=0.75)
+    if which == "perf_bitplanes":
+        kw = dict(common, descriptor="bitplanes", loss="l2", minTranslationMagToKeyFrame=0.1, minRotationMagToKeyFrame=5.0,
+                  sigmaPriorToCensusTransform=0.75, sigmaBitPlanes=1.6)
+    else:
+        kw = dict(common, descriptor="intensity", loss="huber", minSaliency=2.5, nonMaxSuppRadius=2,
+                  minTranslationMagToKeyFrame=1000.0, minRotationMagToKeyFrame=1000.0, maxFractionOfGoodPointsToKeyFrame=0.75)
+    seq = synth.make_sequence(rows, cols, 5, index=11, step_rot=0.006, step_trans=0.04)
+    res = []
+    for b in (hip, orc):
+        ctx = b.create(seq["K"], seq["b"], rows, cols, make_params(b, **kw), n_frames=3, n_pairs=1)
+        out = [ctx.add_frame(img, disp) for img, disp in seq["frames"]]
+        res.append((out, [ctx.vo_num_points_at_level(l) for l in range(3)]))
+    (oh, nh), (oo, no_) = res
+    assert nh == no_ and all(n > 0 for n in nh)
+    assert [r["isKeyFrame"] for r in oh] == [r["isKeyFrame"] for r in oo]
+    assert [r["keyFramingReason"] for r in oh] == [r["keyFramingReason"] for r in oo]
+    for a, b in zip(oh, oo):
+        rot, trans = pose_error(a["pose"], b["pose"])
+        assert rot <= ROT_TOL and trans <= trans_tol(seq["K"]), (which, rot, trans)
