@@ -133,7 +133,36 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
             "gn_iterations_per_pair": gn / (steps * n), "median_trans_err_vs_gt_m": float(np.median(dT))}
 
 
-def other_configs(hip, torch, dev, dev_index, args, batch, other_batch):
+def add_frame_latency(hip, dev_index, seq, which):
+    """Sequential VisualOdometry::addFrame on a 640x480 sequence with the parameters of the reference's own timing runs
+    (conf/perf_intensity.cfg / conf/perf_bitplanes.cfg as AlgorithmParameters(filename) builds them, bpvo/types.cc:68-107):
+    the quantity behind BASELINE.md section 1 (ms per addFrame; there: Tsukuba frames on the author's CPU)."""
+    from bpvo_amd import capi
+    p = hip.default_params()
+    p.numPyramidLevels = 3; p.parameterTolerance = 1e-6; p.functionTolerance = 1e-4; p.gradientTolerance = 1e-6
+    p.maxIterations = 50; p.relaxTolerancesForCoarseLevels = 1; p.gradientEstimation = capi.GRAD_CD5
+    p.minValidDisparity = 1.0; p.goodPointThreshold = 0.75; p.verbosity = capi.VERB_SILENT
+    if which == "perf_bitplanes":
+        p.descriptor = capi.DESC_BITPLANES; p.lossFunction = capi.LOSS_L2
+        p.minTranslationMagToKeyFrame = 0.1; p.minRotationMagToKeyFrame = 5.0
+        p.sigmaPriorToCensusTransform = 0.75; p.sigmaBitPlanes = 1.6
+    else:
+        p.descriptor = capi.DESC_INTENSITY; p.lossFunction = capi.LOSS_HUBER; p.minSaliency = 2.5; p.nonMaxSuppRadius = 2
+        p.minTranslationMagToKeyFrame = 1000.0; p.minRotationMagToKeyFrame = 1000.0; p.maxFractionOfGoodPointsToKeyFrame = 0.75
+    ctx = hip.create(seq["K"], seq["b"], 480, 640, p, device=dev_index, n_frames=3, n_pairs=1)
+    frames = seq["frames"]
+    ctx.add_frame(*frames[0])
+    t0 = time.perf_counter()
+    n_key = 0
+    for img, disp in frames[1:]:
+        n_key += int(ctx.add_frame(img, disp)["isKeyFrame"])
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"frames": len(frames) - 1, "ms_per_frame": 1e3 * dt / (len(frames) - 1), "frames_per_s": (len(frames) - 1) / dt,
+            "keyframes": n_key, "note": "host image + disparity buffers per call (PCIe included), one frame at a time"}
+
+
+def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=None):
     """BASELINE.json configs[1], [2] (640x480) as batches, and configs[3] (one KITTI-shaped pair at a time: the latency-bound
     B = 1 case the roofline section of SURVEY.md asks to report next to the batched one)."""
     n = args.other_configs
@@ -143,6 +172,9 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch):
         "1241x376 bitplanes, 4 levels, tukey, one pair per call (B = 1)":
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1, args.descriptor, args.levels, args.loss, steps=5, warmup=2),
     }
+    if seq640 is not None:
+        out["addFrame 640x480, parameters of conf/perf_intensity.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_intensity")
+        out["addFrame 640x480, parameters of conf/perf_bitplanes.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_bitplanes")
     return out
 
 
@@ -173,8 +205,10 @@ def main():
     t_gen = time.perf_counter() - t0
     # inputs of the extra configs are rendered now as well: the fork pool must not run after the GPU is initialised
     other_batch = None
+    seq640 = None
     if world == 1 and args.other_configs > 0 and (args.rows, args.cols) == (376, 1241):
         other_batch = synth.make_batch(480, 640, args.other_configs, first_index=0, workers=workers)
+        seq640 = synth.make_sequence(480, 640, 25, index=21, step_rot=0.004, step_trans=0.03)
 
     import torch
     import torch.distributed as dist
@@ -295,7 +329,7 @@ def main():
 
         others = None
         if other_batch is not None:
-            others = other_configs(hip, torch, dev, dev_index, args, batch, other_batch)
+            others = other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640)
 
         iters = stats["numIterations"].astype(np.float64)
         out = {
