@@ -377,7 +377,8 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
       const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
       if(c->C == 1) {
-        launch_intensity(c->stream, jobs, g.cols, g.rows, count);
+        if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
+        else launch_intensity(c->stream, jobs, g.cols, g.rows, count);
       } else {
         launch_census(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
         launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k);
@@ -788,8 +789,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   auto unsupported = [&](const char* m) { g_create_error = m; return BPVO_ERR_UNSUPPORTED; };
   if(c->L < 1 || c->L > kMaxLevels) return unsupported("numPyramidLevels out of range (1..8)");
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
-  if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES)
-    return unsupported("descriptor: only Intensity and BitPlanes are on the device path");
+  if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN)
+    return unsupported("descriptor: only Intensity, Laplacian and BitPlanes are on the device path");
+  if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3)
+    return unsupported("laplacianKernelSize: 1 and 3 are on the device path (larger sizes are Sobel-based in OpenCV)");
   if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
     return unsupported("unknown lossFunction");

@@ -95,6 +95,25 @@ __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
   }
 }
 
+// ---- LaplacianDescriptor::compute (reference: bpvo/gradient_descriptor.cc:64-67): cv::Laplacian(u8 -> f32), kernel size 1
+// ({0,1,0,1,-4,1,0,1,0}) or 3 ({2,0,2,0,-8,0,2,0,2}), BORDER_REFLECT_101; integer-valued, hence exact in f32.
+__global__ __launch_bounds__(256) void laplacian_kernel(const FrameJob* jobs, int ksize)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, R), yp = reflect101(y + 1, R);
+  const uint8_t* __restrict__ I = j.img;
+  const float k_edge = ksize == 3 ? 0.0f : 1.0f, k_diag = ksize == 3 ? 2.0f : 0.0f, k_ctr = ksize == 3 ? -8.0f : -4.0f;
+  const uint8_t *rm = I + (size_t) ym * W, *r0 = I + (size_t) y * W, *rp = I + (size_t) yp * W;
+  float v = k_diag * (float) rm[xm] + k_edge * (float) rm[x] + k_diag * (float) rm[xp];
+  v += k_edge * (float) r0[xm] + k_ctr * (float) r0[x] + k_edge * (float) r0[xp];
+  v += k_diag * (float) rp[xm] + k_edge * (float) rp[x] + k_diag * (float) rp[xp];
+  j.desc[(size_t) y * W + x] = v;
+}
+
 // ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
 // bit k = [neighbour_k >= centre], neighbours (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); 1-px border = 0.
 // Workgroups of 64 x 16 pixels: every thread walks 4 rows of one column with a sliding 3 x 3 window (6 rows x 3 bytes loaded
@@ -744,6 +763,10 @@ void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {
   hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes), dim3(256), 0, s, jobs);
+}
+void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize)
+{
+  hipLaunchKernelGGL(laplacian_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs, ksize);
 }
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {

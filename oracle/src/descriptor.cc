@@ -47,6 +47,7 @@ void defaultParams(Params& p)
 
 // DenseDescriptor::Create + compute (bpvo/dense_descriptor.cc:38-90):
 //   kIntensity -> IntensityDescriptor::compute (bpvo/intensity_descriptor.cc:31-43): u8 -> f32, exact (Mat::convertTo).
+//   kLaplacian -> LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): one f32 channel, cv::Laplacian.
 //   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
@@ -59,6 +60,29 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
     d.ch.resize(1);
     d.ch[0].resize(n);
     for(size_t i = 0; i < n; ++i) d.ch[0][i] = (float) img[i];
+    return;
+  }
+  if(p.descriptor == kLaplacian) {
+    // LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): cv::Laplacian(image, CV_32F, ksize).
+    // [ext: OpenCV 2.4 deriv.cpp] ksize 1 / 3 -> filter2D with the 3x3 kernels {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2},
+    // scale 1, delta 0, BORDER_DEFAULT (= REFLECT_101).  Small integers in f32: exact in any evaluation order.
+    if(p.laplacianKernelSize != 1 && p.laplacianKernelSize != 3) throw std::runtime_error("oracle: Laplacian kernel sizes 1 and 3 only");
+    const float k_edge = p.laplacianKernelSize == 3 ? 0.0f : 1.0f, k_diag = p.laplacianKernelSize == 3 ? 2.0f : 0.0f;
+    const float k_ctr = p.laplacianKernelSize == 3 ? -8.0f : -4.0f;
+    auto refl = [](int q, int len) { if(q < 0) q = -q; if(q >= len) q = 2 * len - 2 - q; return q < 0 ? 0 : q; };
+    d.ch.resize(1);
+    d.ch[0].resize(n);
+    for(int y = 0; y < rows; ++y) {
+      const int ym = refl(y - 1, rows), yp = refl(y + 1, rows);
+      for(int x = 0; x < cols; ++x) {
+        const int xm = refl(x - 1, cols), xp = refl(x + 1, cols);
+        auto I = [&](int yy, int xx) { return (float) img[(size_t) yy * cols + xx]; };
+        float v = k_diag * I(ym, xm) + k_edge * I(ym, x) + k_diag * I(ym, xp);
+        v += k_edge * I(y, xm) + k_ctr * I(y, x) + k_edge * I(y, xp);
+        v += k_diag * I(yp, xm) + k_edge * I(yp, x) + k_diag * I(yp, xp);
+        d.ch[0][(size_t) y * cols + x] = v;
+      }
+    }
     return;
   }
   if(p.descriptor != kBitPlanes) throw std::runtime_error("oracle: unsupported descriptor");

@@ -628,3 +628,29 @@ def test_reference_timing_configurations_sequence(hip, orc, which):
     for a, b in zip(oh, oo):
         rot, trans = pose_error(a["pose"], b["pose"])
         assert rot <= ROT_TOL and trans <= trans_tol(seq["K"]), (which, rot, trans)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(480, 640, 4, id="640x480-L4")])
+@pytest.mark.parametrize("ksize", [1, 3])
+def test_laplacian_descriptor_parity(hip, orc, rows, cols, levels, ksize):
+    """kLaplacian (bpvo/gradient_descriptor.cc:64-67, cv::Laplacian with kernel size 1 or 3): one integer-valued f32 channel,
+    then the same single-channel pipeline as Intensity — every stage bit-exact, poses within the bar."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor="laplacian", loss="huber", laplacianKernelSize=ksize)
+    assert ch.Cn == co.Cn == 1
+    for l in range(levels):
+        a, b = ch.get_descriptor_channel(1, l, 0), co.get_descriptor_channel(1, l, 0)
+        assert bits_equal(a, b) and np.array_equal(a, np.round(a)) and np.abs(a).max() <= (8 if ksize == 3 else 4) * 255
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l))
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
+        T = _perturbed_pose(1.0)
+        x, y = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+        assert np.array_equal(ch.get_valid(0), co.get_valid(0)) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+        assert x["sigma"] == y["sigma"] and bits_equal(ch.get_weights(0), co.get_weights(0))
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+    p = make_params(hip, descriptor="laplacian", levels=2, laplacianKernelSize=5)
+    with pytest.raises(capi.BpvoError):
+        hip.create(d["K"], d["b"], rows, cols, p)

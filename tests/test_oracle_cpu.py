@@ -437,3 +437,20 @@ def test_interpolation_variants_against_numpy(orc, interp):
     Te, st = ctx.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Te, d["T_gt"])
     assert rot < 2e-2 and trans < 0.5, (rot, trans)
+
+
+@pytest.mark.parametrize("ksize", [1, 3])
+def test_laplacian_descriptor_against_scipy(orc, ksize):
+    """cv::Laplacian(u8 -> f32, ksize 1 / 3) = correlation with {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2}, BORDER_REFLECT_101
+    (scipy's mode='mirror'); integer-valued, so exact."""
+    rows, cols = 57, 83
+    d = synth.make_pair(rows, cols, 4)
+    p = make_params(orc, descriptor="laplacian", levels=2, laplacianKernelSize=ksize)
+    ctx = orc.create(d["K"], d["b"], rows, cols, p, n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    K = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float64) if ksize == 1 else np.array([[2, 0, 2], [0, -8, 0], [2, 0, 2]], np.float64)
+    for l in range(2):
+        img = ctx.get_image(0, l).astype(np.float64)
+        want = scipy.ndimage.correlate(img, K, mode="mirror")
+        got = ctx.get_descriptor_channel(0, l, 0)
+        assert np.array_equal(got.astype(np.float64), want)
