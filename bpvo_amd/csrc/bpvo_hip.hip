@@ -376,7 +376,9 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
       const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
-      if(c->C == 1) {
+      if(c->C == 3) {
+        launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count);
+      } else if(c->C == 1) {
         if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
         else launch_intensity(c->stream, jobs, g.cols, g.rows, count);
       } else {
@@ -789,15 +791,18 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   auto unsupported = [&](const char* m) { g_create_error = m; return BPVO_ERR_UNSUPPORTED; };
   if(c->L < 1 || c->L > kMaxLevels) return unsupported("numPyramidLevels out of range (1..8)");
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
-  if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN)
-    return unsupported("descriptor: only Intensity, Laplacian and BitPlanes are on the device path");
+  if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN &&
+     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT)
+    return unsupported("descriptor: only Intensity, IntensityAndGradient, Laplacian and BitPlanes are on the device path");
+  if(c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f)
+    return unsupported("IntensityAndGradient with sigmaPriorToCensusTransform > 0 (cv::GaussianBlur with an automatic kernel size) is not on the device path");
   if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3)
     return unsupported("laplacianKernelSize: 1 and 3 are on the device path (larger sizes are Sobel-based in OpenCV)");
   if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
     return unsupported("unknown lossFunction");
   if(c->params.gradientEstimation != BPVO_GRAD_CD3 && c->params.gradientEstimation != BPVO_GRAD_CD5) return unsupported("unknown gradientEstimation");
-  c->C = (c->params.descriptor == BPVO_DESC_BITPLANES) ? 8 : 1;
+  c->C = (c->params.descriptor == BPVO_DESC_BITPLANES) ? 8 : (c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT ? 3 : 1);
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
   if(c->params.sigmaPriorToCensusTransform > 0.0f) {   // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
     const double sg = c->params.sigmaPriorToCensusTransform, scale2X = -0.5 / (sg * sg);
@@ -1058,7 +1063,7 @@ int bpvo_hip_get_pixels(bpvo_hip_ctx* c, int slot, int level, float* pixels)
   std::vector<float> t(tiled_floats(n, C));
   if(n) HIP_CK(c, hipMemcpyAsync(t.data(), f.pix[level], t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : 1, pixels);
+  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : C, pixels);
   return BPVO_OK;
 }
 int bpvo_hip_get_jacobians(bpvo_hip_ctx* c, int slot, int level, float* J)
@@ -1149,7 +1154,7 @@ int bpvo_hip_get_residuals(bpvo_hip_ctx* c, int ws, float* r, size_t* n_out)
   std::vector<float> t(tiled_floats(n, C));
   if(n) HIP_CK(c, hipMemcpyAsync(t.data(), w.r, t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : 1, r);
+  detile_to_channel_major(t.data(), n, C, 1, C == 8 ? 4 : C, r);
   return BPVO_OK;
 }
 int bpvo_hip_get_valid(bpvo_hip_ctx* c, int ws, uint16_t* v, size_t* n_out)

@@ -11,6 +11,7 @@ namespace bpvo_hip {
 void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes);
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
+void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);   // (I, Ix, Iy), C = 3
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);

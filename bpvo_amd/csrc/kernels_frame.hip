@@ -114,6 +114,25 @@ __global__ __launch_bounds__(256) void laplacian_kernel(const FrameJob* jobs, in
   j.desc[(size_t) y * W + x] = v;
 }
 
+// ---- GradientDescriptor::compute (reference: bpvo/gradient_descriptor.cc:42-63) with sigma <= 0: channels (I, Ix, Iy),
+// Ix / Iy = xgradient / ygradient (bpvo/imgproc.h:214-265): 0.5 * central difference, one-sided 0.5 * (I1 - I0) at the borders.
+__global__ __launch_bounds__(256) void gradient_descriptor_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const uint8_t* __restrict__ I = j.img;
+  auto at = [&](int yy, int xx) { return (float) I[(size_t) yy * W + xx]; };
+  const int xa = x == 0 ? 0 : (x == W - 1 ? W - 2 : x - 1), xb = x == 0 ? 1 : (x == W - 1 ? W - 1 : x + 1);
+  const int ya = y == 0 ? 0 : (y == R - 1 ? R - 2 : y - 1), yb = y == 0 ? 1 : (y == R - 1 ? R - 1 : y + 1);
+  float* d = j.desc + ((size_t) y * W + x) * 3;
+  d[0] = at(y, x);
+  d[1] = 0.5f * (at(y, xb) - at(y, xa));
+  d[2] = 0.5f * (at(yb, x) - at(ya, x));
+}
+
 // ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
 // bit k = [neighbour_k >= centre], neighbours (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); 1-px border = 0.
 // Workgroups of 64 x 16 pixels: every thread walks 4 rows of one column with a sliding 3 x 3 window (6 rows x 3 bytes loaded
@@ -364,7 +383,8 @@ __global__ __launch_bounds__(256) void saliency_kernel(const FrameJob* jobs)
       } else if(C == 1) {
         S = grad_abs<C>(I, row + x, W, 0);
       } else if(x >= 4) {
-        S = grad_abs<1>(j.ch0, row + x, W, 0);     // channel 0 from its compact plane
+        if constexpr(C == 8) S = grad_abs<1>(j.ch0, row + x, W, 0);     // channel 0 from its compact plane
+        else S = grad_abs<C>(I, row + x, W, 0);
       } else {
         const int xs = n - 4 + x;
         const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
@@ -701,9 +721,13 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
     store_stream(gv + tile_index<4>(i, 1), make_float4(Ix[4], Ix[5], Ix[6], Ix[7]));
     store_stream(gv + tile_index<4>(i, 2), make_float4(Iy[0], Iy[1], Iy[2], Iy[3]));
     store_stream(gv + tile_index<4>(i, 3), make_float4(Iy[4], Iy[5], Iy[6], Iy[7]));
-  } else {
-    j.pix[i] = pixv[0];
-    reinterpret_cast<float2*>(j.grad)[i] = make_float2(Ix[0], Iy[0]);
+  } else {      // generic C: point-major pix[N][C], grad[N][2][C] (C = 1: pix[N], grad[N] as (Ix, Iy) pairs)
+#pragma unroll
+    for(int c = 0; c < C; ++c) {
+      j.pix[(size_t) i * C + c] = pixv[c];
+      j.grad[((size_t) i * 2 + 0) * C + c] = Ix[c];
+      j.grad[((size_t) i * 2 + 1) * C + c] = Iy[c];
+    }
   }
 }
 
@@ -734,8 +758,8 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
     Ix[0] = a.x; Ix[1] = a.y; Ix[2] = a.z; Ix[3] = a.w; Ix[4] = b.x; Ix[5] = b.y; Ix[6] = b.z; Ix[7] = b.w;
     Iy[0] = c.x; Iy[1] = c.y; Iy[2] = c.z; Iy[3] = c.w; Iy[4] = d.x; Iy[5] = d.y; Iy[6] = d.z; Iy[7] = d.w;
   } else {
-    const float2 g = reinterpret_cast<const float2*>(j.grad)[i];
-    Ix[0] = g.x; Iy[0] = g.y;
+#pragma unroll
+    for(int c = 0; c < C; ++c) { Ix[c] = j.grad[((size_t) i * 2 + 0) * C + c]; Iy[c] = j.grad[((size_t) i * 2 + 1) * C + c]; }
   }
 #pragma unroll
   for(int c = 0; c < C; ++c) {
@@ -768,6 +792,10 @@ void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 {
   hipLaunchKernelGGL(laplacian_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs, ksize);
 }
+void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+{
+  hipLaunchKernelGGL(gradient_descriptor_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+}
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {
   if(blur_taps)
@@ -787,6 +815,7 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes)
 {
   if(C == 1) hipLaunchKernelGGL(saliency_kernel<1>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
+  else if(C == 3) hipLaunchKernelGGL(saliency_kernel<3>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
   else hipLaunchKernelGGL(saliency_kernel<8>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
 }
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
@@ -813,6 +842,7 @@ void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_p
   if(max_points <= 0) return;
   const dim3 g((max_points + 255) / 256, 1, nframes);
   if(C == 1) hipLaunchKernelGGL(template_build_kernel<1>, g, dim3(256), 0, s, jobs, grad_cd5);
+  else if(C == 3) hipLaunchKernelGGL(template_build_kernel<3>, g, dim3(256), 0, s, jobs, grad_cd5);
   else hipLaunchKernelGGL(template_build_kernel<8>, g, dim3(256), 0, s, jobs, grad_cd5);
 }
 
@@ -821,6 +851,7 @@ void launch_export_jacobians(hipStream_t s, const FrameJob* job, int C, int n, f
   if(n <= 0) return;
   const dim3 g((n + 255) / 256);
   if(C == 1) hipLaunchKernelGGL(export_jacobians_kernel<1>, g, dim3(256), 0, s, job, out);
+  else if(C == 3) hipLaunchKernelGGL(export_jacobians_kernel<3>, g, dim3(256), 0, s, job, out);
   else hipLaunchKernelGGL(export_jacobians_kernel<8>, g, dim3(256), 0, s, job, out);
 }
 

@@ -276,7 +276,8 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
         res[0] = 0.0f - t0.x; res[1] = 0.0f - t0.y; res[2] = 0.0f - t0.z; res[3] = 0.0f - t0.w;
         res[4] = 0.0f - t1.x; res[5] = 0.0f - t1.y; res[6] = 0.0f - t1.z; res[7] = 0.0f - t1.w;
       } else {
-        res[0] = 0.0f - j.pix[i];
+#pragma unroll
+        for(int c = 0; c < C; ++c) res[c] = 0.0f - j.pix[(size_t) i * C + c];
       }
     }
   }
@@ -317,8 +318,9 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* 
       float4* o = reinterpret_cast<float4*>(j.r);
       store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
       store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
-    } else {
-      j.r[i] = res[0];
+    } else {      // generic C: point-major records [N][C]
+#pragma unroll
+      for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
     }
   }
   // bracket pass of the exact median (see bracket_block) while the residuals are in registers
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
       I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
     } else {
-      I0[0] = j.pix[i];
+#pragma unroll
+      for(int c = 0; c < C; ++c) I0[c] = j.pix[(size_t) i * C + c];
     }
     if(two_tap) {
       float Cx[2], Cy[2];
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
       o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
     } else {
-      j.r[i] = res[0];
+#pragma unroll
+      for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
     }
   }
   if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
@@ -567,6 +571,12 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
         f(__float_as_uint(b[u].x) & 0x7fffffffu, pt); f(__float_as_uint(b[u].y) & 0x7fffffffu, pt);
         f(__float_as_uint(b[u].z) & 0x7fffffffu, pt); f(__float_as_uint(b[u].w) & 0x7fffffffu, pt);
       }
+    }
+  } else if constexpr(C != 1) {   // generic C: point-major records
+    for(int pt = threadIdx.x; pt < n; pt += MED_THREADS) {
+      if(!j.valid[pt]) continue;
+#pragma unroll
+      for(int c = 0; c < C; ++c) f(__float_as_uint(j.r[(size_t) pt * C + c]) & 0x7fffffffu, pt);
     }
   } else {
     for(int p4 = threadIdx.x * 4; p4 < n; p4 += MED_THREADS * 4) {   // n is a multiple of 16
@@ -908,10 +918,17 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
                    gy0 = load_stream(qg + tile_index<4>(i, 2)), gy1 = load_stream(qg + tile_index<4>(i, 3));
       Ix[0] = gx0.x; Ix[1] = gx0.y; Ix[2] = gx0.z; Ix[3] = gx0.w; Ix[4] = gx1.x; Ix[5] = gx1.y; Ix[6] = gx1.z; Ix[7] = gx1.w;
       Iy[0] = gy0.x; Iy[1] = gy0.y; Iy[2] = gy0.z; Iy[3] = gy0.w; Iy[4] = gy1.x; Iy[5] = gy1.y; Iy[6] = gy1.z; Iy[7] = gy1.w;
-    } else {
+    } else if constexpr(C == 1) {
       rr[0] = j.r[i];
       const float2 g2 = reinterpret_cast<const float2*>(j.grad)[i];
       Ix[0] = g2.x; Iy[0] = g2.y;
+    } else {      // generic C: point-major r[N][C], grad[N][2][C]
+#pragma unroll
+      for(int c = 0; c < C; ++c) {
+        rr[c] = j.r[(size_t) i * C + c];
+        Ix[c] = j.grad[((size_t) i * 2 + 0) * C + c];
+        Iy[c] = j.grad[((size_t) i * 2 + 1) * C + c];
+      }
     }
     float Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, Gx = 0.0f, Gy = 0.0f;
 #pragma unroll
@@ -1233,7 +1250,8 @@ __global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, float*
     o[4] = mest_weight<LOSS>(b.x, sigma_inv); o[5] = mest_weight<LOSS>(b.y, sigma_inv);
     o[6] = mest_weight<LOSS>(b.z, sigma_inv); o[7] = mest_weight<LOSS>(b.w, sigma_inv);
   } else {
-    w_out[i] = mest_weight<LOSS>(job->r[i], sigma_inv);
+#pragma unroll
+    for(int c = 0; c < C; ++c) w_out[(size_t) i * C + c] = mest_weight<LOSS>(job->r[(size_t) i * C + c], sigma_inv);
   }
 }
 
@@ -1252,7 +1270,8 @@ __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, flo
              (mest_weight<LOSS>(b.x, sigma_inv) > thr) + (mest_weight<LOSS>(b.y, sigma_inv) > thr) +
              (mest_weight<LOSS>(b.z, sigma_inv) > thr) + (mest_weight<LOSS>(b.w, sigma_inv) > thr);
     } else {
-      good = mest_weight<LOSS>(job->r[i], sigma_inv) > thr;
+#pragma unroll
+      for(int c = 0; c < C; ++c) good += mest_weight<LOSS>(job->r[(size_t) i * C + c], sigma_inv) > thr;
     }
   }
 #pragma unroll
@@ -1309,14 +1328,17 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
     if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    else if(g.C == 3) hipLaunchKernelGGL(warp_residual_interp_kernel<3>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
     else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
     return;
   }
   if(g.fast_warp) {
     if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    else if(g.C == 3) hipLaunchKernelGGL((warp_residual_kernel<3, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
     else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
   } else {
     if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    else if(g.C == 3) hipLaunchKernelGGL((warp_residual_kernel<3, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
     else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.fuse_frozen ? 1 : 0);
   }
 }
@@ -1338,10 +1360,12 @@ void launch_median(hipStream_t s, const GNLaunch& g)
   bool& attr_set = attr_set_dev[dev & 63];
   if(!attr_set) {
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    (void) hipFuncSetAttribute((const void*) median_finish_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
     attr_set = true;
   }
   if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+  else if(g.C == 3) hipLaunchKernelGGL(median_finish_kernel<3>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
   else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
 }
 
@@ -1369,6 +1393,7 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
   if(g.max_points <= 0) return;
   const int ppb = gn_pts_per_block(g.C);
   if(g.C == 1) launch_irls_c<1>(s, g, ppb);
+  else if(g.C == 3) launch_irls_c<3>(s, g, ppb);
   else launch_irls_c<8>(s, g, ppb);
 }
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count)
@@ -1401,6 +1426,7 @@ void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, f
 {
   if(n <= 0) return;
   if(C == 1) launch_weights_c<1>(s, job, n, loss, w_out);
+  else if(C == 3) launch_weights_c<3>(s, job, n, loss, w_out);
   else launch_weights_c<8>(s, job, n, loss, w_out);
 }
 template <int C>
@@ -1417,6 +1443,7 @@ void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss
 {
   if(n <= 0) return;
   if(C == 1) launch_count_good_c<1>(s, job, n, loss, thr, count);
+  else if(C == 3) launch_count_good_c<3>(s, job, n, loss, thr, count);
   else launch_count_good_c<8>(s, job, n, loss, thr, count);
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records)

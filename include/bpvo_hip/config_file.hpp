@@ -109,7 +109,7 @@ inline InterpolationType InterpolationTypeFromString(const std::string& s)
   if(icompare("Cubic", s)) return kCubic;
   throw Error("unknown InterpolationType");
 }
-inline int DescriptorTypeFromString(const std::string& s)     // numeric DescriptorType; Intensity, Laplacian and BitPlanes are on the device path
+inline int DescriptorTypeFromString(const std::string& s)     // numeric DescriptorType; Intensity, IntensityAndGradient, Laplacian and BitPlanes are on the device path
 {
   if(icompare("Intensity", s)) return BPVO_DESC_INTENSITY;
   if(icompare("BitPlanes", s)) return BPVO_DESC_BITPLANES;

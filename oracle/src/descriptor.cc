@@ -48,6 +48,7 @@ void defaultParams(Params& p)
 // DenseDescriptor::Create + compute (bpvo/dense_descriptor.cc:38-90):
 //   kIntensity -> IntensityDescriptor::compute (bpvo/intensity_descriptor.cc:31-43): u8 -> f32, exact (Mat::convertTo).
 //   kLaplacian -> LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): one f32 channel, cv::Laplacian.
+//   kIntensityAndGradient -> GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): (I, Ix, Iy).
 //   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
@@ -60,6 +61,24 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
     d.ch.resize(1);
     d.ch[0].resize(n);
     for(size_t i = 0; i < n; ++i) d.ch[0][i] = (float) img[i];
+    return;
+  }
+  if(p.descriptor == kIntensityAndGradient) {
+    // GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): channel 0 = intensities (convertTo), channels 1 / 2 =
+    // xgradient / ygradient (bpvo/imgproc.h:214-265) of the intensities — smoothed first with cv::GaussianBlur(Size(), s, s)
+    // only when s = sigmaPriorToCensusTransform > 0, which is not restated (automatic kernel size, [ext]).
+    if(p.sigmaPriorToCensusTransform > 0.0f) throw std::runtime_error("oracle: GradientDescriptor with sigma > 0 is not restated");
+    d.ch.assign(3, std::vector<float>(n));
+    for(size_t i = 0; i < n; ++i) d.ch[0][i] = (float) img[i];
+    const float S = 0.5f;                                         // imgradient_scale<float>() (bpvo/imgproc.h:205-209)
+    const float* I = d.ch[0].data();
+    for(int y = 0; y < rows; ++y)
+      for(int x = 0; x < cols; ++x) {
+        const size_t q = (size_t) y * cols + x;
+        // Ix.col(0) = S*(I.col(1) - I.col(0)); interior S*(I(x+1) - I(x-1)); Ix.col(W-1) = S*(I.col(W-1) - I.col(W-2))
+        d.ch[1][q] = x == 0 ? S * (I[q + 1] - I[q]) : (x == cols - 1 ? S * (I[q] - I[q - 1]) : S * (I[q + 1] - I[q - 1]));
+        d.ch[2][q] = y == 0 ? S * (I[q + cols] - I[q]) : (y == rows - 1 ? S * (I[q] - I[q - cols]) : S * (I[q + cols] - I[q - cols]));
+      }
     return;
   }
   if(p.descriptor == kLaplacian) {

@@ -654,3 +654,42 @@ def test_laplacian_descriptor_parity(hip, orc, rows, cols, levels, ksize):
     p = make_params(hip, descriptor="laplacian", levels=2, laplacianKernelSize=5)
     with pytest.raises(capi.BpvoError):
         hip.create(d["K"], d["b"], rows, cols, p)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(121, 163, 2, id="163x121-L2"),
+                                              pytest.param(480, 640, 4, id="640x480-L4")])
+@pytest.mark.parametrize("loss", ["huber", "tukey"])
+def test_intensity_and_gradient_descriptor_parity(hip, orc, rows, cols, levels, loss):
+    """kIntensityAndGradient (GradientDescriptor, bpvo/gradient_descriptor.cc:42-63 with sigma <= 0): three channels
+    (I, Ix, Iy) through the generic-C forms of every kernel (point-major records) — all stages bit-exact, poses within the bar."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor="gradient", loss=loss)
+    assert ch.Cn == co.Cn == 3
+    for l in range(levels):
+        for c in range(3):
+            assert bits_equal(ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)), (l, c)
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l)), l
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(2.0)):
+            a, b = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+            assert a["sigma"] == b["sigma"] and bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, 3)
+            assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
+            assert abs(ch.fraction_good(0, 0.85) - co.fraction_good(0, 0.85)) < 1e-6
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+    # batch entry point and the smoothed variant, which is not on the device path
+    b3 = synth.make_batch(rows, cols, 3, first_index=40)
+    outs = []
+    for bind in (hip, orc):
+        bc = bind.create(b3["K"], b3["b"], rows, cols, make_params(bind, descriptor="gradient", loss=loss, levels=levels), n_frames=6, n_pairs=3)
+        outs.append(bc.batch_run(b3["images"], b3["disparities"])[0])
+    for k in range(3):
+        rot, trans = pose_error(outs[0][k], outs[1][k])
+        assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
+    with pytest.raises(capi.BpvoError):
+        hip.create(d["K"], d["b"], rows, cols, make_params(hip, descriptor="gradient", levels=2, sigmaPriorToCensusTransform=0.8))

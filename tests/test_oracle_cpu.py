@@ -454,3 +454,19 @@ def test_laplacian_descriptor_against_scipy(orc, ksize):
         want = scipy.ndimage.correlate(img, K, mode="mirror")
         got = ctx.get_descriptor_channel(0, l, 0)
         assert np.array_equal(got.astype(np.float64), want)
+
+
+def test_gradient_descriptor_against_numpy(orc):
+    """GradientDescriptor channels (bpvo/gradient_descriptor.cc:42-63, bpvo/imgproc.h:214-265): I, 0.5 * central differences with
+    one-sided 0.5 * (I1 - I0) borders; saliency = channel 0's |gradient| plus the store-bug contribution of the last channel."""
+    rows, cols = 45, 70
+    d = synth.make_pair(rows, cols, 9)
+    ctx = orc.create(d["K"], d["b"], rows, cols, make_params(orc, descriptor="gradient", levels=1), n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    assert ctx.Cn == 3
+    I = d["imgA"].astype(np.float32)
+    Ix = np.empty_like(I); Iy = np.empty_like(I)
+    Ix[:, 1:-1] = np.float32(0.5) * (I[:, 2:] - I[:, :-2]); Ix[:, 0] = np.float32(0.5) * (I[:, 1] - I[:, 0]); Ix[:, -1] = np.float32(0.5) * (I[:, -1] - I[:, -2])
+    Iy[1:-1] = np.float32(0.5) * (I[2:] - I[:-2]); Iy[0] = np.float32(0.5) * (I[1] - I[0]); Iy[-1] = np.float32(0.5) * (I[-1] - I[-2])
+    assert bits_equal(ctx.get_descriptor_channel(0, 0, 0), I)
+    assert bits_equal(ctx.get_descriptor_channel(0, 0, 1), Ix) and bits_equal(ctx.get_descriptor_channel(0, 0, 2), Iy)
