@@ -42,6 +42,7 @@ struct FrameSlot {
   float* ch0[kMaxLevels] = {};
   float* desc[kMaxLevels] = {};
   float* disp = nullptr;
+  float* scratch = nullptr;   // descriptor fields: kDfPlanes work planes
   float* sal[kMaxLevels] = {};
   uint8_t* flag[kMaxLevels] = {};
   int* blk_count[kMaxLevels] = {};
@@ -104,6 +105,7 @@ struct bpvo_hip_ctx {
   int n_frames, n_pairs;
   LevelGeom geom[kMaxLevels];
   float gauss_k[3];
+  float df_k1[3], df_k2[3];   // 5-tap Gaussians of dfSigma1 / dfSigma2 (descriptor fields)
   hipStream_t stream = nullptr;
   std::vector<FrameSlot> frames;
   std::vector<Workspace> ws;
@@ -198,6 +200,7 @@ void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
   for(int l = 0; l < c->L; ++l) f.desc[l] = cv.take<float>(c->geom[l].npix * c->C);
   for(int l = 0; l < c->L; ++l) f.cen[l] = (c->C == 8) ? cv.take<uint8_t>(c->geom[l].npix) : nullptr;
   for(int l = 0; l < c->L; ++l) f.ch0[l] = (c->C == 8) ? cv.take<float>(c->geom[l].npix) : nullptr;
+  f.scratch = (c->C == 5 || c->C == 10) ? cv.take<float>((size_t) kDfPlanes * c->geom[0].npix) : nullptr;
   if(total) *total = cv.off;
 }
 
@@ -239,6 +242,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   j.img = f.img[l];
   j.cen = f.cen[l];
   j.ch0 = f.ch0[l];
+  j.scratch = f.scratch;
   j.desc = f.desc[l];
   j.sal = f.sal[l];
   j.flag = f.flag[l];
@@ -376,7 +380,9 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
       const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
-      if(c->C == 3) {
+      if(c->C == 5 || c->C == 10) {
+        launch_descriptor_fields(c->stream, jobs, g.cols, g.rows, count, c->C == 10, c->params.dfSigma1, c->df_k1, c->params.dfSigma2, c->df_k2);
+      } else if(c->C == 3) {
         launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count);
       } else if(c->C == 1) {
         if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
@@ -791,9 +797,15 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   auto unsupported = [&](const char* m) { g_create_error = m; return BPVO_ERR_UNSUPPORTED; };
   if(c->L < 1 || c->L > kMaxLevels) return unsupported("numPyramidLevels out of range (1..8)");
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
+  const bool desc_fields = c->params.descriptor == BPVO_DESC_FIELDS_FIRST_ORDER || c->params.descriptor == BPVO_DESC_FIELDS_SECOND_ORDER;
   if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN &&
-     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT)
-    return unsupported("descriptor: only Intensity, IntensityAndGradient, Laplacian and BitPlanes are on the device path");
+     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && !desc_fields)
+    return unsupported("descriptor: Intensity, IntensityAndGradient, DescriptorFields (1st / 2nd order), Laplacian and BitPlanes are on the device path");
+  if(desc_fields) {   // imsmooth (bpvo/imgproc.cc:166-171): max(5, 2*round(sigma)+1) taps
+    auto taps = [](float sg) { return std::max(5, 2 * (int) std::round((double) sg) + 1); };
+    if((c->params.dfSigma1 > 0.0f && taps(c->params.dfSigma1) != 5) || (c->params.dfSigma2 > 0.0f && taps(c->params.dfSigma2) != 5))
+      return unsupported("dfSigma1 / dfSigma2 >= 2.5 (imsmooth kernels larger than 5 x 5) are not on the device path");
+  }
   if(c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f)
     return unsupported("IntensityAndGradient with sigmaPriorToCensusTransform > 0 (cv::GaussianBlur with an automatic kernel size) is not on the device path");
   if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3)
@@ -802,8 +814,16 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
     return unsupported("unknown lossFunction");
   if(c->params.gradientEstimation != BPVO_GRAD_CD3 && c->params.gradientEstimation != BPVO_GRAD_CD5) return unsupported("unknown gradientEstimation");
-  c->C = (c->params.descriptor == BPVO_DESC_BITPLANES) ? 8 : (c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT ? 3 : 1);
+  switch(c->params.descriptor) {
+    case BPVO_DESC_BITPLANES: c->C = 8; break;
+    case BPVO_DESC_INTENSITY_AND_GRADIENT: c->C = 3; break;
+    case BPVO_DESC_FIELDS_FIRST_ORDER: c->C = 5; break;
+    case BPVO_DESC_FIELDS_SECOND_ORDER: c->C = 10; break;
+    default: c->C = 1; break;
+  }
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
+  gaussian_kernel5(c->params.dfSigma1, c->df_k1);
+  gaussian_kernel5(c->params.dfSigma2, c->df_k2);
   if(c->params.sigmaPriorToCensusTransform > 0.0f) {   // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
     const double sg = c->params.sigmaPriorToCensusTransform, scale2X = -0.5 / (sg * sg);
     float kk[3];

@@ -5,6 +5,22 @@
 
 #include "types.h"
 
+#include <type_traits>
+
+// The channel counts the kernels are instantiated for: Intensity / Laplacian 1, IntensityAndGradient 3, DescriptorFields 5,
+// BitPlanes 8, DescriptorFields2ndOrder 10.  f receives std::integral_constant<int, C>.
+template <class F>
+static inline void dispatch_channels(int C, F&& f)
+{
+  switch(C) {
+    case 1: f(std::integral_constant<int, 1>()); break;
+    case 3: f(std::integral_constant<int, 3>()); break;
+    case 5: f(std::integral_constant<int, 5>()); break;
+    case 10: f(std::integral_constant<int, 10>()); break;
+    default: f(std::integral_constant<int, 8>()); break;
+  }
+}
+
 namespace bpvo_hip {
 
 // per-frame stage (batched over frames)
@@ -12,6 +28,8 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
 void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);   // (I, Ix, Iy), C = 3
+void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, float sigma1,
+                              const float k1[3], float sigma2, const float k2[3]);   // C = 5 / 10
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);

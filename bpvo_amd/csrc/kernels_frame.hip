@@ -133,6 +133,56 @@ __global__ __launch_bounds__(256) void gradient_descriptor_kernel(const FrameJob
   d[2] = 0.5f * (at(yb, x) - at(ya, x));
 }
 
+// ---- DescriptorFields / DescriptorFields2ndOrder (reference: bpvo/gradient_descriptor.cc:100-160): chains of plane operations
+// -- convertTo, imsmooth (5 x 5 f32 Gaussian, bpvo/imgproc.cc:166-171), xgradient / ygradient (bpvo/imgproc.h:214-265),
+// splitPosNeg (gradient_descriptor.cc:80-98) -- each one launch of this kernel.  A plane code >= 0 is a work plane of
+// FrameJob::scratch, a code < 0 is descriptor channel -1-code of the interleaved [npix][C] records.
+enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT };
+struct PlaneRef { float* p; int stride; };
+__device__ __forceinline__ PlaneRef df_plane(const FrameJob& j, int code, int C)
+{
+  if(code >= 0) return PlaneRef{j.scratch + (size_t) code * j.rows * j.cols, 1};
+  return PlaneRef{j.desc + (-1 - code), C};
+}
+__global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int op, int src_code, int dst_code, int dst2_code, int C,
+                                                       float k0, float k1, float k2)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const PlaneRef S = df_plane(j, src_code, C), D = df_plane(j, dst_code, C);
+  auto at = [&](int yy, int xx) { return S.p[((size_t) yy * W + xx) * S.stride]; };
+  const size_t q = (size_t) y * W + x;
+  float v;
+  switch(op) {
+    case DF_CONVERT: v = (float) j.img[q]; break;
+    case DF_GAUSS_ROW:   // s = S[0]*k0 + (S[-1]+S[1])*k1 + (S[-2]+S[2])*k2
+      v = at(y, x) * k0 + (at(y, reflect101(x - 1, W)) + at(y, reflect101(x + 1, W))) * k1 +
+          (at(y, reflect101(x - 2, W)) + at(y, reflect101(x + 2, W))) * k2;
+      break;
+    case DF_GAUSS_COL:   // s = k0*S0; s += k1*(S+1 + S-1); s += k2*(S+2 + S-2)
+      v = k0 * at(y, x);
+      v += k1 * (at(reflect101(y + 1, R), x) + at(reflect101(y - 1, R), x));
+      v += k2 * (at(reflect101(y + 2, R), x) + at(reflect101(y - 2, R), x));
+      break;
+    case DF_GRAD_X:
+      v = x == 0 ? 0.5f * (at(y, 1) - at(y, 0)) : (x == W - 1 ? 0.5f * (at(y, x) - at(y, x - 1)) : 0.5f * (at(y, x + 1) - at(y, x - 1)));
+      break;
+    case DF_GRAD_Y:
+      v = y == 0 ? 0.5f * (at(1, x) - at(0, x)) : (y == R - 1 ? 0.5f * (at(y, x) - at(y - 1, x)) : 0.5f * (at(y + 1, x) - at(y - 1, x)));
+      break;
+    default: {           // DF_SPLIT
+      const float s = at(y, x);
+      const PlaneRef N = df_plane(j, dst2_code, C);
+      N.p[q * N.stride] = s < 0 ? s : 0.0f;
+      v = s >= 0 ? s : 0.0f;
+    }
+  }
+  D.p[q * D.stride] = v;
+}
+
 // ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
 // bit k = [neighbour_k >= centre], neighbours (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); 1-px border = 0.
 // Workgroups of 64 x 16 pixels: every thread walks 4 rows of one column with a sliding 3 x 3 window (6 rows x 3 bytes loaded
@@ -796,6 +846,43 @@ void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int 
 {
   hipLaunchKernelGGL(gradient_descriptor_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
 }
+// one level of DescriptorFields (second_order = 0: 5 channels) or DescriptorFields2ndOrder (10 channels); k1 / k2 are the 5-tap
+// kernels (centre, +-1, +-2) of sigma1 / sigma2, used when the sigma is > 0
+void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, float sigma1,
+                              const float k1[3], float sigma2, const float k2[3])
+{
+  const int C = second_order ? 10 : 5;
+  const dim3 grid = grid2d(W, R, nframes);
+  auto op = [&](int o, int src, int dst, int dst2 = 0, const float* k = nullptr) {
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f);
+  };
+  auto ch = [](int c) { return -1 - c; };
+  enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6 };
+  auto smooth = [&](int src, int dst, const float* k) { op(DF_GAUSS_ROW, src, P_TMP, 0, k); op(DF_GAUSS_COL, P_TMP, dst, 0, k); };
+  auto split = [&](int src, int cpos, int cneg) {
+    if(sigma2 > 0.0f) {
+      op(DF_SPLIT, src, P_POS, P_NEG);
+      smooth(P_POS, ch(cpos), k2);
+      smooth(P_NEG, ch(cneg), k2);
+    } else {
+      op(DF_SPLIT, src, ch(cpos), ch(cneg));
+    }
+  };
+  const int I0 = second_order ? P_I0 : ch(0);     // first order keeps the unsmoothed intensities as channel 0
+  op(DF_CONVERT, 0, I0);
+  int I = I0;
+  if(sigma1 > 0.0f) { smooth(I0, P_I, k1); I = P_I; }
+  if(!second_order) {
+    op(DF_GRAD_X, I, P_B1); split(P_B1, 1, 2);
+    op(DF_GRAD_Y, I, P_B1); split(P_B1, 3, 4);
+  } else {
+    op(DF_GRAD_X, I, P_B1);    split(P_B1, 0, 1);   // Ix
+    op(DF_GRAD_X, P_B1, P_B2); split(P_B2, 2, 3);   // Ixx
+    split(P_B2, 4, 5);                              // "Ixy": the reference splits Ixx again (gradient_descriptor.cc:149-150)
+    op(DF_GRAD_Y, I, P_B1);    split(P_B1, 6, 7);   // Iy
+    op(DF_GRAD_Y, P_B1, P_B2); split(P_B2, 8, 9);   // Iyy
+  }
+}
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {
   if(blur_taps)
@@ -814,9 +901,7 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 }
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes)
 {
-  if(C == 1) hipLaunchKernelGGL(saliency_kernel<1>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
-  else if(C == 3) hipLaunchKernelGGL(saliency_kernel<3>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
-  else hipLaunchKernelGGL(saliency_kernel<8>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs);
+  dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(saliency_kernel<decltype(c)::value>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs); });
 }
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border)
@@ -841,18 +926,14 @@ void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_p
 {
   if(max_points <= 0) return;
   const dim3 g((max_points + 255) / 256, 1, nframes);
-  if(C == 1) hipLaunchKernelGGL(template_build_kernel<1>, g, dim3(256), 0, s, jobs, grad_cd5);
-  else if(C == 3) hipLaunchKernelGGL(template_build_kernel<3>, g, dim3(256), 0, s, jobs, grad_cd5);
-  else hipLaunchKernelGGL(template_build_kernel<8>, g, dim3(256), 0, s, jobs, grad_cd5);
+  dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5); });
 }
 
 void launch_export_jacobians(hipStream_t s, const FrameJob* job, int C, int n, float* out)
 {
   if(n <= 0) return;
   const dim3 g((n + 255) / 256);
-  if(C == 1) hipLaunchKernelGGL(export_jacobians_kernel<1>, g, dim3(256), 0, s, job, out);
-  else if(C == 3) hipLaunchKernelGGL(export_jacobians_kernel<3>, g, dim3(256), 0, s, job, out);
-  else hipLaunchKernelGGL(export_jacobians_kernel<8>, g, dim3(256), 0, s, job, out);
+  dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(export_jacobians_kernel<decltype(c)::value>, g, dim3(256), 0, s, job, out); });
 }
 
 }  // namespace bpvo_hip

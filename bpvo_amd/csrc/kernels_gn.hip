@@ -1327,19 +1327,20 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   if(g.max_points <= 0) return;
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
-    if(g.C == 1) hipLaunchKernelGGL(warp_residual_interp_kernel<1>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
-    else if(g.C == 3) hipLaunchKernelGGL(warp_residual_interp_kernel<3>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
-    else hipLaunchKernelGGL(warp_residual_interp_kernel<8>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    dispatch_channels(g.C, [&](auto c) {
+      hipLaunchKernelGGL(warp_residual_interp_kernel<decltype(c)::value>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
+    });
     return;
   }
   if(g.fast_warp) {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
-    else if(g.C == 3) hipLaunchKernelGGL((warp_residual_kernel<3, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    dispatch_channels(g.C, [&](auto c) {
+      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+    });
   } else {
-    if(g.C == 1) hipLaunchKernelGGL((warp_residual_kernel<1, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
-    else if(g.C == 3) hipLaunchKernelGGL((warp_residual_kernel<3, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
-    else hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.fuse_frozen ? 1 : 0);
+    dispatch_channels(g.C, [&](auto c) {
+      constexpr int CC = decltype(c)::value;
+      hipLaunchKernelGGL((warp_residual_kernel<CC, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0);
+    });
   }
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
@@ -1359,14 +1360,15 @@ void launch_median(hipStream_t s, const GNLaunch& g)
   (void) hipGetDevice(&dev);
   bool& attr_set = attr_set_dev[dev & 63];
   if(!attr_set) {
-    (void) hipFuncSetAttribute((const void*) median_finish_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
-    (void) hipFuncSetAttribute((const void*) median_finish_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
-    (void) hipFuncSetAttribute((const void*) median_finish_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+    for(int C : {1, 3, 5, 8, 10})
+      dispatch_channels(C, [&](auto c) {
+        (void) hipFuncSetAttribute((const void*) median_finish_kernel<decltype(c)::value>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      });
     attr_set = true;
   }
-  if(g.C == 1) hipLaunchKernelGGL(median_finish_kernel<1>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
-  else if(g.C == 3) hipLaunchKernelGGL(median_finish_kernel<3>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
-  else hipLaunchKernelGGL(median_finish_kernel<8>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+  dispatch_channels(g.C, [&](auto c) {
+    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+  });
 }
 
 template <int C>
@@ -1392,9 +1394,7 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   const int ppb = gn_pts_per_block(g.C);
-  if(g.C == 1) launch_irls_c<1>(s, g, ppb);
-  else if(g.C == 3) launch_irls_c<3>(s, g, ppb);
-  else launch_irls_c<8>(s, g, ppb);
+  dispatch_channels(g.C, [&](auto c) { launch_irls_c<decltype(c)::value>(s, g, ppb); });
 }
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count)
 {
@@ -1425,9 +1425,7 @@ static void launch_weights_c(hipStream_t s, const PairJob* job, int n, int loss,
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out)
 {
   if(n <= 0) return;
-  if(C == 1) launch_weights_c<1>(s, job, n, loss, w_out);
-  else if(C == 3) launch_weights_c<3>(s, job, n, loss, w_out);
-  else launch_weights_c<8>(s, job, n, loss, w_out);
+  dispatch_channels(C, [&](auto c) { launch_weights_c<decltype(c)::value>(s, job, n, loss, w_out); });
 }
 template <int C>
 static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int loss, float thr, unsigned int* count)
@@ -1442,9 +1440,7 @@ static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int lo
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
 {
   if(n <= 0) return;
-  if(C == 1) launch_count_good_c<1>(s, job, n, loss, thr, count);
-  else if(C == 3) launch_count_good_c<3>(s, job, n, loss, thr, count);
-  else launch_count_good_c<8>(s, job, n, loss, thr, count);
+  dispatch_channels(C, [&](auto c) { launch_count_good_c<decltype(c)::value>(s, job, n, loss, thr, count); });
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records)
 {

@@ -139,12 +139,14 @@ struct PairJob {
 };
 
 // selection / template-build job for one (frame, level)
+constexpr int kDfPlanes = 7;
 struct FrameJob {
   const uint8_t* img;       // level image u8
   uint8_t*       cen;       // census scratch u8 (BitPlanes)
   float*         desc;      // [rows*cols][C]
   float*         ch0;       // [rows*cols] copy of descriptor channel 0 (C = 8): the saliency map needs little else (Q7), and a
                             // compact plane spares it a strided pass over the 32-byte records
+  float*         scratch;   // descriptor fields: kDfPlanes work planes of the level-0 size
   float*         sal;       // [rows*cols]
   uint8_t*       flag;      // [rows*cols] candidate flags
   int*           blk_count; // [nblk] then exclusive offsets

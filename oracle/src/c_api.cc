@@ -109,7 +109,13 @@ int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* c, int mode)
 int bpvo_orc_num_levels(const bpvo_orc_ctx* c) { return c->params.numPyramidLevels; }
 int bpvo_orc_num_channels(const bpvo_orc_ctx* c)
 {
-  return c->params.descriptor == kBitPlanes ? 8 : (c->params.descriptor == kIntensityAndGradient ? 3 : 1);
+  switch(c->params.descriptor) {
+    case kBitPlanes: return 8;
+    case kIntensityAndGradient: return 3;
+    case kDescriptorFieldsFirstOrder: return 5;
+    case kDescriptorFieldsSecondOrder: return 10;
+    default: return 1;
+  }
 }
 int bpvo_orc_level_size(const bpvo_orc_ctx* c, int level, int* rows, int* cols)
 {

@@ -1,6 +1,8 @@
 // ORACLE — test infrastructure only (see orc.h).  Dense descriptors.
 #include "orc.h"
 
+#include <algorithm>
+#include <cmath>
 #include <stdexcept>
 
 namespace orc {
@@ -49,6 +51,7 @@ void defaultParams(Params& p)
 //   kIntensity -> IntensityDescriptor::compute (bpvo/intensity_descriptor.cc:31-43): u8 -> f32, exact (Mat::convertTo).
 //   kLaplacian -> LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): one f32 channel, cv::Laplacian.
 //   kIntensityAndGradient -> GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): (I, Ix, Iy).
+//   kDescriptorFieldsFirstOrder / SecondOrder -> DescriptorFields[2ndOrder]::compute (bpvo/gradient_descriptor.cc:100-160): 5 / 10 channels.
 //   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
@@ -101,6 +104,60 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
         v += k_diag * I(yp, xm) + k_edge * I(yp, x) + k_diag * I(yp, xp);
         d.ch[0][(size_t) y * cols + x] = v;
       }
+    }
+    return;
+  }
+  if(p.descriptor == kDescriptorFieldsFirstOrder || p.descriptor == kDescriptorFieldsSecondOrder) {
+    // DescriptorFields::compute / DescriptorFields2ndOrder::compute (bpvo/gradient_descriptor.cc:100-160).
+    // imsmooth (bpvo/imgproc.cc:166-171): cv::GaussianBlur with k = max(5, 2*round(sigma)+1) taps -> 5 x 5 for sigma < 2.5,
+    // the f32 5 x 5 blur restated in imgproc.cc (larger kernels are not restated).
+    auto ksize = [](float s) { return std::max(5, 2 * (int) std::round((double) s) + 1); };
+    if((p.dfSigma1 > 0.0f && ksize(p.dfSigma1) != 5) || (p.dfSigma2 > 0.0f && ksize(p.dfSigma2) != 5))
+      throw std::runtime_error("oracle: imsmooth kernels larger than 5 x 5 are not restated");
+    typedef std::vector<float> Plane;
+    auto smooth = [&](const Plane& src, float sigma) { Plane o(n); gaussianBlurF32_5x5(src.data(), rows, cols, sigma, o.data()); return o; };
+    const float S = 0.5f;                                         // imgradient_scale<float>() (bpvo/imgproc.h:205-209)
+    auto xgrad = [&](const Plane& I, Plane& o) {                  // bpvo/imgproc.h:214-238
+      o.resize(n);
+      for(int y = 0; y < rows; ++y)
+        for(int x = 0; x < cols; ++x) {
+          const size_t q = (size_t) y * cols + x;
+          o[q] = x == 0 ? S * (I[q + 1] - I[q]) : (x == cols - 1 ? S * (I[q] - I[q - 1]) : S * (I[q + 1] - I[q - 1]));
+        }
+    };
+    auto ygrad = [&](const Plane& I, Plane& o) {                  // bpvo/imgproc.h:240-265
+      o.resize(n);
+      for(int y = 0; y < rows; ++y)
+        for(int x = 0; x < cols; ++x) {
+          const size_t q = (size_t) y * cols + x;
+          o[q] = y == 0 ? S * (I[q + cols] - I[q]) : (y == rows - 1 ? S * (I[q] - I[q - cols]) : S * (I[q + cols] - I[q - cols]));
+        }
+    };
+    auto split = [&](const Plane& src, Plane& pos, Plane& neg) {   // splitPosNeg (gradient_descriptor.cc:80-98)
+      pos.resize(n); neg.resize(n);
+      for(size_t i = 0; i < n; ++i) {
+        pos[i] = src[i] >= 0 ? src[i] : 0.0f;
+        neg[i] = src[i] < 0 ? src[i] : 0.0f;
+      }
+      if(p.dfSigma2 > 0.0f) { pos = smooth(pos, p.dfSigma2); neg = smooth(neg, p.dfSigma2); }
+    };
+    Plane I0(n);
+    for(size_t i = 0; i < n; ++i) I0[i] = (float) img[i];
+    const Plane I = p.dfSigma1 > 0.0f ? smooth(I0, p.dfSigma1) : I0;
+    if(p.descriptor == kDescriptorFieldsFirstOrder) {
+      d.ch.assign(5, Plane());
+      d.ch[0] = I0;                                               // channel 0 keeps the unsmoothed intensities (:105)
+      Plane buffer;
+      xgrad(I, buffer); split(buffer, d.ch[1], d.ch[2]);
+      ygrad(I, buffer); split(buffer, d.ch[3], d.ch[4]);
+    } else {
+      d.ch.assign(10, Plane());
+      Plane buffer1, buffer2;
+      xgrad(I, buffer1);       split(buffer1, d.ch[0], d.ch[1]);   // Ix
+      xgrad(buffer1, buffer2); split(buffer2, d.ch[2], d.ch[3]);   // Ixx
+      ygrad(buffer2, buffer1); split(buffer2, d.ch[4], d.ch[5]);   // "Ixy": the reference splits buffer2 (Ixx) again (:149-150)
+      ygrad(I, buffer1);       split(buffer1, d.ch[6], d.ch[7]);   // Iy
+      ygrad(buffer1, buffer2); split(buffer2, d.ch[8], d.ch[9]);   // Iyy
     }
     return;
   }

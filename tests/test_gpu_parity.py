@@ -693,3 +693,61 @@ def test_intensity_and_gradient_descriptor_parity(hip, orc, rows, cols, levels, 
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
     with pytest.raises(capi.BpvoError):
         hip.create(d["K"], d["b"], rows, cols, make_params(hip, descriptor="gradient", levels=2, sigmaPriorToCensusTransform=0.8))
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(121, 163, 2, id="163x121-L2"),
+                                              pytest.param(480, 640, 4, id="640x480-L4")])
+@pytest.mark.parametrize("descriptor,C", [("fields1", 5), ("fields2", 10)])
+def test_descriptor_fields_parity(hip, orc, rows, cols, levels, descriptor, C):
+    """kDescriptorFieldsFirstOrder / SecondOrder (bpvo/gradient_descriptor.cc:100-160): 5 / 10 channels of smoothed positive and
+    negative gradient parts, through the generic-C kernels — every stage bit-exact, poses within the bar.  Includes the
+    reference's quirk that the second-order "Ixy" channels repeat the Ixx ones."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss="huber")
+    assert ch.Cn == co.Cn == C
+    for l in range(levels):
+        for c in range(C):
+            assert bits_equal(ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)), (l, c)
+        if C == 10:
+            assert bits_equal(ch.get_descriptor_channel(1, l, 4), ch.get_descriptor_channel(1, l, 2))
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l)), l
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(2.0)):
+            a, b = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+            assert a["sigma"] == b["sigma"] and bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, C)
+            assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
+            assert abs(ch.fraction_good(0, 0.85) - co.fraction_good(0, 0.85)) < 1e-6
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+@pytest.mark.parametrize("descriptor", ["fields1", "fields2"])
+def test_descriptor_fields_sigma_variants(hip, orc, descriptor):
+    """dfSigma1 / dfSigma2 <= 0 switch the smoothing steps off (gradient_descriptor.cc:93,107); sigmas >= 2.5 would need
+    imsmooth kernels wider than 5 taps and are refused.  Batch entry point with Tukey weights."""
+    rows, cols, levels = 96, 128, 2
+    for s1, s2 in ((-1.0, -1.0), (1.2, -1.0), (-1.0, 2.4)):
+        ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss="tukey", dfSigma1=s1, dfSigma2=s2)
+        for l in range(levels):
+            for c in range(ch.Cn):
+                assert bits_equal(ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)), (s1, s2, l, c)
+            assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        Th, _ = ch.estimate_pose(0, 0, 1)
+        To, _ = co.estimate_pose(0, 0, 1)
+        rot, trans = pose_error(Th, To)
+        assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (s1, s2, rot, trans)
+    b3 = synth.make_batch(rows, cols, 3, first_index=50)
+    outs = []
+    for bind in (hip, orc):
+        bc = bind.create(b3["K"], b3["b"], rows, cols, make_params(bind, descriptor=descriptor, loss="tukey", levels=levels), n_frames=6, n_pairs=3)
+        outs.append(bc.batch_run(b3["images"], b3["disparities"])[0])
+    for k in range(3):
+        rot, trans = pose_error(outs[0][k], outs[1][k])
+        assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
+    with pytest.raises(capi.BpvoError):
+        hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor=descriptor, levels=2, dfSigma2=2.5))

@@ -470,3 +470,58 @@ def test_gradient_descriptor_against_numpy(orc):
     Iy[1:-1] = np.float32(0.5) * (I[2:] - I[:-2]); Iy[0] = np.float32(0.5) * (I[1] - I[0]); Iy[-1] = np.float32(0.5) * (I[-1] - I[-2])
     assert bits_equal(ctx.get_descriptor_channel(0, 0, 0), I)
     assert bits_equal(ctx.get_descriptor_channel(0, 0, 1), Ix) and bits_equal(ctx.get_descriptor_channel(0, 0, 2), Iy)
+
+
+def test_descriptor_fields_against_numpy(orc):
+    """DescriptorFields / DescriptorFields2ndOrder (bpvo/gradient_descriptor.cc:100-160) against a numpy / scipy restatement:
+    split into the positive and the (still negative) negative part, 5-tap Gaussian with REFLECT_101 borders (scipy 'mirror'),
+    and the reference's repetition of the Ixx channels where Ixy was meant."""
+    from scipy.ndimage import correlate1d
+    rows, cols = 45, 70
+    d = synth.make_pair(rows, cols, 11)
+    s1, s2 = 0.75, 1.75
+
+    def kern(s):
+        x = np.arange(5) - 2.0
+        k = np.exp(-0.5 / (s * s) * x * x).astype(np.float32)
+        return (k * (1.0 / k.astype(np.float64).sum())).astype(np.float32)
+
+    def smooth(a, s):
+        k = kern(s).astype(np.float64)
+        return correlate1d(correlate1d(a.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+
+    def xg(I):
+        o = np.empty_like(I); o[:, 1:-1] = 0.5 * (I[:, 2:] - I[:, :-2]); o[:, 0] = 0.5 * (I[:, 1] - I[:, 0]); o[:, -1] = 0.5 * (I[:, -1] - I[:, -2]); return o
+
+    def yg(I):
+        o = np.empty_like(I); o[1:-1] = 0.5 * (I[2:] - I[:-2]); o[0] = 0.5 * (I[1] - I[0]); o[-1] = 0.5 * (I[-1] - I[-2]); return o
+
+    def split(a):
+        return smooth(np.where(a >= 0, a, 0.0), s2), smooth(np.where(a < 0, a, 0.0), s2)
+
+    I0 = d["imgA"].astype(np.float64)
+    I = smooth(I0, s1)
+    ctx = orc.create(d["K"], d["b"], rows, cols, make_params(orc, descriptor="fields1", levels=1), n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    assert ctx.Cn == 5
+    want = [I0, *split(xg(I)), *split(yg(I))]
+    for c in range(5):
+        got = ctx.get_descriptor_channel(0, 0, c)
+        assert np.abs(got - want[c]).max() <= 2e-4, c
+    assert ctx.get_descriptor_channel(0, 0, 2).max() <= 0.0 and ctx.get_descriptor_channel(0, 0, 1).min() >= 0.0
+
+    ctx = orc.create(d["K"], d["b"], rows, cols, make_params(orc, descriptor="fields2", levels=1), n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    assert ctx.Cn == 10
+    Ix, Iy = xg(I), yg(I)
+    Ixx, Iyy = xg(Ix), yg(Iy)
+    want = [*split(Ix), *split(Ixx), *split(Ixx), *split(Iy), *split(Iyy)]
+    for c in range(10):
+        got = ctx.get_descriptor_channel(0, 0, c)
+        assert np.abs(got - want[c]).max() <= 2e-4, c
+    assert bits_equal(ctx.get_descriptor_channel(0, 0, 4), ctx.get_descriptor_channel(0, 0, 2))
+    # a pose from the 10-channel descriptor: the solver path is channel-count generic
+    ctx = orc.create(d["K"], d["b"], rows, cols, make_params(orc, descriptor="fields2", levels=2, loss="huber"), n_frames=2, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"]); ctx.frame_set_template(0); ctx.frame_set_data(1, d["imgB"], d["dispB"])
+    T, st = ctx.estimate_pose(0, 0, 1)
+    assert np.isfinite(T).all()
