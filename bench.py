@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--fixed-iters", type=int, default=0,
                     help="throughput mode: tolerances 0 and maxIterations=K (K+2 linearisations per level); 0 = converge")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="bounded sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=40, help="bounded sample for the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record HIP events at all")
     ap.add_argument("--profile-all", action="store_true", help="HIP events around every kernel (diagnostics, slower)")
     ap.add_argument("--gen-workers", type=int, default=0)
