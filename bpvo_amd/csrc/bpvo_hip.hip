@@ -106,6 +106,9 @@ struct bpvo_hip_ctx {
   LevelGeom geom[kMaxLevels];
   float gauss_k[3];
   float df_k1[3], df_k2[3];   // 5-tap Gaussians of dfSigma1 / dfSigma2 (descriptor fields)
+  float cd_k_after[3];        // 5-tap Gaussian of centralDifferenceSigmaAfter
+  int cd_taps_before[3] = {0, 0, 0};   // fixed-point taps of the u8 5x5 blur (centralDifferenceSigmaBefore > 0)
+  bool plane_scratch = false; // descriptor built from plane operations (descriptor fields, central difference)
   hipStream_t stream = nullptr;
   std::vector<FrameSlot> frames;
   std::vector<Workspace> ws;
@@ -200,7 +203,7 @@ void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
   for(int l = 0; l < c->L; ++l) f.desc[l] = cv.take<float>(c->geom[l].npix * c->C);
   for(int l = 0; l < c->L; ++l) f.cen[l] = (c->C == 8) ? cv.take<uint8_t>(c->geom[l].npix) : nullptr;
   for(int l = 0; l < c->L; ++l) f.ch0[l] = (c->C == 8) ? cv.take<float>(c->geom[l].npix) : nullptr;
-  f.scratch = (c->C == 5 || c->C == 10) ? cv.take<float>((size_t) kDfPlanes * c->geom[0].npix) : nullptr;
+  f.scratch = c->plane_scratch ? cv.take<float>((size_t) kDfPlanes * c->geom[0].npix) : nullptr;
   if(total) *total = cv.off;
 }
 
@@ -380,7 +383,11 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
       const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
-      if(c->C == 5 || c->C == 10) {
+      if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
+        launch_central_difference(c->stream, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius,
+                                  c->params.centralDifferenceSigmaBefore > 0.0f ? c->cd_taps_before : nullptr,
+                                  c->params.centralDifferenceSigmaAfter > 0.0f ? c->cd_k_after : nullptr);
+      } else if(c->C == 5 || c->C == 10) {
         launch_descriptor_fields(c->stream, jobs, g.cols, g.rows, count, c->C == 10, c->params.dfSigma1, c->df_k1, c->params.dfSigma2, c->df_k2);
       } else if(c->C == 3) {
         launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count);
@@ -799,8 +806,16 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
   const bool desc_fields = c->params.descriptor == BPVO_DESC_FIELDS_FIRST_ORDER || c->params.descriptor == BPVO_DESC_FIELDS_SECOND_ORDER;
   if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN &&
-     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && !desc_fields)
-    return unsupported("descriptor: Intensity, IntensityAndGradient, DescriptorFields (1st / 2nd order), Laplacian and BitPlanes are on the device path");
+     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.descriptor != BPVO_DESC_CENTRAL_DIFFERENCE && !desc_fields)
+    return unsupported("descriptor: every DenseDescriptor of the reference but LATCH is on the device path");
+  if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
+    auto taps = [](float sg) { return std::max(5, 2 * (int) std::round((double) sg) + 1); };
+    if(c->params.centralDifferenceRadius <= 0) { g_create_error = "invalid radius"; return BPVO_ERR_INVALID_ARG; }   // central_difference_descriptor.cc:19
+    if(c->params.centralDifferenceRadius > 3) return unsupported("centralDifferenceRadius: 1, 2 and 3 (8, 24 and 48 channels) are on the device path");
+    if((c->params.centralDifferenceSigmaBefore > 0.0f && taps(c->params.centralDifferenceSigmaBefore) != 5) ||
+       (c->params.centralDifferenceSigmaAfter > 0.0f && taps(c->params.centralDifferenceSigmaAfter) != 5))
+      return unsupported("centralDifferenceSigmaBefore / After >= 2.5 (imsmooth kernels larger than 5 x 5) are not on the device path");
+  }
   if(desc_fields) {   // imsmooth (bpvo/imgproc.cc:166-171): max(5, 2*round(sigma)+1) taps
     auto taps = [](float sg) { return std::max(5, 2 * (int) std::round((double) sg) + 1); };
     if((c->params.dfSigma1 > 0.0f && taps(c->params.dfSigma1) != 5) || (c->params.dfSigma2 > 0.0f && taps(c->params.dfSigma2) != 5))
@@ -819,7 +834,15 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     case BPVO_DESC_INTENSITY_AND_GRADIENT: c->C = 3; break;
     case BPVO_DESC_FIELDS_FIRST_ORDER: c->C = 5; break;
     case BPVO_DESC_FIELDS_SECOND_ORDER: c->C = 10; break;
+    case BPVO_DESC_CENTRAL_DIFFERENCE: c->C = (2 * c->params.centralDifferenceRadius + 1) * (2 * c->params.centralDifferenceRadius + 1) - 1; break;
     default: c->C = 1; break;
+  }
+  c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE;
+  gaussian_kernel5(c->params.centralDifferenceSigmaAfter, c->cd_k_after);
+  if(c->params.centralDifferenceSigmaBefore > 0.0f) {   // cv::getGaussianKernel(5, sigma) in f32, then cvRound(k * 256)
+    float kk[3];
+    gaussian_kernel5(c->params.centralDifferenceSigmaBefore, kk);
+    for(int i = 0; i < 3; ++i) c->cd_taps_before[i] = (int) std::nearbyint((double) kk[i] * 256.0);
   }
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
   gaussian_kernel5(c->params.dfSigma1, c->df_k1);

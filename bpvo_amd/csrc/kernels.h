@@ -17,6 +17,8 @@ static inline void dispatch_channels(int C, F&& f)
     case 3: f(std::integral_constant<int, 3>()); break;
     case 5: f(std::integral_constant<int, 5>()); break;
     case 10: f(std::integral_constant<int, 10>()); break;
+    case 24: f(std::integral_constant<int, 24>()); break;
+    case 48: f(std::integral_constant<int, 48>()); break;
     default: f(std::integral_constant<int, 8>()); break;
   }
 }
@@ -30,6 +32,8 @@ void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);   // (I, Ix, Iy), C = 3
 void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, float sigma1,
                               const float k1[3], float sigma2, const float k2[3]);   // C = 5 / 10
+void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const int* taps_before,
+                               const float* k_after);   // C = 8 / 24 / 48
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);

@@ -137,15 +137,19 @@ __global__ __launch_bounds__(256) void gradient_descriptor_kernel(const FrameJob
 // -- convertTo, imsmooth (5 x 5 f32 Gaussian, bpvo/imgproc.cc:166-171), xgradient / ygradient (bpvo/imgproc.h:214-265),
 // splitPosNeg (gradient_descriptor.cc:80-98) -- each one launch of this kernel.  A plane code >= 0 is a work plane of
 // FrameJob::scratch, a code < 0 is descriptor channel -1-code of the interleaved [npix][C] records.
-enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT };
+enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT, DF_U8_ROW, DF_U8_COL, DF_SHIFT_DIFF, DF_TO_CH0 };
 struct PlaneRef { float* p; int stride; };
 __device__ __forceinline__ PlaneRef df_plane(const FrameJob& j, int code, int C)
 {
   if(code >= 0) return PlaneRef{j.scratch + (size_t) code * j.rows * j.cols, 1};
   return PlaneRef{j.desc + (-1 - code), C};
 }
+// CentralDifferenceDescriptor (bpvo/central_difference_descriptor.cc:36-131) adds: the u8 5 x 5 fixed-point Gaussian of the
+// image (DF_U8_ROW keeps the int row sums as bit patterns in a work plane, DF_U8_COL rounds them to the u8 value, held as
+// float), the image minus its clamped shift by (i0, i1) (DF_SHIFT_DIFF), and the copy of channel 0 into the compact
+// FrameJob::ch0 plane that the C = 8 kernels expect (DF_TO_CH0).
 __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int op, int src_code, int dst_code, int dst2_code, int C,
-                                                       float k0, float k1, float k2)
+                                                       float k0, float k1, float k2, int i0, int i1, int i2)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
@@ -173,6 +177,26 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
     case DF_GRAD_Y:
       v = y == 0 ? 0.5f * (at(1, x) - at(0, x)) : (y == R - 1 ? 0.5f * (at(y, x) - at(y - 1, x)) : 0.5f * (at(y + 1, x) - at(y - 1, x)));
       break;
+    case DF_U8_ROW: {
+      const uint8_t* row = j.img + (size_t) y * W;
+      const int t = row[x] * i0 + (row[reflect101(x - 1, W)] + row[reflect101(x + 1, W)]) * i1 +
+                    (row[reflect101(x - 2, W)] + row[reflect101(x + 2, W)]) * i2;
+      v = __int_as_float(t);
+      break;
+    }
+    case DF_U8_COL: {
+      auto it = [&](int yy) { return __float_as_int(at(yy, x)); };
+      const int t = (it(y) * i0 + (it(reflect101(y - 1, R)) + it(reflect101(y + 1, R))) * i1 +
+                     (it(reflect101(y - 2, R)) + it(reflect101(y + 2, R))) * i2 + (1 << 15)) >> 16;
+      v = (float) min(255, max(0, t));
+      break;
+    }
+    case DF_SHIFT_DIFF:
+      v = at(y, x) - at(min(max(y + i1, 0), R - 1), min(max(x + i0, 0), W - 1));
+      break;
+    case DF_TO_CH0:
+      j.ch0[q] = at(y, x);
+      return;
     default: {           // DF_SPLIT
       const float s = at(y, x);
       const PlaneRef N = df_plane(j, dst2_code, C);
@@ -854,7 +878,7 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
   const int C = second_order ? 10 : 5;
   const dim3 grid = grid2d(W, R, nframes);
   auto op = [&](int o, int src, int dst, int dst2 = 0, const float* k = nullptr) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f);
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0);
   };
   auto ch = [](int c) { return -1 - c; };
   enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6 };
@@ -882,6 +906,38 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
     op(DF_GRAD_Y, I, P_B1);    split(P_B1, 6, 7);   // Iy
     op(DF_GRAD_Y, P_B1, P_B2); split(P_B2, 8, 9);   // Iyy
   }
+}
+// one level of CentralDifferenceDescriptor: C = (2r+1)^2 - 1 channels; taps_before = the u8 blur's fixed-point taps (centre, +-1,
+// +-2) or nullptr, k_after = the f32 5-tap kernel of sigma_after or nullptr
+void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const int* taps_before,
+                               const float* k_after)
+{
+  const int C = (2 * radius + 1) * (2 * radius + 1) - 1;
+  const dim3 grid = grid2d(W, R, nframes);
+  auto op = [&](int o, int src, int dst, const float* k = nullptr, int i0 = 0, int i1 = 0, int i2 = 0) {
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, i0, i1, i2);
+  };
+  enum { P_IMG = 0, P_DIFF = 1, P_TMP = 2 };
+  if(taps_before) {
+    op(DF_U8_ROW, 0, P_TMP, nullptr, taps_before[0], taps_before[1], taps_before[2]);
+    op(DF_U8_COL, P_TMP, P_IMG, nullptr, taps_before[0], taps_before[1], taps_before[2]);
+  } else {
+    op(DF_CONVERT, 0, P_IMG);
+  }
+  int c = 0;
+  for(int oy = -radius; oy <= radius; ++oy)
+    for(int ox = -radius; ox <= radius; ++ox) {
+      if(ox == 0 && oy == 0) continue;
+      if(k_after) {
+        op(DF_SHIFT_DIFF, P_IMG, P_DIFF, nullptr, ox, oy);
+        op(DF_GAUSS_ROW, P_DIFF, P_TMP, k_after);
+        op(DF_GAUSS_COL, P_TMP, -1 - c, k_after);
+      } else {
+        op(DF_SHIFT_DIFF, P_IMG, -1 - c, nullptr, ox, oy);
+      }
+      ++c;
+    }
+  if(C == 8) op(DF_TO_CH0, -1, 0);
 }
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
+#include <utility>
 
 namespace orc {
 
@@ -52,6 +53,7 @@ void defaultParams(Params& p)
 //   kLaplacian -> LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): one f32 channel, cv::Laplacian.
 //   kIntensityAndGradient -> GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): (I, Ix, Iy).
 //   kDescriptorFieldsFirstOrder / SecondOrder -> DescriptorFields[2ndOrder]::compute (bpvo/gradient_descriptor.cc:100-160): 5 / 10 channels.
+//   kCentralDifference -> CentralDifferenceDescriptor::compute (bpvo/central_difference_descriptor.cc:113-131): (2r+1)^2 - 1 channels.
 //   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
@@ -158,6 +160,45 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
       ygrad(buffer2, buffer1); split(buffer2, d.ch[4], d.ch[5]);   // "Ixy": the reference splits buffer2 (Ixx) again (:149-150)
       ygrad(I, buffer1);       split(buffer1, d.ch[6], d.ch[7]);   // Iy
       ygrad(buffer1, buffer2); split(buffer2, d.ch[8], d.ch[9]);   // Iyy
+    }
+    return;
+  }
+  if(p.descriptor == kCentralDifference) {
+    // CentralDifferenceDescriptor::compute (bpvo/central_difference_descriptor.cc:113-131): the u8 image, imsmooth'ed when
+    // sigma_before > 0, minus its copy shifted by every offset of the (2r+1)^2 window except (0,0) (rows outer, columns
+    // inner, clamped at the borders, :52-69), each channel imsmooth'ed when sigma_after > 0 (:71-72).
+    const int R = p.centralDifferenceRadius;
+    if(R <= 0) throw std::runtime_error("invalid radius");       // :19
+    auto ksize = [](float s) { return std::max(5, 2 * (int) std::round((double) s) + 1); };
+    if((p.centralDifferenceSigmaBefore > 0.0f && ksize(p.centralDifferenceSigmaBefore) != 5) ||
+       (p.centralDifferenceSigmaAfter > 0.0f && ksize(p.centralDifferenceSigmaAfter) != 5))
+      throw std::runtime_error("oracle: imsmooth kernels larger than 5 x 5 are not restated");
+    std::vector<uint8_t> I(img, img + n);
+    if(p.centralDifferenceSigmaBefore > 0.0f) gaussianBlurU8_5x5(img, rows, cols, p.centralDifferenceSigmaBefore, I.data());
+    const int C = (2 * R + 1) * (2 * R + 1) - 1;
+    d.ch.assign(C, std::vector<float>());
+    std::vector<std::pair<int, int>> offsets;                    // (x, y)
+    for(int r = -R; r <= R; ++r)
+      for(int c = -R; c <= R; ++c)
+        if(!(r == 0 && c == 0)) offsets.push_back(std::make_pair(c, r));
+    (void) nthreads;
+#pragma omp parallel for num_threads(nthreads) if(nthreads > 1)
+    for(int i = 0; i < C; ++i) {
+      std::vector<float> tmp(n);
+      const int x_off = offsets[i].first, y_off = offsets[i].second;
+      for(int y = 0; y < rows; ++y) {
+        const int y_i = std::min(std::max(y + y_off, 0), rows - 1);
+        for(int x = 0; x < cols; ++x) {
+          const int x_i = std::min(std::max(x + x_off, 0), cols - 1);
+          tmp[(size_t) y * cols + x] = (float) I[(size_t) y * cols + x] - (float) I[(size_t) y_i * cols + x_i];
+        }
+      }
+      if(p.centralDifferenceSigmaAfter > 0.0f) {
+        d.ch[i].resize(n);
+        gaussianBlurF32_5x5(tmp.data(), rows, cols, p.centralDifferenceSigmaAfter, d.ch[i].data());
+      } else {
+        d.ch[i].swap(tmp);
+      }
     }
     return;
   }

@@ -125,6 +125,36 @@ void gaussianBlurU8_3x3(const uint8_t* src, int rows, int cols, float sigma, uin
   }
 }
 
+// cv::GaussianBlur(u8, Size(5,5), s, s) (reference call site: imsmooth of the u8 image, bpvo/central_difference_descriptor.cc:117
+// via bpvo/imgproc.cc:166-171).  Same fixed-point separable filter as the 3 x 3 case above with five taps
+// [ext: OpenCV 2.4 SymmRowSmallFilter<uchar,int>, SymmColumnFilter<FixedPtCastEx<int,uchar>>]: integer arithmetic, so the
+// evaluation order does not matter.  UNPINNED like the 3 x 3 form.
+void gaussianBlurU8_5x5(const uint8_t* src, int rows, int cols, float sigma, uint8_t* dst)
+{
+  float kf[5];
+  gaussianKernelF32(5, sigma, kf);
+  int ki[5];
+  for(int i = 0; i < 5; ++i) ki[i] = (int) std::nearbyint((double) kf[i] * 256.0);
+  std::vector<int> tmp((size_t) rows * cols);
+  for(int y = 0; y < rows; ++y) {
+    const uint8_t* S = src + (size_t) y * cols;
+    for(int x = 0; x < cols; ++x)
+      tmp[(size_t) y * cols + x] = S[x] * ki[2] + (S[reflect101(x - 1, cols)] + S[reflect101(x + 1, cols)]) * ki[3] +
+                                   (S[reflect101(x - 2, cols)] + S[reflect101(x + 2, cols)]) * ki[4];
+  }
+  for(int y = 0; y < rows; ++y) {
+    const int* S0 = tmp.data() + (size_t) y * cols;
+    const int* Sm1 = tmp.data() + (size_t) reflect101(y - 1, rows) * cols;
+    const int* Sp1 = tmp.data() + (size_t) reflect101(y + 1, rows) * cols;
+    const int* Sm2 = tmp.data() + (size_t) reflect101(y - 2, rows) * cols;
+    const int* Sp2 = tmp.data() + (size_t) reflect101(y + 2, rows) * cols;
+    for(int x = 0; x < cols; ++x) {
+      int v = (S0[x] * ki[2] + (Sm1[x] + Sp1[x]) * ki[3] + (Sm2[x] + Sp2[x]) * ki[4] + (1 << 15)) >> 16;
+      dst[(size_t) y * cols + x] = (uint8_t) std::min(255, std::max(0, v));
+    }
+  }
+}
+
 // bpvo/census.cc:42-91 with v128 `>=` (bpvo/v128.h:102-105): bit k of dst(y,x) = [ neighbour_k >= centre ], neighbour
 // order (-1,-1),(-1,0),(-1,+1),(0,-1),(0,+1),(+1,-1),(+1,0),(+1,+1); rows 0 and R-1, cols 0 and W-1 are 0.
 // The 16-wide SSE ops + one overlapping op at the right edge (census.cc:78-83, Q19) cover every interior pixel

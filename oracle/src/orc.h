@@ -37,7 +37,7 @@ namespace orc {
 // ---- enums (bpvo/types.h:127-169, 418-441): same numeric values
 enum { kHuber = 0x10, kTukey = 0x11, kL2 = 0x12 };
 enum { kIntensity = 0x30, kIntensityAndGradient = 0x31, kDescriptorFieldsFirstOrder = 0x32, kDescriptorFieldsSecondOrder = 0x33,
-       kLaplacian = 0x36, kBitPlanes = 0x37 };
+       kCentralDifference = 0x35, kLaplacian = 0x36, kBitPlanes = 0x37 };
 enum { kCD3 = 0, kCD5 = 1 };
 enum { kLinear = 0, kCosine = 1, kCubic = 2, kCubicHermite = 3 };
 enum { kParameterTolReached = 0x30, kFunctionTolReached, kGradientTolReached, kMaxIterations, kSolverError };
@@ -72,6 +72,7 @@ M44 inverse44(const M44& a);                    // general cofactor inverse (Eig
 void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst, int& drows, int& dcols); // cv::pyrDown
 void gaussianBlurF32_5x5(const float* src, int rows, int cols, float sigma, float* dst);   // cv::GaussianBlur f32 5x5
 void gaussianBlurU8_3x3(const uint8_t* src, int rows, int cols, float sigma, uint8_t* dst); // cv::GaussianBlur u8 3x3 (2.4)
+void gaussianBlurU8_5x5(const uint8_t* src, int rows, int cols, float sigma, uint8_t* dst); // cv::GaussianBlur u8 5x5 (2.4)
 void census(const uint8_t* src, int rows, int cols, float sigma_ct, uint8_t* dst);          // bpvo/census.cc:59-91
 void gradientAbsoluteMagnitude(const float* src, int rows, int cols, float* dst);           // bpvo/imgproc.cc:45-74
 void gradientAbsoluteMagnitudeAcc(const float* src, int rows, int cols, float* dst);        // bpvo/imgproc.cc:104-127

@@ -751,3 +751,61 @@ def test_descriptor_fields_sigma_variants(hip, orc, descriptor):
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
     with pytest.raises(capi.BpvoError):
         hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor=descriptor, levels=2, dfSigma2=2.5))
+
+
+@pytest.mark.parametrize("radius,rows,cols,levels,loss", [pytest.param(1, 120, 160, 3, "tukey", id="r1-8ch-160x120"),
+                                                          pytest.param(2, 121, 163, 2, "huber", id="r2-24ch-163x121"),
+                                                          pytest.param(3, 120, 160, 3, "huber", id="r3-48ch-160x120"),
+                                                          pytest.param(1, 480, 640, 4, "huber", id="r1-8ch-640x480")])
+def test_central_difference_descriptor_parity(hip, orc, radius, rows, cols, levels, loss):
+    """kCentralDifference (bpvo/central_difference_descriptor.cc:36-131): the smoothed u8 image minus its shifts over a
+    (2r+1)^2 window, each channel smoothed — 8 / 24 / 48 channels.  Radius 1 runs through the tuned 8-channel kernels (tiled
+    records, tap cache), radius 2 / 3 through the generic-C forms.  Every stage bit-exact, poses within the bar."""
+    C = (2 * radius + 1) ** 2 - 1
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor="centraldiff", loss=loss, centralDifferenceRadius=radius)
+    assert ch.Cn == co.Cn == C
+    for l in range(levels):
+        for c in range(C):
+            assert bits_equal(ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)), (l, c)
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l)), l
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(2.0)):
+            a, b = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+            assert a["sigma"] == b["sigma"] and bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, C)
+            assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
+    Th, _ = ch.estimate_pose(0, 0, 1)
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+def test_central_difference_variants(hip, orc):
+    """Smoothing steps switched off (sigma <= 0: the raw u8 differences), the batch entry point, and the refused settings."""
+    rows, cols, levels = 96, 128, 2
+    for sb, sa in ((-1.0, -1.0), (1.1, -1.0), (-1.0, 0.9)):
+        ch, co, d = both(hip, orc, rows, cols, levels, descriptor="centraldiff", loss="tukey", centralDifferenceRadius=1,
+                         centralDifferenceSigmaBefore=sb, centralDifferenceSigmaAfter=sa)
+        for l in range(levels):
+            for c in range(8):
+                assert bits_equal(ch.get_descriptor_channel(1, l, c), co.get_descriptor_channel(1, l, c)), (sb, sa, l, c)
+            assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        Th, _ = ch.estimate_pose(0, 0, 1)
+        To, _ = co.estimate_pose(0, 0, 1)
+        rot, trans = pose_error(Th, To)
+        assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (sb, sa, rot, trans)
+    b3 = synth.make_batch(rows, cols, 3, first_index=60)
+    outs = []
+    for bind in (hip, orc):
+        bc = bind.create(b3["K"], b3["b"], rows, cols, make_params(bind, descriptor="centraldiff", loss="huber", levels=levels,
+                                                                     centralDifferenceRadius=2), n_frames=6, n_pairs=3)
+        outs.append(bc.batch_run(b3["images"], b3["disparities"])[0])
+    for k in range(3):
+        rot, trans = pose_error(outs[0][k], outs[1][k])
+        assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
+    for kw in (dict(centralDifferenceRadius=4), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=3.0)):
+        with pytest.raises(capi.BpvoError):
+            hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor="centraldiff", levels=2, **kw))

@@ -525,3 +525,38 @@ def test_descriptor_fields_against_numpy(orc):
     ctx.frame_set_data(0, d["imgA"], d["dispA"]); ctx.frame_set_template(0); ctx.frame_set_data(1, d["imgB"], d["dispB"])
     T, st = ctx.estimate_pose(0, 0, 1)
     assert np.isfinite(T).all()
+
+
+def test_central_difference_against_numpy(orc):
+    """CentralDifferenceDescriptor (bpvo/central_difference_descriptor.cc:36-131) without smoothing against numpy: channel
+    order (rows outer, columns inner, centre skipped) and clamped shifts; with smoothing against scipy within rounding."""
+    from scipy.ndimage import correlate1d
+    rows, cols, R = 40, 57, 2
+    d = synth.make_pair(rows, cols, 12)
+    p = make_params(orc, descriptor="centraldiff", levels=1, centralDifferenceRadius=R, centralDifferenceSigmaBefore=-1.0,
+                    centralDifferenceSigmaAfter=-1.0)
+    ctx = orc.create(d["K"], d["b"], rows, cols, p, n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    assert ctx.Cn == 24
+    I = d["imgA"].astype(np.float32)
+    ys, xs = np.mgrid[0:rows, 0:cols]
+    offs = [(ox, oy) for oy in range(-R, R + 1) for ox in range(-R, R + 1) if (ox, oy) != (0, 0)]
+    for c, (ox, oy) in enumerate(offs):
+        want = I - I[np.clip(ys + oy, 0, rows - 1), np.clip(xs + ox, 0, cols - 1)]
+        assert bits_equal(ctx.get_descriptor_channel(0, 0, c), want), c
+    # default sigmas (0.75 before on the u8 image: fixed point, rounds to u8; 1.75 after in f32)
+    p = make_params(orc, descriptor="centraldiff", levels=1, centralDifferenceRadius=1)
+    ctx = orc.create(d["K"], d["b"], rows, cols, p, n_frames=1, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+
+    def kern(s):
+        x = np.arange(5) - 2.0
+        k = np.exp(-0.5 / (s * s) * x * x).astype(np.float32)
+        return (k * (1.0 / k.astype(np.float64).sum())).astype(np.float64)
+
+    def smooth(a, s):
+        return correlate1d(correlate1d(a.astype(np.float64), kern(s), axis=1, mode="mirror"), kern(s), axis=0, mode="mirror")
+
+    Is = smooth(I, 0.75)                       # the reference rounds this to u8 (fixed point): within 1 grey level
+    want0 = smooth(Is - Is[np.clip(ys - 1, 0, rows - 1), np.clip(xs - 1, 0, cols - 1)], 1.75)
+    assert np.abs(ctx.get_descriptor_channel(0, 0, 0) - want0).max() <= 1.5
