@@ -37,8 +37,12 @@ __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { ret
 template <int C>
 __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, const float (&res)[C])
 {
+  // one "inside the bracket" bit per channel: 64 bits once a point has more than 32 channels (central difference, 48)
+  using mask_t = typename std::conditional<(C > 32), unsigned long long, unsigned>::type;
+  static_assert(C <= 64, "bracket_block keeps one mask bit per channel");
   unsigned keys[C];
-  unsigned below = 0, cnt = 0, mask = 0;
+  unsigned below = 0, cnt = 0;
+  mask_t mask = 0;
 #pragma unroll
   for(int c = 0; c < C; ++c) {
     const unsigned k = __float_as_uint(res[c]) & 0x7fffffffu;
@@ -46,7 +50,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     const bool in = v && (k >= lo) && (k < hi);
     below += (v && k < lo) ? 1u : 0u;
     cnt += in ? 1u : 0u;
-    mask |= (in ? 1u : 0u) << c;
+    mask |= (mask_t) (in ? 1u : 0u) << c;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u;
@@ -81,7 +85,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     unsigned pos = woff + incl - cnt;
 #pragma unroll
     for(int c = 0; c < C; ++c)
-      if(mask & (1u << c)) seg[pos++] = keys[c];
+      if(mask & ((mask_t) 1u << c)) seg[pos++] = keys[c];
   }
 }
 

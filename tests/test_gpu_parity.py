@@ -809,3 +809,29 @@ def test_central_difference_variants(hip, orc):
     for kw in (dict(centralDifferenceRadius=4), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=3.0)):
         with pytest.raises(capi.BpvoError):
             hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor="centraldiff", levels=2, **kw))
+
+
+@pytest.mark.parametrize("descriptor,kw", [("gradient", {}), ("fields1", {}), ("fields2", {}),
+                                           ("centraldiff", dict(centralDifferenceRadius=1)),
+                                           ("centraldiff", dict(centralDifferenceRadius=2)),
+                                           ("centraldiff", dict(centralDifferenceRadius=3, centralDifferenceSigmaAfter=-1.0))])
+def test_scale_sequence_every_channel_count(hip, orc, descriptor, kw):
+    """The bracketed median (second and later linearisations of a level: bracket_block + median_finish) for every channel
+    count the kernels are instantiated for — found by scripts/fuzz_parity.py: a 32-bit channel mask broke it for 48 channels.
+    Same pose sequence on both sides, same sigma / weights every time, and the bracketed path must actually be taken."""
+    rows, cols = 50, 265
+    ch, co, d = both(hip, orc, rows, cols, 1, descriptor=descriptor, loss="huber", **kw)
+    To, so, trace = co.estimate_pose_trace(0, 0, 1)
+    before = ch.median_path_counts()
+    for k, rec in enumerate(trace[:12]):
+        T = rec[:16].reshape(4, 4)
+        a = ch.linearize(0, 0, 1, 0, T, reset_scale=(k == 0))
+        b = co.linearize(0, 0, 1, 0, T, reset_scale=(k == 0))
+        assert a["sigma"] == b["sigma"] and np.isfinite(a["sigma"]), (k, a["sigma"], b["sigma"])
+        assert a["sigma"] == rec[59], (k, a["sigma"], rec[59])
+        assert bits_equal(ch.get_weights(0), co.get_weights(0)), k
+    after = ch.median_path_counts()
+    assert after[0] - before[0] >= 1, (before, after)       # bracketed selections happened
+    Th, sh = ch.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans, sh, so)
