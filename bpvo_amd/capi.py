@@ -132,7 +132,8 @@ class Context:
         self._ck(self.b.fn(name)(self.h, *args))
 
     def set_warp_formulation(self, mode):
-        """0 = PhotoError f64 (active reference path, default), 1 = projectPoints / BilinearInterp all-f32 formulation."""
+        """0 = PhotoError f64 (active reference path, default), 1 = projectPoints / BilinearInterp all-f32 formulation,
+        2 = DisparitySpaceWarp as the warp (+ the f32 interpolation); drops the templates when the warp changes."""
         self.call("set_warp_formulation", int(mode))
 
     # -- geometry

@@ -134,6 +134,7 @@ struct bpvo_hip_ctx {
   // measurement
   double points_fused = 0;     // points linearised through the fused path since the last counter reset
   int fast_warp = 0;           // bpvo_hip_set_warp_formulation
+  int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
   int fuse_frozen = 0;         // estimate loops: fused residual + reduction once a workspace's scale is frozen; opt-in with
                                // BPVO_HIP_FUSE_FROZEN=1 (+2 % GN iterations/s)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
@@ -262,6 +263,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   j.nms_radius = g.nms_radius;
   std::memcpy(j.K, g.K, sizeof(j.K));
   j.b = g.b;
+  j.dspace = c->dspace;
   return j;
 }
 
@@ -280,6 +282,8 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.desc = fc.desc[l];
   j.rows = g.rows; j.cols = g.cols;
   std::memcpy(j.K, g.K, sizeof(j.K));
+  j.b = g.b;
+  j.dspace = c->dspace;
   j.r = c->ws[ws].r;
   j.valid = c->ws[ws].valid;
   j.cand = c->ws[ws].cand;
@@ -431,7 +435,8 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
   {
     // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
     ScopedTimer t(c, KC_NORMALIZATION, 0.0);
-    launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, p.withNormalization);
+    // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
+    launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, c->dspace ? 0 : p.withNormalization);
   }
   // one read-back of the point counts: the host needs them to size the template-build and GN grids
   launch_gather_counts(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, c->d_ints);
@@ -1252,10 +1257,17 @@ static int check_template_not_empty(bpvo_hip_ctx* c, int ref_slot)
 int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* c, int mode)
 {
   CHECK_CTX(c);
-  if(mode != BPVO_WARP_PHOTO_ERROR_F64 && mode != BPVO_WARP_PROJECT_POINTS_F32) return fail(c, BPVO_ERR_INVALID_ARG, "unknown warp formulation");
-  if(mode == BPVO_WARP_PROJECT_POINTS_F32 && c->params.interp != BPVO_INTERP_LINEAR)
-    return fail(c, BPVO_ERR_UNSUPPORTED, "the projectPoints f32 formulation is kLinear only (bpvo/photo_error.cc:118-214)");
-  c->fast_warp = (mode == BPVO_WARP_PROJECT_POINTS_F32) ? 1 : 0;
+  if(mode != BPVO_WARP_PHOTO_ERROR_F64 && mode != BPVO_WARP_PROJECT_POINTS_F32 && mode != BPVO_WARP_DISPARITY_SPACE_F32)
+    return fail(c, BPVO_ERR_INVALID_ARG, "unknown warp formulation");
+  if(mode != BPVO_WARP_PHOTO_ERROR_F64 && c->params.interp != BPVO_INTERP_LINEAR)
+    return fail(c, BPVO_ERR_UNSUPPORTED, "the f32 formulations are kLinear only (bpvo/photo_error.cc:118-214)");
+  const int dspace = (mode == BPVO_WARP_DISPARITY_SPACE_F32) ? 1 : 0;
+  if(dspace != c->dspace) {
+    // templates hold the points / gradients of the other warp: they have to be rebuilt (frame data stays)
+    for(auto& f : c->frames) f.has_template = false;
+  }
+  c->dspace = dspace;
+  c->fast_warp = (mode != BPVO_WARP_PHOTO_ERROR_F64) ? 1 : 0;
   return BPVO_OK;
 }
 
@@ -1316,7 +1328,8 @@ static int build_point_cloud(bpvo_hip_ctx* c)
       x[r] = s;
     }
     const float z_i = 1.0f / x[2];
-    const float u = z_i * x[0], v = z_i * x[1];
+    float u = z_i * x[0], v = z_i * x[1];
+    if(c->dspace) { u = X[0] + Kl[2]; v = X[1] + Kl[5]; }   // DisparitySpaceWarp::getImagePoint (disparity_space_warp.h:73-76)
     uint8_t col = 0;
     if(v >= 0 && v < c->rows && u >= 0 && u < c->cols) col = img[(size_t) ((int) v) * c->cols + (int) u];
     bpvo_hip_point_with_info& pw = c->cloud[i];

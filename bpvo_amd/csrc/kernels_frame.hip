@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
     const float Z = (float) ((double) Bf * (1.0 / (double) d));
     const float X = ((float) x - cx) * Z * (1.0f / fx);
     const float Y = ((float) y - cy) * Z * (1.0f / fy);
-    j.pts[r] = make_float4(X, Y, Z, 1.0f);
+    // DisparitySpaceWarp::makePoint (bpvo/disparity_space_warp.h:31-34): (x - cx, y - cy, d, 1)
+    j.pts[r] = j.dspace ? make_float4((float) x - cx, (float) y - cy, d, 1.0f) : make_float4(X, Y, Z, 1.0f);
     j.inds[r] = p;
   }
 }
@@ -737,7 +738,8 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   if(i >= N) return;
   const int W = j.cols;
   const int ii = j.inds[i];
-  const float fx = j.K[0], fy = j.K[4];
+  // DisparitySpaceWarp::jacobian takes the raw gradients (multiplying by 1.0f is exact)
+  const float fx = j.dspace ? 1.0f : j.K[0], fy = j.dspace ? 1.0f : j.K[4];
   const float* __restrict__ D = j.desc;
   float pixv[C], Ix[C], Iy[C];
   const float NN = 1.0f / 18.0f;
@@ -838,7 +840,8 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 #pragma unroll
   for(int c = 0; c < C; ++c) {
     float J[6];
-    jac_row(jp, Ix[c], Iy[c], J);
+    if(j.dspace) dspace_jac_row(P.x, P.y, P.z, j.K[0], j.K[4], 1.0f / j.K[0], 1.0f / j.K[4], 1.0f / j.b, Ix[c], Iy[c], J);
+    else jac_row(jp, Ix[c], Iy[c], J);
     float* o = out + ((size_t) c * N + i) * 6;
 #pragma unroll
     for(int k = 0; k < 6; ++k) o[k] = J[k];

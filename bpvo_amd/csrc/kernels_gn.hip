@@ -117,6 +117,22 @@ __device__ __forceinline__ void projection_matrix(const PairJob& j, const float*
     }
 }
 
+// DisparitySpaceWarp::setPose (bpvo/disparity_space_warp.h:36): H = G * T * G_inv in f32, the two fixed 4x4 products left
+// to right, G / G_inv as the constructor fills them (bpvo/disparity_space_warp.cc:26-47).  P <- rows 0, 1, 3 of H: with
+// them operator() (:66-71) is the projectPoints form below plus the principal point (x = pw0 * (1 / pw3) + cx).
+__device__ __forceinline__ void dspace_matrix(const PairJob& j, const float* __restrict__ T, float (&P)[12])
+{
+  const float fx = j.K[0], fy = j.K[4];
+  M44 G, Gi, Tm;
+  for(int i = 0; i < 16; ++i) { G.m[i] = 0.0f; Gi.m[i] = 0.0f; Tm.m[i] = T[i]; }
+  G.m[0] = fx; G.m[5] = fy; G.m[11] = fx * j.b; G.m[14] = 1.0f;
+  Gi.m[0] = (float) (1.0 / (double) fx); Gi.m[5] = (float) (1.0 / (double) fy); Gi.m[11] = 1.0f;
+  Gi.m[14] = (float) (1.0 / (double) (fx * j.b));
+  const M44 H = m44_mul(m44_mul(G, Tm), Gi);
+#pragma unroll
+  for(int c = 0; c < 4; ++c) { P[c] = H.m[c]; P[4 + c] = H.m[4 + c]; P[8 + c] = H.m[12 + c]; }
+}
+
 // One template point of warp_residual: projection, validity, (cached) bilinear taps, residuals of all C channels.
 // `in_block` gates the tap-cache update (lanes past the end of a block redo the last point, loads only).  Returns valid.
 // HALF (C = 8, f64 formulation): the taps are fetched and consumed in two groups of four channels, which halves the
@@ -164,6 +180,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
     }
     const float w_i = 1.0f / u[2];
     float fx = w_i * u[0], fy = w_i * u[1];
+    if(j.dspace) { fx = fx + j.K[2]; fy = fy + j.K[5]; }   // DisparitySpaceWarp::operator() (disparity_space_warp.h:66-71)
     // (int) xf: cvttss2si gives INT_MIN for NaN / out-of-range, never a valid pixel
     const bool in_range = (fx > -2147483648.0f) && (fx < 2147483648.0f) && (fy > -2147483648.0f) && (fy < 2147483648.0f);
     if(in_range) { xi = (int) fx; yi = (int) fy; }
@@ -307,7 +324,8 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* 
   if(mode != 2 && blockIdx.x == 0 && threadIdx.x == 0) j.cnt[4] += (unsigned long long) n;   // points this kernel processes
 
   float P[12];
-  projection_matrix(j, mode == 2 ? st->T_lin : st->T, P);
+  if(FAST && j.dspace) dspace_matrix(j, mode == 2 ? st->T_lin : st->T, P);
+  else projection_matrix(j, mode == 2 ? st->T_lin : st->T, P);
 
   // lanes past the end of the last block redo the last point (loads only) so that the whole block reaches the
   // block-level bracket step below; their stores are masked
@@ -889,6 +907,8 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
   const int p_end = min(n, p_begin + pts_per_block);
   const float sigma_inv = 1.0f / st->scale;
   const float s_nrm[4] = {j.nrm[0], j.nrm[1], j.nrm[2], j.nrm[3]};
+  const bool dspace = j.dspace != 0;      // uniform over the launch
+  const float ds_fx = j.K[0], ds_fy = j.K[4], ds_fx_i = 1.0f / j.K[0], ds_fy_i = 1.0f / j.K[4], ds_b_i = 1.0f / j.b;
 
   float acc[kNumAcc];
 #pragma unroll
@@ -947,10 +967,19 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
       Gy += wy * r;
       acc[27] += (w * r) * r;
     }
-    const JacPoint jp = jac_point(Pt.x, Pt.y, Pt.z, s_nrm);
-    const float t_xz2 = jp.x * jp.rz2, t_yz2 = jp.y * jp.rz2;
-    const float A[6] = {-(t_xz2 * jp.yc2), jp.zc3 * jp.rz + t_xz2 * jp.xc1, -(jp.yc2 * jp.rz), jp.rzs, 0.0f, -(jp.s_i * t_xz2)};
-    const float B[6] = {-(jp.zc3 * jp.rz) - t_yz2 * jp.yc2, t_yz2 * jp.xc1, jp.xc1 * jp.rz, 0.0f, jp.rzs, -(jp.s_i * t_yz2)};
+    float A[6], B[6];
+    if(!dspace) {
+      const JacPoint jp = jac_point(Pt.x, Pt.y, Pt.z, s_nrm);
+      const float t_xz2 = jp.x * jp.rz2, t_yz2 = jp.y * jp.rz2;
+      A[0] = -(t_xz2 * jp.yc2); A[1] = jp.zc3 * jp.rz + t_xz2 * jp.xc1; A[2] = -(jp.yc2 * jp.rz); A[3] = jp.rzs; A[4] = 0.0f; A[5] = -(jp.s_i * t_xz2);
+      B[0] = -(jp.zc3 * jp.rz) - t_yz2 * jp.yc2; B[1] = t_yz2 * jp.xc1; B[2] = jp.xc1 * jp.rz; B[3] = 0.0f; B[4] = jp.rzs; B[5] = -(jp.s_i * t_yz2);
+    } else {
+      // DisparitySpaceWarp::jacobian (types.h dspace_jac_row) expanded in the raw gradients Ix, Iy; point = (x, y, d, 1)
+      const float x = Pt.x, y = Pt.y, d = Pt.z;
+      const float xfi = x * ds_fx_i, yfi = y * ds_fy_i, dbi = d * ds_b_i;
+      A[0] = -(x * yfi); A[1] = ds_fx + x * xfi; A[2] = -(ds_fx * yfi); A[3] = dbi; A[4] = 0.0f; A[5] = -(dbi * xfi);
+      B[0] = -ds_fy - y * yfi; B[1] = y * xfi; B[2] = ds_fy * xfi; B[3] = 0.0f; B[4] = dbi * (ds_fy * ds_fx_i); B[5] = -(dbi * (y * ds_fx_i));
+    }
     {
       int idx = 0;
 #pragma unroll
@@ -1005,7 +1034,8 @@ __device__ void gn_update_pose(GNState* st, const float* nrm)
   for(int i = 0; i < 6; ++i) mdp[i] = -st->dp[i];
   M44 T;
   for(int i = 0; i < 16; ++i) T.m[i] = st->T[i];
-  const M44 Tn = m44_mul(T, params_to_pose(nrm, mdp));
+  // nrm[4] != 0: DisparitySpaceWarp::paramsToPose = TwistToMatrix(p), scalePose is the identity (disparity_space_warp.h:79-91)
+  const M44 Tn = m44_mul(T, nrm[4] != 0.0f ? twist_to_matrix(mdp) : params_to_pose(nrm, mdp));
   for(int i = 0; i < 16; ++i) st->T[i] = Tn.m[i];
 }
 
@@ -1122,10 +1152,11 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
   __shared__ uint32_t s_state[kWords];
   __shared__ float s_sum[kPartialStride];
-  __shared__ float s_nrm[4];
+  __shared__ float s_nrm[5];
   __shared__ SolveScratch s_scratch;
   for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
   if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
+  if(threadIdx.x == 4) s_nrm[4] = j.dspace ? 1.0f : 0.0f;
 
   const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
   if(threadIdx.x < kNumAcc) {                        // deterministic: block order, f64

@@ -66,6 +66,21 @@ __host__ __device__ inline void jac_row(const JacPoint& p, float Ix, float Iy, f
   J[5] = -((p.s_i * xIx_yIy) * p.rz2);                               // :295-299
 }
 
+// The same for DisparitySpaceWarp (reference: DisparitySpaceWarp::jacobian, bpvo/disparity_space_warp.h:40-64 — scalar f32,
+// C++ evaluation order; the point is (x - cx, y - cy, d, 1), Ix / Iy are the RAW channel gradients).  fx_i, fy_i, b_i are
+// the constructor's 1.0f / fx, 1.0f / fy, 1.0f / b (bpvo/disparity_space_warp.cc:31-33).
+__host__ __device__ inline void dspace_jac_row(float x, float y, float d, float fx, float fy, float fx_i, float fy_i, float b_i,
+                                               float Ix, float Iy, float* J)
+{
+  const float t2 = x * Ix, t3 = y * Iy, t4 = t2 + t3;
+  J[0] = ((-Iy) * fy) - ((t4 * fy_i) * y);
+  J[1] = (Ix * fx) + ((t4 * fx_i) * x);
+  J[2] = (((Iy * fy) * fx_i) * x) - (((Ix * fx) * fy_i) * y);
+  J[3] = (Ix * d) * b_i;
+  J[4] = (((Iy * d) * fy) * fx_i) * b_i;
+  J[5] = (((-d) * t4) * fx_i) * b_i;
+}
+
 // phases of the device-side PoseEstimatorBase::run state machine (gn_step kernel)
 enum { PHASE_FIRST = 0, PHASE_LOOP = 1, PHASE_DONE = 2 };
 
@@ -124,6 +139,8 @@ struct PairJob {
   const float*  desc;
   int           rows, cols;
   float         K[9];     // level intrinsics (K * 0.5^l, K(2,2) = 1)
+  float         b;        // level baseline (b * 2^l)
+  int           dspace;   // 1: DisparitySpaceWarp (BPVO_WARP_DISPARITY_SPACE_F32): pts = (x - cx, y - cy, d, 1), grad = raw (Ix, Iy)
   // workspace
   float*        r;        // [N][C] residuals, tiled
   uint8_t*      valid;    // [N]
@@ -162,6 +179,7 @@ struct FrameJob {
   int            nms_radius;   // <= 0: NMS off for this level
   float          K[9];
   float          b;
+  int            dspace;    // 1: DisparitySpaceWarp points / raw gradients (see PairJob)
 };
 
 }  // namespace bpvo_hip

@@ -185,8 +185,16 @@ int bpvo_hip_fraction_good(bpvo_hip_ctx* ctx, int ws, float threshold, float* fr
  *       interpolation in double, Floor(), invalid -> r = 0 (bpvo/photo_error.cc:336-459);
  *   BPVO_WARP_PROJECT_POINTS_F32 — the inactive all-float path (PHOTO_ERROR_OPT): projectPoints + interpolation
  *       coefficients + dot product (bpvo/project_points.cc:180-214, bpvo/photo_error.cc:82-214, bpvo/interp_util.h:49-71):
- *       (int) truncation, C = [(1-xf)(1-yf), xf(1-yf), (1-xf)yf, xf*yf] in its expanded form, invalid -> r = -I0. */
-enum { BPVO_WARP_PHOTO_ERROR_F64 = 0, BPVO_WARP_PROJECT_POINTS_F32 = 1 };
+ *       (int) truncation, C = [(1-xf)(1-yf), xf(1-yf), (1-xf)yf, xf*yf] in its expanded form, invalid -> r = -I0;
+ *   BPVO_WARP_DISPARITY_SPACE_F32 — DisparitySpaceWarp in the place of RigidBodyWarp (bpvo/disparity_space_warp.{h,cc}; the
+ *       reference declares the class and its warp_traits but typedefs TemplateData::WarpType to RigidBodyWarp,
+ *       bpvo/template_data.h:42, so no build of it runs this): template points (x - cx, y - cy, d, 1) (makePoint :31-34),
+ *       H = G * T * G_inv (setPose :36), x = (H p)_0 / (H p)_3 + cx (operator() :66-71, all f32) followed by the
+ *       interpolation of the projectPoints formulation, Jacobian rows of jacobian() (:40-64), no normalisation (:87-91),
+ *       paramsToPose = TwistToMatrix (:79-84).  bpvo_hip_get_points then returns disparity-space points.
+ * Switching to or from the disparity-space warp drops the templates (has_template = 0 on every slot; the frame data
+ * stay): call it before bpvo_hip_frame_set_template / the first bpvo_hip_add_frame. */
+enum { BPVO_WARP_PHOTO_ERROR_F64 = 0, BPVO_WARP_PROJECT_POINTS_F32 = 1, BPVO_WARP_DISPARITY_SPACE_F32 = 2 };
 int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* ctx, int mode);
 
 /* ---- VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93):

@@ -98,11 +98,13 @@ int bpvo_orc_set_num_threads(bpvo_orc_ctx* c, int n)
 
 int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* c, int mode)
 {
-  if(mode != 0 && mode != 1) return fail(c, "unknown warp formulation");
+  if(mode != 0 && mode != 1 && mode != 2) return fail(c, "unknown warp formulation");
+  // mode 2: DisparitySpaceWarp as the warp of TemplateData (points, Jacobians, pose update) + the all-f32 formulation;
+  // templates built before the switch hold points of the other warp and must be rebuilt by the caller
   for(auto& f : c->frames)
-    for(auto& td : f->tdata) td.fast_warp = mode;
+    for(auto& td : f->tdata) { td.fast_warp = mode; td.warp.dspace = (mode == 2); }
   for(Frame* f : {c->vo.ref.get(), c->vo.cur.get(), c->vo.prev.get()})
-    for(auto& td : f->tdata) td.fast_warp = mode;
+    for(auto& td : f->tdata) { td.fast_warp = mode; td.warp.dspace = (mode == 2); }
   return 0;
 }
 

@@ -92,6 +92,8 @@ struct Warp {
   float K[9]; float b;           // level intrinsics / baseline
   float P[12];                   // 3x4 K*T[0:3]
   M44 T, T_inv;                  // normalisation
+  int dspace = 0;                // 1: DisparitySpaceWarp (bpvo/disparity_space_warp.{h,cc}) instead of RigidBodyWarp; P then
+                                 // holds rows 0, 1, 3 of H = G * T * G_inv (operator(): x = pw0/pw3 + cx, y = pw1/pw3 + cy)
   void init(const float K_[9], float b_);
   void makePoint(float x, float y, float d, float out[4]) const;          // rigid_body_warp.h:47-60
   void setNormalization(const std::vector<float>& pts);                   // warps.cc:27-48, rigid_body_warp.h:62-71
@@ -111,6 +113,7 @@ struct TemplateData {
   std::vector<float> saliency;    // kept for parity inspection
   int numChannels = 0;
   int fast_warp = 0;              // 1: projectPoints / BilinearInterp all-f32 formulation (PHOTO_ERROR_OPT branch)
+                                  // 2: the same with DisparitySpaceWarp as the warp (warp.dspace = 1)
   int numPoints() const { return (int)(points.size() / 4); }
   void setData(const Descriptor& desc, const float* D, int Dcols);        // template_data.cc:37-142
   // template_data.cc:174-189 + photo_error.cc:344-451 (standard branch)

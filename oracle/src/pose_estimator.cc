@@ -343,7 +343,8 @@ void VisualOdometry::addFrame(const uint8_t* I, const float* D, Result& ret)
           x[r] = s;
         }
         const float z_i = 1.0f / x[2];
-        const float u = z_i * x[0], v = z_i * x[1];
+        float u = z_i * x[0], v = z_i * x[1];
+        if(td.warp.dspace) { u = X[0] + Kl[2]; v = X[1] + Kl[5]; }   // DisparitySpaceWarp::getImagePoint (disparity_space_warp.h:73-76)
         uint8_t c = 0;
         if(v >= 0 && v < rows && u >= 0 && u < cols) c = ref->image[(size_t) ((int) v) * cols + (int) u];
         PointWithInfo& p = ret.cloud[i];

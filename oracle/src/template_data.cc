@@ -165,6 +165,9 @@ void TemplateData::computeResiduals(const Descriptor& desc, const M44& pose, std
       }
       const float w_i = 1.0f / x[2];
       float xf = w_i * x[0], yf = w_i * x[1];
+      // DisparitySpaceWarp::operator() (bpvo/disparity_space_warp.h:66-71): pw = H * p, (pw0 * w_i + cx, pw1 * w_i + cy);
+      // warp.P holds rows 0, 1, 3 of H
+      if(warp.dspace) { xf = xf + warp.K[2]; yf = yf + warp.K[5]; }
       // (int) of a float that does not fit is UB in C++; cvttss2si returns INT_MIN, restated explicitly
       const bool in_range = (xf > -2147483648.0f) && (xf < 2147483648.0f) && (yf > -2147483648.0f) && (yf < 2147483648.0f);
       const int xi = in_range ? (int) xf : INT32_MIN, yi = in_range ? (int) yf : INT32_MIN;

@@ -72,6 +72,10 @@ void Warp::init(const float K_[9], float b_)
 void Warp::makePoint(float x, float y, float d, float out[4]) const
 {
   const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  if(dspace) {   // DisparitySpaceWarp::makePoint (bpvo/disparity_space_warp.h:31-34)
+    out[0] = x - cx; out[1] = y - cy; out[2] = d; out[3] = 1.0f;
+    return;
+  }
   const float Bf = b * fx;
   const float Z = (float) (Bf * (1.0 / d));
   const float X = (x - cx) * Z * (1.0f / fx);
@@ -86,6 +90,7 @@ void Warp::makePoint(float x, float y, float d, float out[4]) const
 // is used.
 void Warp::setNormalization(const std::vector<float>& pts)
 {
+  if(dspace) return;   // "no normalization for dspace, we do not need it" (bpvo/disparity_space_warp.h:87-90)
   const size_t N = pts.size() / 4;
   float c[4] = {0, 0, 0, 0};
   for(size_t i = 0; i < N; ++i)
@@ -112,6 +117,19 @@ void Warp::setNormalization(const std::vector<float>& pts)
 // bpvo/rigid_body_warp.h:111-114: P = K * T.block<3,4>(0,0), f32, index-order sums over k = 0..2.
 void Warp::setPose(const M44& pose)
 {
+  if(dspace) {
+    // DisparitySpaceWarp::setPose: _H = _G * T * _G_inv (bpvo/disparity_space_warp.h:36), G and G_inv as the constructor
+    // fills them (bpvo/disparity_space_warp.cc:26-47: 1.0/fx etc. in double, narrowed by the << initialiser); the two
+    // fixed 4x4 f32 products left to right.
+    const float fx = K[0], fy = K[4];
+    M44 G, Gi;
+    for(int i = 0; i < 16; ++i) G.m[i] = Gi.m[i] = 0.0f;
+    G.m[0] = fx; G.m[5] = fy; G.m[11] = fx * b; G.m[14] = 1.0f;
+    Gi.m[0] = (float) (1.0 / fx); Gi.m[5] = (float) (1.0 / fy); Gi.m[11] = 1.0f; Gi.m[14] = (float) (1.0 / (fx * b));
+    const M44 H = mul44(mul44(G, pose), Gi);
+    for(int j = 0; j < 4; ++j) { P[0 * 4 + j] = H.m[0 * 4 + j]; P[1 * 4 + j] = H.m[1 * 4 + j]; P[2 * 4 + j] = H.m[3 * 4 + j]; }
+    return;
+  }
   for(int i = 0; i < 3; ++i)
     for(int j = 0; j < 4; ++j) {
       float s = K[i * 3 + 0] * pose.m[0 * 4 + j];
@@ -129,6 +147,23 @@ void Warp::setPose(const M44& pose)
 void Warp::computeJacobian(const float* pts, int N, const float* IxIy, float* J) const
 {
   const float fx = K[0], fy = K[4];
+  if(dspace) {
+    // DisparitySpaceWarp::jacobian (bpvo/disparity_space_warp.h:40-64), scalar f32, C++ evaluation order
+    const float t5 = 1.0f / fx, t6 = 1.0f / fy, t7 = 1.0f / b;        // _fx_i, _fy_i, _b_i (disparity_space_warp.cc:32-34)
+    for(int i = 0; i < N; ++i) {
+      const float x = pts[4 * i + 0], y = pts[4 * i + 1], d = pts[4 * i + 2];
+      const float Ix = IxIy[2 * i + 0], Iy = IxIy[2 * i + 1];
+      const float t2 = x * Ix, t3 = y * Iy, t4 = t2 + t3;
+      float* Ji = J + 6 * (size_t) i;
+      Ji[0] = ((-Iy) * fy) - ((t4 * t6) * y);
+      Ji[1] = (Ix * fx) + ((t4 * t5) * x);
+      Ji[2] = (((Iy * fy) * t5) * x) - (((Ix * fx) * t6) * y);
+      Ji[3] = (Ix * d) * t7;
+      Ji[4] = (((Iy * d) * fy) * t5) * t7;
+      Ji[5] = (((-d) * t4) * t5) * t7;
+    }
+    return;
+  }
   const float s = T.m[0], c1 = T_inv.m[3], c2 = T_inv.m[7], c3 = T_inv.m[11];
   const float s_i = (float) (1.0 / s);                       // _mm_set1_ps(1.0 / s), rigid_body_warp.cc:272
   for(int i = 0; i < N; ++i) {
@@ -191,6 +226,7 @@ M44 twistToMatrix(const float p[6])
 // paramsToPose = scalePose(TwistToMatrix(p)) = T_inv * Tw * T (bpvo/rigid_body_warp.h:130-138), left to right.
 M44 Warp::paramsToPose(const float p[6]) const
 {
+  if(dspace) return twistToMatrix(p);   // bpvo/disparity_space_warp.h:79-84; scalePose is the identity (:91)
   return mul44(mul44(T_inv, twistToMatrix(p)), T);
 }
 

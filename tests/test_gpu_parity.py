@@ -428,6 +428,63 @@ def test_project_points_f32_formulation_parity(hip, orc, rows, cols, levels, des
 
 
 @pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("descriptor,loss", [("intensity", "huber"), ("bitplanes", "tukey"), ("gradient", "l2")])
+def test_disparity_space_warp_parity(hip, orc, rows, cols, levels, descriptor, loss):
+    """DisparitySpaceWarp in the place of RigidBodyWarp (bpvo/disparity_space_warp.{h,cc}; named by the north star, never
+    instantiated by the reference): points (x - cx, y - cy, d, 1), H = G T G^-1, operator() in f32, its jacobian(), no
+    normalisation, paramsToPose = TwistToMatrix.  Points, Jacobians, valid masks, residuals, sigma, weights bit-exact
+    against the restatement; H / G against an f64 evaluation; the pose within the bar of the oracle's and of the rigid warp's."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss=loss)
+    T_rigid, _ = ch.estimate_pose(0, 0, 1)
+    for ctx in (ch, co):
+        ctx.set_warp_formulation(2)
+        if ctx is ch:
+            assert not ctx.frame_state(0)[1]           # the rigid-warp template was dropped
+            with pytest.raises(capi.BpvoError):
+                ctx.estimate_pose(0, 0, 1)
+        ctx.frame_set_template(0)
+    K = np.asarray(d["K"], np.float32)
+    for l in range(levels):
+        ph, po = ch.get_points(0, l), co.get_points(0, l)
+        assert bits_equal(ph, po), f"points level {l}"
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        # makePoint: pixel coordinates relative to the principal point of the level, raw disparity
+        lr, lc = ch.level_size(l)
+        inds = co.get_point_indices(0, l)
+        cx, cy = np.float32(K[0, 2] * 0.5 ** l), np.float32(K[1, 2] * 0.5 ** l)
+        assert np.array_equal(po[:, 0], (inds % lc).astype(np.float32) - cx) and np.array_equal(po[:, 1], (inds // lc).astype(np.float32) - cy)
+        assert np.array_equal(po[:, 2], d["dispA"].ravel()[(1 << l) * ((inds // lc) * cols + inds % lc)])
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l))
+        assert bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l)), f"jacobians level {l}"
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(1.0), _perturbed_pose(8.0)):
+            a = ch.linearize(0, 0, 1, l, T)
+            b = co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo), f"valid level {l}"
+            assert bits_equal(ch.get_residuals(0), co.get_residuals(0)), f"residuals level {l}"
+            assert a["sigma"] == b["sigma"] and a["num_valid"] == b["num_valid"]
+            assert bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, ch.Cn)
+            assert np.abs(a["H"] - H64).max() <= 4e-6 * np.abs(H64).max()
+            assert np.abs(a["G"] - G64).max() <= 2e-5 * max(np.abs(G64).max(), 1e-3 * np.sqrt(np.abs(H64).max()))
+    Th, sh = ch.estimate_pose(0, 0, 1)
+    To, so = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(Th, To)
+    assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans, sh, so)
+    # the same motion as the rigid-body warp finds (different parametrisation of the same problem)
+    rot, trans = pose_error(Th, T_rigid)
+    assert rot <= 1e-3 and trans <= 10 * trans_tol(d["K"]), (rot, trans)
+    # a batch in this mode equals the pair run alone
+    if rows <= 120:
+        n = 3
+        b = synth.make_batch(rows, cols, n, first_index=0)
+        bc = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels), n_frames=2 * n, n_pairs=n)
+        bc.set_warp_formulation(2)
+        poses, _ = bc.batch_run(b["images"], b["disparities"])
+        assert bits_equal(poses[0], Th)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
 @pytest.mark.parametrize("interp", ["cosine", "cubic", "cubic_hermite"])
 @pytest.mark.parametrize("descriptor,loss", [("intensity", "huber"), ("bitplanes", "tukey")])
 def test_interpolation_variants_parity(hip, orc, rows, cols, levels, interp, descriptor, loss):

@@ -342,6 +342,48 @@ def test_f32_formulation_close_to_f64_formulation(orc):
     assert np.array_equal(r32[:, ~v32], -pix[:, ~v32]) and np.all(r64[:, ~v64] == 0)
 
 
+def test_disparity_space_warp_is_the_rigid_warp_reparametrised(orc):
+    """DisparitySpaceWarp (bpvo/disparity_space_warp.{h,cc}) describes the same motion model in (x - cx, y - cy, d)
+    coordinates: with x' = fx X / Z, d = b fx / Z its projection H p and its Jacobian rows equal RigidBodyWarp's (without
+    Hartley normalisation) up to float rounding.  Independent check of the restatement: the two warps are written from
+    different source files and must agree with each other."""
+    kw = dict(descriptor="bitplanes", levels=2, withNormalization=0)
+    ctx, d, _ = setup_pair(orc, 96, 128, **kw)
+    T = synth.twist_to_matrix([0.004, -0.003, 0.002, 0.02, -0.015, 0.03]).astype(np.float32)
+    ctx.set_warp_formulation(1)
+    ctx.linearize(0, 0, 1, 0, T)
+    v1, r1 = ctx.get_valid(0).astype(bool), ctx.get_residuals(0).reshape(8, -1)
+    J1, X1 = ctx.get_jacobians(0, 0), ctx.get_points(0, 0)
+    T1, _ = ctx.estimate_pose(0, 0, 1)
+
+    ctx.set_warp_formulation(2)
+    ctx.frame_set_template(0)
+    K, b = np.asarray(d["K"], np.float64), float(d["b"])
+    P = ctx.get_points(0, 0)
+    inds = ctx.get_point_indices(0, 0)
+    assert np.array_equal(P[:, 0], (inds % 128).astype(np.float32) - np.float32(K[0, 2]))
+    assert np.array_equal(P[:, 1], (inds // 128).astype(np.float32) - np.float32(K[1, 2]))
+    assert np.array_equal(P[:, 2], d["dispA"].ravel()[inds]) and np.all(P[:, 3] == 1.0)
+    # the same 3-D points: X = x' Z / fx, Z = b fx / d
+    Z = b * K[0, 0] / P[:, 2].astype(np.float64)
+    assert np.allclose(P[:, 0] * Z / K[0, 0], X1[:, 0], rtol=1e-5, atol=1e-6) and np.allclose(Z, X1[:, 2], rtol=1e-5)
+    ctx.linearize(0, 0, 1, 0, T)
+    v2, r2 = ctx.get_valid(0).astype(bool), ctx.get_residuals(0).reshape(8, -1)
+    assert (v1 != v2).sum() <= 0.01 * len(v1)
+    both_valid = v1 & v2
+    assert np.abs(r1[:, both_valid] - r2[:, both_valid]).max() < 1e-3
+    J2 = ctx.get_jacobians(0, 0)
+    scale = np.abs(J1).max(axis=0)
+    assert np.all(np.abs(J1 - J2).max(axis=0) <= 1e-4 * scale), np.abs(J1 - J2).max(axis=0) / scale
+    T2, st = ctx.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(T1, T2)
+    assert rot < 2e-4 and trans < 4e-3, (rot, trans)
+    # switching back restores the rigid warp
+    ctx.set_warp_formulation(0)
+    ctx.frame_set_template(0)
+    assert np.array_equal(ctx.get_points(0, 0), X1)
+
+
 # --------------------------------------------------------------------------------------- interpolation variants (8f.3)
 def _np_project(ctx, d, T, level=0):
     """f64 projection of PhotoError::Impl::init with the oracle's own P = K*T[0:3] in f32."""
