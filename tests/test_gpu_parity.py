@@ -176,8 +176,10 @@ def test_fixed_iteration_mode_counts(hip, orc):
     assert rot <= ROT_TOL and trans <= trans_tol(synth.calibration(rows, cols)[0])
 
 
-def test_visual_odometry_add_frame_sequence(hip, orc):
-    """VisualOdometry::addFrame state machine (bpvo/vo.cc:125-224) on a short synthetic trajectory."""
+@pytest.mark.parametrize("formulation", [pytest.param(0, id="rigid-body-warp"), pytest.param(2, id="disparity-space-warp")])
+def test_visual_odometry_add_frame_sequence(hip, orc, formulation):
+    """VisualOdometry::addFrame state machine (bpvo/vo.cc:125-224) on a short synthetic trajectory; also with
+    DisparitySpaceWarp as the warp (its getImagePoint colours the point cloud, bpvo/disparity_space_warp.h:73-76)."""
     rows, cols, levels = 120, 160, 3
     seq = synth.make_sequence(rows, cols, 7, index=5, step_rot=0.01, step_trans=0.06)
     res = []
@@ -185,10 +187,23 @@ def test_visual_odometry_add_frame_sequence(hip, orc):
         p = make_params(b, descriptor="intensity", loss="huber", levels=levels, minTranslationMagToKeyFrame=0.1,
                         minRotationMagToKeyFrame=2.5, maxFractionOfGoodPointsToKeyFrame=0.7, goodPointThreshold=0.8)
         ctx = b.create(seq["K"], seq["b"], rows, cols, p, n_frames=3, n_pairs=1)
-        out = [ctx.add_frame(img, disp) for img, disp in seq["frames"]]
-        res.append((out, ctx.trajectory(), ctx.vo_num_points_at_level(), ctx.get_point_cloud()))
+        if formulation:
+            ctx.set_warp_formulation(formulation)
+        out, clouds = [], []
+        for img, disp in seq["frames"]:
+            out.append(ctx.add_frame(img, disp))
+            if out[-1]["hasPointCloud"]:          # a Result owns its point cloud (bpvo/types.h:549-563): fetch it now
+                clouds.append(ctx.get_point_cloud())
+        res.append((out, ctx.trajectory(), ctx.vo_num_points_at_level(), ctx.get_point_cloud(), clouds))
         assert ctx.add_frame_null() != 0        # THROW_ERROR_IF(nullptr) -> error status
-    (oh, trh, nh, (pch, pph)), (oo, tro, no_, (pco, ppo)) = res
+    (oh, trh, nh, (pch, pph), clh), (oo, tro, no_, (pco, ppo), clo) = res
+    assert len(clh) == len(clo) and len(clh) >= 1
+    for (ph, Ph), (po, Po) in zip(clh, clo):
+        assert len(ph) == len(po) and len(ph) > 0
+        assert np.array_equal(ph["xyzw"], po["xyzw"]) and np.array_equal(ph["rgba"], po["rgba"])
+        assert len(np.unique(ph["rgba"][:, 0])) > 8               # colours were looked up, not defaulted
+        assert np.abs(ph["weight"] - po["weight"]).max() < 1e-3
+        assert np.abs(Ph - Po).max() < 5e-3
     assert nh == no_
     assert [r["keyFramingReason"] for r in oh] == [r["keyFramingReason"] for r in oo]
     assert [r["isKeyFrame"] for r in oh] == [r["isKeyFrame"] for r in oo]
