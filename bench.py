@@ -314,7 +314,7 @@ def main():
 
         cpu = None
         pose_vs_cpu = None
-        if args.cpu_pairs > 0:
+        if args.cpu_pairs > 0 and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would wait for it)
             cpu = cpu_baseline(args, batch, args.cpu_pairs)
             # pose agreement of the GPU path with the CPU path on the pairs both ran (BASELINE.json: "pose RMSE vs ref")
             cp = cpu.pop("_poses").astype(np.float64)
