@@ -27,6 +27,8 @@ CASES = [
     dict(name="bp_tukey_96x128", rows=96, cols=128, levels=3, descriptor="bitplanes", loss="tukey", index=0),
     dict(name="int_huber_96x128", rows=96, cols=128, levels=3, descriptor="intensity", loss="huber", index=1),
     dict(name="int_l2_1level_96x128", rows=96, cols=128, levels=1, descriptor="intensity", loss="l2", index=2),
+    # DisparitySpaceWarp as the warp (set_warp_formulation(2)): disparity-space points, its Jacobian, f32 projection
+    dict(name="bp_huber_dspace_96x128", rows=96, cols=128, levels=2, descriptor="bitplanes", loss="huber", index=3, formulation=2),
 ]
 
 
@@ -38,11 +40,15 @@ def build_case(orc, c):
     d = synth.make_pair(c["rows"], c["cols"], c["index"])
     p = make_params(orc, descriptor=c["descriptor"], loss=c["loss"], levels=c["levels"])
     ctx = orc.create(d["K"], d["b"], c["rows"], c["cols"], p, n_frames=2, n_pairs=1)
+    if c.get("formulation", 0):
+        ctx.set_warp_formulation(c["formulation"])
     ctx.frame_set_data(0, d["imgA"], d["dispA"])
     ctx.frame_set_template(0)
     ctx.frame_set_data(1, d["imgB"], d["dispB"])
     out = dict(imgA=d["imgA"], dispA=d["dispA"], imgB=d["imgB"], K=d["K"], baseline=np.float32(d["b"]),
                levels=np.int32(c["levels"]), descriptor=np.bytes_(c["descriptor"]), loss=np.bytes_(c["loss"]))
+    if c.get("formulation", 0):
+        out["formulation"] = np.int32(c["formulation"])
     T_lin = synth.twist_to_matrix([0.003, -0.002, 0.001, 0.01, -0.02, 0.015]).astype(np.float32)
     out["T_lin"] = T_lin
     for l in range(c["levels"]):

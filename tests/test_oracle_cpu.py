@@ -22,6 +22,8 @@ def run_case(binding, g):
     p = make_params(binding, descriptor=g["descriptor"].item().decode(), loss=g["loss"].item().decode(), levels=levels)
     rows, cols = g["imgA"].shape
     ctx = binding.create(g["K"], float(g["baseline"]), rows, cols, p, n_frames=2, n_pairs=1)
+    if "formulation" in g:
+        ctx.set_warp_formulation(int(g["formulation"]))
     ctx.frame_set_data(0, g["imgA"], g["dispA"])
     ctx.frame_set_template(0)
     ctx.frame_set_data(1, g["imgB"], g["dispA"])
@@ -83,7 +85,7 @@ def test_hip_matches_golden(hip, path):
 
 
 def test_golden_fixtures_present():
-    assert len(GOLDEN) >= 3
+    assert len(GOLDEN) >= 4
 
 
 # ------------------------------------------------------------------------------------------- independent cross-checks
