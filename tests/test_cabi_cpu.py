@@ -30,6 +30,35 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert not missing, f"declared in c_api.h but not exported: {missing}"
 
 
+def test_multi_gpu_library_exports_its_header_and_shards_like_the_python_helper():
+    """include/bpvo_hip/multi_gpu.h (libbpvo_hip_mgpu.so: one ctx + host thread per GPU, one RCCL gather): every declared
+    symbol is exported; the pure sharding rule — the only part that runs without a GPU — equals bpvo_amd.distributed's."""
+    import __graft_entry__ as ge
+    from bpvo_amd.distributed import shard_range
+    path = ge.build_mgpu()
+    lib = C.CDLL(path)
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bpvo_hip", "multi_gpu.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(bpvo_hip_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) == 8 and "bpvo_hip_gather_records" in names and "bpvo_hip_node_batch_run" in names
+    assert not [n for n in names if not hasattr(lib, n)]
+    lo, hi = C.c_int(), C.c_int()
+    for n_total, world in ((1024, 8), (1024, 3), (5, 8), (0, 2), (7, 1)):
+        covered = []
+        for rank in range(world):
+            lib.bpvo_hip_shard_range(n_total, rank, world, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == shard_range(n_total, rank, world)
+            covered += list(range(lo.value, hi.value))
+        assert covered == list(range(n_total))
+    # no device here: creating a node fails loudly
+    if not _has_gpu():
+        lib.bpvo_hip_node_last_error.restype = C.c_char_p
+        node = C.c_void_p()
+        K = (C.c_float * 9)(500, 0, 80, 0, 500, 60, 0, 0, 1)
+        p = bpvo_amd.load().default_params()
+        rc = lib.bpvo_hip_node_create(C.byref(node), 1, None, K, C.c_float(0.1), 120, 160, C.byref(p), 2)
+        assert rc != 0 and not node.value and lib.bpvo_hip_node_last_error(None)
+
+
 def test_struct_layouts_match_header():
     src = open(HEADER).read()
     body = re.search(r"typedef struct bpvo_hip_params \{(.*?)\} bpvo_hip_params;", src, re.S).group(1)
