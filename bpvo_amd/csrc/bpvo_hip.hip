@@ -1137,11 +1137,17 @@ int bpvo_hip_get_jacobians(bpvo_hip_ctx* c, int slot, int level, float* J)
 int bpvo_hip_get_normalization(bpvo_hip_ctx* c, int slot, int level, float T[16], float T_inv[16])
 {
   TMPL(c, slot, level);
-  (void) n;
+  M44 t = m44_identity(), ti = m44_identity();
+  // no normalisation was set (withNormalization off, an empty level, or DisparitySpaceWarp, whose setNormalization is a
+  // no-op): the warp keeps the Identity it was constructed with (bpvo/rigid_body_warp.cc:27-28), not [1, -1 * 0]
+  if(!c->params.withNormalization || c->dspace || n == 0) {
+    std::memcpy(T, t.m, 64);
+    std::memcpy(T_inv, ti.m, 64);
+    return BPVO_OK;
+  }
   float nrm[4];
   HIP_CK(c, hipMemcpyAsync(nrm, f.nrm + 4 * level, sizeof(nrm), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
-  M44 t = m44_identity(), ti = m44_identity();
   t.m[0] = t.m[5] = t.m[10] = nrm[0];
   t.m[3] = -nrm[0] * nrm[1]; t.m[7] = -nrm[0] * nrm[2]; t.m[11] = -nrm[0] * nrm[3];
   ti.m[0] = ti.m[5] = ti.m[10] = 1.0f / nrm[0];

@@ -680,43 +680,79 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     if(tid == 0) { j.nrm[0] = 1.0f; j.nrm[1] = 0.0f; j.nrm[2] = 0.0f; j.nrm[3] = 0.0f; }
     return;
   }
-  // Chunks of 1024 points are staged in LDS with coalesced loads; wave 0 then adds them strictly in point order, every
-  // lane reading the same LDS address (a broadcast, no bank conflict) so the result is uniform across the wave.
-  __shared__ float4 s_pts[NRM_CHUNK];
-  __shared__ float s_dist[NRM_CHUNK];
+  // Chunks of 1024 points are staged in LDS with coalesced loads; wave 0 then adds them strictly in point order.  The
+  // dependent f32 adds are the whole cost (26 k points at level 0 of a 1241x376 frame), so (a) lane l of wave 0 keeps the
+  // chain of component l & 3 — one add per point instead of four, (b) the global loads of chunk i + 1 are in flight while
+  // chunk i is being added (registers -> the other LDS buffer afterwards), and (c) in the second pass every thread forms
+  // the distances of chunk i + 1 while wave 0 accumulates those of chunk i.  Same order, same roundings.
+  __shared__ float4 s_pts[2][NRM_CHUNK];
+  __shared__ float s_dist[2][NRM_CHUNK];
   __shared__ float s_c[4];
-  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, c3 = 0.0f;
-  for(int base = 0; base < N; base += NRM_CHUNK) {
-    const int cnt = min(NRM_CHUNK, N - base);
-    __syncthreads();
-    for(int k = tid; k < cnt; k += NRM_THREADS) s_pts[k] = j.pts[base + k];
-    __syncthreads();
-    if(tid < 64) {
-#pragma unroll 8
-      for(int k = 0; k < cnt; ++k) {
-        const float4 p = s_pts[k];
-        c0 += p.x; c1 += p.y; c2 += p.z; c3 += p.w;
-      }
+  constexpr int PER = NRM_CHUNK / NRM_THREADS;     // points per thread and chunk
+  const int nchunks = (N + NRM_CHUNK - 1) / NRM_CHUNK;
+  const int comp = tid & 3;
+  float4 pre[PER];
+  auto fetch = [&](int chunk) {
+    const int base = chunk * NRM_CHUNK;
+#pragma unroll
+    for(int q = 0; q < PER; ++q) {
+      const int k = base + q * NRM_THREADS + tid;
+      pre[q] = (k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+  };
+  fetch(0);
+#pragma unroll
+  for(int q = 0; q < PER; ++q) s_pts[0][q * NRM_THREADS + tid] = pre[q];
+  __syncthreads();
+  float c = 0.0f;
+  for(int ch = 0; ch < nchunks; ++ch) {
+    const int cur = ch & 1;
+    const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
+    if(ch + 1 < nchunks) fetch(ch + 1);
+    if(tid < 64) {
+      const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + comp;
+#pragma unroll 16
+      for(int k = 0; k < cnt; ++k) c += sp[4 * k];
+    }
+    if(ch + 1 < nchunks) {
+#pragma unroll
+      for(int q = 0; q < PER; ++q) s_pts[cur ^ 1][q * NRM_THREADS + tid] = pre[q];
+    }
+    __syncthreads();
   }
   const float fN = (float) N;
-  if(tid == 0) { s_c[0] = c0 / fN; s_c[1] = c1 / fN; s_c[2] = c2 / fN; s_c[3] = c3 / fN; }
+  if(tid < 4) s_c[tid] = c / fN;
   __syncthreads();
-  c0 = s_c[0]; c1 = s_c[1]; c2 = s_c[2]; c3 = s_c[3];
-  float m = 0.0f;
-  for(int base = 0; base < N; base += NRM_CHUNK) {
-    const int cnt = min(NRM_CHUNK, N - base);
-    __syncthreads();
-    for(int k = tid; k < cnt; k += NRM_THREADS) {
-      const float4 p = j.pts[base + k];
+  const float c0 = s_c[0], c1 = s_c[1], c2 = s_c[2], c3 = s_c[3];
+  float dpre[PER];
+  auto dists = [&](int chunk) {
+    const int base = chunk * NRM_CHUNK;
+#pragma unroll
+    for(int q = 0; q < PER; ++q) {
+      const int k = base + q * NRM_THREADS + tid;
+      const float4 p = (k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
-      s_dist[k] = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      dpre[q] = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    }
+  };
+  dists(0);
+#pragma unroll
+  for(int q = 0; q < PER; ++q) s_dist[0][q * NRM_THREADS + tid] = dpre[q];
+  __syncthreads();
+  float m = 0.0f;
+  for(int ch = 0; ch < nchunks; ++ch) {
+    const int cur = ch & 1;
+    const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
+    if(ch + 1 < nchunks) dists(ch + 1);
+    if(tid < 64) {
+#pragma unroll 16
+      for(int k = 0; k < cnt; ++k) m += s_dist[cur][k];
+    }
+    if(ch + 1 < nchunks) {
+#pragma unroll
+      for(int q = 0; q < PER; ++q) s_dist[cur ^ 1][q * NRM_THREADS + tid] = dpre[q];
     }
     __syncthreads();
-    if(tid < 64) {
-#pragma unroll 8
-      for(int k = 0; k < cnt; ++k) m += s_dist[k];
-    }
   }
   if(tid == 0) {
     m /= fN;
