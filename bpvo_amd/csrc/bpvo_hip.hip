@@ -521,7 +521,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // (ActiveSet, kernels.h) whose count the host reads: it is the workspace dimension of the next round's grids, so
     // finished workspaces cost nothing from then on (inside a round their workgroups exit on the first load).
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
-    constexpr int kItersPerSync = 4;
+    // small groups are bound by the host round trip (~30 us per synchronisation against ~35 us per iteration for one pair),
+    // large ones by the tail of workspaces that have already finished: 8 iterations per round for up to 8 pairs, else 4
+    const int kItersPerSync = n <= 8 ? 8 : 4;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
     int* const lists[2] = {ln->d_list, ln->d_list + NP};
     int round = 0, n_active = n;
