@@ -909,6 +909,11 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipMalloc(&f.data_slab, data_total));
     carve_frame_data(cp, f, (unsigned char*) f.data_slab, nullptr);
   }
+  // sequential-VO contexts (up to 3 slots) get their template storage now: allocated on first use it is a ~10 ms hiccup on
+  // the frame that switches keyframes; batch contexts keep it lazy (only every other slot of a pair batch is a template)
+  if(n_frames <= 3)
+    for(auto& f : cp->frames)
+      if(ensure_template_storage(cp, f) != BPVO_OK) return dev_fail(hipErrorOutOfMemory, "template storage");
   cp->ws.resize(n_pairs);
   const size_t nblk_max = (size_t) gn_num_blocks(cp->cap_max);
   for(auto& w : cp->ws) {
