@@ -921,9 +921,9 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
     CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max));
-    if(cp->C == 8) {
+    if(cp->C == 8 || cp->C == 1) {      // tap cache of warp_residual: 4 taps x C floats per point
       CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
-      CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 32 * (size_t) cp->cap_max));
+      CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
     }
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
   }

@@ -142,6 +142,15 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
 {
   const int W = j.cols, R = j.rows;
   const float4 X = load_stream(j.pts + i);
+  // C = 1: the launches are short and latency-bound, so the key, the cached taps and the template pixel are requested
+  // together with the point instead of after the projection (16 speculative bytes per point; for C = 8 the same
+  // speculation costs 128 bytes and was measured slower)
+  unsigned spec_key = 0; float4 spec_taps = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float spec_pix = 0.0f;
+  if constexpr(C == 1) {
+    spec_key = j.tapkey[i];
+    spec_taps = load_stream(reinterpret_cast<const float4*>(j.tapcache) + i);
+    spec_pix = j.pix[i];
+  }
   int xi = 0, yi = 0;
   bool valid;
   double xf = 0.0, yf = 0.0;       // fractional parts (standard formulation)
@@ -269,6 +278,18 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       I10[0] = b0.x; I10[1] = b0.y; I10[2] = b0.z; I10[3] = b0.w; I10[4] = b1.x; I10[5] = b1.y; I10[6] = b1.z; I10[7] = b1.w;
       I11[0] = b2.x; I11[1] = b2.y; I11[2] = b2.z; I11[3] = b2.w; I11[4] = b3.x; I11[5] = b3.y; I11[6] = b3.z; I11[7] = b3.w;
       I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
+    } else if constexpr(C == 1) {
+      // the same tap cache for single-channel descriptors: the four taps of a point are one 16-byte record.  The gather
+      // costs two (mostly distinct) HBM lines per point at the sparse levels for 16 useful bytes; a hit is one coalesced load.
+      const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+      float4* tc = reinterpret_cast<float4*>(j.tapcache);
+      float4 t = spec_taps;
+      if(spec_key != key) {
+        t = make_float4(d0[0], d0[1], d1[0], d1[1]);
+        if(in_block) { store_stream(tc + i, t); j.tapkey[i] = key; }
+      }
+      I00[0] = t.x; I01[0] = t.y; I10[0] = t.z; I11[0] = t.w;
+      I0[0] = spec_pix;
     } else {
 #pragma unroll
       for(int c = 0; c < C; ++c) {
@@ -1354,7 +1375,7 @@ void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int leve
 }
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
 {
-  if(g.max_points <= 0 || g.C != 8) return;
+  if(g.max_points <= 0 || (g.C != 8 && g.C != 1)) return;
   hipLaunchKernelGGL(reset_tapkeys_kernel, dim3((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs), dim3(GN_BLOCK), 0, s, g.jobs);
 }
 void launch_warp_residual(hipStream_t s, const GNLaunch& g)

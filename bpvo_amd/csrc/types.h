@@ -144,8 +144,8 @@ struct PairJob {
   // workspace
   float*        r;        // [N][C] residuals, tiled
   uint8_t*      valid;    // [N]
-  uint32_t*     tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 only)
-  float*        tapcache; // [N][32] tiled: the 4 taps x 8 channels of the footprint last gathered for the point
+  uint32_t*     tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 and C = 1)
+  float*        tapcache; // C = 8: [N][32] tiled, the 4 taps x 8 channels of the footprint last gathered for the point; C = 1: [N] float4
   uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, -} of the bracket pass
   float*        partials; // [nblocks][kPartialStride]
