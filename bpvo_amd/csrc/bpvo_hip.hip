@@ -92,7 +92,13 @@ struct Lane {
   unsigned k6_seq = 0;             // warp_residual launches of this lane since bpvo_hip_profiling (event sampling)
   std::string err;
 };
-constexpr int kDefaultLanes = 1;   // BPVO_HIP_LANES=2 gains ~5 % on 128-pair batches but makes per-launch timings overlap
+// Estimation lanes (streams driven by host threads) of a batch.  8-channel descriptors: 1 — a second lane gains 3.5 % at 1024
+// pairs but makes the per-launch timings of the two lanes overlap, and the roofline of warp_residual<8> is quoted per
+// launch.  Narrower descriptors: 2 — their launches are short, the one-workgroup-per-pair kernels (median_finish, gn_step)
+// are a third of an iteration, and a second lane hides them behind the other lane's wide kernels (+7 % at 1024 pairs of
+// 640x480 intensity).  BPVO_HIP_LANES overrides either.  Results do not depend on the number of lanes (test_gpu_parity.py).
+constexpr int kDefaultLanes = 1;
+constexpr int kDefaultLanesNarrow = 2;
 constexpr int kMinPairsPerLane = 8;
 
 }  // namespace
@@ -932,7 +938,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
   {
-    int max_lanes = kDefaultLanes;
+    int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));

@@ -280,6 +280,26 @@ def test_unsupported_and_invalid_create(hip):
     assert ctx.L == 1 + round(np.log2(480 / 40.0))      # auto pyramid levels (bpvo/vo.cc:101-105)
 
 
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
+def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
+    """BPVO_HIP_LANES (read by bpvo_hip_create): a batch split over 2 or 3 estimation streams driven by host threads gives,
+    pair for pair, the bits of the single-lane run — the lanes only change what overlaps in time."""
+    import os
+    rows, cols, levels, n = 120, 160, 3, 40
+    batch = synth.make_batch(rows, cols, n, first_index=60, workers=1)
+    out = {}
+    for lanes in (1, 2, 3):
+        monkeypatch.setenv("BPVO_HIP_LANES", str(lanes))
+        ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels),
+                         n_frames=2 * n, n_pairs=n)
+        out[lanes] = ctx.batch_run(batch["images"], batch["disparities"])
+        ctx.close()
+    for lanes in (2, 3):
+        assert bits_equal(out[lanes][0], out[1][0]), lanes
+        assert np.array_equal(out[lanes][1]["numIterations"], out[1][1]["numIterations"])
+        assert np.array_equal(out[lanes][1]["status"], out[1][1]["status"])
+
+
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
