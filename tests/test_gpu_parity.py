@@ -300,30 +300,6 @@ def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
         assert np.array_equal(out[lanes][1]["status"], out[1][1]["status"])
 
 
-def test_full_size_batch_properties(hip):
-    """Size-independent properties at the full size of BASELINE.json's configs 4 / 5 (1241x376 bit-planes, 4 levels, Tukey),
-    where the oracle is too slow to check many pairs: a batch is deterministic (same bits when run again), invariant under a
-    permutation of its pairs (pair p's result does not depend on which workspace / slots it lands in or on who else is in
-    the batch), equal to the pair run alone on a single-pair context, and close to the ground-truth motion."""
-    rows, cols, levels, n = 376, 1241, 4, 6
-    b = synth.make_batch(rows, cols, n, first_index=1000, workers=1)
-    p = make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels)
-    ctx = hip.create(b["K"], b["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
-    poses, stats = ctx.batch_run(b["images"], b["disparities"])
-    again, stats2 = ctx.batch_run(b["images"], b["disparities"])
-    assert bits_equal(poses, again) and np.array_equal(stats["numIterations"], stats2["numIterations"])
-    perm = np.array([4, 2, 5, 0, 3, 1])
-    idx = np.stack([2 * perm, 2 * perm + 1], axis=1).ravel()
-    pp, ps = ctx.batch_run(b["images"][idx], b["disparities"][idx])
-    assert bits_equal(pp, poses[perm]) and np.array_equal(ps["numIterations"], stats["numIterations"][perm])
-    one = hip.create(b["K"], b["b"], rows, cols, p, n_frames=2, n_pairs=1)
-    for k in (0, n - 1):
-        p1, s1 = one.batch_run(b["images"][2 * k: 2 * k + 2], b["disparities"][2 * k: 2 * k + 2])
-        assert bits_equal(p1[0], poses[k]) and np.array_equal(s1["numIterations"][0], stats["numIterations"][k])
-    dt = np.linalg.norm(poses[:, :3, 3] - b["T_gt"][:, :3, 3], axis=1)
-    assert dt.max() < 5e-2, dt
-
-
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
