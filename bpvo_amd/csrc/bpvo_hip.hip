@@ -111,10 +111,10 @@ struct bpvo_hip_ctx {
   int n_frames, n_pairs;
   LevelGeom geom[kMaxLevels];
   float gauss_k[3];
-  float df_k1[3], df_k2[3];   // 5-tap Gaussians of dfSigma1 / dfSigma2 (descriptor fields)
-  float cd_k_after[3];        // 5-tap Gaussian of centralDifferenceSigmaAfter
-  int cd_taps_before[3] = {0, 0, 0};   // fixed-point taps of the u8 5x5 blur (centralDifferenceSigmaBefore > 0)
-  bool plane_scratch = false; // descriptor built from plane operations (descriptor fields, central difference)
+  GaussTaps df_g1, df_g2;       // imsmooth kernels of dfSigma1 / dfSigma2 (descriptor fields); n = 0: sigma <= 0
+  GaussTaps cd_before, cd_after; // imsmooth kernels of centralDifferenceSigmaBefore (u8 fixed point) / After (f32)
+  GaussTaps grad_pre;           // cv::GaussianBlur(Size(), sigma) of GradientDescriptor (sigmaPriorToCensusTransform > 0)
+  bool plane_scratch = false; // descriptor built from plane operations (descriptor fields, central difference, smoothed gradient)
   hipStream_t stream = nullptr;
   std::vector<FrameSlot> frames;
   std::vector<Workspace> ws;
@@ -201,6 +201,30 @@ void gaussian_kernel5(double sigma, float k[3])
   for(int i = 0; i < 5; ++i) kk[i] = (float) (kk[i] * sum);
   k[0] = kk[2]; k[1] = kk[3]; k[2] = kk[4];
 }
+
+// cv::getGaussianKernel(n, sigma, CV_32F) for sigma > 0 and the 8-bit fixed-point taps cvRound(k * 256) of the u8 filters
+void gaussian_taps(int n, double sigma, GaussTaps* g)
+{
+  *g = GaussTaps();
+  if(!(sigma > 0) || n <= 0 || n > kMaxGaussTaps) return;
+  g->n = n;
+  const double scale2X = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for(int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    g->k[i] = (float) std::exp(scale2X * x * x);
+    sum += g->k[i];
+  }
+  sum = 1. / sum;
+  for(int i = 0; i < n; ++i) {
+    g->k[i] = (float) (g->k[i] * sum);
+    g->ki[i] = (int) std::nearbyint((double) g->k[i] * 256.0);
+  }
+}
+// imsmooth (bpvo/imgproc.cc:166-171): max(5, 2 * round(sigma) + 1) taps
+int imsmooth_taps(float sigma) { return std::max(5, 2 * (int) std::round((double) sigma) + 1); }
+// cv::GaussianBlur(Size(), sigma) on a CV_32F image (OpenCV 2.4 createGaussianFilter): cvRound(sigma * 4 * 2 + 1) | 1
+int auto_gauss_taps_f32(float sigma) { return ((int) std::nearbyint((double) sigma * 8.0 + 1.0)) | 1; }
 
 void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t* total)
 {
@@ -394,13 +418,11 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
       const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
       if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
-        launch_central_difference(c->stream, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius,
-                                  c->params.centralDifferenceSigmaBefore > 0.0f ? c->cd_taps_before : nullptr,
-                                  c->params.centralDifferenceSigmaAfter > 0.0f ? c->cd_k_after : nullptr);
+        launch_central_difference(c->stream, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius, c->cd_before, c->cd_after);
       } else if(c->C == 5 || c->C == 10) {
-        launch_descriptor_fields(c->stream, jobs, g.cols, g.rows, count, c->C == 10, c->params.dfSigma1, c->df_k1, c->params.dfSigma2, c->df_k2);
+        launch_descriptor_fields(c->stream, jobs, g.cols, g.rows, count, c->C == 10, c->df_g1, c->df_g2);
       } else if(c->C == 3) {
-        launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count);
+        launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count, c->grad_pre);
       } else if(c->C == 1) {
         if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
         else launch_intensity(c->stream, jobs, g.cols, g.rows, count);
@@ -822,20 +844,22 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
      c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.descriptor != BPVO_DESC_CENTRAL_DIFFERENCE && !desc_fields)
     return unsupported("descriptor: every DenseDescriptor of the reference but LATCH is on the device path");
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
-    auto taps = [](float sg) { return std::max(5, 2 * (int) std::round((double) sg) + 1); };
     if(c->params.centralDifferenceRadius <= 0) { g_create_error = "invalid radius"; return BPVO_ERR_INVALID_ARG; }   // central_difference_descriptor.cc:19
     if(c->params.centralDifferenceRadius > 3) return unsupported("centralDifferenceRadius: 1, 2 and 3 (8, 24 and 48 channels) are on the device path");
-    if((c->params.centralDifferenceSigmaBefore > 0.0f && taps(c->params.centralDifferenceSigmaBefore) != 5) ||
-       (c->params.centralDifferenceSigmaAfter > 0.0f && taps(c->params.centralDifferenceSigmaAfter) != 5))
-      return unsupported("centralDifferenceSigmaBefore / After >= 2.5 (imsmooth kernels larger than 5 x 5) are not on the device path");
+    if((c->params.centralDifferenceSigmaBefore > 0.0f && imsmooth_taps(c->params.centralDifferenceSigmaBefore) > kMaxGaussTaps) ||
+       (c->params.centralDifferenceSigmaAfter > 0.0f && imsmooth_taps(c->params.centralDifferenceSigmaAfter) > kMaxGaussTaps))
+      return unsupported("centralDifferenceSigmaBefore / After: imsmooth kernels of up to 31 taps (sigma < 15.5) are on the device path");
   }
   if(desc_fields) {   // imsmooth (bpvo/imgproc.cc:166-171): max(5, 2*round(sigma)+1) taps
-    auto taps = [](float sg) { return std::max(5, 2 * (int) std::round((double) sg) + 1); };
-    if((c->params.dfSigma1 > 0.0f && taps(c->params.dfSigma1) != 5) || (c->params.dfSigma2 > 0.0f && taps(c->params.dfSigma2) != 5))
-      return unsupported("dfSigma1 / dfSigma2 >= 2.5 (imsmooth kernels larger than 5 x 5) are not on the device path");
+    if((c->params.dfSigma1 > 0.0f && imsmooth_taps(c->params.dfSigma1) > kMaxGaussTaps) ||
+       (c->params.dfSigma2 > 0.0f && imsmooth_taps(c->params.dfSigma2) > kMaxGaussTaps))
+      return unsupported("dfSigma1 / dfSigma2: imsmooth kernels of up to 31 taps (sigma < 15.5) are on the device path");
   }
-  if(c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f)
-    return unsupported("IntensityAndGradient with sigmaPriorToCensusTransform > 0 (cv::GaussianBlur with an automatic kernel size) is not on the device path");
+  if(c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f) {
+    const int k = auto_gauss_taps_f32(c->params.sigmaPriorToCensusTransform);   // cv::GaussianBlur(Size(), sigma): automatic kernel size
+    if(k < 5 || k > kMaxGaussTaps)
+      return unsupported("IntensityAndGradient: pre-smoothing kernels of 5 to 31 taps (0.44 <= sigmaPriorToCensusTransform <= 3.8) are on the device path");
+  }
   if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3)
     return unsupported("laplacianKernelSize: 1 and 3 are on the device path (larger sizes are Sobel-based in OpenCV)");
   if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
@@ -850,16 +874,18 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     case BPVO_DESC_CENTRAL_DIFFERENCE: c->C = (2 * c->params.centralDifferenceRadius + 1) * (2 * c->params.centralDifferenceRadius + 1) - 1; break;
     default: c->C = 1; break;
   }
-  c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE;
-  gaussian_kernel5(c->params.centralDifferenceSigmaAfter, c->cd_k_after);
-  if(c->params.centralDifferenceSigmaBefore > 0.0f) {   // cv::getGaussianKernel(5, sigma) in f32, then cvRound(k * 256)
-    float kk[3];
-    gaussian_kernel5(c->params.centralDifferenceSigmaBefore, kk);
-    for(int i = 0; i < 3; ++i) c->cd_taps_before[i] = (int) std::nearbyint((double) kk[i] * 256.0);
+  const bool grad_smoothed = c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f;
+  c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE || grad_smoothed;
+  if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
+    gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaBefore), c->params.centralDifferenceSigmaBefore, &c->cd_before);
+    gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaAfter), c->params.centralDifferenceSigmaAfter, &c->cd_after);
   }
+  if(desc_fields) {
+    gaussian_taps(imsmooth_taps(c->params.dfSigma1), c->params.dfSigma1, &c->df_g1);
+    gaussian_taps(imsmooth_taps(c->params.dfSigma2), c->params.dfSigma2, &c->df_g2);
+  }
+  if(grad_smoothed) gaussian_taps(auto_gauss_taps_f32(c->params.sigmaPriorToCensusTransform), c->params.sigmaPriorToCensusTransform, &c->grad_pre);
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
-  gaussian_kernel5(c->params.dfSigma1, c->df_k1);
-  gaussian_kernel5(c->params.dfSigma2, c->df_k2);
   if(c->params.sigmaPriorToCensusTransform > 0.0f) {   // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
     const double sg = c->params.sigmaPriorToCensusTransform, scale2X = -0.5 / (sg * sg);
     float kk[3];

@@ -25,15 +25,21 @@ static inline void dispatch_channels(int C, F&& f)
 
 namespace bpvo_hip {
 
+// A Gaussian smoothing kernel of cv::GaussianBlur as the descriptors use it: n taps (odd; 0 = no smoothing), k the f32 taps
+// of cv::getGaussianKernel, ki their 8-bit fixed-point form cvRound(k * 256) for u8 images.  n = 5 runs the small-kernel
+// forms of OpenCV's filter engine, n >= 7 the generic ones (kernels_frame.hip, df_plane_kernel).
+constexpr int kMaxGaussTaps = 31;
+struct GaussTaps { int n = 0; float k[kMaxGaussTaps] = {}; int ki[kMaxGaussTaps] = {}; };
+
 // per-frame stage (batched over frames)
 void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes);
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
-void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);   // (I, Ix, Iy), C = 3
-void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, float sigma1,
-                              const float k1[3], float sigma2, const float k2[3]);   // C = 5 / 10
-void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const int* taps_before,
-                               const float* k_after);   // C = 8 / 24 / 48
+void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre);   // (I, Ix, Iy), C = 3
+void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, const GaussTaps& g1,
+                              const GaussTaps& g2);   // C = 5 / 10
+void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const GaussTaps& before,
+                               const GaussTaps& after);   // C = 8 / 24 / 48
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);

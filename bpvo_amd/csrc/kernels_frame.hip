@@ -19,6 +19,14 @@ __device__ __forceinline__ int reflect101(int p, int len)
   return p;
 }
 
+// the same for halos that may exceed the image (wide smoothing kernels on the coarsest levels): reflect until inside
+__device__ __forceinline__ int reflect101_wide(int p, int len)
+{
+  if(len == 1) return 0;
+  while(p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+  return p;
+}
+
 // ---- input ingest: one launch copies the u8 image and f32 disparity of every frame of a batch from a packed device
 // buffer ([frame][rows*cols]) into the frame slots (VisualOdometryFrame::setData's image.copyTo / disparity.copyTo,
 // reference: bpvo/vo_frame.cc:50-51) instead of 2 memcpy calls per frame.
@@ -137,7 +145,8 @@ __global__ __launch_bounds__(256) void gradient_descriptor_kernel(const FrameJob
 // -- convertTo, imsmooth (5 x 5 f32 Gaussian, bpvo/imgproc.cc:166-171), xgradient / ygradient (bpvo/imgproc.h:214-265),
 // splitPosNeg (gradient_descriptor.cc:80-98) -- each one launch of this kernel.  A plane code >= 0 is a work plane of
 // FrameJob::scratch, a code < 0 is descriptor channel -1-code of the interleaved [npix][C] records.
-enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT, DF_U8_ROW, DF_U8_COL, DF_SHIFT_DIFF, DF_TO_CH0 };
+enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT, DF_U8_ROW, DF_U8_COL, DF_SHIFT_DIFF, DF_TO_CH0,
+       DF_GAUSS_ROW_N, DF_GAUSS_COL_N, DF_U8_ROW_N, DF_U8_COL_N };
 struct PlaneRef { float* p; int stride; };
 __device__ __forceinline__ PlaneRef df_plane(const FrameJob& j, int code, int C)
 {
@@ -148,8 +157,11 @@ __device__ __forceinline__ PlaneRef df_plane(const FrameJob& j, int code, int C)
 // image (DF_U8_ROW keeps the int row sums as bit patterns in a work plane, DF_U8_COL rounds them to the u8 value, held as
 // float), the image minus its clamped shift by (i0, i1) (DF_SHIFT_DIFF), and the copy of channel 0 into the compact
 // FrameJob::ch0 plane that the C = 8 kernels expect (DF_TO_CH0).
+// Kernels wider than 5 taps (imsmooth with sigma >= 2.5, the automatic size of GradientDescriptor's pre-smoothing) take
+// the generic forms of OpenCV 2.4's filter engine: DF_GAUSS_ROW_N s = k[0]*S[x-r]; s += k[j]*S[x-r+j] (RowFilter, left to
+// right), DF_GAUSS_COL_N s = k[r]*S0; s += k[r+j]*(S[+j] + S[-j]) (SymmColumnFilter); DF_U8_*_N the 8-bit fixed-point pair.
 __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int op, int src_code, int dst_code, int dst2_code, int C,
-                                                       float k0, float k1, float k2, int i0, int i1, int i2)
+                                                       float k0, float k1, float k2, int i0, int i1, int i2, GaussTaps gt)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
@@ -194,6 +206,34 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
     case DF_SHIFT_DIFF:
       v = at(y, x) - at(min(max(y + i1, 0), R - 1), min(max(x + i0, 0), W - 1));
       break;
+    case DF_GAUSS_ROW_N: {
+      const int r = gt.n >> 1;
+      v = gt.k[0] * at(y, reflect101_wide(x - r, W));
+      for(int t = 1; t < gt.n; ++t) v += gt.k[t] * at(y, reflect101_wide(x - r + t, W));
+      break;
+    }
+    case DF_GAUSS_COL_N: {
+      const int r = gt.n >> 1;
+      v = gt.k[r] * at(y, x);
+      for(int t = 1; t <= r; ++t) v += gt.k[r + t] * (at(reflect101_wide(y + t, R), x) + at(reflect101_wide(y - t, R), x));
+      break;
+    }
+    case DF_U8_ROW_N: {
+      const uint8_t* row = j.img + (size_t) y * W;
+      const int r = gt.n >> 1;
+      int t = 0;
+      for(int q = 0; q < gt.n; ++q) t += gt.ki[q] * row[reflect101_wide(x - r + q, W)];
+      v = __int_as_float(t);
+      break;
+    }
+    case DF_U8_COL_N: {
+      const int r = gt.n >> 1;
+      int t = 0;
+      for(int q = 0; q < gt.n; ++q) t += gt.ki[q] * __float_as_int(at(reflect101_wide(y - r + q, R), x));
+      t = (t + (1 << 15)) >> 16;
+      v = (float) min(255, max(0, t));
+      break;
+    }
     case DF_TO_CH0:
       j.ch0[q] = at(y, x);
       return;
@@ -905,28 +945,58 @@ void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
 {
   hipLaunchKernelGGL(laplacian_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs, ksize);
 }
-void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+// smoothing of a work plane / channel with either form of the kernel (5 taps: the small-kernel ops, wider: the generic ones)
+template <class Op>
+static void df_smooth(Op&& op, int src, int tmp, int dst, const GaussTaps& g)
 {
-  hipLaunchKernelGGL(gradient_descriptor_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+  if(g.n == 5) {
+    const float k[3] = {g.k[2], g.k[3], g.k[4]};
+    op(DF_GAUSS_ROW, src, tmp, k, nullptr);
+    op(DF_GAUSS_COL, tmp, dst, k, nullptr);
+  } else {
+    op(DF_GAUSS_ROW_N, src, tmp, nullptr, &g);
+    op(DF_GAUSS_COL_N, tmp, dst, nullptr, &g);
+  }
 }
-// one level of DescriptorFields (second_order = 0: 5 channels) or DescriptorFields2ndOrder (10 channels); k1 / k2 are the 5-tap
-// kernels (centre, +-1, +-2) of sigma1 / sigma2, used when the sigma is > 0
-void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, float sigma1,
-                              const float k1[3], float sigma2, const float k2[3])
+void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre)
+{
+  if(pre.n == 0) {
+    hipLaunchKernelGGL(gradient_descriptor_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
+    return;
+  }
+  // GradientDescriptor::compute with sigma > 0 (bpvo/gradient_descriptor.cc:42-63): channel 0 keeps the unsmoothed
+  // intensities, the gradients are taken of cv::GaussianBlur(I, Size(), sigma)
+  const dim3 grid = grid2d(W, R, nframes);
+  auto op = [&](int o, int src, int dst, const float* k, const GaussTaps* g) {
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, 3, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0,
+                       g ? *g : GaussTaps());
+  };
+  enum { P_S = 0, P_TMP = 1 };
+  op(DF_CONVERT, 0, -1, nullptr, nullptr);
+  df_smooth(op, -1, P_TMP, P_S, pre);
+  op(DF_GRAD_X, P_S, -2, nullptr, nullptr);
+  op(DF_GRAD_Y, P_S, -3, nullptr, nullptr);
+}
+// one level of DescriptorFields (second_order = 0: 5 channels) or DescriptorFields2ndOrder (10 channels); g1 / g2 are the
+// imsmooth kernels of sigma1 / sigma2 (n = 0: sigma <= 0, no smoothing)
+void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, const GaussTaps& g1,
+                              const GaussTaps& g2)
 {
   const int C = second_order ? 10 : 5;
   const dim3 grid = grid2d(W, R, nframes);
-  auto op = [&](int o, int src, int dst, int dst2 = 0, const float* k = nullptr) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0);
+  auto op5 = [&](int o, int src, int dst, const float* k, const GaussTaps* g, int dst2 = 0) {
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0,
+                       g ? *g : GaussTaps());
   };
+  auto op = [&](int o, int src, int dst, int dst2 = 0) { op5(o, src, dst, nullptr, nullptr, dst2); };
   auto ch = [](int c) { return -1 - c; };
   enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6 };
-  auto smooth = [&](int src, int dst, const float* k) { op(DF_GAUSS_ROW, src, P_TMP, 0, k); op(DF_GAUSS_COL, P_TMP, dst, 0, k); };
+  auto smooth = [&](int src, int dst, const GaussTaps& g) { df_smooth(op5, src, P_TMP, dst, g); };
   auto split = [&](int src, int cpos, int cneg) {
-    if(sigma2 > 0.0f) {
+    if(g2.n > 0) {
       op(DF_SPLIT, src, P_POS, P_NEG);
-      smooth(P_POS, ch(cpos), k2);
-      smooth(P_NEG, ch(cneg), k2);
+      smooth(P_POS, ch(cpos), g2);
+      smooth(P_NEG, ch(cneg), g2);
     } else {
       op(DF_SPLIT, src, ch(cpos), ch(cneg));
     }
@@ -934,7 +1004,7 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
   const int I0 = second_order ? P_I0 : ch(0);     // first order keeps the unsmoothed intensities as channel 0
   op(DF_CONVERT, 0, I0);
   int I = I0;
-  if(sigma1 > 0.0f) { smooth(I0, P_I, k1); I = P_I; }
+  if(g1.n > 0) { smooth(I0, P_I, g1); I = P_I; }
   if(!second_order) {
     op(DF_GRAD_X, I, P_B1); split(P_B1, 1, 2);
     op(DF_GRAD_Y, I, P_B1); split(P_B1, 3, 4);
@@ -946,37 +1016,41 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
     op(DF_GRAD_Y, P_B1, P_B2); split(P_B2, 8, 9);   // Iyy
   }
 }
-// one level of CentralDifferenceDescriptor: C = (2r+1)^2 - 1 channels; taps_before = the u8 blur's fixed-point taps (centre, +-1,
-// +-2) or nullptr, k_after = the f32 5-tap kernel of sigma_after or nullptr
-void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const int* taps_before,
-                               const float* k_after)
+// one level of CentralDifferenceDescriptor: C = (2r+1)^2 - 1 channels; before = the u8 blur of sigma_before (fixed-point taps),
+// after = the f32 kernel of sigma_after (n = 0: not applied)
+void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const GaussTaps& before,
+                               const GaussTaps& after)
 {
   const int C = (2 * radius + 1) * (2 * radius + 1) - 1;
   const dim3 grid = grid2d(W, R, nframes);
-  auto op = [&](int o, int src, int dst, const float* k = nullptr, int i0 = 0, int i1 = 0, int i2 = 0) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, i0, i1, i2);
+  auto opi = [&](int o, int src, int dst, const float* k, const GaussTaps* g, int i0 = 0, int i1 = 0, int i2 = 0) {
+    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, i0, i1, i2,
+                       g ? *g : GaussTaps());
   };
+  auto op5 = [&](int o, int src, int dst, const float* k, const GaussTaps* g) { opi(o, src, dst, k, g); };
   enum { P_IMG = 0, P_DIFF = 1, P_TMP = 2 };
-  if(taps_before) {
-    op(DF_U8_ROW, 0, P_TMP, nullptr, taps_before[0], taps_before[1], taps_before[2]);
-    op(DF_U8_COL, P_TMP, P_IMG, nullptr, taps_before[0], taps_before[1], taps_before[2]);
+  if(before.n == 5) {
+    opi(DF_U8_ROW, 0, P_TMP, nullptr, nullptr, before.ki[2], before.ki[3], before.ki[4]);
+    opi(DF_U8_COL, P_TMP, P_IMG, nullptr, nullptr, before.ki[2], before.ki[3], before.ki[4]);
+  } else if(before.n > 5) {
+    opi(DF_U8_ROW_N, 0, P_TMP, nullptr, &before);
+    opi(DF_U8_COL_N, P_TMP, P_IMG, nullptr, &before);
   } else {
-    op(DF_CONVERT, 0, P_IMG);
+    opi(DF_CONVERT, 0, P_IMG, nullptr, nullptr);
   }
   int c = 0;
   for(int oy = -radius; oy <= radius; ++oy)
     for(int ox = -radius; ox <= radius; ++ox) {
       if(ox == 0 && oy == 0) continue;
-      if(k_after) {
-        op(DF_SHIFT_DIFF, P_IMG, P_DIFF, nullptr, ox, oy);
-        op(DF_GAUSS_ROW, P_DIFF, P_TMP, k_after);
-        op(DF_GAUSS_COL, P_TMP, -1 - c, k_after);
+      if(after.n > 0) {
+        opi(DF_SHIFT_DIFF, P_IMG, P_DIFF, nullptr, nullptr, ox, oy);
+        df_smooth(op5, P_DIFF, P_TMP, -1 - c, after);
       } else {
-        op(DF_SHIFT_DIFF, P_IMG, -1 - c, nullptr, ox, oy);
+        opi(DF_SHIFT_DIFF, P_IMG, -1 - c, nullptr, nullptr, ox, oy);
       }
       ++c;
     }
-  if(C == 8) op(DF_TO_CH0, -1, 0);
+  if(C == 8) opi(DF_TO_CH0, -1, 0, nullptr, nullptr);
 }
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {

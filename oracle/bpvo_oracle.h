@@ -86,6 +86,10 @@ int bpvo_orc_total_linearizations(bpvo_orc_ctx* ctx, uint64_t* n);
 int bpvo_orc_pyrdown_u8(const uint8_t* src, int rows, int cols, uint8_t* dst /* ((rows+1)/2)*((cols+1)/2) */);
 int bpvo_orc_census(const uint8_t* src, int rows, int cols, float sigma_ct, uint8_t* dst);
 int bpvo_orc_gaussian5x5_f32(const float* src, int rows, int cols, float sigma, float* dst);
+int bpvo_orc_gaussian_f32(const float* src, int rows, int cols, int ksize, float sigma, float* dst);     /* ksize 5 or 7..31 */
+int bpvo_orc_gaussian_u8(const uint8_t* src, int rows, int cols, int ksize, float sigma, uint8_t* dst);   /* 8-bit fixed point */
+int bpvo_orc_imsmooth_taps(float sigma);            /* bpvo/imgproc.cc:168 */
+int bpvo_orc_auto_gauss_taps_f32(float sigma);      /* cv::GaussianBlur(Size(), sigma) on CV_32F */
 float bpvo_orc_median(const float* data, size_t n);            /* bpvo/utils.h:224-252 on a copy */
 int bpvo_orc_solve(const float H[36], const float G[6], float dp[6]);   /* returns 1 if solved */
 void bpvo_orc_twist_to_matrix(const float p[6], float T[16]);

@@ -405,6 +405,18 @@ int bpvo_orc_pyrdown_u8(const uint8_t* src, int rows, int cols, uint8_t* dst)
 }
 int bpvo_orc_census(const uint8_t* src, int rows, int cols, float sigma_ct, uint8_t* dst)
 { census(src, rows, cols, sigma_ct, dst); return 0; }
+int bpvo_orc_gaussian_f32(const float* src, int rows, int cols, int ksize, float sigma, float* dst)
+{
+  try { gaussianBlurF32(src, rows, cols, ksize, sigma, dst); } catch(const std::exception&) { return -1; }
+  return 0;
+}
+int bpvo_orc_gaussian_u8(const uint8_t* src, int rows, int cols, int ksize, float sigma, uint8_t* dst)
+{
+  try { gaussianBlurU8(src, rows, cols, ksize, sigma, dst); } catch(const std::exception&) { return -1; }
+  return 0;
+}
+int bpvo_orc_imsmooth_taps(float sigma) { return imsmoothTaps(sigma); }
+int bpvo_orc_auto_gauss_taps_f32(float sigma) { return autoGaussTapsF32(sigma); }
 int bpvo_orc_gaussian5x5_f32(const float* src, int rows, int cols, float sigma, float* dst)
 { gaussianBlurF32_5x5(src, rows, cols, sigma, dst); return 0; }
 float bpvo_orc_median(const float* data, size_t n)

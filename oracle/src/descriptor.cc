@@ -71,12 +71,19 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
   if(p.descriptor == kIntensityAndGradient) {
     // GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): channel 0 = intensities (convertTo), channels 1 / 2 =
     // xgradient / ygradient (bpvo/imgproc.h:214-265) of the intensities — smoothed first with cv::GaussianBlur(Size(), s, s)
-    // only when s = sigmaPriorToCensusTransform > 0, which is not restated (automatic kernel size, [ext]).
-    if(p.sigmaPriorToCensusTransform > 0.0f) throw std::runtime_error("oracle: GradientDescriptor with sigma > 0 is not restated");
+    // when s = sigmaPriorToCensusTransform > 0 (the factory hands that parameter over, bpvo/dense_descriptor.cc:47-50); the
+    // kernel size is OpenCV's automatic one for CV_32F, restated for 5 taps and more (s >= 0.44).  Channel 0 stays unsmoothed.
     d.ch.assign(3, std::vector<float>(n));
     for(size_t i = 0; i < n; ++i) d.ch[0][i] = (float) img[i];
     const float S = 0.5f;                                         // imgradient_scale<float>() (bpvo/imgproc.h:205-209)
-    const float* I = d.ch[0].data();
+    std::vector<float> smoothed;
+    if(p.sigmaPriorToCensusTransform > 0.0f) {
+      const int k = autoGaussTapsF32(p.sigmaPriorToCensusTransform);
+      if(k < 5 || k > kMaxGaussTaps) throw std::runtime_error("oracle: GradientDescriptor sigma outside the restated kernel sizes");
+      smoothed.resize(n);
+      gaussianBlurF32(d.ch[0].data(), rows, cols, k, p.sigmaPriorToCensusTransform, smoothed.data());
+    }
+    const float* I = smoothed.empty() ? d.ch[0].data() : smoothed.data();
     for(int y = 0; y < rows; ++y)
       for(int x = 0; x < cols; ++x) {
         const size_t q = (size_t) y * cols + x;
@@ -113,11 +120,10 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
     // DescriptorFields::compute / DescriptorFields2ndOrder::compute (bpvo/gradient_descriptor.cc:100-160).
     // imsmooth (bpvo/imgproc.cc:166-171): cv::GaussianBlur with k = max(5, 2*round(sigma)+1) taps -> 5 x 5 for sigma < 2.5,
     // the f32 5 x 5 blur restated in imgproc.cc (larger kernels are not restated).
-    auto ksize = [](float s) { return std::max(5, 2 * (int) std::round((double) s) + 1); };
-    if((p.dfSigma1 > 0.0f && ksize(p.dfSigma1) != 5) || (p.dfSigma2 > 0.0f && ksize(p.dfSigma2) != 5))
-      throw std::runtime_error("oracle: imsmooth kernels larger than 5 x 5 are not restated");
+    if((p.dfSigma1 > 0.0f && imsmoothTaps(p.dfSigma1) > kMaxGaussTaps) || (p.dfSigma2 > 0.0f && imsmoothTaps(p.dfSigma2) > kMaxGaussTaps))
+      throw std::runtime_error("oracle: imsmooth kernels wider than 31 taps are not restated");
     typedef std::vector<float> Plane;
-    auto smooth = [&](const Plane& src, float sigma) { Plane o(n); gaussianBlurF32_5x5(src.data(), rows, cols, sigma, o.data()); return o; };
+    auto smooth = [&](const Plane& src, float sigma) { Plane o(n); gaussianBlurF32(src.data(), rows, cols, imsmoothTaps(sigma), sigma, o.data()); return o; };
     const float S = 0.5f;                                         // imgradient_scale<float>() (bpvo/imgproc.h:205-209)
     auto xgrad = [&](const Plane& I, Plane& o) {                  // bpvo/imgproc.h:214-238
       o.resize(n);
@@ -169,12 +175,12 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
     // inner, clamped at the borders, :52-69), each channel imsmooth'ed when sigma_after > 0 (:71-72).
     const int R = p.centralDifferenceRadius;
     if(R <= 0) throw std::runtime_error("invalid radius");       // :19
-    auto ksize = [](float s) { return std::max(5, 2 * (int) std::round((double) s) + 1); };
-    if((p.centralDifferenceSigmaBefore > 0.0f && ksize(p.centralDifferenceSigmaBefore) != 5) ||
-       (p.centralDifferenceSigmaAfter > 0.0f && ksize(p.centralDifferenceSigmaAfter) != 5))
-      throw std::runtime_error("oracle: imsmooth kernels larger than 5 x 5 are not restated");
+    if((p.centralDifferenceSigmaBefore > 0.0f && imsmoothTaps(p.centralDifferenceSigmaBefore) > kMaxGaussTaps) ||
+       (p.centralDifferenceSigmaAfter > 0.0f && imsmoothTaps(p.centralDifferenceSigmaAfter) > kMaxGaussTaps))
+      throw std::runtime_error("oracle: imsmooth kernels wider than 31 taps are not restated");
     std::vector<uint8_t> I(img, img + n);
-    if(p.centralDifferenceSigmaBefore > 0.0f) gaussianBlurU8_5x5(img, rows, cols, p.centralDifferenceSigmaBefore, I.data());
+    if(p.centralDifferenceSigmaBefore > 0.0f)
+      gaussianBlurU8(img, rows, cols, imsmoothTaps(p.centralDifferenceSigmaBefore), p.centralDifferenceSigmaBefore, I.data());
     const int C = (2 * R + 1) * (2 * R + 1) - 1;
     d.ch.assign(C, std::vector<float>());
     std::vector<std::pair<int, int>> offsets;                    // (x, y)
@@ -195,7 +201,7 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
       }
       if(p.centralDifferenceSigmaAfter > 0.0f) {
         d.ch[i].resize(n);
-        gaussianBlurF32_5x5(tmp.data(), rows, cols, p.centralDifferenceSigmaAfter, d.ch[i].data());
+        gaussianBlurF32(tmp.data(), rows, cols, imsmoothTaps(p.centralDifferenceSigmaAfter), p.centralDifferenceSigmaAfter, d.ch[i].data());
       } else {
         d.ch[i].swap(tmp);
       }

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <stdexcept>
+#include <vector>
 
 namespace orc {
 
@@ -45,6 +47,11 @@ void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst
       d[x] = (uint8_t) ((r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x] + 128) >> 8);
   }
 }
+
+int imsmoothTaps(float sigma) { return std::max(5, 2 * (int) std::round((double) sigma) + 1); }
+// cv::GaussianBlur with ksize = Size() on a CV_32F image [ext: OpenCV 2.4 smooth.cpp createGaussianFilter]:
+// cvRound(sigma * 4 * 2 + 1) | 1 (cvRound = round half to even)
+int autoGaussTapsF32(float sigma) { return ((int) std::nearbyint((double) sigma * 4.0 * 2.0 + 1.0)) | 1; }
 
 // cv::getGaussianKernel(n, sigma, CV_32F) for sigma > 0 [ext: OpenCV 2.4 imgproc/smooth.cpp]:
 // t = exp(-0.5/sigma^2 * x^2) in double, stored as float, sum of the floats in double, scaled by 1/sum.
@@ -96,6 +103,68 @@ void gaussianBlurF32_5x5(const float* src, int rows, int cols, float sigma, floa
       d[x] = s0;
     }
   }
+}
+
+// cv::GaussianBlur(f32, Size(k,k), sigma, sigma) for k >= 7 (imsmooth with sigma >= 2.5, bpvo/imgproc.cc:166-171; the
+// automatic kernel size of GradientDescriptor, bpvo/gradient_descriptor.cc:53).  [ext: OpenCV 2.4 filter.cpp — kernels
+// wider than 5 leave the "small" row filter: RowFilter<float,float> s = k[0]*S[0]; s += k[j]*S[j] for j = 1..k-1 over the
+// window's leftmost to rightmost tap, and SymmColumnFilter<Cast<float,float>> s = k0*S0; s += kj*(S+j + S-j)], f32,
+// BORDER_REFLECT_101.  UNPINNED like every other OpenCV restatement here.
+void gaussianBlurF32(const float* src, int rows, int cols, int ksize, float sigma, float* dst)
+{
+  if(ksize == 5) { gaussianBlurF32_5x5(src, rows, cols, sigma, dst); return; }
+  if(ksize < 7 || ksize > kMaxGaussTaps || !(ksize & 1)) throw std::runtime_error("oracle: Gaussian kernel size not restated");
+  float kern[kMaxGaussTaps];
+  gaussianKernelF32(ksize, sigma, kern);
+  const int r = ksize / 2;
+  std::vector<float> tmp((size_t) rows * cols);
+  for(int y = 0; y < rows; ++y) {
+    const float* S = src + (size_t) y * cols;
+    float* t = tmp.data() + (size_t) y * cols;
+    for(int x = 0; x < cols; ++x) {
+      float s0 = kern[0] * S[reflect101(x - r, cols)];
+      for(int j = 1; j < ksize; ++j) s0 += kern[j] * S[reflect101(x - r + j, cols)];
+      t[x] = s0;
+    }
+  }
+  for(int y = 0; y < rows; ++y) {
+    float* d = dst + (size_t) y * cols;
+    for(int x = 0; x < cols; ++x) {
+      float s0 = kern[r] * tmp[(size_t) y * cols + x];
+      for(int j = 1; j <= r; ++j)
+        s0 += kern[r + j] * (tmp[(size_t) reflect101(y + j, rows) * cols + x] + tmp[(size_t) reflect101(y - j, rows) * cols + x]);
+      d[x] = s0;
+    }
+  }
+}
+
+// cv::GaussianBlur(u8, Size(k,k), sigma, sigma) for any odd k >= 5 in OpenCV 2.4's 8-bit fixed point (taps cvRound(k * 256),
+// row pass u8 -> int, column pass (sum + 2^15) >> 16 saturated): integer sums, so the order of the taps does not matter.
+void gaussianBlurU8(const uint8_t* src, int rows, int cols, int ksize, float sigma, uint8_t* dst)
+{
+  if(ksize == 5) { gaussianBlurU8_5x5(src, rows, cols, sigma, dst); return; }
+  if(ksize < 7 || ksize > kMaxGaussTaps || !(ksize & 1)) throw std::runtime_error("oracle: Gaussian kernel size not restated");
+  float kf[kMaxGaussTaps];
+  gaussianKernelF32(ksize, sigma, kf);
+  int ki[kMaxGaussTaps];
+  for(int i = 0; i < ksize; ++i) ki[i] = (int) std::nearbyint((double) kf[i] * 256.0);
+  const int r = ksize / 2;
+  std::vector<int> tmp((size_t) rows * cols);
+  for(int y = 0; y < rows; ++y) {
+    const uint8_t* S = src + (size_t) y * cols;
+    for(int x = 0; x < cols; ++x) {
+      int s0 = 0;
+      for(int j = 0; j < ksize; ++j) s0 += ki[j] * S[reflect101(x - r + j, cols)];
+      tmp[(size_t) y * cols + x] = s0;
+    }
+  }
+  for(int y = 0; y < rows; ++y)
+    for(int x = 0; x < cols; ++x) {
+      int s0 = 0;
+      for(int j = 0; j < ksize; ++j) s0 += ki[j] * tmp[(size_t) reflect101(y - r + j, rows) * cols + x];
+      const int v = (s0 + (1 << 15)) >> 16;
+      dst[(size_t) y * cols + x] = (uint8_t) std::min(255, std::max(0, v));
+    }
 }
 
 // cv::GaussianBlur(u8, Size(3,3), s, s) (reference call site: bpvo/census.cc:65, only when sigma_ct > 0).

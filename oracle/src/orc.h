@@ -71,6 +71,11 @@ M44 inverse44(const M44& a);                    // general cofactor inverse (Eig
 // ---- imgproc.cc
 void pyrDownU8(const uint8_t* src, int rows, int cols, std::vector<uint8_t>& dst, int& drows, int& dcols); // cv::pyrDown
 void gaussianBlurF32_5x5(const float* src, int rows, int cols, float sigma, float* dst);   // cv::GaussianBlur f32 5x5
+constexpr int kMaxGaussTaps = 31;                                                          // widest kernel restated
+int imsmoothTaps(float sigma);                                                             // bpvo/imgproc.cc:168: max(5, 2*round(sigma)+1)
+int autoGaussTapsF32(float sigma);                                                         // cv::GaussianBlur(Size(), sigma) on CV_32F: cvRound(sigma*8+1)|1
+void gaussianBlurF32(const float* src, int rows, int cols, int ksize, float sigma, float* dst);    // k = 5: the small-kernel form, k >= 7: generic
+void gaussianBlurU8(const uint8_t* src, int rows, int cols, int ksize, float sigma, uint8_t* dst); // 8-bit fixed point, any odd k >= 5
 void gaussianBlurU8_3x3(const uint8_t* src, int rows, int cols, float sigma, uint8_t* dst); // cv::GaussianBlur u8 3x3 (2.4)
 void gaussianBlurU8_5x5(const uint8_t* src, int rows, int cols, float sigma, uint8_t* dst); // cv::GaussianBlur u8 5x5 (2.4)
 void census(const uint8_t* src, int rows, int cols, float sigma_ct, uint8_t* dst);          // bpvo/census.cc:59-91

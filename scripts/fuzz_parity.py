@@ -46,12 +46,14 @@ def draw(rng):
         kw.update(sigmaBitPlanes=float(rng.choice([-1.0, 0.5, 1.2])), sigmaPriorToCensusTransform=float(rng.choice([-1.0, 0.8])))
     elif descriptor == "laplacian":
         kw.update(laplacianKernelSize=int(rng.choice([1, 3])))
-    elif descriptor in ("fields1", "fields2"):
-        kw.update(dfSigma1=float(rng.choice([-1.0, 0.75, 1.3])), dfSigma2=float(rng.choice([-1.0, 1.75, 0.6])))
+    elif descriptor in ("fields1", "fields2"):        # 2.6 / 3.6: imsmooth kernels of 7 / 9 taps (the generic filter forms)
+        kw.update(dfSigma1=float(rng.choice([-1.0, 0.75, 1.3, 2.6])), dfSigma2=float(rng.choice([-1.0, 1.75, 0.6, 3.6])))
     elif descriptor == "centraldiff":
         kw.update(centralDifferenceRadius=int(rng.choice([1, 1, 2, 3])),
-                  centralDifferenceSigmaBefore=float(rng.choice([-1.0, 0.75])),
-                  centralDifferenceSigmaAfter=float(rng.choice([-1.0, 1.75])))
+                  centralDifferenceSigmaBefore=float(rng.choice([-1.0, 0.75, 2.7])),
+                  centralDifferenceSigmaAfter=float(rng.choice([-1.0, 1.75, 3.4])))
+    elif descriptor == "gradient":                    # pre-smoothing with OpenCV's automatic kernel size: 5 / 9 taps
+        kw.update(sigmaPriorToCensusTransform=float(rng.choice([-1.0, -1.0, 0.5, 1.0])))
     scene = int(rng.integers(0, 3))       # 0: synthetic plane pair, 1: tiled texture + shift, 2: same with noise disparity
     # library switches outside AlgorithmParameters: the all-f32 projectPoints formulation (kLinear only) and the fused
     # residual + reduction path for frozen scales (environment variable read by bpvo_hip_create; bit-identical by design)

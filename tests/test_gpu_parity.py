@@ -774,7 +774,7 @@ def test_intensity_and_gradient_descriptor_parity(hip, orc, rows, cols, levels, 
     To, _ = co.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
-    # batch entry point and the smoothed variant, which is not on the device path
+    # batch entry point
     b3 = synth.make_batch(rows, cols, 3, first_index=40)
     outs = []
     for bind in (hip, orc):
@@ -783,8 +783,22 @@ def test_intensity_and_gradient_descriptor_parity(hip, orc, rows, cols, levels, 
     for k in range(3):
         rot, trans = pose_error(outs[0][k], outs[1][k])
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
-    with pytest.raises(capi.BpvoError):
-        hip.create(d["K"], d["b"], rows, cols, make_params(hip, descriptor="gradient", levels=2, sigmaPriorToCensusTransform=0.8))
+    # the optional pre-smoothing of the gradient channels (cv::GaussianBlur with OpenCV's automatic kernel size: 5 taps for
+    # sigma 0.5 — the small-kernel filter forms — and 9 taps for sigma 1.0, the generic ones); channel 0 stays unsmoothed
+    for sg in (0.5, 1.0):
+        sh, so, _ = both(hip, orc, rows, cols, levels, descriptor="gradient", loss=loss, sigmaPriorToCensusTransform=sg)
+        for l in range(levels):
+            assert np.array_equal(sh.get_descriptor_channel(1, l, 0), sh.get_image(1, l).astype(np.float32))
+            for c in range(3):
+                assert bits_equal(sh.get_descriptor_channel(1, l, c), so.get_descriptor_channel(1, l, c)), (sg, l, c)
+            assert not np.array_equal(sh.get_descriptor_channel(1, l, 1), ch.get_descriptor_channel(1, l, 1))
+        Ts, _ = sh.estimate_pose(0, 0, 1)
+        To2, _ = so.estimate_pose(0, 0, 1)
+        rot, trans = pose_error(Ts, To2)
+        assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (sg, rot, trans)
+    for sg in (0.3, 4.0):     # 3 taps (another filter form) and more than 31 taps are refused
+        with pytest.raises(capi.BpvoError):
+            hip.create(d["K"], d["b"], rows, cols, make_params(hip, descriptor="gradient", levels=2, sigmaPriorToCensusTransform=sg))
 
 
 @pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(121, 163, 2, id="163x121-L2"),
@@ -820,10 +834,11 @@ def test_descriptor_fields_parity(hip, orc, rows, cols, levels, descriptor, C):
 
 @pytest.mark.parametrize("descriptor", ["fields1", "fields2"])
 def test_descriptor_fields_sigma_variants(hip, orc, descriptor):
-    """dfSigma1 / dfSigma2 <= 0 switch the smoothing steps off (gradient_descriptor.cc:93,107); sigmas >= 2.5 would need
-    imsmooth kernels wider than 5 taps and are refused.  Batch entry point with Tukey weights."""
+    """dfSigma1 / dfSigma2 <= 0 switch the smoothing steps off (gradient_descriptor.cc:93,107); sigmas >= 2.5 make imsmooth
+    pick kernels wider than 5 taps (7 for 2.6, 9 for 3.6: the generic filter forms); beyond 31 taps is refused.  Batch entry
+    point with Tukey weights."""
     rows, cols, levels = 96, 128, 2
-    for s1, s2 in ((-1.0, -1.0), (1.2, -1.0), (-1.0, 2.4)):
+    for s1, s2 in ((-1.0, -1.0), (1.2, -1.0), (-1.0, 2.4), (2.6, 0.8), (0.75, 3.6)):
         ch, co, d = both(hip, orc, rows, cols, levels, descriptor=descriptor, loss="tukey", dfSigma1=s1, dfSigma2=s2)
         for l in range(levels):
             for c in range(ch.Cn):
@@ -842,7 +857,7 @@ def test_descriptor_fields_sigma_variants(hip, orc, descriptor):
         rot, trans = pose_error(outs[0][k], outs[1][k])
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
     with pytest.raises(capi.BpvoError):
-        hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor=descriptor, levels=2, dfSigma2=2.5))
+        hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor=descriptor, levels=2, dfSigma2=15.6))
 
 
 @pytest.mark.parametrize("radius,rows,cols,levels,loss", [pytest.param(1, 120, 160, 3, "tukey", id="r1-8ch-160x120"),
@@ -878,7 +893,8 @@ def test_central_difference_descriptor_parity(hip, orc, radius, rows, cols, leve
 def test_central_difference_variants(hip, orc):
     """Smoothing steps switched off (sigma <= 0: the raw u8 differences), the batch entry point, and the refused settings."""
     rows, cols, levels = 96, 128, 2
-    for sb, sa in ((-1.0, -1.0), (1.1, -1.0), (-1.0, 0.9)):
+    # (2.7, 3.4): imsmooth picks 7 taps for the u8 blur before and 7 for the f32 blur after — the generic filter forms
+    for sb, sa in ((-1.0, -1.0), (1.1, -1.0), (-1.0, 0.9), (2.7, 3.4), (0.75, 4.6)):
         ch, co, d = both(hip, orc, rows, cols, levels, descriptor="centraldiff", loss="tukey", centralDifferenceRadius=1,
                          centralDifferenceSigmaBefore=sb, centralDifferenceSigmaAfter=sa)
         for l in range(levels):
@@ -898,7 +914,7 @@ def test_central_difference_variants(hip, orc):
     for k in range(3):
         rot, trans = pose_error(outs[0][k], outs[1][k])
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
-    for kw in (dict(centralDifferenceRadius=4), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=3.0)):
+    for kw in (dict(centralDifferenceRadius=4), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=16.0)):
         with pytest.raises(capi.BpvoError):
             hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor="centraldiff", levels=2, **kw))
 

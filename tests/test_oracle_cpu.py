@@ -142,6 +142,34 @@ def test_gaussian_against_scipy(orc):
         assert np.abs(out - ref).max() < 2e-6
 
 
+def test_wide_gaussians_against_scipy(orc):
+    """imsmooth with sigma >= 2.5 (7 and more taps) and GradientDescriptor's automatic kernel size: the generic forms of the
+    filter engine against an f64 correlation with the same kernel (f32) and an exact integer evaluation (u8 fixed point)."""
+    rng = np.random.default_rng(12)
+    taps = _fn(orc, "imsmooth_taps")
+    auto = _fn(orc, "auto_gauss_taps_f32")
+    assert [taps(C.c_float(s)) for s in (0.3, 1.75, 2.4, 2.5, 2.6, 3.5, 3.6, 15.4)] == [5, 5, 5, 7, 7, 9, 9, 31]     # std::round: half away
+    assert [auto(C.c_float(s)) for s in (0.3, 0.5, 0.75, 1.0, 2.0, 3.75)] == [3, 5, 7, 9, 17, 31]                   # cvRound(8 s + 1) | 1
+    src = rng.random((37, 23)).astype(np.float32) * 255.0       # narrower than the widest kernel: repeated reflection
+    for ksize, sigma in ((7, 2.6), (9, 1.0), (31, 15.4)):
+        out = np.empty_like(src)
+        assert _fn(orc, "gaussian_f32")(src.ctypes.data_as(C.c_void_p), 37, 23, ksize, C.c_float(sigma), out.ctypes.data_as(C.c_void_p)) == 0
+        x = np.arange(ksize) - (ksize - 1) / 2.0
+        k = np.exp(-0.5 * x * x / sigma ** 2).astype(np.float32).astype(np.float64)
+        k = (k / k.sum()).astype(np.float32).astype(np.float64)
+        ref = scipy.ndimage.correlate1d(scipy.ndimage.correlate1d(src.astype(np.float64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        assert np.abs(out - ref).max() < 2e-4, (ksize, np.abs(out - ref).max())
+        img = rng.integers(0, 256, (37, 23), dtype=np.uint8)
+        o8 = np.empty_like(img)
+        assert _fn(orc, "gaussian_u8")(img.ctypes.data_as(C.c_void_p), 37, 23, ksize, C.c_float(sigma), o8.ctypes.data_as(C.c_void_p)) == 0
+        ki = np.rint(k * 256.0).astype(np.int64)
+        rows_ = scipy.ndimage.correlate1d(img.astype(np.int64), ki, axis=1, mode="mirror")
+        ref8 = np.clip((scipy.ndimage.correlate1d(rows_, ki, axis=0, mode="mirror") + (1 << 15)) >> 16, 0, 255)
+        assert np.array_equal(o8, ref8.astype(np.uint8)), ksize
+    out = np.empty_like(src)
+    assert _fn(orc, "gaussian_f32")(src.ctypes.data_as(C.c_void_p), 37, 23, 3, C.c_float(0.3), out.ctypes.data_as(C.c_void_p)) != 0   # not restated
+
+
 def test_median_rule(orc):
     rng = np.random.default_rng(3)
     f = _fn(orc, "median", C.c_float)
