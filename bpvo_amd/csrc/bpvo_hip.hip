@@ -860,8 +860,9 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(k < 5 || k > kMaxGaussTaps)
       return unsupported("IntensityAndGradient: pre-smoothing kernels of 5 to 31 taps (0.44 <= sigmaPriorToCensusTransform <= 3.8) are on the device path");
   }
-  if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3)
-    return unsupported("laplacianKernelSize: 1 and 3 are on the device path (larger sizes are Sobel-based in OpenCV)");
+  if(c->params.descriptor == BPVO_DESC_LAPLACIAN && c->params.laplacianKernelSize != 1 && c->params.laplacianKernelSize != 3 &&
+     c->params.laplacianKernelSize != 5 && c->params.laplacianKernelSize != 7)
+    return unsupported("laplacianKernelSize: 1, 3, 5 and 7 are on the device path (from 11 on OpenCV's f32 sums are no longer exact integers)");
   if(c->params.interp < BPVO_INTERP_LINEAR || c->params.interp > BPVO_INTERP_CUBIC_HERMITE) return unsupported("unknown interp");
   if(c->params.lossFunction != BPVO_LOSS_HUBER && c->params.lossFunction != BPVO_LOSS_TUKEY && c->params.lossFunction != BPVO_LOSS_L2)
     return unsupported("unknown lossFunction");

@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
 }
 
 // ---- LaplacianDescriptor::compute (reference: bpvo/gradient_descriptor.cc:64-67): cv::Laplacian(u8 -> f32), kernel size 1
-// ({0,1,0,1,-4,1,0,1,0}) or 3 ({2,0,2,0,-8,0,2,0,2}), BORDER_REFLECT_101; integer-valued, hence exact in f32.
+// ({0,1,0,1,-4,1,0,1,0}), 3 ({2,0,2,0,-8,0,2,0,2}), 5 or 7 (Sobel second derivatives), BORDER_REFLECT_101; integer-valued,
+// hence exact in f32.
 __global__ __launch_bounds__(256) void laplacian_kernel(const FrameJob* jobs, int ksize)
 {
   const FrameJob& j = jobs[blockIdx.z];
@@ -112,8 +113,27 @@ __global__ __launch_bounds__(256) void laplacian_kernel(const FrameJob* jobs, in
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if(x >= W || y >= R) return;
-  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, R), yp = reflect101(y + 1, R);
   const uint8_t* __restrict__ I = j.img;
+  if(ksize > 3) {
+    // ksize 5 / 7: d2/dx2 + d2/dy2 with the separable Sobel kernels of cv::getSobelKernels (second derivative x binomial
+    // smoothing): [1 0 -2 0 1] x [1 4 6 4 1] and [1 2 -1 -4 -1 2 1] x [1 6 15 20 15 6 1].  Integer sums far below 2^24
+    // (and below the 16-bit work type OpenCV uses for ksize 5): exact in any order.
+    const int d5[5] = {1, 0, -2, 0, 1}, s5[5] = {1, 4, 6, 4, 1};
+    const int d7[7] = {1, 2, -1, -4, -1, 2, 1}, s7[7] = {1, 6, 15, 20, 15, 6, 1};
+    const int r = ksize >> 1;
+    int acc = 0;
+    for(int dy = 0; dy < ksize; ++dy) {
+      const uint8_t* row = I + (size_t) reflect101_wide(y - r + dy, R) * W;
+      const int dyk = ksize == 5 ? d5[dy] : d7[dy], syk = ksize == 5 ? s5[dy] : s7[dy];
+      for(int dx = 0; dx < ksize; ++dx) {
+        const int dxk = ksize == 5 ? d5[dx] : d7[dx], sxk = ksize == 5 ? s5[dx] : s7[dx];
+        acc += (dxk * syk + sxk * dyk) * (int) row[reflect101_wide(x - r + dx, W)];
+      }
+    }
+    j.desc[(size_t) y * W + x] = (float) acc;
+    return;
+  }
+  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, R), yp = reflect101(y + 1, R);
   const float k_edge = ksize == 3 ? 0.0f : 1.0f, k_diag = ksize == 3 ? 2.0f : 0.0f, k_ctr = ksize == 3 ? -8.0f : -4.0f;
   const uint8_t *rm = I + (size_t) ym * W, *r0 = I + (size_t) y * W, *rp = I + (size_t) yp * W;
   float v = k_diag * (float) rm[xm] + k_edge * (float) rm[x] + k_diag * (float) rm[xp];

@@ -97,7 +97,42 @@ void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, 
     // LaplacianDescriptor::compute (bpvo/gradient_descriptor.cc:64-67): cv::Laplacian(image, CV_32F, ksize).
     // [ext: OpenCV 2.4 deriv.cpp] ksize 1 / 3 -> filter2D with the 3x3 kernels {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2},
     // scale 1, delta 0, BORDER_DEFAULT (= REFLECT_101).  Small integers in f32: exact in any evaluation order.
-    if(p.laplacianKernelSize != 1 && p.laplacianKernelSize != 3) throw std::runtime_error("oracle: Laplacian kernel sizes 1 and 3 only");
+    // ksize 5 / 7 -> Sobel second derivatives d2/dx2 + d2/dy2 with the separable kernels of cv::getSobelKernels
+    // ([1 0 -2 0 1] x [1 4 6 4 1], [1 2 -1 -4 -1 2 1] x [1 6 15 20 15 6 1]; work type 16S for ksize 5 on u8, never saturated:
+    // |d2x + d2y| <= 16320), integer-valued as well.
+    if(p.laplacianKernelSize == 5 || p.laplacianKernelSize == 7) {
+      const int K = p.laplacianKernelSize, r = K / 2;
+      static const int d5[5] = {1, 0, -2, 0, 1}, s5[5] = {1, 4, 6, 4, 1};
+      static const int d7[7] = {1, 2, -1, -4, -1, 2, 1}, s7[7] = {1, 6, 15, 20, 15, 6, 1};
+      const int* dk = K == 5 ? d5 : d7;
+      const int* sk = K == 5 ? s5 : s7;
+      auto reflw = [](int q, int len) { if(len == 1) return 0; while(q < 0 || q >= len) q = q < 0 ? -q : 2 * len - 2 - q; return q; };
+      d.ch.resize(1);
+      d.ch[0].resize(n);
+      std::vector<int> dxx(n), sxx(n);                        // row passes: second derivative / smoothing along x
+      for(int y = 0; y < rows; ++y)
+        for(int x = 0; x < cols; ++x) {
+          int a = 0, b = 0;
+          for(int t = 0; t < K; ++t) {
+            const int v = img[(size_t) y * cols + reflw(x - r + t, cols)];
+            a += dk[t] * v;
+            b += sk[t] * v;
+          }
+          dxx[(size_t) y * cols + x] = a;
+          sxx[(size_t) y * cols + x] = b;
+        }
+      for(int y = 0; y < rows; ++y)
+        for(int x = 0; x < cols; ++x) {
+          int acc = 0;
+          for(int t = 0; t < K; ++t) {
+            const size_t q = (size_t) reflw(y - r + t, rows) * cols + x;
+            acc += sk[t] * dxx[q] + dk[t] * sxx[q];
+          }
+          d.ch[0][(size_t) y * cols + x] = (float) acc;
+        }
+      return;
+    }
+    if(p.laplacianKernelSize != 1 && p.laplacianKernelSize != 3) throw std::runtime_error("oracle: Laplacian kernel sizes 1, 3, 5 and 7 only");
     const float k_edge = p.laplacianKernelSize == 3 ? 0.0f : 1.0f, k_diag = p.laplacianKernelSize == 3 ? 2.0f : 0.0f;
     const float k_ctr = p.laplacianKernelSize == 3 ? -8.0f : -4.0f;
     auto refl = [](int q, int len) { if(q < 0) q = -q; if(q >= len) q = 2 * len - 2 - q; return q < 0 ? 0 : q; };

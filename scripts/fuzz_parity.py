@@ -45,7 +45,7 @@ def draw(rng):
     if descriptor == "bitplanes":
         kw.update(sigmaBitPlanes=float(rng.choice([-1.0, 0.5, 1.2])), sigmaPriorToCensusTransform=float(rng.choice([-1.0, 0.8])))
     elif descriptor == "laplacian":
-        kw.update(laplacianKernelSize=int(rng.choice([1, 3])))
+        kw.update(laplacianKernelSize=int(rng.choice([1, 3, 5, 7])))
     elif descriptor in ("fields1", "fields2"):        # 2.6 / 3.6: imsmooth kernels of 7 / 9 taps (the generic filter forms)
         kw.update(dfSigma1=float(rng.choice([-1.0, 0.75, 1.3, 2.6])), dfSigma2=float(rng.choice([-1.0, 1.75, 0.6, 3.6])))
     elif descriptor == "centraldiff":

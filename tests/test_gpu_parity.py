@@ -723,15 +723,15 @@ def test_reference_timing_configurations_sequence(hip, orc, which):
 
 
 @pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(480, 640, 4, id="640x480-L4")])
-@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7])
 def test_laplacian_descriptor_parity(hip, orc, rows, cols, levels, ksize):
-    """kLaplacian (bpvo/gradient_descriptor.cc:64-67, cv::Laplacian with kernel size 1 or 3): one integer-valued f32 channel,
+    """kLaplacian (bpvo/gradient_descriptor.cc:64-67, cv::Laplacian with kernel size 1, 3, 5 or 7): one integer-valued f32 channel,
     then the same single-channel pipeline as Intensity — every stage bit-exact, poses within the bar."""
     ch, co, d = both(hip, orc, rows, cols, levels, descriptor="laplacian", loss="huber", laplacianKernelSize=ksize)
     assert ch.Cn == co.Cn == 1
     for l in range(levels):
         a, b = ch.get_descriptor_channel(1, l, 0), co.get_descriptor_channel(1, l, 0)
-        assert bits_equal(a, b) and np.array_equal(a, np.round(a)) and np.abs(a).max() <= (8 if ksize == 3 else 4) * 255
+        assert bits_equal(a, b) and np.array_equal(a, np.round(a)) and np.abs(a).max() <= {1: 4, 3: 8, 5: 64, 7: 768}[ksize] * 255
         assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l))
         assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
         assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
@@ -743,7 +743,7 @@ def test_laplacian_descriptor_parity(hip, orc, rows, cols, levels, ksize):
     To, _ = co.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
-    p = make_params(hip, descriptor="laplacian", levels=2, laplacianKernelSize=5)
+    p = make_params(hip, descriptor="laplacian", levels=2, laplacianKernelSize=9)
     with pytest.raises(capi.BpvoError):
         hip.create(d["K"], d["b"], rows, cols, p)
 

@@ -511,16 +511,29 @@ def test_interpolation_variants_against_numpy(orc, interp):
     assert rot < 2e-2 and trans < 0.5, (rot, trans)
 
 
-@pytest.mark.parametrize("ksize", [1, 3])
+@pytest.mark.parametrize("ksize", [1, 3, 5, 7])
 def test_laplacian_descriptor_against_scipy(orc, ksize):
-    """cv::Laplacian(u8 -> f32, ksize 1 / 3) = correlation with {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2}, BORDER_REFLECT_101
-    (scipy's mode='mirror'); integer-valued, so exact."""
+    """cv::Laplacian(u8 -> f32, ksize 1 / 3) = correlation with {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2}; ksize 5 / 7 = Sobel
+    second derivatives d2/dx2 + d2/dy2, whose separable kernels are re-derived here the way cv::getSobelKernels builds them
+    (binomial smoothing [1 1]^k, differences [-1 1]); BORDER_REFLECT_101 (scipy's mode='mirror'); integer-valued, so exact."""
     rows, cols = 57, 83
     d = synth.make_pair(rows, cols, 4)
     p = make_params(orc, descriptor="laplacian", levels=2, laplacianKernelSize=ksize)
     ctx = orc.create(d["K"], d["b"], rows, cols, p, n_frames=1, n_pairs=1)
     ctx.frame_set_data(0, d["imgA"], d["dispA"])
-    K = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float64) if ksize == 1 else np.array([[2, 0, 2], [0, -8, 0], [2, 0, 2]], np.float64)
+    if ksize <= 3:
+        K = np.array([[0, 1, 0], [1, -4, 1], [0, 1, 0]], np.float64) if ksize == 1 else np.array([[2, 0, 2], [0, -8, 0], [2, 0, 2]], np.float64)
+    else:
+        def sobel_1d(order):
+            k = np.array([1.0])
+            for _ in range(ksize - order - 1):
+                k = np.convolve(k, [1.0, 1.0])
+            for _ in range(order):
+                k = np.convolve(k, [-1.0, 1.0])
+            return k
+        d2, sm = sobel_1d(2), sobel_1d(0)
+        assert list(d2) == ([1, 0, -2, 0, 1] if ksize == 5 else [1, 2, -1, -4, -1, 2, 1]) and sm.sum() == 2 ** (ksize - 1)
+        K = np.outer(sm, d2) + np.outer(d2, sm)           # rows = y, columns = x
     for l in range(2):
         img = ctx.get_image(0, l).astype(np.float64)
         want = scipy.ndimage.correlate(img, K, mode="mirror")
