@@ -925,7 +925,7 @@ def test_central_difference_variants(hip, orc):
                                            ("centraldiff", dict(centralDifferenceRadius=3, centralDifferenceSigmaAfter=-1.0))])
 def test_scale_sequence_every_channel_count(hip, orc, descriptor, kw):
     """The bracketed median (second and later linearisations of a level: bracket_block + median_finish) for every channel
-    count the kernels are instantiated for — found by scripts/fuzz_parity.py: a 32-bit channel mask broke it for 48 channels.
+    count the kernels are instantiated for — found by tests/tools/fuzz_parity.py: a 32-bit channel mask broke it for 48 channels.
     Same pose sequence on both sides, same sigma / weights every time, and the bracketed path must actually be taken."""
     rows, cols = 50, 265
     ch, co, d = both(hip, orc, rows, cols, 1, descriptor=descriptor, loss="huber", **kw)

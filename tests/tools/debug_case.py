@@ -2,8 +2,8 @@
 """Debug aid: replay the oracle's pose sequence of one fuzz case on the HIP path, linearisation by linearisation."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import bpvo_amd, __graft_entry__ as ge
 from bpvo_amd import capi
 from util import make_params, bits_equal

@@ -5,7 +5,7 @@ normalisation on / off, ragged image sizes, synthetic scenes and noise images.  
 bit-identical, the poses within the north-star bar (scaled by the conditioning for noise images, as in
 tests/test_gpu_parity.py).  Run through gpurun:
 
-    gpurun --timeout 900 -- 'python scripts/fuzz_parity.py --seconds 300 --seed 1 > gpurun_out/fuzz.log 2>&1'
+    gpurun --timeout 900 -- 'python tests/tools/fuzz_parity.py --seconds 300 --seed 1 > gpurun_out/fuzz.log 2>&1'
 
 Prints one line per failing configuration and a summary; exit code 1 if anything failed."""
 import argparse
@@ -16,7 +16,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,7 +1,7 @@
 """Soak: many random synthetic pairs through the HIP batch path and the CPU oracle; reports the worst pose disagreement and
 any difference in per-level status.  usage: soak_parity.py [n_pairs] [rows cols] [descriptor] [loss]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as ge
 import bpvo_amd
