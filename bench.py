@@ -58,6 +58,8 @@ def parse_args():
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only for functional tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="functional test only: every rank uses GPU 0 (needs --dist-backend gloo)")
+    ap.add_argument("--dump-records", default="", help="rank 0 saves the gathered [world * pairs, 32] result records of the last "
+                    "step here (.npy); slots [30], [31] of every record carry the rank and the device ordinal that produced it")
     return ap.parse_args()
 
 
@@ -238,8 +240,10 @@ def main():
     def step():
         poses, stats = ctx.batch_run_device(P, d_images.data_ptr(), d_disps.data_ptr())
         gathered = None
-        if world > 1:
+        if world > 1 or args.dump_records:
             ctx.batch_copy_records_device(d_records.data_ptr(), P)
+            d_records[:, 30] = float(rank)         # who produced the record (slots the library leaves at 0)
+            d_records[:, 31] = float(dev_index)
             gathered = gather_records(d_records if coll_dev.type == "cuda" else d_records.cpu(), dst=0)
         return poses, stats, gathered
 
@@ -284,6 +288,8 @@ def main():
         if gathered is not None:
             gp, _, _ = records_to_poses(gathered)
             assert gp.shape[0] == n_pairs_total and np.array_equal(gp[:P, :3, :], poses[:, :3, :])
+            if args.dump_records:
+                np.save(args.dump_records, gathered.detach().cpu().numpy())
 
         roofline = None
         kernels = {}
@@ -336,6 +342,7 @@ def main():
             "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS)"
             if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s",
             "value": gn_total / elapsed_max, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "dist_backend": (args.dist_backend if world > 1 else None),
             "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 projection/interpolation)", "data": "synthetic",
             "config": {"workload": f"batch of {n_pairs_total} independent {args.cols}x{args.rows} stereo pairs "

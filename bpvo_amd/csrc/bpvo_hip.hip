@@ -21,7 +21,8 @@ using namespace bpvo_hip;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // bpvo_hip_last_error(nullptr): the failed create of THIS thread (contexts are created
+                                           // concurrently by the per-GPU host threads of multi_gpu.hip)
 
 struct LevelGeom {
   int rows, cols;
@@ -141,8 +142,8 @@ struct bpvo_hip_ctx {
   double points_fused = 0;     // points linearised through the fused path since the last counter reset
   int fast_warp = 0;           // bpvo_hip_set_warp_formulation
   int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
-  int fuse_frozen = 0;         // estimate loops: fused residual + reduction once a workspace's scale is frozen; opt-in with
-                               // BPVO_HIP_FUSE_FROZEN=1 (+2 % GN iterations/s)
+  int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
+                               // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
@@ -586,7 +587,10 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     }
   }
   launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
-  LANE_CK(ln, hipMemcpyAsync(ln->h_states, c->d_states, sizeof(GNState) * c->n_pairs, hipMemcpyDeviceToHost, ln->stream));
+  // only this group's states: other lanes may still be writing theirs
+  int ws_lo = wss[0], ws_hi = wss[0];
+  for(int i = 1; i < n; ++i) { ws_lo = std::min(ws_lo, wss[i]); ws_hi = std::max(ws_hi, wss[i]); }
+  LANE_CK(ln, hipMemcpyAsync(ln->h_states + ws_lo, c->d_states + ws_lo, sizeof(GNState) * (size_t) (ws_hi - ws_lo + 1), hipMemcpyDeviceToHost, ln->stream));
   LANE_CK(ln, hipStreamSynchronize(ln->stream));
   LANE_CK(ln, hipGetLastError());
   for(int i = 0; i < n; ++i) {

@@ -11,6 +11,8 @@
 // No MFMA anywhere: ~1 flop/byte, HBM-bound gather + rank-1 accumulate.
 #include <float.h>
 
+#include <mutex>
+
 #include "kernels.h"
 
 namespace bpvo_hip {
@@ -1411,17 +1413,16 @@ static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 
 void launch_median(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
-  static bool attr_set_dev[64] = {};   // the attribute is per device: a process may hold contexts on several
+  // the attribute is per device (a process may hold contexts on several) and the lanes' host threads race here
+  static std::once_flag attr_once[64];
   int dev = 0;
   (void) hipGetDevice(&dev);
-  bool& attr_set = attr_set_dev[dev & 63];
-  if(!attr_set) {
-    for(int C : {1, 3, 5, 8, 10})
+  std::call_once(attr_once[dev & 63], [] {
+    for(int C : {1, 3, 5, 8, 10, 24, 48})
       dispatch_channels(C, [&](auto c) {
         (void) hipFuncSetAttribute((const void*) median_finish_kernel<decltype(c)::value>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
       });
-    attr_set = true;
-  }
+  });
   dispatch_channels(g.C, [&](auto c) {
     hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
   });

@@ -261,6 +261,26 @@ class VisualOdometry {
                  int device = 0)
       : _dev(std::make_shared<detail::Device>(K, baseline, image_size, params, 3, 1, device)), _max_test_level(params.maxTestLevel) {}
 
+  /* reference: template <class CalibrationT> VisualOdometry(const CalibrationT&, ImageSize, const AlgorithmParameters&)
+   * (bpvo/vo.h:49-52): any type with members K (Matrix33) and baseline */
+  template <class CalibrationT>
+  VisualOdometry(const CalibrationT& calib, ImageSize image_size, const AlgorithmParameters& params = AlgorithmParameters())
+      : VisualOdometry(calib.K, calib.baseline, image_size, params) {}
+
+  /* reference: template <class DataLoaderT> VisualOdometry(const DataLoaderT*, const AlgorithmParameters&) (bpvo/vo.h:57-60):
+   * any type with calibration() and imageSize() — what apps/vo_perf.cc:56 calls with its Dataset */
+  template <class DataLoaderT>
+  VisualOdometry(const DataLoaderT* data_loader, const AlgorithmParameters& params = AlgorithmParameters())
+      : VisualOdometry(data_loader->calibration(), data_loader->imageSize(), params) {}
+
+  /* reference: template <class FramePointer> Result addFrame(const FramePointer&) (bpvo/vo.h:76-80): a (smart) pointer to a
+   * frame whose image() / disparity() return matrices with a cv::Mat-style ptr<T>() (utils/dataset.h DatasetFrame) */
+  template <class FramePointer>
+  Result addFrame(const FramePointer& frame)
+  {
+    return this->addFrame(frame->image().template ptr<const uint8_t>(), frame->disparity().template ptr<const float>());
+  }
+
   /* reference: Result addFrame(const uint8_t* image, const float* disparity) (bpvo/vo.h:71, bpvo/vo.cc:66-72) */
   Result addFrame(const uint8_t* image, const float* disparity)
   {

@@ -4,9 +4,15 @@
 //   v128 operators            bpvo/v128.h:36-130     (the byte comparisons of the census transform, bpvo/census.cc:42-57)
 //   bpvo::ConfigFile, icompare bpvo/config_file.{h,cc}, bpvo/utils.{h,cc}   (the conf/*.cfg reader)
 //   simd::dot, simd::abs      bpvo/simd.h:60-80      (4-float dot product of the projectPoints formulation, |x| of the saliency map)
+//   Huber, Tukey              bpvo/robust_loss.h:50-72 (the reference's OTHER statement of the two M-estimator weights: w(r / (sigma k));
+//                             no translation unit includes it — the running code is the SIMD body of bpvo/mestimator.cc, which needs
+//                             Eigen — so it pins the weight FUNCTION of the restatement to rounding, not its bits)
 // The reference sources are compiled where they lie under /root/reference (oracle/Makefile, target `ref`); nothing is
 // copied.  The wrappers only marshal arguments; census_bytes() composes the reference's operators in the order
 // censusOp (bpvo/census.cc:42-57) does, because that function itself sits in a translation unit that needs OpenCV.
+#include <algorithm>
+#include <cmath>
+#include <bpvo/robust_loss.h>   // self-contained but for <cmath> / <algorithm> (std::max, std::fabs), included above
 #include <bpvo/config_file.h>
 #include <bpvo/simd.h>
 #include <bpvo/utils.h>
@@ -43,6 +49,9 @@ void ref_census_bytes(const uint8_t nbr[8][16], const uint8_t c16[16], uint8_t o
 
 float ref_simd_dot(const float a[4], const float b[4]) { return bpvo::simd::dot(_mm_loadu_ps(a), _mm_loadu_ps(b)); }
 void ref_simd_abs(const float a[4], float out[4]) { _mm_storeu_ps(out, bpvo::simd::abs(_mm_loadu_ps(a))); }
+
+float ref_huber_weight(float sigma, float r) { return bpvo::Huber(sigma).weight(r); }
+float ref_tukey_weight(float sigma, float r) { return bpvo::Tukey(sigma).weight(r); }
 
 int ref_icompare(const char* a, const char* b) { return bpvo::icompare(a, b) ? 1 : 0; }
 

@@ -423,5 +423,14 @@ float bpvo_orc_median(const float* data, size_t n)
 { std::vector<float> v(data, data + n); return medianOf(v); }
 int bpvo_orc_solve(const float H[36], const float G[6], float dp[6]) { return solveSystem(H, G, dp) ? 1 : 0; }
 void bpvo_orc_twist_to_matrix(const float p[6], float T[16]) { M44 m = twistToMatrix(p); std::memcpy(T, m.m, 64); }
+// MEstimator::ComputeWeights on raw arrays (r [n], valid [n] u16 -> w [n]); n a multiple of 16 runs the SIMD body only
+int bpvo_orc_compute_weights(int loss, const float* r, const uint16_t* valid, size_t n, float sigma, float* w)
+{
+  std::vector<float> rv(r, r + n), wv;
+  std::vector<uint16_t> vv(valid, valid + n);
+  computeWeights(loss, rv, vv, sigma, wv);
+  std::memcpy(w, wv.data(), n * sizeof(float));
+  return 0;
+}
 
 }  // extern "C"

@@ -1,6 +1,37 @@
 // Compile-only check of the C++ facade: every public member of the reference's API surface is instantiated.
 #include <bpvo_hip/vo.hpp>
 
+// The call pattern of the reference's apps/vo_perf.cc:52-85 (`VisualOdometry(dataset.get(), params)`, `vo.addFrame(frame)`)
+// with stand-ins for the dataset classes of libbpvo_utils (out of scope: utils/dataset.h): the templated overloads of
+// bpvo/vo.h:49-60,76-80 must accept them unchanged.
+namespace vo_perf_like {
+struct Mat {
+  const void* p;
+  template <typename T> T* ptr() const { return static_cast<T*>(p); }
+};
+struct Calibration { bpvo::Matrix33 K; float baseline; };
+struct Frame {
+  Mat img, dmap;
+  const Mat& image() const { return img; }
+  const Mat& disparity() const { return dmap; }
+};
+struct Dataset {
+  Calibration calib;
+  Calibration calibration() const { return calib; }
+  bpvo::ImageSize imageSize() const { return bpvo::ImageSize(64, 64); }
+  std::unique_ptr<Frame> getFrame(int) const { return std::unique_ptr<Frame>(new Frame{{nullptr}, {nullptr}}); }
+};
+int run(const Dataset* dataset, const bpvo::AlgorithmParameters& params)
+{
+  auto vo = bpvo::VisualOdometry(dataset, params);                        // apps/vo_perf.cc:56
+  bpvo::VisualOdometry vo2(dataset->calibration(), dataset->imageSize());  // bpvo/vo.h:49-52
+  std::unique_ptr<Frame> frame = dataset->getFrame(0);
+  bpvo::Result result = vo.addFrame(frame);                               // apps/vo_perf.cc:85 (vo.addFrame(frame.get()) there)
+  bpvo::Result result2 = vo2.addFrame(frame.get());
+  return (int) result.optimizerStatistics.size() + (int) result2.isKeyFrame;
+}
+}  // namespace vo_perf_like
+
 int facade_surface()
 {
   bpvo::AlgorithmParameters p;

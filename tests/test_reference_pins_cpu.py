@@ -141,3 +141,29 @@ def test_simd_dot_and_abs_match_the_restated_forms(ref):
     out = np.empty(4, np.float32)
     ref.ref_simd_abs(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert out.tobytes() == np.array([0.0, 1.5, 2.25, np.inf], np.float32).tobytes()
+
+
+def test_weight_functions_agree_with_robust_loss_h(ref, orc):
+    """bpvo/robust_loss.h:50-72 (Huber::weight, Tukey::weight: w(r / (sigma * k))) — the reference's header-only statement of
+    the two M-estimator weights, the only one that compiles here — against the oracle's restatement of the SIMD bodies of
+    bpvo/mestimator.cc:242-366 (w = k / max(|r / sigma|, k); (1 - (r / sigma / t)^2)^2 for |r / sigma| < t).  Different
+    operation order (one reciprocal of sigma * k there, 1 / sigma then * (1 / t) here), so the bar is rounding: 4 ulp-ish."""
+    ref.ref_huber_weight.restype = C.c_float
+    ref.ref_huber_weight.argtypes = [C.c_float, C.c_float]
+    ref.ref_tukey_weight.restype = C.c_float
+    ref.ref_tukey_weight.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(21)
+    n = 4096
+    for sigma in (0.02, 0.37, 1.0, 3.5, 40.0):
+        r = (rng.standard_normal(n) * sigma * rng.choice([0.05, 1.0, 3.0, 8.0], n)).astype(np.float32)
+        r[:4] = [0.0, -0.0, sigma * 1.345, -sigma * 4.685]
+        valid = np.ones(n, np.uint16)
+        for loss, fn in ((0x10, ref.ref_huber_weight), (0x11, ref.ref_tukey_weight)):
+            w = np.empty(n, np.float32)
+            assert orc.lib.bpvo_orc_compute_weights(loss, r.ctypes.data_as(C.c_void_p), valid.ctypes.data_as(C.c_void_p), C.c_size_t(n),
+                                                    C.c_float(sigma), w.ctypes.data_as(C.c_void_p)) == 0
+            want = np.array([fn(sigma, float(x)) for x in r], np.float32)
+            # at the Tukey cut-off the two forms may disagree on which side of t a residual falls: compare away from it
+            edge = np.abs(np.abs(r / np.float32(sigma)) - (4.685 if loss == 0x11 else 1.345)) < 1e-4
+            assert np.all(np.abs(w - want)[~edge] <= 1e-6), (sigma, loss, np.abs(w - want)[~edge].max())
+            assert np.all((w >= 0) & (w <= 1))
