@@ -382,6 +382,16 @@ class Context:
         self.call("fused_point_counts", C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def tap_cache_counts(self):
+        """(hits, lookups, hits in the first 8 linearisations of a level, lookups there) since the last counter reset."""
+        a = (C.c_uint64 * 4)()
+        self.call("tap_cache_counts", a)
+        return tuple(int(x) for x in a)
+
+    def set_launch_chain(self, mode):
+        """0 auto, 1 four-launch chain, 2 fused-tail chain (HIP library only; all bit-identical)."""
+        self.call("set_launch_chain", int(mode))
+
     def total_linearizations(self):
         n = C.c_uint64()
         self.call("total_linearizations", C.byref(n))

@@ -64,6 +64,7 @@ struct Workspace {
   uint32_t* tapkey = nullptr;
   float* tapcache = nullptr;
   float* partials = nullptr;
+  uint32_t* tickets = nullptr;    // [2] arrival counters of the fused-tail chain (PairJob::tickets)
   int last_ref = -1, last_cur = -1, last_level = -1;
 };
 
@@ -84,9 +85,10 @@ struct Lane {
   PairJob* d_pjobs = nullptr;      // [L][n_pairs]
   float* h_T = nullptr;            // pinned [n_pairs][16]
   float* d_Tinit = nullptr;
-  int* d_active = nullptr;         // [2] ([0]: count of the active list)
-  int* d_list = nullptr;           // [2][n_pairs] active-workspace lists of alternating host rounds (ActiveSet)
+  int* d_active = nullptr;         // [3] counts of the active lists
+  int* d_list = nullptr;           // [3][n_pairs] active-workspace lists of the host rounds in flight (ActiveSet)
   int* h_active = nullptr;         // pinned [4]
+  hipEvent_t round_ev[3] = {};     // "compaction of round r and its count have landed"
   GNState* h_states = nullptr;     // pinned [n_pairs]
   std::vector<EventPair> ev_pending;
   std::vector<hipEvent_t> ev_pool;
@@ -144,6 +146,9 @@ struct bpvo_hip_ctx {
   int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
+  int chain_mode = 0;          // GN launch chain: 0 auto (fused tails for groups of >= tail_min_pairs active workspaces, the four-launch
+                               // chain below), 1 always four launches, 2 always fused tails; BPVO_HIP_CHAIN=auto|classic|tails
+  int tail_min_pairs = 12;     // BPVO_HIP_TAIL_MIN_PAIRS
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
@@ -151,6 +156,7 @@ struct bpvo_hip_ctx {
   double kc_units[KC_COUNT] = {};
   uint64_t kc_launches[KC_COUNT] = {};
   uint64_t total_lin = 0, median_bracketed = 0, median_full = 0;
+  uint64_t tap_counts[4] = {};
   std::string err;
 };
 
@@ -322,6 +328,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.tapcache = c->ws[ws].tapcache;
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
+  j.tickets = c->ws[ws].tickets;
   j.st = c->d_states + ws;
   j.cnt = c->d_counters + kWsCounters * (size_t) ws;
   return j;
@@ -542,48 +549,62 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
     g.fuse_frozen = c->fuse_frozen;
+    g.prm.mode = 0;
+    g.prm.max_iterations = p.maxIterations;
+    g.prm.max_fun_evals = max_fun_evals;
+    g.prm.p_tol = p.parameterTolerance; g.prm.f_tol = p.functionTolerance; g.prm.g_tol = p.gradientTolerance;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
-    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393).  The host queues a round of
-    // kItersPerSync iterations back to back; the round ends with a compaction of the list of still-active workspaces
-    // (ActiveSet, kernels.h) whose count the host reads: it is the workspace dimension of the next round's grids, so
-    // finished workspaces cost nothing from then on (inside a round their workgroups exit on the first load).
+    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); in the fused-tail chain a
+    // workspace whose median bracket missed repeats warp_residual in the next iteration slot, so the loop runs until the
+    // device reports no active workspace (the state machine on the device enforces the iteration limits).  The host queues
+    // rounds of kItersPerSync iterations; every round ends with a compaction of the list of still-active workspaces
+    // (ActiveSet, kernels.h) and the copy of its count.  The rounds are PIPELINED: round r + 1 is queued with the list and
+    // count that came out of round r - 1, as soon as those have landed — the device never waits for the host (a
+    // synchronisation per round was a ~30 us bubble: 7 % of a round at 128 pairs, 11 % for a single pair).  Workspaces that
+    // finished in between are still dispatched for one more round (their workgroups exit on the first load), and the
+    // level ends with one round of empty launches.
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
-    // small groups are bound by the host round trip (~30 us per synchronisation against ~35 us per iteration for one pair),
-    // large ones by the tail of workspaces that have already finished: 8 iterations per round for up to 8 pairs, else 4
-    const int kItersPerSync = n <= 8 ? 8 : 4;
+    const int kItersPerSync = 4;
+    const int max_rounds = (2 * max_lin + 8) / kItersPerSync + 3;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
-    int* const lists[2] = {ln->d_list, ln->d_list + NP};
-    int round = 0, n_active = n;
-    g.active.list = nullptr;                // first round: every workspace of the group, in order
-    for(int it = 0; it < max_lin; ++round) {
-      g.npairs = n_active;
-      for(int k = 0; k < kItersPerSync && it < max_lin; ++k, ++it) {
+    const bool tails_ok = gn_tails_supported(g.max_points);
+    int* const lists[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
+    int n_cur = n;
+    g.active.list = nullptr;                // first rounds: every workspace of the group, in order
+    for(int round = 0; round < max_rounds; ++round) {
+      g.npairs = n_cur;
+      g.tails = (tails_ok && (c->chain_mode == 2 || (c->chain_mode == 0 && n_cur >= c->tail_min_pairs))) ? 1 : 0;
+      for(int k = 0; k < kItersPerSync; ++k) {
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
         { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
-        if(c->profile_all) {
+        if(g.tails) {
+          ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all);
+          launch_irls_reduce(ln->stream, g);
+        } else if(c->profile_all) {
           { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
-          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
-            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                           p.gradientTolerance); }
+          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln); launch_gn_step(ln->stream, g); }
         } else {
           launch_median(ln->stream, g);
           launch_irls_reduce(ln->stream, g);
-          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                         p.gradientTolerance);
+          launch_gn_step(ln->stream, g);
         }
       }
-      int* const next = lists[round & 1];
-      launch_compact_active(ln->stream, g.jobs, g.active, n_active, next, ln->d_active);
-      LANE_CK(ln, hipMemcpyAsync(ln->h_active, ln->d_active, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
-      LANE_CK(ln, hipStreamSynchronize(ln->stream));
-      n_active = ln->h_active[0];
-      if(n_active <= 0) break;
-      g.active.list = next;
+      const int slot = round % 3;
+      launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + slot);
+      LANE_CK(ln, hipMemcpyAsync(ln->h_active + slot, ln->d_active + slot, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
+      LANE_CK(ln, hipEventRecord(ln->round_ev[slot], ln->stream));
+      if(round == 0) continue;              // nothing to learn yet: queue the second round behind the first
+      const int prev = (round - 1) % 3;
+      LANE_CK(ln, hipEventSynchronize(ln->round_ev[prev]));
+      const int n_prev = ln->h_active[prev];
+      if(n_prev <= 0) break;                // (the round just queued runs empty)
+      n_cur = n_prev;
+      g.active.list = lists[prev];
     }
   }
   launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
@@ -668,6 +689,7 @@ int refresh_counters(bpvo_hip_ctx* c)
     for(int k = 0; k < kWsCounters; ++k) h[k] += all[kWsCounters * (size_t) w + k];
   c->median_bracketed = h[2];
   c->median_full = h[3];
+  for(int k = 0; k < 4; ++k) c->tap_counts[k] = h[5 + k];
   c->total_lin = h[1];
   // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
   // warp_residual at profiling level 1 is timed on a 1-in-kProfileEvery sample of its launches: its units are scaled to
@@ -963,6 +985,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
     }
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
+    CREATE_CK(hipMalloc((void**) &w.tickets, 64));     // own 64-byte line: the counters are hammered with device-scope atomics
+    CREATE_CK(hipMemset(w.tickets, 0, 64));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
@@ -972,6 +996,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_CHAIN")) cp->chain_mode = !std::strcmp(e, "classic") ? 1 : (!std::strcmp(e, "tails") ? 2 : 0);
+    if(const char* e = std::getenv("BPVO_HIP_TAIL_MIN_PAIRS")) cp->tail_min_pairs = std::max(1, std::atoi(e));
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
   for(size_t k = 0; k < cp->lanes.size(); ++k) {
@@ -980,8 +1006,9 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     else { CREATE_CK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
     CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipMalloc((void**) &ln.d_active, 2 * sizeof(int)));
-    CREATE_CK(hipMalloc((void**) &ln.d_list, 2 * sizeof(int) * (size_t) n_pairs));
+    CREATE_CK(hipMalloc((void**) &ln.d_active, 4 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_list, 3 * sizeof(int) * (size_t) n_pairs));
+    for(auto& e : ln.round_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
@@ -1008,7 +1035,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipSetDevice(c->device);
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
-  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
+  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); (void) hipFree(w.tickets); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
@@ -1019,6 +1046,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     (void) hipHostFree(ln.h_pjobs); (void) hipHostFree(ln.h_T); (void) hipHostFree(ln.h_active); (void) hipHostFree(ln.h_states);
     for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
     for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
+    for(auto e : ln.round_ev) if(e) (void) hipEventDestroy(e);
     if(ln.owns_stream && ln.stream) (void) hipStreamDestroy(ln.stream);
   }
   if(c->stream) (void) hipStreamDestroy(c->stream);
@@ -1220,11 +1248,18 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   g.fast_warp = c->fast_warp;
   g.interp = c->params.interp;
+  g.prm.mode = 1;
+  g.tails = (c->chain_mode == 2 && gn_tails_supported(g.max_points)) ? 1 : 0;   // single linearisations: four launches unless forced
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
-  { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0); }
+  if(g.tails) {
+    launch_warp_residual(c->stream, g, /*repeat_pass=*/1);     // only does something after a bracket miss
+    { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+  } else {
+    { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+    { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+    { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g); }
+  }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   HIP_CK(c, hipGetLastError());
@@ -1600,6 +1635,23 @@ int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* 
   if(rc) return rc;
   *bracketed = c->median_bracketed;
   *full = c->median_full;
+  return BPVO_OK;
+}
+int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
+{
+  CHECK_CTX(c);
+  (void) hipSetDevice(c->device);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  int rc = refresh_counters(c);
+  if(rc) return rc;
+  for(int k = 0; k < 4; ++k) out[k] = c->tap_counts[k];
+  return BPVO_OK;
+}
+int bpvo_hip_set_launch_chain(bpvo_hip_ctx* c, int mode)
+{
+  CHECK_CTX(c);
+  if(mode < 0 || mode > 2) return fail(c, BPVO_ERR_INVALID_ARG, "launch chain: 0 auto, 1 four launches, 2 fused tails");
+  c->chain_mode = mode;
   return BPVO_OK;
 }
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* c, uint64_t* n)

@@ -137,14 +137,17 @@ def test_config5_shard_iteration_counts_with_the_reference_timing_tolerances(hip
     ctx.close()
     picks = shard["picks"]
     ref = _oracle_pairs(orc, batch, picks, kw)
-    for k, r in zip(picks, ref):
-        rot, tr = pose_error(poses[k], r["T"])
-        assert rot <= ROT_TOL and tr <= TRANS_TOL, (k, rot, tr)
     t = _iteration_table(stats["numIterations"][picks], stats["status"][picks], np.array([r["its"] for r in ref]),
                          np.array([r["status"] for r in ref]))
+    errs = np.array([pose_error(poses[k], r["T"]) for k, r in zip(picks, ref)])
     print("\nconfig-5 shard iteration statistics (timing tolerances):", json.dumps(t))
+    print("pose disagreement (rad, m) per pair:", np.array2string(errs, precision=2, max_line_width=200))
+    for k, r, e in zip(picks, ref, errs):
+        print(k, "hip", stats["numIterations"][k].tolist(), [hex(x) for x in stats["status"][k].tolist()], "orc", r["its"], [hex(x) for x in r["status"]],
+              "err %.2e %.2e" % tuple(e))
     assert t["within_1"] >= 0.9 and t["same_status"] >= 0.85, t
     assert t["abs_delta_mean"] <= 1.0, t
+    assert errs[:, 0].max() <= ROT_TOL and errs[:, 1].max() <= TRANS_TOL, (errs[:, 0].max(), errs[:, 1].max())
 
 
 # ---- multi-rank: bench.py under torch.distributed.run ---------------------------------------------------------------
