@@ -265,6 +265,7 @@ def main():
 
     gn_local = ctx.total_linearizations()
     med_paths = ctx.median_path_counts()
+    tap = ctx.tap_cache_counts()
     fused_pts = ctx.fused_point_counts()
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
     points_linearized = all_kstats["irls_reduce"]["units"]     # device-side count: sum over linearisations of N
@@ -359,6 +360,10 @@ def main():
             "pose_check": pose_err,
             "pose_vs_cpu": pose_vs_cpu,
             "median_selections": {"bracketed": med_paths[0], "full": med_paths[1]},
+            "tap_cache": {"hits": tap[0], "lookups": tap[1], "hit_rate": (tap[0] / tap[1]) if tap[1] else None,
+                          "first_8_linearisations_of_a_level": {"hits": tap[2], "lookups": tap[3], "hit_rate": (tap[2] / tap[3]) if tap[3] else None},
+                          "later_linearisations": {"hit_rate": ((tap[0] - tap[2]) / (tap[1] - tap[3])) if tap[1] > tap[3] else None},
+                          "note": "lookups = valid template points; counted by the fused-tail launch chain"},
             "fused_path": {"points": fused_pts[0], "of": fused_pts[1],
                            "note": "linearisations with a frozen robust scale: residuals recomputed inside irls_reduce, warp_residual skips them"},
             "roofline": roofline,
