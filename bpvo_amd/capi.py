@@ -383,8 +383,9 @@ class Context:
         return a.value, b.value
 
     def tap_cache_counts(self):
-        """(hits, lookups, hits in the first 8 linearisations of a level, lookups there) since the last counter reset."""
-        a = (C.c_uint64 * 4)()
+        """(hits, lookups, hits in the first 8 linearisations of a level, lookups there, candidate keys of the median tails)
+        since the last counter reset."""
+        a = (C.c_uint64 * 5)()
         self.call("tap_cache_counts", a)
         return tuple(int(x) for x in a)
 

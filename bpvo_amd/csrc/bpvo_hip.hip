@@ -146,6 +146,7 @@ struct bpvo_hip_ctx {
   int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
+  bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int chain_mode = 0;          // GN launch chain: 0 auto (fused tails for groups of >= tail_min_pairs active workspaces, the four-launch
                                // chain below), 1 always four launches, 2 always fused tails; BPVO_HIP_CHAIN=auto|classic|tails
   int tail_min_pairs = 12;     // BPVO_HIP_TAIL_MIN_PAIRS
@@ -157,6 +158,7 @@ struct bpvo_hip_ctx {
   uint64_t kc_launches[KC_COUNT] = {};
   uint64_t total_lin = 0, median_bracketed = 0, median_full = 0;
   uint64_t tap_counts[4] = {};
+  uint64_t tail_candidates = 0;
   std::string err;
 };
 
@@ -435,8 +437,11 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
         if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
         else launch_intensity(c->stream, jobs, g.cols, g.rows, count);
       } else {
-        launch_census(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
-        launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k);
+        // census fused into the bit-planes kernel unless the census is taken of the smoothed image or the planes stay unsmoothed
+        const bool fused_census = !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f && !c->split_census;
+        if(!fused_census)
+          launch_census(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
+        launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k, fused_census ? 1 : 0);
       }
     }
   }
@@ -580,8 +585,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
-        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
+        // fused-tail chain: median_finish (first linearisations of the level, bracket misses) runs in the first iteration of a round
+        const int mf = (!g.tails || k == 0) ? 1 : 0;
+        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g, mf); }
         if(g.tails) {
+          if(mf) { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all); launch_median(ln->stream, g); }
           ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all);
           launch_irls_reduce(ln->stream, g);
         } else if(c->profile_all) {
@@ -690,6 +698,7 @@ int refresh_counters(bpvo_hip_ctx* c)
   c->median_bracketed = h[2];
   c->median_full = h[3];
   for(int k = 0; k < 4; ++k) c->tap_counts[k] = h[5 + k];
+  c->tail_candidates = h[9];
   c->total_lin = h[1];
   // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
   // warp_residual at profiling level 1 is timed on a 1-in-kProfileEvery sample of its launches: its units are scaled to
@@ -996,6 +1005,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_CHAIN")) cp->chain_mode = !std::strcmp(e, "classic") ? 1 : (!std::strcmp(e, "tails") ? 2 : 0);
     if(const char* e = std::getenv("BPVO_HIP_TAIL_MIN_PAIRS")) cp->tail_min_pairs = std::max(1, std::atoi(e));
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
@@ -1253,7 +1263,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   if(g.tails) {
-    launch_warp_residual(c->stream, g, /*repeat_pass=*/1);     // only does something after a bracket miss
+    { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }    // first linearisation / bracket miss; nothing otherwise
     { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
   } else {
     { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
@@ -1637,7 +1647,7 @@ int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* 
   *full = c->median_full;
   return BPVO_OK;
 }
-int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
+int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[5])
 {
   CHECK_CTX(c);
   (void) hipSetDevice(c->device);
@@ -1645,6 +1655,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
   int rc = refresh_counters(c);
   if(rc) return rc;
   for(int k = 0; k < 4; ++k) out[k] = c->tap_counts[k];
+  out[4] = c->tail_candidates;
   return BPVO_OK;
 }
 int bpvo_hip_set_launch_chain(bpvo_hip_ctx* c, int mode)

@@ -42,7 +42,8 @@ void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R
                                const GaussTaps& after);   // C = 8 / 24 / 48
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
-void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3]);
+// from_image: the census transform is computed inside the bit-planes kernel (no launch_census, sigma_bp > 0 and sigma_ct <= 0)
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image);
 void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes);
 void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
                    float max_disp, int border);
@@ -94,7 +95,7 @@ void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 // out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);
 bool gn_tails_supported(int max_points);   // the fused-tail chain indexes at most 2048 bracket chunks per workspace
-void launch_warp_residual(hipStream_t s, const GNLaunch& g, int repeat_pass = 0);
+void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows = 1);   // mf_follows: launch_median comes next (fused-tail chain)
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
 void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);

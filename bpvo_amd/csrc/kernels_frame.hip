@@ -372,27 +372,44 @@ constexpr int BP_STACK = 32 / BP_TH;   // vertically adjacent tiles per workgrou
 // The workgroup walks BP_STACK vertically adjacent tiles; the census bytes of the next tile are fetched into registers
 // before the current tile's passes run, so the global-load latency is hidden behind the LDS/VALU work instead of being
 // exposed once per (short-lived) workgroup.
+// FROM_IMAGE (sigma_ct <= 0, the default): the census transform is fused in — the workgroup stages the u8 IMAGE tile with a
+// 3-px halo and computes the census bytes of its tile + 2-px halo in LDS (reference: bpvo/census.cc:42-91, see census_kernel:
+// same bits, 0 on the 1-px image border), so the census image never exists in HBM: one launch and ~2.3 B/px of traffic less
+// per level.  The REFLECT_101 of the blur acts on CENSUS coordinates, so a staged census position outside the image maps to
+// an interior one first and reads the image around that.
+template <bool FROM_IMAGE>
 __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2)
 {
   constexpr int CR = BP_TH + 2 * BP_HALO, CC = BP_TW + 2 * BP_HALO;   // staged census rows / columns
   constexpr int CW = CC + 4;                                             // padded LDS row pitch of the census tile
-  constexpr int NPRE = (CR * CC + 255) / 256;                            // census bytes per thread
+  constexpr int IR = CR + 2, IC = CC + 2, IW = IC + 2;                   // image window rows / columns / LDS pitch (FROM_IMAGE)
+  constexpr int NSRC = FROM_IMAGE ? IR * IC : CR * CC;                   // bytes staged per tile
+  constexpr int NPRE = (NSRC + 255) / 256;                               // ... per thread
   __shared__ uint8_t s_cen[CR * CW];
+  __shared__ uint8_t s_img[FROM_IMAGE ? IR * IW : 4];
   __shared__ float s_row[CR * BP_TW * 8];
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
   const int x0 = blockIdx.x * BP_TW;
   const int tid = threadIdx.x;
-  const uint8_t* __restrict__ cen = j.cen;
+  const uint8_t* __restrict__ cen = FROM_IMAGE ? j.img : j.cen;
 
   uint8_t pre[NPRE];
   auto prefetch = [&](int y0) {
 #pragma unroll
     for(int k = 0; k < NPRE; ++k) {
       const int i = tid + k * 256;
-      const int ly = i / CC, lx = i - ly * CC;
-      const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
-      pre[k] = (i < CR * CC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
+      if constexpr(FROM_IMAGE) {
+        // image window rows y0-3 .. y0+BP_TH+2, columns x0-3 .. x0+BP_TW+2, clamped (clamped positions are never used: a census
+        // position on the image border is 0 without looking at its neighbours)
+        const int ly = i / IC, lx = i - ly * IC;
+        const int gy = min(max(y0 + ly - BP_HALO - 1, 0), R - 1), gx = min(max(x0 + lx - BP_HALO - 1, 0), W - 1);
+        pre[k] = (i < IR * IC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
+      } else {
+        const int ly = i / CC, lx = i - ly * CC;
+        const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
+        pre[k] = (i < CR * CC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
+      }
     }
   };
   const int ybase = blockIdx.y * BP_TH * BP_STACK;
@@ -400,10 +417,33 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   for(int t = 0; t < BP_STACK; ++t) {
     const int y0 = ybase + t * BP_TH;
     if(y0 >= R) break;
+    if constexpr(FROM_IMAGE) {
 #pragma unroll
-    for(int k = 0; k < NPRE; ++k) {
-      const int i = tid + k * 256;
-      if(i < CR * CC) { const int ly = i / CC, lx = i - ly * CC; s_cen[ly * CW + lx] = pre[k]; }
+      for(int k = 0; k < NPRE; ++k) {
+        const int i = tid + k * 256;
+        if(i < IR * IC) { const int ly = i / IC, lx = i - ly * IC; s_img[ly * IW + lx] = pre[k]; }
+      }
+      __syncthreads();
+      // census of the staged positions: (gy, gx) = REFLECT_101 of the census coordinate, read from the image window
+      for(int i = tid; i < CR * CC; i += 256) {
+        const int ly = i / CC, lx = i - ly * CC;
+        const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
+        uint8_t out = 0;
+        if(gx > 0 && gx < W - 1 && gy > 0 && gy < R - 1) {
+          // window origin: image row y0 - 3, column x0 - 3 (the reflected position lies inside the window: |reflection| <= 2 px)
+          const uint8_t* p = s_img + (gy - (y0 - BP_HALO - 1)) * IW + (gx - (x0 - BP_HALO - 1));
+          const uint8_t c = p[0];
+          out = (uint8_t) (((p[-IW - 1] >= c) << 0) | ((p[-IW] >= c) << 1) | ((p[-IW + 1] >= c) << 2) | ((p[-1] >= c) << 3) |
+                           ((p[1] >= c) << 4) | ((p[IW - 1] >= c) << 5) | ((p[IW] >= c) << 6) | ((p[IW + 1] >= c) << 7));
+        }
+        s_cen[ly * CW + lx] = out;
+      }
+    } else {
+#pragma unroll
+      for(int k = 0; k < NPRE; ++k) {
+        const int i = tid + k * 256;
+        if(i < CR * CC) { const int ly = i / CC, lx = i - ly * CC; s_cen[ly * CW + lx] = pre[k]; }
+      }
     }
     __syncthreads();
     if(t + 1 < BP_STACK && y0 + BP_TH < R) prefetch(y0 + BP_TH);
@@ -1080,11 +1120,13 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
   else
     hipLaunchKernelGGL(census_kernel, dim3((W + 63) / 64, (R + 4 * CENSUS_ROWS - 1) / (4 * CENSUS_ROWS), nframes), dim3(256), 0, s, jobs);
 }
-void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3])
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image)
 {
-  if(sigma > 0.0f)
-    hipLaunchKernelGGL(bitplanes_blur_kernel, dim3((W + BP_TW - 1) / BP_TW, (R + BP_TH * BP_STACK - 1) / (BP_TH * BP_STACK), nframes), dim3(256), 0, s,
-                       jobs, k[0], k[1], k[2]);
+  const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * BP_STACK - 1) / (BP_TH * BP_STACK), nframes);
+  if(sigma > 0.0f && from_image)
+    hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2]);
+  else if(sigma > 0.0f)
+    hipLaunchKernelGGL(bitplanes_blur_kernel<false>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2]);
   else
     hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
 }

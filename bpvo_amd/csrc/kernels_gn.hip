@@ -109,10 +109,11 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
 // order or on the workgroup -> XCD placement.  The bulk streams (residuals, valid flags, tap cache) still change hands at
 // kernel boundaries only.
 //
-// The median tail only ever reads candidate segments.  The first linearisation of a level (no previous median) publishes
-// ALL valid keys (bracket [0, 2^32)); a bracket miss leaves k8_go = 0, the workspace sits out this iteration's irls_reduce
-// and repeats warp_residual with the all-keys bracket in the next iteration slot — same pose, same residuals, so the
-// result is the exact median either way.
+// The median tail only ever reads the bracket counters and candidate segments of its workspace (a few KB): it serves the
+// BRACKETED selections.  Whatever needs all keys — the first linearisation of a level, a bracket miss (0.7 % of the
+// selections), a degenerate sample — is left to median_finish_kernel, which the host launches in the first iteration of
+// every round of kItersPerSync and which only looks at workspaces that still lack their scale (k8_go == 0): after a miss a
+// workspace sits out the iterations until then (irls_reduce skips it, warp_residual does not recompute its residuals).
 typedef unsigned bpvo_v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned kRsrcWord3 = 0x00020000u;   // raw buffer descriptor, 32-bit untyped data (gfx9 family)
 
@@ -147,12 +148,14 @@ __device__ __forceinline__ void tail_acquire()
 constexpr int TAIL_BINS = 1024;            // 10-bit digits (LDS of the tail counts against every workgroup of warp_residual)
 constexpr unsigned kTailDigit = 10u;
 constexpr int TAIL_MAX_BLOCKS = 1024;      // bracket chunks per workspace the tail can index (prefix offsets in LDS): 262 144 points
+constexpr int TAIL_CACHE = 3072;           // candidate keys the tail keeps in LDS after its first pass over them
+constexpr unsigned kPadKey = 0xffffffffu;  // pads a candidate run to whole 16-byte pieces; key - lo_key >= 2^31: never selected
 template <int C>
 struct alignas(16) K6TailLds {
-  // candidate staging of the publish step, then the two digit histograms of the selection
-  static constexpr int kStage = K6_BLOCK * C > 2 * TAIL_BINS ? K6_BLOCK * C : 2 * TAIL_BINS;
+  // candidate staging of the publish step; then the two digit histograms [0, 2 * TAIL_BINS) + the candidate cache
+  static constexpr int kStage = K6_BLOCK * C + 4 > 2 * TAIL_BINS + TAIL_CACHE ? K6_BLOCK * C + 4 : 2 * TAIL_BINS + TAIL_CACHE;
   unsigned buf[kStage];
-  unsigned off[TAIL_MAX_BLOCKS + 1];       // exclusive prefix of the per-chunk candidate counts
+  unsigned off[TAIL_MAX_BLOCKS + 1];       // exclusive prefix of the per-chunk candidate runs, in 16-byte pieces
   unsigned list_lo[K6_BLOCK], list_hi[K6_BLOCK];
   unsigned wave[4 * K6_WAVES + 4];         // scan / block-sum scratch
   unsigned cur[4];                         // MedCursor lo, hi
@@ -235,8 +238,9 @@ __device__ __forceinline__ void bracket_publish(const PairJob& j, K6TailLds<C>& 
     for(int c = 0; c < C; ++c)
       if(mask & ((mask_t) 1u << c)) L.buf[pos++] = keys[c];
   }
+  if(threadIdx.x < ((tot + 3u) & ~3u) - tot) L.buf[tot + threadIdx.x] = kPadKey;
   __syncthreads();
-  // coalesced write-through stores of the staged run (the last 16-byte piece may carry up to 3 stale words: never read)
+  // coalesced write-through stores of the staged run, padded to whole 16-byte pieces
   {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.cand + (size_t) blockIdx.x * K6_BLOCK * C, 0,
                                                                         K6_BLOCK * C * (int) sizeof(unsigned), kRsrcWord3);
@@ -323,17 +327,18 @@ __device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, i
   tail_acquire();
   unsigned* hist_lo = L.buf;
   unsigned* hist_hi = L.buf + TAIL_BINS;
+  unsigned* cache = L.buf + 2 * TAIL_BINS;
   MedCursor* cur = reinterpret_cast<MedCursor*>(L.cur);
 
-  // totals of the per-chunk counters + exclusive prefix of the candidate counts (flat candidate index -> chunk)
-  unsigned c_below = 0, c_valid = 0, c_hit = 0, run = 0;
+  // totals of the per-chunk counters + exclusive prefix of the candidate runs in 16-byte pieces (flat piece index -> chunk)
+  unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0, run = 0;
   for(int base = 0; base < nblk; base += NT) {
     const int b = base + tid;
     uint4 o = make_uint4(0u, 0u, 0u, 0u);
     if(b < nblk) o = reinterpret_cast<const uint4*>(j.med_blk)[b];
-    c_below += o.x; c_valid += o.z; c_hit += o.w;
+    c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
     unsigned chunk_total;
-    const unsigned ex = block_excl_scan_nt<NT>(o.y, L.wave, chunk_total);
+    const unsigned ex = block_excl_scan_nt<NT>((o.y + 3u) >> 2, L.wave, chunk_total);
     if(b < nblk) L.off[b] = run + ex;
     run += chunk_total;
   }
@@ -341,41 +346,55 @@ __device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, i
 #pragma unroll
   for(int o = 32; o >= 1; o >>= 1) {
     c_below += __shfl_down(c_below, o);
+    c_in += __shfl_down(c_in, o);
     c_valid += __shfl_down(c_valid, o);
     c_hit += __shfl_down(c_hit, o);
   }
   __syncthreads();
-  if((tid & 63) == 0) { L.wave[(tid >> 6) * 3 + 0] = c_below; L.wave[(tid >> 6) * 3 + 1] = c_valid; L.wave[(tid >> 6) * 3 + 2] = c_hit; }
+  if((tid & 63) == 0) { unsigned* w = L.wave + (tid >> 6) * 4; w[0] = c_below; w[1] = c_in; w[2] = c_valid; w[3] = c_hit; }
   __syncthreads();
-  unsigned t_below = 0, t_valid = 0, t_hit = 0;
+  unsigned t_below = 0, m = 0, t_valid = 0, t_hit = 0;
 #pragma unroll
-  for(int w = 0; w < K6_WAVES; ++w) { t_below += L.wave[w * 3 + 0]; t_valid += L.wave[w * 3 + 1]; t_hit += L.wave[w * 3 + 2]; }
+  for(int w = 0; w < K6_WAVES; ++w) { t_below += L.wave[w * 4 + 0]; m += L.wave[w * 4 + 1]; t_valid += L.wave[w * 4 + 2]; t_hit += L.wave[w * 4 + 3]; }
   __syncthreads();
-  const unsigned m = run;                       // candidates inside the bracket
+  const unsigned pieces = run;                  // 16-byte pieces of candidates (m keys + padding)
   const unsigned nt = (unsigned) C * t_valid;   // size_t n of estimateScale
-  const bool all_keys = !st->median_valid;      // bracket [0, 2^32): every valid key is a candidate
-  const unsigned lo_key = all_keys ? 0u : st->lo_key;
-  const unsigned range = all_keys ? 0x7fffffffu : st->hi_key - st->lo_key;
+  const unsigned lo_key = st->lo_key;
+  const unsigned range = st->hi_key - st->lo_key;
+  const bool cached = pieces * 4u <= (unsigned) TAIL_CACHE;
+  bool filled = false;
 
-  // flat walk over the candidates: thread t takes candidates t, t + NT, ...; kU loads in flight per lane
+  // all candidates as offsets d = key - lo_key.  First call: flat walk over the 16-byte pieces in HBM (thread t takes pieces
+  // t, t + NT, ...; kU loads in flight per lane), which also fills the LDS cache when the candidates fit; later calls read
+  // the cache.  Padding keys give d >= 2^31 and match no cursor.
   auto src = [&](auto f) {
+    if(cached && filled) {
+      for(unsigned i = tid; i < pieces * 4u; i += NT) f(cache[i]);
+      return;
+    }
     constexpr int kU = 4;
 #pragma unroll 1
-    for(unsigned g0 = tid; g0 < m; g0 += NT * kU) {
-      unsigned k[kU];
+    for(unsigned p0 = tid; p0 < pieces; p0 += NT * kU) {
+      uint4 k[kU];
 #pragma unroll
       for(int u = 0; u < kU; ++u) {
-        const unsigned g = g0 + (unsigned) u * NT;
-        k[u] = 0u;
-        if(g < m) {
-          int a = 0, b = nblk;               // last chunk with off[chunk] <= g
-          while(b - a > 1) { const int mid = (a + b) >> 1; if(L.off[mid] <= g) a = mid; else b = mid; }
-          k[u] = j.cand[(size_t) a * K6_BLOCK * C + (g - L.off[a])];
+        const unsigned pc = p0 + (unsigned) u * NT;
+        k[u] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+        if(pc < pieces) {
+          int a = 0, b = nblk;               // last chunk with off[chunk] <= pc
+          while(b - a > 1) { const int mid = (a + b) >> 1; if(L.off[mid] <= pc) a = mid; else b = mid; }
+          k[u] = *reinterpret_cast<const uint4*>(j.cand + (size_t) a * K6_BLOCK * C + 4u * (pc - L.off[a]));
         }
       }
 #pragma unroll
-      for(int u = 0; u < kU; ++u)
-        if(g0 + (unsigned) u * NT < m) f(k[u] - lo_key);
+      for(int u = 0; u < kU; ++u) {
+        const unsigned pc = p0 + (unsigned) u * NT;
+        if(pc < pieces) {
+          const uint4 d = make_uint4(k[u].x - lo_key, k[u].y - lo_key, k[u].z - lo_key, k[u].w - lo_key);
+          if(cached) *reinterpret_cast<uint4*>(cache + 4u * pc) = d;
+          f(d.x); f(d.y); f(d.z); f(d.w);
+        }
+      }
     }
   };
 
@@ -385,13 +404,14 @@ __device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, i
   if(nt >= 3 && k_lo >= t_below && k_hi < t_below + m && range > 0) {
     MedCursor lo, hi;
     lo.prefix = 0; hi.prefix = 0; lo.rank = k_lo - t_below; hi.rank = k_hi - t_below;
-    const unsigned nbits = 32u - (unsigned) __clz((int) range);        // offsets d = key - lo_key are <= range < 2^nbits
+    const unsigned nbits = 32u - (unsigned) __clz((int) range);        // offsets d = key - lo_key are < range < 2^nbits
     unsigned remaining = nbits;
     while(remaining > 0) {
       const unsigned width = remaining > kTailDigit ? kTailDigit : remaining;
       const bool was_split = lo.prefix != hi.prefix;
       remaining -= width;
       refine_pass_nt<NT>(src, remaining, width, lo, hi, hist_lo, hist_hi, L.wave, cur);
+      filled = true;
       if(remaining == 0) break;
       // the selected bins usually hold a handful of keys: finish by direct ranking (each thread ranks one key of the bin by
       // counting the smaller ones) instead of more histogram passes
@@ -432,29 +452,21 @@ __device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, i
     const float v_lo = __uint_as_float(lo_key + lo.prefix), v_hi = __uint_as_float(lo_key + hi.prefix);
     median = (nt % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
     done = true;
-  } else if(all_keys) {
-    // median(): data.size() < 3 -> data[0], the first valid entry in channel-major order (Q5; reachable for C == 1 only):
-    // the first candidate of the first chunk that has one is the first valid point's key
-    if(nt > 0 && m > 0) {
-      int a = 0;
-      while(a < nblk && L.off[a + 1] == 0u) ++a;
-      median = __uint_as_float(j.cand[(size_t) a * K6_BLOCK * C]);
-    }
-    done = true;
   }
 
   if(tid == 0) {
     unsigned long long* cnt = j.cnt;
-    cnt[(done && !all_keys) ? 2 : 3] += 1ull;                               // bracketed | all-keys selections and misses
+    if(done) cnt[2] += 1ull;                                                 // bracketed selections (median_finish counts the others)
     cnt[5] += (unsigned long long) t_hit;  cnt[6] += (unsigned long long) t_valid;     // tap-cache hits / lookups (valid points)
     if(st->num_fun_evals < 8) { cnt[7] += (unsigned long long) t_hit; cnt[8] += (unsigned long long) t_valid; }
+    cnt[9] += (unsigned long long) m;                                        // candidate keys the tails went through
     if(done) {
       const unsigned long long nm6 = (unsigned long long) nt - 6ull;        // size_t wrap for n < 6 (Q5)
       float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
       if((double) s < 1e-6) s = 1.0f;
       st->delta_scale = fabsf(s - st->scale);
       st->scale = s;
-      if(nt >= 3 && median > 0.0f) {
+      if(median > 0.0f) {
         float rel = 0.25f;
         if(st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
         st->last_median = median;
@@ -466,7 +478,7 @@ __device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, i
       }
       st->k8_go = 1;
     } else {
-      st->median_valid = 0;      // bracket miss: all-keys repeat in the next iteration slot (last_median stays: it widens the next bracket)
+      st->median_valid = 0;      // bracket miss / degenerate sample: median_finish of the next round (last_median stays: it widens the next bracket)
     }
     __hip_atomic_store(j.tickets + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
   }
@@ -716,20 +728,22 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
 // TAIL: the median tail is rarely executed code that must not decide the kernel's register allocation — the budget of 4
 // waves per SIMD (128 VGPRs; the streaming part needs ~65) is imposed and whatever the tail needs beyond it spills
 template <int C, bool FAST, bool TAIL>
-__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? K6_TAIL_WAVES : 1, 8))) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
+__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? K6_TAIL_WAVES : 1, 8))) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode,
+                                                                                                int mf_follows)
 {
   // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
   // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
   // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
-  // TAIL: fused-tail chain — the last-arriving workgroup of a workspace selects the median (median_tail); mode 3 there:
-  // the repeat pass of a single linearisation (bpvo_hip_linearize): only workspaces whose bracket missed (k8_go == 0).
+  // TAIL: fused-tail chain — the last-arriving workgroup of a workspace selects the median among the bracket candidates
+  // (median_tail).  A workspace without a bracket (first linearisation of a level, after a miss) needs median_finish_kernel:
+  // its residuals are only computed in the iterations in which the host launches that kernel next (mf_follows).
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(mode == 2) { if(!st->r_stale) return; }
   else {
     if(!st->active) return;
     if(mode == 1 && !(st->delta_scale > 1e-6f)) return;
-    if(mode == 3 && (st->k8_go || !(st->delta_scale > 1e-6f))) return;
+    if(TAIL && !mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for median_finish
   }
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
@@ -762,10 +776,9 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   };
   const bool moving = st->delta_scale > 1e-6f;
   if constexpr(TAIL) {
-    if(mode != 2 && moving) {
+    if(mode != 2 && moving && st->median_valid) {
       __shared__ K6TailLds<C> L;
-      const bool all_keys = !st->median_valid;      // first linearisation of a level, or the repeat after a bracket miss
-      bracket_publish<C>(j, L, all_keys ? 0u : st->lo_key, all_keys ? 0x80000000u : st->hi_key, valid && in_block, hit && valid && in_block, res);
+      bracket_publish<C>(j, L, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res);
       const int nblk = (n + K6_BLOCK - 1) / K6_BLOCK;
       ticket_arrive(j.tickets + 0, (unsigned) nblk, &L.misc[0]);
       store_residuals();        // bulk stream: changes hands at the kernel boundary, overlaps the ticket's round trip
@@ -829,12 +842,12 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
 }
 
 template <int C, bool TAIL>
-__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? 2 : 1, 8))) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp, int mode)
+__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? 2 : 1, 8))) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp, int mf_follows)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(mode == 3 && (st->k8_go || !(st->delta_scale > 1e-6f))) return;   // repeat pass of a single linearisation (see warp_residual_kernel)
+  if(TAIL && !mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for median_finish (see warp_residual_kernel)
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
 
@@ -941,10 +954,9 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   };
   const bool moving = st->delta_scale > 1e-6f;
   if constexpr(TAIL) {
-    if(moving) {
+    if(moving && st->median_valid) {
       __shared__ K6TailLds<C> L;
-      const bool all_keys = !st->median_valid;
-      bracket_publish<C>(j, L, all_keys ? 0u : st->lo_key, all_keys ? 0x80000000u : st->hi_key, valid && in_block, false, res);
+      bracket_publish<C>(j, L, st->lo_key, st->hi_key, valid && in_block, false, res);
       const int nblk = (n + K6_BLOCK - 1) / K6_BLOCK;
       ticket_arrive(j.tickets + 0, (unsigned) nblk, &L.misc[0]);
       store_residuals();
@@ -1113,6 +1125,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
+  if(st->k8_go) return;                    // fused-tail chain: the tail of warp_residual has already selected this median
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
@@ -1287,7 +1300,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
     // change + 2 % (first use: 25 %), at most 50 %
     if(n_total >= 3 && median > 0.0f) {
       float rel = 0.25f;
-      if(st->median_valid && st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
+      if(st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
       st->last_median = median;
       st->lo_key = __float_as_uint(median * (1.0f - rel));
       st->hi_key = __float_as_uint(median * (1.0f + rel)) + 1u;
@@ -1295,6 +1308,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
     } else {
       st->median_valid = 0;
     }
+    st->k8_go = 1;
   }
 }
 
@@ -1863,41 +1877,39 @@ void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
 bool gn_tails_supported(int max_points) { return gn_num_blocks(max_points) <= TAIL_MAX_BLOCKS; }
 
 template <bool TAIL>
-static void launch_warp_residual_t(hipStream_t s, const GNLaunch& g, int repeat_pass)
+static void launch_warp_residual_t(hipStream_t s, const GNLaunch& g, int mf_follows)
 {
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL((warp_residual_interp_kernel<decltype(c)::value, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp,
-                         repeat_pass ? 3 : 0);
+      hipLaunchKernelGGL((warp_residual_interp_kernel<decltype(c)::value, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp, mf_follows);
     });
     return;
   }
   if(g.fast_warp) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, repeat_pass ? 3 : 0);
+      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0, mf_follows);
     });
   } else {
     dispatch_channels(g.C, [&](auto c) {
       constexpr int CC = decltype(c)::value;
-      hipLaunchKernelGGL((warp_residual_kernel<CC, false, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active,
-                         repeat_pass ? 3 : ((CC == 8 && g.fuse_frozen) ? 1 : 0));
+      hipLaunchKernelGGL((warp_residual_kernel<CC, false, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0, mf_follows);
     });
   }
 }
-// repeat_pass (fused-tail chain, single linearisations): only the workspaces whose bracket missed in the pass before
-void launch_warp_residual(hipStream_t s, const GNLaunch& g, int repeat_pass)
+// mf_follows (fused-tail chain): launch_median comes next, so workspaces without a usable bracket compute their residuals
+void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows)
 {
   if(g.max_points <= 0) return;
-  if(g.tails) launch_warp_residual_t<true>(s, g, repeat_pass);
-  else if(!repeat_pass) launch_warp_residual_t<false>(s, g, 0);
+  if(g.tails) launch_warp_residual_t<true>(s, g, mf_follows);
+  else launch_warp_residual_t<false>(s, g, 1);
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0 || g.C != 8) return;
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
-  hipLaunchKernelGGL((warp_residual_kernel<8, false, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2, 1);
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);

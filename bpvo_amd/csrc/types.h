@@ -109,8 +109,8 @@ struct GNState {
   float T_lin[16];
   int   r_stale;
   // Fused-tail chain (kernels_gn.hip): 1 once the robust scale of the pending linearisation is known — set by the median
-  // tail of warp_residual, or ahead of time by the gn tail when the scale is frozen; irls_reduce waits for it (a bracket
-  // miss leaves it 0: the workspace repeats warp_residual with an all-keys bracket in the next iteration slot)
+  // tail of warp_residual, by median_finish, or ahead of time by gn_step when the scale is frozen; the irls_reduce of the
+  // fused-tail chain waits for it (a bracket miss leaves it 0 until the next median_finish launch)
   int   k8_go;
 };
 
@@ -159,7 +159,8 @@ struct PairJob {
                            // [2] bracketed / [3] full median selections (fused-tail chain: [3] = all-keys selections + bracket
                            // misses), [4] points processed by warp_residual (the rest went through the fused path of
                            // irls_reduce), [5] tap-cache hits / [6] lookups (= valid points), [7] / [8] the same over the first 8
-                           // linearisations of a level (counted by the fused-tail chain only); written by one thread each: no atomics
+                           // linearisations of a level, [9] candidate keys the median tails went through (counted by the fused-tail chain only);
+                           // written by one thread each: no atomics
   GNState*      st;
 };
 
