@@ -43,6 +43,10 @@ def parse_args():
     ap.add_argument("--descriptor", default="bitplanes", choices=["bitplanes", "intensity"])
     ap.add_argument("--loss", default="tukey", choices=["tukey", "huber", "l2"])
     ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --pairs-per-gpu is the TOTAL batch (BASELINE config 5: 1024 pairs), every rank runs total / N of it")
+    ap.add_argument("--tolerances", default="default", choices=["default", "timing"],
+                    help="default = AlgorithmParameters() (1e-7 / 1e-6 / 1e-8); timing = the reference's conf/perf_*.cfg (1e-6 / 1e-4 / 1e-6)")
     ap.add_argument("--fixed-iters", type=int, default=0,
                     help="throughput mode: tolerances 0 and maxIterations=K (K+2 linearisations per level); 0 = converge")
     ap.add_argument("--cpu-pairs", type=int, default=40, help="bounded sample for the CPU baseline (0 = skip)")
@@ -70,6 +74,10 @@ def make_params(binding, args):
     p.descriptor = capi.DESC_BITPLANES if args.descriptor == "bitplanes" else capi.DESC_INTENSITY
     p.lossFunction = {"tukey": capi.LOSS_TUKEY, "huber": capi.LOSS_HUBER, "l2": capi.LOSS_L2}[args.loss]
     p.verbosity = capi.VERB_SILENT
+    if getattr(args, "tolerances", "default") == "timing":
+        p.parameterTolerance = 1e-6
+        p.functionTolerance = 1e-4
+        p.gradientTolerance = 1e-6
     if args.fixed_iters > 0:
         p.maxIterations = args.fixed_iters
         p.parameterTolerance = 0.0
@@ -112,16 +120,16 @@ def cpu_baseline(args, batch, n_sample):
     }
 
 
-def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, levels, loss, steps=3, warmup=1):
+def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, levels, loss, steps=3, warmup=1, tolerances="default"):
     """GN iterations/s of one more configuration (same step definition as the headline, inputs resident in HBM)."""
     from types import SimpleNamespace
-    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0))
+    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0, tolerances=tolerances))
     ctx = hip.create(batch["K"], batch["b"], rows, cols, p, device=dev_index, n_frames=2 * n, n_pairs=n)
     d_i = torch.from_numpy(batch["images"][: 2 * n]).to(dev)
     d_d = torch.from_numpy(batch["disparities"][: 2 * n]).to(dev)
     for _ in range(warmup):
         ctx.batch_run_device(n, d_i.data_ptr(), d_d.data_ptr())
-    ctx.profiling(0)
+    ctx.profiling(1)          # events around the frame stages only cost a few launches' gaps; warp_residual is sampled 1 in 5
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -129,10 +137,16 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gn = ctx.total_linearizations()
+    ks = {k["name"]: k for k in ctx.kernel_stats()}
+    frame_ms = sum(ks[k]["total_ms"] for k in ("pyramid", "descriptor", "saliency_select", "normalization", "template_build")) / steps
+    k6 = ks["warp_residual"]
+    k6_frac = (k6["units"] * k6["bytes_per_unit"] / (k6["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if k6["total_ms"] > 0 else None
     dT = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - batch["T_gt"][:n, :3, 3], axis=1)
     ctx.close()
     return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "frames_per_s": 2.0 * n * steps / dt, "ms_per_step": 1e3 * dt / steps,
-            "gn_iterations_per_pair": gn / (steps * n), "median_trans_err_vs_gt_m": float(np.median(dT))}
+            "frame_stage_ms_per_step": frame_ms, "warp_residual_hbm_frac": k6_frac,
+            "gn_iterations_per_pair": gn / (steps * n), "numIterations_per_pair": float(stats["numIterations"].sum()) / n,
+            "median_trans_err_vs_gt_m": float(np.median(dT))}
 
 
 def add_frame_latency(hip, dev_index, seq, which):
@@ -174,6 +188,17 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
         "1241x376 bitplanes, 4 levels, tukey, one pair per call (B = 1)":
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1, args.descriptor, args.levels, args.loss, steps=5, warmup=2),
     }
+    npairs = batch["images"].shape[0] // 2
+    if npairs >= 128:
+        # BASELINE config 5 as it is really sharded: 1024 pairs over 8 GPUs = 128 pairs per GPU (strong scaling; `--strong --gpus 8`
+        # runs exactly this on every rank)
+        out["config-5 shard: 128 of the 1024 pairs (1241x376 bitplanes, 4 levels, tukey) on one GPU"] = \
+            timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 128, args.descriptor, args.levels, args.loss, steps=10, warmup=2)
+    if npairs >= 1024:
+        # the reference's own timing tolerances (conf/perf_*.cfg: 1e-6 / 1e-4 / 1e-6, 3 levels): ~7x fewer iterations per level than the
+        # AlgorithmParameters() defaults, so the per-frame stages are about half of the step
+        out["1241x376 bitplanes, 3 levels, tukey, tolerances of conf/perf_bitplanes.cfg (1e-6/1e-4/1e-6), 1024 pairs"] = \
+            timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1024, args.descriptor, 3, args.loss, steps=3, warmup=1, tolerances="timing")
     if seq640 is not None:
         out["addFrame 640x480, parameters of conf/perf_intensity.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_intensity")
         out["addFrame 640x480, parameters of conf/perf_bitplanes.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_bitplanes")
@@ -190,8 +215,15 @@ def main():
     from bpvo_amd.distributed import RECORD_FLOATS, gather_records, records_to_poses, shard_range
 
     # ---- synthetic inputs for this rank's shard (rendered on the CPU before anything touches the GPU)
-    P = args.pairs_per_gpu
-    lo, hi = shard_range(P * world, rank, world)
+    if args.strong:
+        total = args.pairs_per_gpu
+        lo, hi = shard_range(total, rank, world)
+        P = hi - lo
+        if P <= 0 or total % world:
+            raise SystemExit("--strong needs the total batch to divide by the number of ranks")
+    else:
+        P = args.pairs_per_gpu
+        lo, hi = shard_range(P * world, rank, world)
     workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
     t0 = time.perf_counter()
     cache = os.path.join(args.input_cache, f"synth_{args.rows}x{args.cols}_{lo}_{hi}") if args.input_cache else ""
@@ -270,15 +302,19 @@ def main():
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
     points_linearized = all_kstats["irls_reduce"]["units"]     # device-side count: sum over linearisations of N
     kstats = all_kstats if not args.no_profile else {}
-    t = torch.tensor([elapsed, float(gn_local)], dtype=torch.float64, device=coll_dev)
+    # the reference's own iteration counter (OptimizerStatistics::numIterations, bpvo/pose_estimator_base.h:392-398) summed over
+    # pairs and levels of the LAST step; `gn_local` counts linearisations (= _num_fun_evals, pose_estimator_gn.h:78), 1-2 more per level
+    numit_last_step = float(stats["numIterations"].sum())
+    frame_ms_local = sum(all_kstats[k]["total_ms"] for k in ("pyramid", "descriptor", "saliency_select", "normalization", "template_build"))
+    t = torch.tensor([elapsed, float(gn_local), numit_last_step, frame_ms_local], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, gn_total = float(tmax[0]), float(tsum[1])
+        elapsed_max, gn_total, numit_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
     else:
-        elapsed_max, gn_total = elapsed, float(gn_local)
+        elapsed_max, gn_total, numit_total = elapsed, float(gn_local), numit_last_step
 
     if rank == 0:
         n_pairs_total = P * world
@@ -319,6 +355,17 @@ def main():
                         "bytes_per_point": 18 + 24 * (8 if args.descriptor == "bitplanes" else 1),
                         "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"]}
 
+        # the whole Gauss-Newton loop against the HBM roofline: algorithmic bytes of one iteration (20 + 56 C per point)
+        # x points linearised, over the step time that is not spent in the per-frame stages (HIP events around those)
+        gn_loop = None
+        if not args.no_profile and points_linearized > 0:
+            C_ = 8 if args.descriptor == "bitplanes" else 1
+            gn_s = elapsed - frame_ms_local * 1e-3
+            gbps = (20 + 56 * C_) * points_linearized / gn_s / 1e9
+            gn_loop = {"bytes_per_point": 20 + 56 * C_, "points_linearized": points_linearized, "seconds": gn_s,
+                       "frame_stage_seconds": frame_ms_local * 1e-3, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
+                       "note": "rank 0; everything between the frame stages and the end of the step counts as loop time (launch gaps, host round trips, the narrow per-pair work)"}
+
         cpu = None
         pose_vs_cpu = None
         if args.cpu_pairs > 0 and world == 1:      # the CPU leg runs at N = 1 only (the other ranks would wait for it)
@@ -340,21 +387,27 @@ def main():
 
         iters = stats["numIterations"].astype(np.float64)
         out = {
-            "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS)"
+            "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS; one iteration = one "
+                      "linearisation + solve + pose update, counted like the reference's _num_fun_evals)"
             if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s",
             "value": gn_total / elapsed_max, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "dist_backend": (args.dist_backend if world > 1 else None),
-            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 projection/interpolation)", "data": "synthetic",
             "config": {"workload": f"batch of {n_pairs_total} independent {args.cols}x{args.rows} stereo pairs "
                                    f"({P} per GPU), {args.descriptor} descriptor, {args.levels} pyramid levels, {args.loss} loss, "
-                                   + ("converge with AlgorithmParameters() tolerances" if args.fixed_iters == 0 else
+                                   + (("converge with AlgorithmParameters() tolerances" if args.tolerances == "default" else
+                                       "converge with the tolerances of conf/perf_*.cfg (1e-6 / 1e-4 / 1e-6)") if args.fixed_iters == 0 else
                                       f"fixed {args.fixed_iters} iterations/level (tolerances 0)"),
                        "pairs_per_gpu": P, "sharding": f"pairs/{world} ranks, one RCCL gather of 32-float records" if world > 1 else "single GPU",
                        "step": "setData(A,B) + setTemplate(A) + estimatePose(A,B) per pair, inputs resident in HBM"},
             "frames_per_s": 2.0 * n_pairs_total * args.steps / elapsed_max,
             "pairs_per_s": n_pairs_total * args.steps / elapsed_max,
             "gn_iterations_per_step": gn_total / args.steps,
+            "numIterations_per_s": numit_total * args.steps / elapsed_max,
+            "numIterations_note": "sum over pairs and levels of OptimizerStatistics::numIterations (the reference's reported count: 1-2 below "
+                                  "the linearisations of a level) per second — the like-for-like figure next to `value`",
+            "gn_loop_roofline": gn_loop,
             "points_linearized_rank0": points_linearized,
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,

@@ -585,19 +585,20 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
-        // fused-tail chain: median_finish (first linearisations of the level, bracket misses) runs in the first iteration of a round
-        const int mf = (!g.tails || k == 0) ? 1 : 0;
+        // the full (all-keys) median selection — first linearisations of a level, bracket misses — runs in the first iteration
+        // of a round only; in between a workspace that misses its bracket waits (0.7 % of the selections)
+        const int mf = (k == 0) ? 1 : 0;
         { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g, mf); }
         if(g.tails) {
           if(mf) { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all); launch_median(ln->stream, g); }
           ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all);
           launch_irls_reduce(ln->stream, g);
         } else if(c->profile_all) {
-          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
+          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g, mf); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
           { ScopedTimer t(c, KC_GN_STEP, 0.0, ln); launch_gn_step(ln->stream, g); }
         } else {
-          launch_median(ln->stream, g);
+          launch_median(ln->stream, g, mf);
           launch_irls_reduce(ln->stream, g);
           launch_gn_step(ln->stream, g);
         }
@@ -708,7 +709,7 @@ int refresh_counters(bpvo_hip_ctx* c)
   const bool sampled = c->profiling && !c->profile_all && all_k6 > 0;
   // (h[4]: the points warp_residual itself processed; workspaces with a frozen scale go through irls_reduce's fused path)
   c->kc_units[KC_WARP_RESIDUAL] = sampled ? (double) h[4] * (double) c->kc_launches[KC_WARP_RESIDUAL] / all_k6 : (double) h[4];
-  c->points_fused = (double) h[0] - (double) h[4];
+  c->points_fused = (double) h[10];
   c->kc_units[KC_IRLS_REDUCE] = (double) h[0];
   c->kc_units[KC_MEDIAN] = (double) h[0];
   c->kc_units[KC_GN_STEP] = (double) h[1];

@@ -95,9 +95,9 @@ void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 // out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);
 bool gn_tails_supported(int max_points);   // the fused-tail chain indexes at most 2048 bracket chunks per workspace
-void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows = 1);   // mf_follows: launch_median comes next (fused-tail chain)
+void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows = 1);   // mf_follows: launch_median(allow_full = 1) comes next
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
-void launch_median(hipStream_t s, const GNLaunch& g);
+void launch_median(hipStream_t s, const GNLaunch& g, int allow_full = 1);   // allow_full = 0: bracketed selections only (misses wait)
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 void launch_gn_step(hipStream_t s, const GNLaunch& g);   // g.prm; not needed when g.tails
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);

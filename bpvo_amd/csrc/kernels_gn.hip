@@ -735,15 +735,16 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
   // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
   // TAIL: fused-tail chain — the last-arriving workgroup of a workspace selects the median among the bracket candidates
-  // (median_tail).  A workspace without a bracket (first linearisation of a level, after a miss) needs median_finish_kernel:
-  // its residuals are only computed in the iterations in which the host launches that kernel next (mf_follows).
+  // (median_tail).  Both chains: a workspace without a bracket (first linearisation of a level, after a miss) needs the full
+  // selection of median_finish_kernel: its residuals are only computed in the iterations in which the host launches that
+  // kernel with allow_full next (mf_follows).
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(mode == 2) { if(!st->r_stale) return; }
   else {
     if(!st->active) return;
     if(mode == 1 && !(st->delta_scale > 1e-6f)) return;
-    if(TAIL && !mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for median_finish
+    if(!mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // no bracket: waits for the next full median_finish
   }
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
@@ -847,7 +848,7 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(TAIL && !mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for median_finish (see warp_residual_kernel)
+  if(!mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for the next full median_finish (see warp_residual_kernel)
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
 
@@ -1118,14 +1119,19 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 }
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
+// allow_full = 0: bracketed selections only — a bracket miss (or a missing bracket) leaves the workspace without its scale
+// (median_valid = 0, k8_go = 0): it sits out irls_reduce / gn_step and the following iterations until a launch with
+// allow_full = 1 (the first iteration of every host round), whose warp_residual recomputes its residuals.  A launch then
+// never waits for the ~40 us three-pass selection of the 0.7 % of workspaces that miss.
 template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int allow_full)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
   if(st->k8_go) return;                    // fused-tail chain: the tail of warp_residual has already selected this median
+  if(!allow_full && !st->median_valid) return;   // no bracket and no fresh residuals: waits for the next full launch
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
@@ -1237,6 +1243,10 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   }
 
   // ---- full path
+  if(!done && !allow_full) {                 // bracket miss in a bracketed-only launch
+    if(tid == 0) st->median_valid = 0;
+    return;
+  }
   if(!done) {
     for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
     if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
@@ -1364,7 +1374,7 @@ __global__ __launch_bounds__(GN_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(TAIL && !st->k8_go) return;   // fused-tail chain: the robust scale of this linearisation is not known yet (bracket miss)
+  if(!st->k8_go) return;           // the robust scale of this linearisation is not known yet (bracket miss: waits for a full median_finish)
   // two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves,
   // FUSED = true (137 VGPRs instead of 125: kept out of the plain kernel's register budget) the frozen ones
   if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
@@ -1674,6 +1684,7 @@ __device__ __forceinline__ void gn_step_body(const PairJob& j, K8TailLds& T, int
     cnt[1] += 1ull;
     if(prm.fuse_frozen && frozen) {         // tap-cache statistics of the fused path (the others: median_tail)
       cnt[5] += (unsigned long long) T.sum[29]; cnt[6] += (unsigned long long) T.sum[28];
+      cnt[10] += (unsigned long long) j.n;  // points linearised through the fused path
     }
   }
   __syncthreads();
@@ -1691,7 +1702,7 @@ __device__ __forceinline__ void gn_tail(const PairJob& j, K8TailLds& T, int nblk
 __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, ActiveSet act, GNParams prm)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
-  if(!j.st->active) return;
+  if(!j.st->active || !j.st->k8_go) return;
   __shared__ K8TailLds T;
   gn_step_body<64>(j, T, (j.n + pts_per_block - 1) / pts_per_block, prm);
 }
@@ -1897,12 +1908,12 @@ static void launch_warp_residual_t(hipStream_t s, const GNLaunch& g, int mf_foll
     });
   }
 }
-// mf_follows (fused-tail chain): launch_median comes next, so workspaces without a usable bracket compute their residuals
+// mf_follows: launch_median(allow_full = 1) comes next, so workspaces without a usable bracket compute their residuals
 void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows)
 {
   if(g.max_points <= 0) return;
   if(g.tails) launch_warp_residual_t<true>(s, g, mf_follows);
-  else launch_warp_residual_t<false>(s, g, 1);
+  else launch_warp_residual_t<false>(s, g, mf_follows);
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
@@ -1913,7 +1924,7 @@ void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
-void launch_median(hipStream_t s, const GNLaunch& g)
+void launch_median(hipStream_t s, const GNLaunch& g, int allow_full)
 {
   if(g.max_points <= 0) return;
   // the attribute is per device (a process may hold contexts on several) and the lanes' host threads race here
@@ -1927,7 +1938,7 @@ void launch_median(hipStream_t s, const GNLaunch& g)
       });
   });
   dispatch_channels(g.C, [&](auto c) {
-    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active, allow_full);
   });
 }
 

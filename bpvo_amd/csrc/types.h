@@ -159,7 +159,7 @@ struct PairJob {
                            // [2] bracketed / [3] full median selections (fused-tail chain: [3] = all-keys selections + bracket
                            // misses), [4] points processed by warp_residual (the rest went through the fused path of
                            // irls_reduce), [5] tap-cache hits / [6] lookups (= valid points), [7] / [8] the same over the first 8
-                           // linearisations of a level, [9] candidate keys the median tails went through (counted by the fused-tail chain only);
+                           // linearisations of a level, [9] candidate keys the median tails went through (counted by the fused-tail chain only), [10] points linearised through the fused path;
                            // written by one thread each: no atomics
   GNState*      st;
 };
