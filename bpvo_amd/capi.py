@@ -383,15 +383,10 @@ class Context:
         return a.value, b.value
 
     def tap_cache_counts(self):
-        """(hits, lookups, hits in the first 8 linearisations of a level, lookups there, candidate keys of the median tails)
-        since the last counter reset."""
-        a = (C.c_uint64 * 5)()
+        """(hits, lookups, hits in the first 8 linearisations of a level, lookups there) since the last counter reset."""
+        a = (C.c_uint64 * 4)()
         self.call("tap_cache_counts", a)
         return tuple(int(x) for x in a)
-
-    def set_launch_chain(self, mode):
-        """0 auto, 1 four-launch chain, 2 fused-tail chain (HIP library only; all bit-identical)."""
-        self.call("set_launch_chain", int(mode))
 
     def total_linearizations(self):
         n = C.c_uint64()

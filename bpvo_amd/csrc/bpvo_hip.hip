@@ -64,7 +64,6 @@ struct Workspace {
   uint32_t* tapkey = nullptr;
   float* tapcache = nullptr;
   float* partials = nullptr;
-  uint32_t* tickets = nullptr;    // [2] arrival counters of the fused-tail chain (PairJob::tickets)
   int last_ref = -1, last_cur = -1, last_level = -1;
 };
 
@@ -147,9 +146,6 @@ struct bpvo_hip_ctx {
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
-  int chain_mode = 0;          // GN launch chain: 0 auto (fused tails for groups of >= tail_min_pairs active workspaces, the four-launch
-                               // chain below), 1 always four launches, 2 always fused tails; BPVO_HIP_CHAIN=auto|classic|tails
-  int tail_min_pairs = 12;     // BPVO_HIP_TAIL_MIN_PAIRS
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
@@ -158,7 +154,6 @@ struct bpvo_hip_ctx {
   uint64_t kc_launches[KC_COUNT] = {};
   uint64_t total_lin = 0, median_bracketed = 0, median_full = 0;
   uint64_t tap_counts[4] = {};
-  uint64_t tail_candidates = 0;
   std::string err;
 };
 
@@ -330,7 +325,6 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.tapcache = c->ws[ws].tapcache;
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
-  j.tickets = c->ws[ws].tickets;
   j.st = c->d_states + ws;
   j.cnt = c->d_counters + kWsCounters * (size_t) ws;
   return j;
@@ -554,53 +548,41 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
     g.fuse_frozen = c->fuse_frozen;
-    g.prm.mode = 0;
-    g.prm.max_iterations = p.maxIterations;
-    g.prm.max_fun_evals = max_fun_evals;
-    g.prm.p_tol = p.parameterTolerance; g.prm.f_tol = p.functionTolerance; g.prm.g_tol = p.gradientTolerance;
     launch_level_begin(ln->stream, g.jobs, n, l);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
-    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); in the fused-tail chain a
-    // workspace whose median bracket missed repeats warp_residual in the next iteration slot, so the loop runs until the
-    // device reports no active workspace (the state machine on the device enforces the iteration limits).  The host queues
-    // rounds of kItersPerSync iterations; every round ends with a compaction of the list of still-active workspaces
-    // (ActiveSet, kernels.h) and the copy of its count.  The rounds are PIPELINED: round r + 1 is queued with the list and
-    // count that came out of round r - 1, as soon as those have landed — the device never waits for the host (a
-    // synchronisation per round was a ~30 us bubble: 7 % of a round at 128 pairs, 11 % for a single pair).  Workspaces that
-    // finished in between are still dispatched for one more round (their workgroups exit on the first load), and the
-    // level ends with one round of empty launches.
+    // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); the state machine on the device
+    // enforces the limits, the host queues rounds of kItersPerSync iterations until the device reports no active workspace.
+    // Every round ends with a compaction of the list of still-active workspaces (ActiveSet, kernels.h) and the copy of its
+    // count.  The rounds are PIPELINED: round r + 1 is queued with the list and count that came out of round r - 1, as soon
+    // as those have landed — the device never waits for the host (a synchronisation per round was a ~30 us bubble: 7 % of a
+    // round at 128 pairs, 11 % for a single pair).  Workspaces that finished in between are still dispatched for one more
+    // round (their workgroups exit on the first load), and the level ends with one round of empty launches.
     const int max_lin = std::min(p.maxIterations + 2, max_fun_evals);
     const int kItersPerSync = 4;
-    const int max_rounds = (2 * max_lin + 8) / kItersPerSync + 3;
+    const int max_rounds = (max_lin + kItersPerSync - 1) / kItersPerSync + 2;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
-    const bool tails_ok = gn_tails_supported(g.max_points);
     int* const lists[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
     int n_cur = n;
     g.active.list = nullptr;                // first rounds: every workspace of the group, in order
     for(int round = 0; round < max_rounds; ++round) {
       g.npairs = n_cur;
-      g.tails = (tails_ok && (c->chain_mode == 2 || (c->chain_mode == 0 && n_cur >= c->tail_min_pairs))) ? 1 : 0;
       for(int k = 0; k < kItersPerSync; ++k) {
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
         const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
-        // the full (all-keys) median selection — first linearisations of a level, bracket misses — runs in the first iteration
-        // of a round only; in between a workspace that misses its bracket waits (0.7 % of the selections)
-        const int mf = (k == 0) ? 1 : 0;
-        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g, mf); }
-        if(g.tails) {
-          if(mf) { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all); launch_median(ln->stream, g); }
-          ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all);
-          launch_irls_reduce(ln->stream, g);
-        } else if(c->profile_all) {
-          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g, mf); }
+        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
+        if(c->profile_all) {
+          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
-          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln); launch_gn_step(ln->stream, g); }
+          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
+            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                           p.gradientTolerance); }
         } else {
-          launch_median(ln->stream, g, mf);
+          launch_median(ln->stream, g);
           launch_irls_reduce(ln->stream, g);
-          launch_gn_step(ln->stream, g);
+          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                         p.gradientTolerance);
         }
       }
       const int slot = round % 3;
@@ -699,7 +681,6 @@ int refresh_counters(bpvo_hip_ctx* c)
   c->median_bracketed = h[2];
   c->median_full = h[3];
   for(int k = 0; k < 4; ++k) c->tap_counts[k] = h[5 + k];
-  c->tail_candidates = h[9];
   c->total_lin = h[1];
   // units of the GN kernels = points linearised (device-side count: only the pairs still active in a launch count)
   // warp_residual at profiling level 1 is timed on a 1-in-kProfileEvery sample of its launches: its units are scaled to
@@ -995,8 +976,6 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
     }
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
-    CREATE_CK(hipMalloc((void**) &w.tickets, 64));     // own 64-byte line: the counters are hammered with device-scope atomics
-    CREATE_CK(hipMemset(w.tickets, 0, 64));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
@@ -1007,8 +986,6 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
-    if(const char* e = std::getenv("BPVO_HIP_CHAIN")) cp->chain_mode = !std::strcmp(e, "classic") ? 1 : (!std::strcmp(e, "tails") ? 2 : 0);
-    if(const char* e = std::getenv("BPVO_HIP_TAIL_MIN_PAIRS")) cp->tail_min_pairs = std::max(1, std::atoi(e));
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
   for(size_t k = 0; k < cp->lanes.size(); ++k) {
@@ -1046,7 +1023,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipSetDevice(c->device);
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
-  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); (void) hipFree(w.tickets); }
+  for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
@@ -1259,18 +1236,11 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   g.fast_warp = c->fast_warp;
   g.interp = c->params.interp;
-  g.prm.mode = 1;
-  g.tails = (c->chain_mode == 2 && gn_tails_supported(g.max_points)) ? 1 : 0;   // single linearisations: four launches unless forced
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-  if(g.tails) {
-    { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }    // first linearisation / bracket miss; nothing otherwise
-    { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-  } else {
-    { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
-    { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
-    { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g); }
-  }
+  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
+  { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+  { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0); }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));
   HIP_CK(c, hipGetLastError());
@@ -1648,7 +1618,7 @@ int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* 
   *full = c->median_full;
   return BPVO_OK;
 }
-int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[5])
+int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
 {
   CHECK_CTX(c);
   (void) hipSetDevice(c->device);
@@ -1656,14 +1626,6 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[5])
   int rc = refresh_counters(c);
   if(rc) return rc;
   for(int k = 0; k < 4; ++k) out[k] = c->tap_counts[k];
-  out[4] = c->tail_candidates;
-  return BPVO_OK;
-}
-int bpvo_hip_set_launch_chain(bpvo_hip_ctx* c, int mode)
-{
-  CHECK_CTX(c);
-  if(mode < 0 || mode > 2) return fail(c, BPVO_ERR_INVALID_ARG, "launch chain: 0 auto, 1 four launches, 2 fused tails");
-  c->chain_mode = mode;
   return BPVO_OK;
 }
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* c, uint64_t* n)

@@ -325,23 +325,4 @@ BPVO_HD bool solve_system(const float H[36], const float G[6], float dp[6], Solv
   return ok;
 }
 
-// The same with the f32 factorisation on the caller's LDS-resident scratch as well (LDLT6<float>: operation order of
-// ldlt6_solve_f32, run-time indices instead of registers) — for callers that cannot afford ~180 VGPRs.
-BPVO_HD bool solve_system_lds(const float H[36], const float G[6], float dp[6], SolveScratch* ws)
-{
-  ws->f.compute(H, 1.1920928955078125e-07f);
-  ws->f.solve(G, dp, 1.0f / 3.4028234663852886e+38f);
-  if(is_approx_Hdp_G<float>(H, dp, G, 1e-5f)) return true;
-  float maxd = H[0];
-  for(int i = 1; i < 6; ++i) maxd = H[i * 6 + i] > maxd ? H[i * 6 + i] : maxd;
-  const double u = 0.001 * (double) maxd;
-  for(int i = 0; i < 36; ++i) ws->Hd[i] = (double) H[i];
-  for(int i = 0; i < 6; ++i) { ws->Gd[i] = (double) G[i]; ws->Hd[i * 6 + i] += u; }
-  ws->d.compute(ws->Hd, 2.220446049250313e-16);
-  ws->d.solve(ws->Gd, ws->dpd, 1.0 / 1.7976931348623157e+308);
-  const bool ok = is_approx_Hdp_G<double>(ws->Hd, ws->dpd, ws->Gd, 1e-12);
-  for(int i = 0; i < 6; ++i) dp[i] = (float) ws->dpd[i];
-  return ok;
-}
-
 }  // namespace bpvo_hip

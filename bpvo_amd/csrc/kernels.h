@@ -64,15 +64,6 @@ struct ActiveSet {
   const int* list = nullptr;   // device [npairs]
 };
 
-// what gn_step needs to know (PoseEstimatorParameters, bpvo/pose_estimator_params.h:30-56): a kernel argument of gn_step_kernel
-// and, in the fused-tail chain, of irls_reduce_kernel
-struct GNParams {
-  int mode = 0;            // 0: full PoseEstimatorBase::run step (solve, update, convergence); 1: linearize only (H, G, f_norm)
-  int max_iterations = 0, max_fun_evals = 0;
-  float p_tol = 0.0f, f_tol = 0.0f, g_tol = 0.0f;
-  int fuse_frozen = 0;     // filled in by the launchers
-};
-
 struct GNLaunch {
   const PairJob* jobs;   // device, [npairs] for the level
   int npairs;            // grid size in workspaces (= number of list entries when an ActiveSet is given)
@@ -84,9 +75,6 @@ struct GNLaunch {
   int fuse_frozen = 0;   // estimate loops, C = 8, kLinear, f64 formulation: once a workspace's scale is frozen, irls_reduce
                          // recomputes the residuals itself and warp_residual skips the workspace
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
-  int tails = 0;         // 1: fused-tail chain (kernels_gn.hip): warp_residual ends in the median selection, irls_reduce in gn_step —
-                         // two launches per GN iteration; 0: the four-launch chain with the one-workgroup-per-pair kernels
-  GNParams prm;
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
@@ -94,12 +82,13 @@ void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int leve
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 // out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);
-bool gn_tails_supported(int max_points);   // the fused-tail chain indexes at most 2048 bracket chunks per workspace
-void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows = 1);   // mf_follows: launch_median(allow_full = 1) comes next
+void launch_warp_residual(hipStream_t s, const GNLaunch& g);
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
-void launch_median(hipStream_t s, const GNLaunch& g, int allow_full = 1);   // allow_full = 0: bracketed selections only (misses wait)
+void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
-void launch_gn_step(hipStream_t s, const GNLaunch& g);   // g.prm; not needed when g.tails
+// mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
+void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
+                    float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
 int  gn_pts_per_block(int C);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);

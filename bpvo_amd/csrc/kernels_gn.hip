@@ -26,9 +26,6 @@ constexpr int GN_BLOCK = 256;
 #endif
 constexpr int K6_BLOCK = K6_BLOCK_VALUE;
 constexpr int K6_WAVES = K6_BLOCK / 64;
-#ifndef K6_TAIL_WAVES
-#define K6_TAIL_WAVES 4   // measured on the ISA: 77 VGPRs, no scratch (a budget of 6 spills an address pair in the streaming part)
-#endif
 
 // workspace of a workgroup: k-th entry of the active list, or k itself without a list
 __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
@@ -40,7 +37,7 @@ __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { ret
 // candidate segment cand[b * 256 * C ...]; the in-block compaction is a wave scan + LDS offsets.  All 256 threads of the
 // block must call it.
 template <int C>
-__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, const float (&res)[C])
+__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C])
 {
   // one "inside the bracket" bit per channel: 64 bits once a point has more than 32 channels (central difference, 48)
   using mask_t = typename std::conditional<(C > 32), unsigned long long, unsigned>::type;
@@ -58,7 +55,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     mask |= (mask_t) (in ? 1u : 0u) << c;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u;
+  unsigned incl = cnt, sum_below = below, sum_valid = (v ? 1u : 0u) | (hit ? 0x10000u : 0u);   // valid points | tap-cache hits << 16
 #pragma unroll
   for(int o = 1; o < 64; o <<= 1) {
     const unsigned t = __shfl_up(incl, o);
@@ -72,7 +69,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
   unsigned woff = 0;
   if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
     const unsigned t_in = __shfl(incl, 63);
-    if(lane == 0) reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = make_uint4(sum_below, t_in, sum_valid, 0u);
+    if(lane == 0) reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
   } else {
     __shared__ unsigned s_in[K6_WAVES], s_below[K6_WAVES], s_valid[K6_WAVES];
     if(lane == 63) s_in[wave] = incl;
@@ -81,7 +78,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     for(int w = 0; w < wave; ++w) woff += s_in[w];
     if(threadIdx.x == 0) {
       uint4 o = make_uint4(0u, 0u, 0u, 0u);
-      for(int w = 0; w < K6_WAVES; ++w) { o.x += s_below[w]; o.y += s_in[w]; o.z += s_valid[w]; }
+      for(int w = 0; w < K6_WAVES; ++w) { o.x += s_below[w]; o.y += s_in[w]; o.z += s_valid[w] & 0xffffu; o.w += s_valid[w] >> 16; }
       reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
     }
   }
@@ -91,396 +88,6 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
 #pragma unroll
     for(int c = 0; c < C; ++c)
       if(mask & ((mask_t) 1u << c)) seg[pos++] = keys[c];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Fused-tail chain.  At batch sizes that fill the chip the two narrow per-pair kernels (median_finish: one workgroup per
-// pair; gn_step: one wave per pair) cost more than they should: a launch lasts as long as its slowest workgroup and nothing
-// else runs meanwhile.  In this chain they are the TAILS of the wide kernels instead: every warp_residual workgroup of a
-// workspace publishes its bracket counters and candidate keys, takes a ticket, and the LAST arriver selects the median and
-// updates the robust scale while the workgroups of the other workspaces keep streaming; irls_reduce does the same with its
-// partial sums and the solve / pose update / convergence logic of gn_step.  Two launches per GN iteration instead of four.
-//
-// In-launch hand-off (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "inter-workgroup visibility"; the eight
-// XCDs have private L2s): the payload is stored WRITE-THROUGH (sc1: 16-byte buffer stores, 4-byte agent-scope atomic
-// stores), every storing wave drains its stores (s_waitcnt vmcnt(0)), one lane takes the ticket with a relaxed agent-scope
-// fetch_add, and the last arriver issues ONE agent-scope acquire before its plain loads.  Nothing depends on dispatch
-// order or on the workgroup -> XCD placement.  The bulk streams (residuals, valid flags, tap cache) still change hands at
-// kernel boundaries only.
-//
-// The median tail only ever reads the bracket counters and candidate segments of its workspace (a few KB): it serves the
-// BRACKETED selections.  Whatever needs all keys — the first linearisation of a level, a bracket miss (0.7 % of the
-// selections), a degenerate sample — is left to median_finish_kernel, which the host launches in the first iteration of
-// every round of kItersPerSync and which only looks at workspaces that still lack their scale (k8_go == 0): after a miss a
-// workspace sits out the iterations until then (irls_reduce skips it, warp_residual does not recompute its residuals).
-typedef unsigned bpvo_v4u __attribute__((ext_vector_type(4)));
-constexpr unsigned kRsrcWord3 = 0x00020000u;   // raw buffer descriptor, 32-bit untyped data (gfx9 family)
-
-__device__ __forceinline__ void store_wt16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, bpvo_v4u v)
-{
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int) byte_off, 0, /*aux: sc1 = write-through*/ 16);
-}
-// all threads of the block: drain this wave's stores, barrier, one ticket; ticket_is_last is true in EVERY thread of the
-// last-arriving workgroup (of `expected`).  `flag` is a word of the kernel's single LDS object.
-__device__ __forceinline__ void ticket_arrive(unsigned* ticket, unsigned expected, unsigned* flag)
-{
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave
-  __syncthreads();
-  if(threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *flag = (t + 1u == expected) ? 1u : 0u;
-  }
-}
-// ... the caller may issue stores that are NOT part of the hand-off here, then:
-__device__ __forceinline__ bool ticket_is_last(const unsigned* flag)
-{
-  __syncthreads();
-  return *flag != 0u;
-}
-// first statement of a tail: one lane's agent-scope acquire covers the workgroup once the barrier has passed
-__device__ __forceinline__ void tail_acquire()
-{
-  if(threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-}
-
-constexpr int TAIL_BINS = 1024;            // 10-bit digits (LDS of the tail counts against every workgroup of warp_residual)
-constexpr unsigned kTailDigit = 10u;
-constexpr int TAIL_MAX_BLOCKS = 1024;      // bracket chunks per workspace the tail can index (prefix offsets in LDS): 262 144 points
-constexpr int TAIL_CACHE = 3072;           // candidate keys the tail keeps in LDS after its first pass over them
-constexpr unsigned kPadKey = 0xffffffffu;  // pads a candidate run to whole 16-byte pieces; key - lo_key >= 2^31: never selected
-template <int C>
-struct alignas(16) K6TailLds {
-  // candidate staging of the publish step; then the two digit histograms [0, 2 * TAIL_BINS) + the candidate cache
-  static constexpr int kStage = K6_BLOCK * C + 4 > 2 * TAIL_BINS + TAIL_CACHE ? K6_BLOCK * C + 4 : 2 * TAIL_BINS + TAIL_CACHE;
-  unsigned buf[kStage];
-  unsigned off[TAIL_MAX_BLOCKS + 1];       // exclusive prefix of the per-chunk candidate runs, in 16-byte pieces
-  unsigned list_lo[K6_BLOCK], list_hi[K6_BLOCK];
-  unsigned wave[4 * K6_WAVES + 4];         // scan / block-sum scratch
-  unsigned cur[4];                         // MedCursor lo, hi
-  unsigned misc[4];                        // [0] ticket flag, [1..2] list fill
-};
-
-template <int NT>
-__device__ __forceinline__ unsigned block_excl_scan_nt(unsigned v, unsigned* s_wave /*[NT/64]*/, unsigned& total)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = v;
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
-  }
-  __syncthreads();
-  if(lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  unsigned woff = 0, tot = 0;
-#pragma unroll
-  for(int w = 0; w < NT / 64; ++w) {
-    const unsigned t = s_wave[w];
-    if(w < wave) woff += t;
-    tot += t;
-  }
-  total = tot;
-  return woff + incl - v;
-}
-
-// The bracket step of the fused-tail chain: like bracket_block, but the candidate keys of the workgroup are compacted in LDS
-// and leave as one coalesced run of 16-byte write-through stores, and the counters {below, inside, valid points, tap-cache
-// hits} as one 16-byte write-through store.  All K6_BLOCK threads must call it.
-template <int C>
-__device__ __forceinline__ void bracket_publish(const PairJob& j, K6TailLds<C>& L, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C])
-{
-  using mask_t = typename std::conditional<(C > 32), unsigned long long, unsigned>::type;
-  static_assert(C <= 64, "one mask bit per channel");
-  unsigned keys[C];
-  unsigned below = 0, cnt = 0;
-  mask_t mask = 0;
-#pragma unroll
-  for(int c = 0; c < C; ++c) {
-    const unsigned k = __float_as_uint(res[c]) & 0x7fffffffu;
-    keys[c] = k;
-    const bool in = v && (k >= lo) && (k < hi);
-    below += (v && k < lo) ? 1u : 0u;
-    cnt += in ? 1u : 0u;
-    mask |= (mask_t) (in ? 1u : 0u) << c;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = cnt, sum_below = below, sum_valid = v ? 1u : 0u, sum_hit = hit ? 1u : 0u;
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
-  }
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) {
-    sum_below += __shfl_down(sum_below, o);
-    sum_valid += __shfl_down(sum_valid, o);
-    sum_hit += __shfl_down(sum_hit, o);
-  }
-  if(lane == 63) L.wave[wave] = incl;
-  if(lane == 0) { L.wave[K6_WAVES + wave] = sum_below; L.wave[2 * K6_WAVES + wave] = sum_valid; L.wave[3 * K6_WAVES + wave] = sum_hit; }
-  __syncthreads();
-  unsigned woff = 0, tot = 0, t_below = 0, t_valid = 0, t_hit = 0;
-#pragma unroll
-  for(int w = 0; w < K6_WAVES; ++w) {
-    const unsigned t = L.wave[w];
-    if(w < wave) woff += t;
-    tot += t;
-    t_below += L.wave[K6_WAVES + w];
-    t_valid += L.wave[2 * K6_WAVES + w];
-    t_hit += L.wave[3 * K6_WAVES + w];
-  }
-  if(cnt) {
-    unsigned pos = woff + incl - cnt;
-#pragma unroll
-    for(int c = 0; c < C; ++c)
-      if(mask & ((mask_t) 1u << c)) L.buf[pos++] = keys[c];
-  }
-  if(threadIdx.x < ((tot + 3u) & ~3u) - tot) L.buf[tot + threadIdx.x] = kPadKey;
-  __syncthreads();
-  // coalesced write-through stores of the staged run, padded to whole 16-byte pieces
-  {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.cand + (size_t) blockIdx.x * K6_BLOCK * C, 0,
-                                                                        K6_BLOCK * C * (int) sizeof(unsigned), kRsrcWord3);
-    const bpvo_v4u* stage = reinterpret_cast<const bpvo_v4u*>(L.buf);
-    for(unsigned q = threadIdx.x; q * 4u < tot; q += K6_BLOCK) store_wt16(rs, q * 16u, stage[q]);
-  }
-  if(threadIdx.x == 0) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(j.med_blk + (size_t) blockIdx.x * 4, 0, 16, kRsrcWord3);
-    bpvo_v4u o; o.x = t_below; o.y = tot; o.z = t_valid; o.w = t_hit;
-    store_wt16(rs, 0u, o);
-  }
-}
-
-// every thread owns TAIL_BINS / NT consecutive bins of a histogram held in LDS: find the bins holding ranks k_lo / k_hi
-struct MedCursor { unsigned prefix; unsigned rank; };
-template <int NT>
-__device__ __forceinline__ void find_ranks_nt(const unsigned* hist, unsigned nbins, unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2]*/)
-{
-  constexpr unsigned BPT = TAIL_BINS / NT;
-  const unsigned b0 = BPT * threadIdx.x;
-  if(b0 >= nbins) return;
-  unsigned e = excl;
-#pragma unroll
-  for(unsigned k = 0; k < BPT; ++k) {
-    const unsigned h = hist[b0 + k];
-    if(k_lo >= e && k_lo < e + h) { out[0].prefix = b0 + k; out[0].rank = k_lo - e; }
-    if(k_hi >= e && k_hi < e + h) { out[1].prefix = b0 + k; out[1].rank = k_hi - e; }
-    e += h;
-  }
-}
-
-// One refinement pass of the two-cursor radix select with NT threads (the form of refine_pass below, which runs with 1024).
-template <int NT, typename Src>
-__device__ __forceinline__ void refine_pass_nt(Src&& src, unsigned shift, unsigned width, MedCursor& lo, MedCursor& hi, unsigned* hist_lo,
-                                               unsigned* hist_hi, unsigned* s_wave, MedCursor* cur)
-{
-  constexpr unsigned BPT = TAIL_BINS / NT;
-  const unsigned tid = threadIdx.x;
-  const bool split = lo.prefix != hi.prefix;
-  const unsigned nbins = 1u << width, up = shift + width;
-  __syncthreads();
-  for(unsigned i = tid; i < (unsigned) TAIL_BINS; i += NT) { hist_lo[i] = 0; hist_hi[i] = 0; }   // all bins: a thread sums its BPT whatever nbins is
-  __syncthreads();
-  src([&](unsigned key) {
-    const unsigned top = (up >= 32u) ? 0u : (key >> up);
-    const unsigned dg = (key >> shift) & (nbins - 1u);
-    if(top == lo.prefix) atomicAdd(&hist_lo[dg], 1u);
-    else if(split && top == hi.prefix) atomicAdd(&hist_hi[dg], 1u);
-  });
-  __syncthreads();
-  unsigned dummy;
-  unsigned sa = 0, sb = 0;
-  if(BPT * tid < nbins) {
-#pragma unroll
-    for(unsigned k = 0; k < BPT; ++k) { sa += hist_lo[BPT * tid + k]; sb += hist_hi[BPT * tid + k]; }
-  }
-  const unsigned ea = block_excl_scan_nt<NT>(sa, s_wave, dummy);
-  MedCursor tmp[2];
-  tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
-  find_ranks_nt<NT>(hist_lo, nbins, ea, lo.rank, split ? 0xffffffffu : hi.rank, tmp);
-  if(tmp[0].prefix != 0xffffffffu) { cur[0].prefix = (lo.prefix << width) | tmp[0].prefix; cur[0].rank = tmp[0].rank; }
-  if(!split && tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
-  if(split) {
-    const unsigned eb = block_excl_scan_nt<NT>(sb, s_wave, dummy);
-    tmp[1].prefix = 0xffffffffu;
-    find_ranks_nt<NT>(hist_hi, nbins, eb, 0xffffffffu, hi.rank, tmp);
-    if(tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
-  }
-  __syncthreads();
-  lo = cur[0];
-  hi = cur[1];
-  __syncthreads();
-}
-
-// The median tail of warp_residual: executed by the last-arriving workgroup of a workspace (K6_BLOCK threads).
-// reference: AutoScaleEstimator::estimateScale / median() — see K7 below; same exact order statistics, same scale update.
-// VARIANT only separates the copies called from kernels with different register budgets (a shared copy gets the loosest)
-template <int C, int VARIANT>
-__device__ __forceinline__ void median_tail(const PairJob& j, K6TailLds<C>& L, int nblk)
-{
-  constexpr int NT = K6_BLOCK;
-  GNState* st = j.st;
-  const int tid = threadIdx.x;
-  tail_acquire();
-  unsigned* hist_lo = L.buf;
-  unsigned* hist_hi = L.buf + TAIL_BINS;
-  unsigned* cache = L.buf + 2 * TAIL_BINS;
-  MedCursor* cur = reinterpret_cast<MedCursor*>(L.cur);
-
-  // totals of the per-chunk counters + exclusive prefix of the candidate runs in 16-byte pieces (flat piece index -> chunk)
-  unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0, run = 0;
-  for(int base = 0; base < nblk; base += NT) {
-    const int b = base + tid;
-    uint4 o = make_uint4(0u, 0u, 0u, 0u);
-    if(b < nblk) o = reinterpret_cast<const uint4*>(j.med_blk)[b];
-    c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
-    unsigned chunk_total;
-    const unsigned ex = block_excl_scan_nt<NT>((o.y + 3u) >> 2, L.wave, chunk_total);
-    if(b < nblk) L.off[b] = run + ex;
-    run += chunk_total;
-  }
-  if(tid == 0) L.off[nblk] = run;
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) {
-    c_below += __shfl_down(c_below, o);
-    c_in += __shfl_down(c_in, o);
-    c_valid += __shfl_down(c_valid, o);
-    c_hit += __shfl_down(c_hit, o);
-  }
-  __syncthreads();
-  if((tid & 63) == 0) { unsigned* w = L.wave + (tid >> 6) * 4; w[0] = c_below; w[1] = c_in; w[2] = c_valid; w[3] = c_hit; }
-  __syncthreads();
-  unsigned t_below = 0, m = 0, t_valid = 0, t_hit = 0;
-#pragma unroll
-  for(int w = 0; w < K6_WAVES; ++w) { t_below += L.wave[w * 4 + 0]; m += L.wave[w * 4 + 1]; t_valid += L.wave[w * 4 + 2]; t_hit += L.wave[w * 4 + 3]; }
-  __syncthreads();
-  const unsigned pieces = run;                  // 16-byte pieces of candidates (m keys + padding)
-  const unsigned nt = (unsigned) C * t_valid;   // size_t n of estimateScale
-  const unsigned lo_key = st->lo_key;
-  const unsigned range = st->hi_key - st->lo_key;
-  const bool cached = pieces * 4u <= (unsigned) TAIL_CACHE;
-  bool filled = false;
-
-  // all candidates as offsets d = key - lo_key.  First call: flat walk over the 16-byte pieces in HBM (thread t takes pieces
-  // t, t + NT, ...; kU loads in flight per lane), which also fills the LDS cache when the candidates fit; later calls read
-  // the cache.  Padding keys give d >= 2^31 and match no cursor.
-  auto src = [&](auto f) {
-    if(cached && filled) {
-      for(unsigned i = tid; i < pieces * 4u; i += NT) f(cache[i]);
-      return;
-    }
-    constexpr int kU = 4;
-#pragma unroll 1
-    for(unsigned p0 = tid; p0 < pieces; p0 += NT * kU) {
-      uint4 k[kU];
-#pragma unroll
-      for(int u = 0; u < kU; ++u) {
-        const unsigned pc = p0 + (unsigned) u * NT;
-        k[u] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
-        if(pc < pieces) {
-          int a = 0, b = nblk;               // last chunk with off[chunk] <= pc
-          while(b - a > 1) { const int mid = (a + b) >> 1; if(L.off[mid] <= pc) a = mid; else b = mid; }
-          k[u] = *reinterpret_cast<const uint4*>(j.cand + (size_t) a * K6_BLOCK * C + 4u * (pc - L.off[a]));
-        }
-      }
-#pragma unroll
-      for(int u = 0; u < kU; ++u) {
-        const unsigned pc = p0 + (unsigned) u * NT;
-        if(pc < pieces) {
-          const uint4 d = make_uint4(k[u].x - lo_key, k[u].y - lo_key, k[u].z - lo_key, k[u].w - lo_key);
-          if(cached) *reinterpret_cast<uint4*>(cache + 4u * pc) = d;
-          f(d.x); f(d.y); f(d.z); f(d.w);
-        }
-      }
-    }
-  };
-
-  float median = 0.0f;
-  bool done = false;
-  const unsigned k_hi = nt / 2, k_lo = (nt % 2 == 0 && nt > 0) ? k_hi - 1 : k_hi;
-  if(nt >= 3 && k_lo >= t_below && k_hi < t_below + m && range > 0) {
-    MedCursor lo, hi;
-    lo.prefix = 0; hi.prefix = 0; lo.rank = k_lo - t_below; hi.rank = k_hi - t_below;
-    const unsigned nbits = 32u - (unsigned) __clz((int) range);        // offsets d = key - lo_key are < range < 2^nbits
-    unsigned remaining = nbits;
-    while(remaining > 0) {
-      const unsigned width = remaining > kTailDigit ? kTailDigit : remaining;
-      const bool was_split = lo.prefix != hi.prefix;
-      remaining -= width;
-      refine_pass_nt<NT>(src, remaining, width, lo, hi, hist_lo, hist_hi, L.wave, cur);
-      filled = true;
-      if(remaining == 0) break;
-      // the selected bins usually hold a handful of keys: finish by direct ranking (each thread ranks one key of the bin by
-      // counting the smaller ones) instead of more histogram passes
-      const unsigned dmask = (1u << width) - 1u;
-      const unsigned n_lo = hist_lo[lo.prefix & dmask];
-      const unsigned n_hi = was_split ? hist_hi[hi.prefix & dmask] : hist_lo[hi.prefix & dmask];
-      if(n_lo > (unsigned) NT || n_hi > (unsigned) NT) continue;
-      const bool same_bin = lo.prefix == hi.prefix;
-      __syncthreads();
-      if(tid == 0) { L.misc[1] = 0; L.misc[2] = 0; }
-      __syncthreads();
-      const unsigned p_lo = lo.prefix, p_hi = hi.prefix, sh = remaining;
-      src([&](unsigned d) {
-        const unsigned top = d >> sh;
-        if(top == p_lo) L.list_lo[atomicAdd(&L.misc[1], 1u)] = d;
-        else if(!same_bin && top == p_hi) L.list_hi[atomicAdd(&L.misc[2], 1u)] = d;
-      });
-      __syncthreads();
-      auto pick = [&](const unsigned* list, unsigned cnt, unsigned want, unsigned* out) {
-        if((unsigned) tid < cnt) {
-          const unsigned mine = list[tid];
-          unsigned rk = 0;
-          for(unsigned q = 0; q < cnt; ++q) {
-            const unsigned o = list[q];
-            rk += (o < mine || (o == mine && q < (unsigned) tid)) ? 1u : 0u;
-          }
-          if(rk == want) *out = mine;
-        }
-      };
-      pick(L.list_lo, n_lo, lo.rank, &cur[0].prefix);
-      if(same_bin) pick(L.list_lo, n_lo, hi.rank, &cur[1].prefix);
-      else pick(L.list_hi, n_hi, hi.rank, &cur[1].prefix);
-      __syncthreads();
-      lo.prefix = cur[0].prefix; hi.prefix = cur[1].prefix;     // full offsets d now
-      __syncthreads();
-      remaining = 0;
-    }
-    const float v_lo = __uint_as_float(lo_key + lo.prefix), v_hi = __uint_as_float(lo_key + hi.prefix);
-    median = (nt % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
-    done = true;
-  }
-
-  if(tid == 0) {
-    unsigned long long* cnt = j.cnt;
-    if(done) cnt[2] += 1ull;                                                 // bracketed selections (median_finish counts the others)
-    cnt[5] += (unsigned long long) t_hit;  cnt[6] += (unsigned long long) t_valid;     // tap-cache hits / lookups (valid points)
-    if(st->num_fun_evals < 8) { cnt[7] += (unsigned long long) t_hit; cnt[8] += (unsigned long long) t_valid; }
-    cnt[9] += (unsigned long long) m;                                        // candidate keys the tails went through
-    if(done) {
-      const unsigned long long nm6 = (unsigned long long) nt - 6ull;        // size_t wrap for n < 6 (Q5)
-      float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
-      if((double) s < 1e-6) s = 1.0f;
-      st->delta_scale = fabsf(s - st->scale);
-      st->scale = s;
-      if(median > 0.0f) {
-        float rel = 0.25f;
-        if(st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
-        st->last_median = median;
-        st->lo_key = __float_as_uint(median * (1.0f - rel));
-        st->hi_key = __float_as_uint(median * (1.0f + rel)) + 1u;
-        st->median_valid = 1;
-      } else {
-        st->median_valid = 0;
-      }
-      st->k8_go = 1;
-    } else {
-      st->median_valid = 0;      // bracket miss / degenerate sample: median_finish of the next round (last_median stays: it widens the next bracket)
-    }
-    __hip_atomic_store(j.tickets + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero between launches
   }
 }
 
@@ -725,26 +332,18 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
   return valid;
 }
 
-// TAIL: the median tail is rarely executed code that must not decide the kernel's register allocation — the budget of 4
-// waves per SIMD (128 VGPRs; the streaming part needs ~65) is imposed and whatever the tail needs beyond it spills
-template <int C, bool FAST, bool TAIL>
-__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? K6_TAIL_WAVES : 1, 8))) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode,
-                                                                                                int mf_follows)
+template <int C, bool FAST>
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
 {
   // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
   // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
   // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
-  // TAIL: fused-tail chain — the last-arriving workgroup of a workspace selects the median among the bracket candidates
-  // (median_tail).  Both chains: a workspace without a bracket (first linearisation of a level, after a miss) needs the full
-  // selection of median_finish_kernel: its residuals are only computed in the iterations in which the host launches that
-  // kernel with allow_full next (mf_follows).
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(mode == 2) { if(!st->r_stale) return; }
   else {
     if(!st->active) return;
     if(mode == 1 && !(st->delta_scale > 1e-6f)) return;
-    if(!mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // no bracket: waits for the next full median_finish
   }
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
@@ -763,9 +362,8 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   float res[C];
   bool hit;
   const bool valid = warp_point<C, FAST>(j, P, i, in_block, res, hit);
-  auto store_residuals = [&]() {
-    if(!in_block) return;
-    j.valid[i] = valid ? 1 : 0;
+  if(in_block) j.valid[i] = valid ? 1 : 0;
+  if(in_block) {
     if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
       float4* o = reinterpret_cast<float4*>(j.r);
       store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
@@ -774,24 +372,9 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
 #pragma unroll
       for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
     }
-  };
-  const bool moving = st->delta_scale > 1e-6f;
-  if constexpr(TAIL) {
-    if(mode != 2 && moving && st->median_valid) {
-      __shared__ K6TailLds<C> L;
-      bracket_publish<C>(j, L, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res);
-      const int nblk = (n + K6_BLOCK - 1) / K6_BLOCK;
-      ticket_arrive(j.tickets + 0, (unsigned) nblk, &L.misc[0]);
-      store_residuals();        // bulk stream: changes hands at the kernel boundary, overlaps the ticket's round trip
-      if(ticket_is_last(&L.misc[0])) median_tail<C, 0>(j, L, nblk);
-      return;
-    }
-    store_residuals();
-  } else {
-    store_residuals();
-    // bracket pass of the exact median (see bracket_block) while the residuals are in registers
-    if(mode != 2 && moving && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
   }
+  // bracket pass of the exact median (see bracket_block) while the residuals are in registers
+  if(mode != 2 && (st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res);
 }
 
 // clears r_stale after a refresh launch (one thread per workspace)
@@ -842,13 +425,12 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
   return (a0 * b[0] + a1 * b[1]) + (a2 * b[2] + a3 * b[3]);
 }
 
-template <int C, bool TAIL>
-__global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? 2 : 1, 8))) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp, int mf_follows)
+template <int C>
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(!mf_follows && (st->delta_scale > 1e-6f) && !st->median_valid) return;   // waits for the next full median_finish (see warp_residual_kernel)
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
 
@@ -890,6 +472,8 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   }
   const bool valid = in_range && xi >= border_lo && xi < W - border_hi && yi >= border_lo && yi < R - 1;
   const float xf = (float) (x - (double) xi), yf = (float) (y - (double) yi);
+  if(in_block) j.valid[i] = valid ? 1 : 0;
+
   float res[C];
 #pragma unroll
   for(int c = 0; c < C; ++c) res[c] = 0.0f;
@@ -941,9 +525,7 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
       }
     }
   }
-  auto store_residuals = [&]() {
-    if(!in_block) return;
-    j.valid[i] = valid ? 1 : 0;
+  if(in_block) {
     if constexpr(C == 8) {
       float4* o = reinterpret_cast<float4*>(j.r);
       o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
@@ -952,23 +534,8 @@ __global__ __launch_bounds__(K6_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
 #pragma unroll
       for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
     }
-  };
-  const bool moving = st->delta_scale > 1e-6f;
-  if constexpr(TAIL) {
-    if(moving && st->median_valid) {
-      __shared__ K6TailLds<C> L;
-      bracket_publish<C>(j, L, st->lo_key, st->hi_key, valid && in_block, false, res);
-      const int nblk = (n + K6_BLOCK - 1) / K6_BLOCK;
-      ticket_arrive(j.tickets + 0, (unsigned) nblk, &L.misc[0]);
-      store_residuals();
-      if(ticket_is_last(&L.misc[0])) median_tail<C, 1>(j, L, nblk);
-      return;
-    }
-    store_residuals();
-  } else {
-    store_residuals();
-    if(moving && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, res);
   }
+  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, false, res);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -991,6 +558,8 @@ constexpr int MED_THREADS = 1024;
 constexpr int MED_COPIES = 4;
 constexpr int MED_BINS = 2048;
 constexpr int MED_CACHE = 20480;
+
+struct MedCursor { unsigned prefix; unsigned rank; };
 
 __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s_wave /*[16]*/, unsigned& total)
 {
@@ -1119,19 +688,13 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 }
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
-// allow_full = 0: bracketed selections only — a bracket miss (or a missing bracket) leaves the workspace without its scale
-// (median_valid = 0, k8_go = 0): it sits out irls_reduce / gn_step and the following iterations until a launch with
-// allow_full = 1 (the first iteration of every host round), whose warp_residual recomputes its residuals.  A launch then
-// never waits for the ~40 us three-pass selection of the 0.7 % of workspaces that miss.
 template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int allow_full)
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
-  if(st->k8_go) return;                    // fused-tail chain: the tail of warp_residual has already selected this median
-  if(!allow_full && !st->median_valid) return;   // no bracket and no fresh residuals: waits for the next full launch
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
@@ -1145,30 +708,33 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   float median = 0.0f;
   unsigned n_total = 0;
   bool done = false;
+  unsigned tap_hits = 0, tap_lookups = 0;      // tap-cache statistics of this linearisation's warp_residual pass (bracket counters)
 
   // ---- bracketed path
   if(st->median_valid) {
     // totals of the per-block counters written by the bracket step of warp_residual (bracket_block)
     const int nblk = (j.n + K6_BLOCK - 1) / K6_BLOCK;
-    unsigned c_below = 0, c_in = 0, c_valid = 0;
+    unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0;
     for(int b = tid; b < nblk; b += MED_THREADS) {
       const uint4 o = reinterpret_cast<const uint4*>(j.med_blk)[b];
-      c_below += o.x; c_in += o.y; c_valid += o.z;
+      c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
     }
     unsigned t_below, t_in, t_valid;
-    {   // three block sums with one LDS round
+    {   // four block sums with one LDS round
 #pragma unroll
       for(int o = 32; o >= 1; o >>= 1) {
         c_below += __shfl_down(c_below, o);
         c_in += __shfl_down(c_in, o);
         c_valid += __shfl_down(c_valid, o);
+        c_hit += __shfl_down(c_hit, o);
       }
       __syncthreads();
-      if((tid & 63) == 0) { cache[(tid >> 6) * 3 + 0] = c_below; cache[(tid >> 6) * 3 + 1] = c_in; cache[(tid >> 6) * 3 + 2] = c_valid; }
+      if((tid & 63) == 0) { unsigned* w4 = cache + (tid >> 6) * 4; w4[0] = c_below; w4[1] = c_in; w4[2] = c_valid; w4[3] = c_hit; }
       __syncthreads();
       t_below = t_in = t_valid = 0;
 #pragma unroll
-      for(int w = 0; w < 16; ++w) { t_below += cache[w * 3 + 0]; t_in += cache[w * 3 + 1]; t_valid += cache[w * 3 + 2]; }
+      for(int w = 0; w < 16; ++w) { t_below += cache[w * 4 + 0]; t_in += cache[w * 4 + 1]; t_valid += cache[w * 4 + 2]; tap_hits += cache[w * 4 + 3]; }
+      tap_lookups = t_valid;
       __syncthreads();
     }
     const unsigned nt = (unsigned) C * t_valid, below = t_below, m = t_in;
@@ -1243,10 +809,6 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   }
 
   // ---- full path
-  if(!done && !allow_full) {                 // bracket miss in a bracketed-only launch
-    if(tid == 0) st->median_valid = 0;
-    return;
-  }
   if(!done) {
     for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
     if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
@@ -1301,6 +863,10 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
 
   if(tid == 0) {
     j.cnt[done ? 2 : 3] += 1ull;                                            // measurement: bracketed vs full selections
+    // tap cache: a linearisation without bracket counters is the first of a level (keys reset: no hits, every valid point looks up)
+    if(!st->median_valid) tap_lookups = n_total / (unsigned) C;
+    j.cnt[5] += tap_hits; j.cnt[6] += tap_lookups;
+    if(st->num_fun_evals < 8) { j.cnt[7] += tap_hits; j.cnt[8] += tap_lookups; }
     const unsigned long long nm6 = (unsigned long long) n_total - 6ull;     // size_t wrap for n < 6 (Q5)
     float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
     if((double) s < 1e-6) s = 1.0f;
@@ -1318,7 +884,6 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
     } else {
       st->median_valid = 0;
     }
-    st->k8_go = 1;
   }
 }
 
@@ -1350,31 +915,12 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
   return 1.0f;
 }
 
-// LDS of the serial part: the state lives in HBM between launches; the bookkeeping runs on an LDS copy (global-memory round
-// trips would otherwise dominate: every field access is a dependent ~1 us load)
-constexpr int kStateWords = (int) (sizeof(GNState) / sizeof(uint32_t));
-static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
-struct K8TailLds {
-  uint32_t state[kStateWords];
-  float sum[kPartialStride];
-  float nrm[5];
-  unsigned flag;
-  SolveScratch scratch;
-};
-__device__ __forceinline__ unsigned* tail_flag(K8TailLds& T) { return &T.flag; }
-
-// waves per SIMD the TAIL instantiations of irls_reduce are held to (= what the streaming part reaches on its own): the gn tail spills beyond
-constexpr int k8_tail_waves(int C, bool fused) { return fused ? 3 : (C == 8 ? 4 : 5); }
-template <int BUDGET> __device__ void gn_tail(const PairJob& j, K8TailLds& T, int nblk, const GNParams& prm);
-
-template <int C, int LOSS, bool FUSED, bool TAIL>
-__global__ __launch_bounds__(GN_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ? k8_tail_waves(C, FUSED) : 1, 8))) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen,
-                                                               GNParams prm)
+template <int C, int LOSS, bool FUSED>
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(!st->k8_go) return;           // the robust scale of this linearisation is not known yet (bracket miss: waits for a full median_finish)
   // two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves,
   // FUSED = true (137 VGPRs instead of 125: kept out of the plain kernel's register budget) the frozen ones
   if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
@@ -1506,16 +1052,7 @@ __global__ __launch_bounds__(GN_BLOCK) __attribute__((amdgpu_waves_per_eu(TAIL ?
   __syncthreads();
   if(threadIdx.x < kNumAcc) {
     const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-    float* dst = j.partials + (size_t) blockIdx.x * kPartialStride + threadIdx.x;
-    if constexpr(TAIL) __hip_atomic_store(reinterpret_cast<unsigned*>(dst), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
-    else *dst = v;
-  }
-  if constexpr(TAIL) {
-    // fused-tail chain: the last-arriving workgroup of the workspace is its gn_step
-    __shared__ K8TailLds T;
-    const int nblk = (n + pts_per_block - 1) / pts_per_block;
-    ticket_arrive(j.tickets + 1, (unsigned) nblk, tail_flag(T));
-    if(ticket_is_last(tail_flag(T))) gn_tail<k8_tail_waves(C, FUSED)>(j, T, nblk, prm);
+    j.partials[(size_t) blockIdx.x * kPartialStride + threadIdx.x] = v;
   }
 }
 
@@ -1558,16 +1095,6 @@ __device__ void gn_finalize(GNState* st)
 
 // the serial part of gn_step, executed by lane 0 on the LDS copy of the state; returns true if another linearisation
 // is requested (the workspace stays active)
-// REGS: the f32 solve with the 6x6 matrix in registers (ldlt6_solve_f32: ~180 VGPRs, fine for the one-wave kernel) or the
-// same operations on the LDS-resident scratch (LDLT6<float>: the tail of irls_reduce must not raise that kernel's
-// register allocation); bit-identical results (tests/test_host_math_cpu.py pins both against the oracle's)
-template <bool REGS>
-__device__ __forceinline__ bool gn_solve(const float* H, const float* G, float* dp, SolveScratch* ws)
-{
-  if constexpr(REGS) return solve_system(H, G, dp, ws);
-  else return solve_system_lds(H, G, dp, ws);
-}
-template <bool REGS>
 __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, SolveScratch* scratch, int mode, int max_iterations,
                          int max_fun_evals, float p_tol, float f_tol, float g_tol_param)
 {
@@ -1601,7 +1128,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
       st->phase = PHASE_DONE; st->active = 0;
       return false;
     }
-    if(!gn_solve<REGS>(st->H, st->G, st->dp, scratch)) {           // :356-362
+    if(!solve_system(st->H, st->G, st->dp, scratch)) {           // :356-362
       bpvo_hip_stats& s = st->stats[st->level];
       s.status = BPVO_STATUS_SOLVER_ERROR; s.finalError = f_norm; s.numIterations = 0; s.firstOrderOptimality = 0.0f;
       st->status = BPVO_STATUS_SOLVER_ERROR;
@@ -1614,7 +1141,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
     gn_update_pose(st, nrm);                            // :371
   } else {
     // runIteration's solve (pose_estimator_gn.h:89-97)
-    if(!gn_solve<REGS>(st->H, st->G, st->dp, scratch)) {
+    if(!solve_system(st->H, st->G, st->dp, scratch)) {
       st->status = BPVO_STATUS_SOLVER_ERROR;
       gn_finalize(st);                                  // `break`: no ++ on the way out
       return false;
@@ -1651,60 +1178,53 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
   return false;
 }
 
-// gn_step for one workspace by NT threads (64: the one-wave-per-pair kernel; GN_BLOCK: the tail of irls_reduce): lanes
-// 0..kNumAcc-1 sum the per-block partials in block order in f64 (deterministic), thread 0 runs gn_logic.
-template <int NT>
-__device__ __forceinline__ void gn_step_body(const PairJob& j, K8TailLds& T, int nblk, const GNParams& prm)
+__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
+                                                     int max_iterations, int max_fun_evals, float p_tol, float f_tol,
+                                                     float g_tol_param, ActiveSet act, int fuse_frozen)
 {
+  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* gst = j.st;
-  for(int i = threadIdx.x; i < kStateWords; i += NT) T.state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
-  if(threadIdx.x < 4) T.nrm[threadIdx.x] = j.nrm[threadIdx.x];
-  if(threadIdx.x == 4) T.nrm[4] = j.dspace ? 1.0f : 0.0f;
+  if(!gst->active) return;
+
+  // the state lives in HBM between launches; the serial bookkeeping runs on an LDS copy (global-memory round trips
+  // would otherwise dominate this kernel: every field access is a dependent ~1 us load)
+  constexpr int kWords = (int) (sizeof(GNState) / sizeof(uint32_t));
+  static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
+  __shared__ uint32_t s_state[kWords];
+  __shared__ float s_sum[kPartialStride];
+  __shared__ float s_nrm[5];
+  __shared__ SolveScratch s_scratch;
+  for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
+  if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
+  if(threadIdx.x == 4) s_nrm[4] = j.dspace ? 1.0f : 0.0f;
+
+  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
   if(threadIdx.x < kNumAcc) {                        // deterministic: block order, f64
     double s = 0.0;
     const float* __restrict__ pp = j.partials + threadIdx.x;
 #pragma unroll 8
     for(int b = 0; b < nblk; ++b) s += (double) pp[(size_t) b * kPartialStride];
-    T.sum[threadIdx.x] = (float) s;
+    s_sum[threadIdx.x] = (float) s;
   }
   __syncthreads();
 
   if(threadIdx.x == 0) {
-    GNState* st = reinterpret_cast<GNState*>(T.state);
+    GNState* st = reinterpret_cast<GNState*>(s_state);
     // the linearisation consumed here was taken at st->T; with the fused path its residuals were never written
-    const bool frozen = !(st->delta_scale > 1e-6f);
     for(int i = 0; i < 16; ++i) st->T_lin[i] = st->T[i];
-    st->r_stale = (prm.fuse_frozen && frozen) ? 1 : 0;
-    const bool again = gn_logic<(NT == 64)>(st, T.nrm, T.sum, &T.scratch, prm.mode, prm.max_iterations, prm.max_fun_evals, prm.p_tol, prm.f_tol, prm.g_tol);
+    const bool fused_lin = fuse_frozen && !(st->delta_scale > 1e-6f);
+    st->r_stale = fused_lin ? 1 : 0;
+    const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
     (void) again;   // who is still active is read from st->active by compact_active_kernel once per host round
-    // fused-tail chain: a frozen scale needs no median, so the next linearisation may go straight to irls_reduce
-    st->k8_go = frozen ? 1 : 0;
-    unsigned long long* cnt = j.cnt;
-    cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
-    cnt[1] += 1ull;
-    if(prm.fuse_frozen && frozen) {         // tap-cache statistics of the fused path (the others: median_tail)
-      cnt[5] += (unsigned long long) T.sum[29]; cnt[6] += (unsigned long long) T.sum[28];
-      cnt[10] += (unsigned long long) j.n;  // points linearised through the fused path
+    j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
+    j.cnt[1] += 1ull;
+    if(fused_lin) {                           // the fused path keeps its own tap-cache statistics (the others: median_finish)
+      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += (unsigned long long) s_sum[28];
+      j.cnt[10] += (unsigned long long) j.n;
     }
   }
   __syncthreads();
-  for(int i = threadIdx.x; i < kStateWords; i += NT) reinterpret_cast<uint32_t*>(gst)[i] = T.state[i];
-}
-
-template <int BUDGET>
-__device__ __forceinline__ void gn_tail(const PairJob& j, K8TailLds& T, int nblk, const GNParams& prm)
-{
-  tail_acquire();
-  gn_step_body<GN_BLOCK>(j, T, nblk, prm);
-  if(threadIdx.x == 0) __hip_atomic_store(j.tickets + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, ActiveSet act, GNParams prm)
-{
-  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
-  if(!j.st->active || !j.st->k8_go) return;
-  __shared__ K8TailLds T;
-  gn_step_body<64>(j, T, (j.n + pts_per_block - 1) / pts_per_block, prm);
+  for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1769,7 +1289,6 @@ __global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level)
   st->level = level;
   st->median_valid = 0;
   st->last_median = 0.0f;
-  st->k8_go = 0;
   for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
   for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
   st->active = (jobs[p].n > 0) ? 1 : 0;
@@ -1793,7 +1312,6 @@ __global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int
   if(reset_scale || st->level != level) { st->median_valid = 0; st->last_median = 0.0f; }
   st->level = level;
   st->active = 1;
-  st->k8_go = (st->delta_scale > 1e-6f) ? 0 : 1;
 }
 
 // weights of the last linearisation, recomputed from r / valid / sigma on request
@@ -1885,46 +1403,37 @@ void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
   if(g.max_points <= 0 || (g.C != 8 && g.C != 1)) return;
   hipLaunchKernelGGL(reset_tapkeys_kernel, dim3((g.max_points + GN_BLOCK - 1) / GN_BLOCK, g.npairs), dim3(GN_BLOCK), 0, s, g.jobs);
 }
-bool gn_tails_supported(int max_points) { return gn_num_blocks(max_points) <= TAIL_MAX_BLOCKS; }
-
-template <bool TAIL>
-static void launch_warp_residual_t(hipStream_t s, const GNLaunch& g, int mf_follows)
+void launch_warp_residual(hipStream_t s, const GNLaunch& g)
 {
+  if(g.max_points <= 0) return;
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL((warp_residual_interp_kernel<decltype(c)::value, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp, mf_follows);
+      hipLaunchKernelGGL(warp_residual_interp_kernel<decltype(c)::value>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
     });
     return;
   }
   if(g.fast_warp) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0, mf_follows);
+      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
     });
   } else {
     dispatch_channels(g.C, [&](auto c) {
       constexpr int CC = decltype(c)::value;
-      hipLaunchKernelGGL((warp_residual_kernel<CC, false, TAIL>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0, mf_follows);
+      hipLaunchKernelGGL((warp_residual_kernel<CC, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0);
     });
   }
-}
-// mf_follows: launch_median(allow_full = 1) comes next, so workspaces without a usable bracket compute their residuals
-void launch_warp_residual(hipStream_t s, const GNLaunch& g, int mf_follows)
-{
-  if(g.max_points <= 0) return;
-  if(g.tails) launch_warp_residual_t<true>(s, g, mf_follows);
-  else launch_warp_residual_t<false>(s, g, mf_follows);
 }
 // refresh the residual / valid buffers of the workspaces marked r_stale (fused path) from T_lin, then clear the marks
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0 || g.C != 8) return;
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
-  hipLaunchKernelGGL((warp_residual_kernel<8, false, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2, 1);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
-void launch_median(hipStream_t s, const GNLaunch& g, int allow_full)
+void launch_median(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   // the attribute is per device (a process may hold contexts on several) and the lanes' host threads race here
@@ -1938,52 +1447,46 @@ void launch_median(hipStream_t s, const GNLaunch& g, int allow_full)
       });
   });
   dispatch_channels(g.C, [&](auto c) {
-    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active, allow_full);
+    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
   });
 }
 
-static GNParams gn_params(const GNLaunch& g)
-{
-  GNParams prm = g.prm;
-  prm.fuse_frozen = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
-  return prm;
-}
-template <int C, bool TAIL>
+template <int C>
 static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 {
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
-  const GNParams prm = gn_params(g);
-  const int fuse = prm.fuse_frozen;
+  const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   switch(g.loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
-    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
   }
   if constexpr(C == 8) {
     if(!fuse) return;
     switch(g.loss) {
-      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
-      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
-      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true, TAIL>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, prm); break;
+      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
     }
   }
 }
-// g.tails: the kernel's last-arriving workgroup per workspace is that workspace's gn_step (g.prm), no launch_gn_step follows
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
   const int ppb = gn_pts_per_block(g.C);
-  if(g.tails) dispatch_channels(g.C, [&](auto c) { launch_irls_c<decltype(c)::value, true>(s, g, ppb); });
-  else dispatch_channels(g.C, [&](auto c) { launch_irls_c<decltype(c)::value, false>(s, g, ppb); });
+  dispatch_channels(g.C, [&](auto c) { launch_irls_c<decltype(c)::value>(s, g, ppb); });
 }
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count)
 {
   hipLaunchKernelGGL(compact_active_kernel, dim3(1), dim3(1024), 0, s, jobs, in, n_in, out_list, out_count);
 }
-void launch_gn_step(hipStream_t s, const GNLaunch& g)
+void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
+                    float f_tol, float g_tol)
 {
   const int ppb = gn_pts_per_block(g.C);
-  hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, g.active, gn_params(g));
+  const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
+  hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
+                     f_tol, g_tol, g.active, fuse);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {

@@ -108,10 +108,6 @@ struct GNState {
   // and r_stale says that the buffers have to be refreshed from it before anything reads them (done on demand).
   float T_lin[16];
   int   r_stale;
-  // Fused-tail chain (kernels_gn.hip): 1 once the robust scale of the pending linearisation is known — set by the median
-  // tail of warp_residual, by median_finish, or ahead of time by gn_step when the scale is frozen; the irls_reduce of the
-  // fused-tail chain waits for it (a bracket miss leaves it 0 until the next median_finish launch)
-  int   k8_go;
 };
 
 // Streaming (non-temporal) 16-byte accesses for data that is read or written exactly once per launch and is far larger
@@ -152,15 +148,12 @@ struct PairJob {
   float*        tapcache; // C = 8: [N][32] tiled, the 4 taps x 8 channels of the footprint last gathered for the point; C = 1: [N] float4
   uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, tap-cache hits} of the bracket pass
-  uint32_t*     tickets;  // [2] arrival counters of the fused-tail chain: [0] warp_residual blocks, [1] irls_reduce blocks; zero
-                          // between launches (the last arriver resets its counter)
   float*        partials; // [nblocks][kPartialStride]
   unsigned long long* cnt; // [kWsCounters] per-workspace measurement counters: [0] points linearised, [1] linearisations,
-                           // [2] bracketed / [3] full median selections (fused-tail chain: [3] = all-keys selections + bracket
-                           // misses), [4] points processed by warp_residual (the rest went through the fused path of
-                           // irls_reduce), [5] tap-cache hits / [6] lookups (= valid points), [7] / [8] the same over the first 8
-                           // linearisations of a level, [9] candidate keys the median tails went through (counted by the fused-tail chain only), [10] points linearised through the fused path;
-                           // written by one thread each: no atomics
+                           // [2] bracketed / [3] full median selections, [4] points processed by warp_residual (the rest
+                           // went through the fused path of irls_reduce), [5] tap-cache hits / [6] lookups (= valid points),
+                           // [7] / [8] the same over the first 8 linearisations of a level, [10] points linearised through the
+                           // fused path; written by one thread each: no atomics
   GNState*      st;
 };
 

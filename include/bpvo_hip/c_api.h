@@ -247,12 +247,8 @@ int bpvo_hip_median_path_counts(bpvo_hip_ctx* ctx, uint64_t* bracketed, uint64_t
  * irls_reduce takes once a workspace's robust scale is frozen for the level (warp_residual skips those workspaces) */
 int bpvo_hip_fused_point_counts(bpvo_hip_ctx* ctx, uint64_t* fused, uint64_t* total);
 /* tap cache of warp_residual since the last counter reset: out[0] hits, out[1] lookups (= valid points), out[2] / out[3] the same over
- * the first 8 linearisations of every level (the moving-pose regime), out[4] candidate keys the median tails selected among; counted
- * by the fused-tail launch chain only */
-int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[5]);
-/* GN launch chain (measurement / tests; BPVO_HIP_CHAIN does the same at create): 0 auto, 1 always the four-launch chain
- * (warp_residual, median_finish, irls_reduce, gn_step), 2 always the fused-tail chain (two launches per iteration).  All bit-identical. */
-int bpvo_hip_set_launch_chain(bpvo_hip_ctx* ctx, int mode);
+ * the first 8 linearisations of every level (the moving-pose regime) */
+int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

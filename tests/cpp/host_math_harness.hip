@@ -10,13 +10,6 @@ int host_solve_system(const float* H, const float* G, float* dp)
   return bpvo_hip::solve_system(H, G, dp, &s) ? 1 : 0;
 }
 
-// the LDS-resident form the tail of irls_reduce uses (fused-tail launch chain)
-int host_solve_system_lds(const float* H, const float* G, float* dp)
-{
-  bpvo_hip::SolveScratch s;
-  return bpvo_hip::solve_system_lds(H, G, dp, &s) ? 1 : 0;
-}
-
 void host_twist_to_matrix(const float* p, float* T)
 {
   const bpvo_hip::M44 m = bpvo_hip::twist_to_matrix(p);

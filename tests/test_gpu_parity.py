@@ -280,54 +280,6 @@ def test_unsupported_and_invalid_create(hip):
     assert ctx.L == 1 + round(np.log2(480 / 40.0))      # auto pyramid levels (bpvo/vo.cc:101-105)
 
 
-@pytest.mark.parametrize("rows,cols,levels,n", [pytest.param(120, 160, 3, 40, id="160x120-L3-40pairs"), pytest.param(376, 1241, 4, 6, id="kitti-1241x376-L4-6pairs")])
-@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber"), ("gradient", "l2")])
-def test_launch_chains_are_bit_identical(hip, orc, rows, cols, levels, n, descriptor, loss, monkeypatch):
-    """The GN iteration as four launches (warp_residual, median_finish, irls_reduce, gn_step) or as two (the fused-tail chain:
-    the last-arriving workgroup of a workspace selects the median at the end of warp_residual and runs gn_step at the end of
-    irls_reduce; a bracket miss repeats warp_residual with an all-keys bracket): poses, statistics, residuals, valid masks
-    and weights of every pair identical bit for bit, with and without the fused frozen-scale path; and single
-    linearisations through the tails equal the oracle's like the four-launch form does."""
-    batch = synth.make_batch(rows, cols, n, first_index=200, workers=1)
-    out = {}
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("BPVO_HIP_FUSE_FROZEN", fuse)
-        for chain in (1, 2, 0):
-            ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels),
-                             n_frames=2 * n, n_pairs=n)
-            ctx.set_launch_chain(chain)
-            poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
-            out[(fuse, chain)] = dict(poses=poses, stats=stats, r=ctx.get_residuals(n - 1), v=ctx.get_valid(n - 1), w=ctx.get_weights(n - 1),
-                                      med=ctx.median_path_counts(), lin=ctx.total_linearizations(), tap=ctx.tap_cache_counts())
-            ctx.close()
-    ref = out[("1", 1)]
-    for key, o in out.items():
-        assert bits_equal(o["poses"], ref["poses"]), key
-        assert o["stats"].tobytes() == ref["stats"].tobytes(), key
-        assert np.array_equal(o["v"], ref["v"]) and bits_equal(o["r"], ref["r"]) and bits_equal(o["w"], ref["w"]), key
-        assert o["lin"] == ref["lin"], key
-    # the tails ran (tap-cache statistics are theirs), every selection was counted, hits never exceed lookups
-    t = out[("1", 2)]
-    assert t["med"][0] + t["med"][1] >= ref["med"][0] + ref["med"][1]        # misses repeat
-    if descriptor in ("bitplanes", "intensity"):
-        assert 0 < t["tap"][0] <= t["tap"][1] and 0 < t["tap"][3] <= t["tap"][1] and t["tap"][2] <= t["tap"][3]
-    # single linearisations through the tails (all-keys first, bracketed after, repeat pass on a miss) against the oracle
-    d = synth.make_pair(rows, cols, 3)
-    kw = dict(descriptor=descriptor, loss=loss, levels=levels)
-    ch, _, _ = setup_pair(hip, rows, cols, index=3, **kw)
-    co, _, _ = setup_pair(orc, rows, cols, index=3, **kw)
-    ch.set_launch_chain(2)
-    l = levels - 1
-    poses = [np.eye(4, dtype=np.float32), _perturbed_pose(1.0), _perturbed_pose(1.02), _perturbed_pose(1.02), _perturbed_pose(6.0), _perturbed_pose(1.0)]
-    for k, T in enumerate(poses):       # the jump to 6x and back leaves the bracket: exercises the repeat pass
-        a = ch.linearize(0, 0, 1, l, T, reset_scale=(k == 0))
-        b = co.linearize(0, 0, 1, l, T, reset_scale=(k == 0))
-        assert a["sigma"] == b["sigma"] and a["num_valid"] == b["num_valid"], (k, a["sigma"], b["sigma"])
-        assert np.array_equal(ch.get_valid(0), co.get_valid(0)) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
-        assert bits_equal(ch.get_weights(0), co.get_weights(0))
-        assert np.abs(a["H"] - b["H"]).max() <= 2e-4 * np.abs(b["H"]).max()
-
-
 @pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
 def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
     """BPVO_HIP_LANES (read by bpvo_hip_create): a batch split over 2 or 3 estimation streams driven by host threads gives,
@@ -474,6 +426,13 @@ def test_full_size_batch_properties(hip):
     ctx.batch_copy_records_device(rec.data_ptr(), n)
     rp, it, _ = records_to_poses(rec)
     assert np.array_equal(rp[:, :3, :], poses[:, :3, :]) and np.array_equal(it[:, :levels], stats["numIterations"])
+    # measurement counters: every valid template point of every linearisation looks up the tap cache once; the first linearisation
+    # of a level starts with an empty cache, later ones mostly hit
+    hits, lookups, hits8, lookups8 = ctx.tap_cache_counts()
+    assert 0 < hits < lookups and 0 < hits8 < lookups8 < lookups and hits8 <= hits
+    assert hits / lookups > 0.9 and hits8 / lookups8 < hits / lookups
+    med = ctx.median_path_counts()
+    assert med[1] >= 2 * n * levels and med[0] > med[1]           # >= one full selection per level, pair and run; the rest bracketed
 
 
 @pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
