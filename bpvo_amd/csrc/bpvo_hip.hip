@@ -145,6 +145,7 @@ struct bpvo_hip_ctx {
   int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
+  int irls_merge_below = 384;  // fuse_frozen: fewer active workspaces than this -> one merged irls_reduce launch; BPVO_HIP_IRLS_MERGE_BELOW
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
@@ -567,6 +568,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.active.list = nullptr;                // first rounds: every workspace of the group, in order
     for(int round = 0; round < max_rounds; ++round) {
       g.npairs = n_cur;
+      g.merge_irls = n_cur < c->irls_merge_below ? 1 : 0;
       for(int k = 0; k < kItersPerSync; ++k) {
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
@@ -985,6 +987,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }

@@ -915,15 +915,10 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
   return 1.0f;
 }
 
+// the work of one workgroup of irls_reduce on workspace j
 template <int C, int LOSS, bool FUSED>
-__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen)
+__device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __restrict__ st, int pts_per_block)
 {
-  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
-  const GNState* __restrict__ st = j.st;
-  if(!st->active) return;
-  // two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves,
-  // FUSED = true (137 VGPRs instead of 125: kept out of the plain kernel's register budget) the frozen ones
-  if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
   // Fused path (C = 8): the robust scale is frozen for the rest of the level, so nothing separates the residuals from
   // their weights any more — they are recomputed here exactly as warp_residual does (same warp_point, same tap cache) and
   // never written: the r write + read, the second point read and the valid byte (82 of 341 B per point and iteration)
@@ -1054,6 +1049,31 @@ __global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __
     const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
     j.partials[(size_t) blockIdx.x * kPartialStride + threadIdx.x] = v;
   }
+}
+
+// Two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves, FUSED =
+// true (136 VGPRs instead of 103: kept out of the plain kernel's register budget) the frozen ones.
+template <int C, int LOSS, bool FUSED>
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen)
+{
+  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active) return;
+  if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
+  irls_block<C, LOSS, FUSED>(j, st, pts_per_block);
+}
+// ... or ONE launch serves both kinds with a per-workspace branch (C = 8): every workgroup then runs at the fused form's
+// register budget (3 waves per SIMD instead of 4), but small launches — the 128-pair shard of config 5, single pairs — do not
+// pay a second, half-empty launch per iteration (each costs its ramp and drain: at 128 pairs the two launches took 59 us where
+// the bytes are worth 38).
+template <int LOSS>
+__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_both_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block)
+{
+  const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
+  const GNState* __restrict__ st = j.st;
+  if(!st->active) return;
+  if(st->delta_scale > 1e-6f) irls_block<8, LOSS, false>(j, st, pts_per_block);
+  else irls_block<8, LOSS, true>(j, st, pts_per_block);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1456,6 +1476,16 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 {
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
   const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
+  if constexpr(C == 8) {
+    if(fuse && g.merge_irls) {
+      switch(g.loss) {
+        case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
+        case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
+        default: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_L2>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
+      }
+      return;
+    }
+  }
   switch(g.loss) {
     case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
     case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;

@@ -592,8 +592,10 @@ def test_fused_frozen_scale_path_is_bit_identical(hip, rows, cols, levels, loss,
     itself and warp_residual skips the workspace; the residual / valid buffers are refreshed on demand from the pose of the
     last linearisation.  Everything observable must equal the two-kernel form bit for bit."""
     out = []
-    for fuse in ("0", "1"):
+    for fuse, merge in (("0", "0"), ("1", "0"), ("1", "100000")):
+        # merge: the two irls_reduce instantiations (plain / fused) as one launch with a per-workspace branch (small batches) or two
         monkeypatch.setenv("BPVO_HIP_FUSE_FROZEN", fuse)
+        monkeypatch.setenv("BPVO_HIP_IRLS_MERGE_BELOW", merge)
         ctx, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss=loss)
         T, st = ctx.estimate_pose(0, 0, 1)
         rec = dict(T=T, st=st, frac=ctx.fraction_good(0, 0.85), r=ctx.get_residuals(0), v=ctx.get_valid(0), w=ctx.get_weights(0),
@@ -607,14 +609,16 @@ def test_fused_frozen_scale_path_is_bit_identical(hip, rows, cols, levels, loss,
         rec["br"] = bctx.get_residuals(2)
         rec["bw"] = bctx.get_weights(2)
         out.append(rec)
-    a, b = out
-    assert a["fused"][0] == 0 and b["fused"][0] > 0 and a["fused"][1] == b["fused"][1]
-    assert bits_equal(a["T"], b["T"]) and bits_equal(a["bposes"], b["bposes"])
-    assert a["st"] == b["st"]
-    assert a["bstats"].tobytes() == b["bstats"].tobytes()
-    assert a["frac"] == b["frac"]
-    assert np.array_equal(a["v"], b["v"]) and bits_equal(a["r"], b["r"]) and bits_equal(a["w"], b["w"])
-    assert bits_equal(a["br"], b["br"]) and bits_equal(a["bw"], b["bw"])
+    a = out[0]
+    assert a["fused"][0] == 0
+    for b in out[1:]:
+        assert b["fused"][0] > 0 and a["fused"][1] == b["fused"][1]
+        assert bits_equal(a["T"], b["T"]) and bits_equal(a["bposes"], b["bposes"])
+        assert a["st"] == b["st"]
+        assert a["bstats"].tobytes() == b["bstats"].tobytes()
+        assert a["frac"] == b["frac"]
+        assert np.array_equal(a["v"], b["v"]) and bits_equal(a["r"], b["r"]) and bits_equal(a["w"], b["w"])
+        assert bits_equal(a["br"], b["br"]) and bits_equal(a["bw"], b["bw"])
 
 
 @pytest.mark.parametrize("seed", range(6))
