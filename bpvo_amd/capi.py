@@ -388,6 +388,10 @@ class Context:
         self.call("tap_cache_counts", a)
         return tuple(int(x) for x in a)
 
+    def set_max_lanes(self, n):
+        """Cap (n >= 1) or uncap (n <= 0) the estimation lanes of later batch calls (HIP library only)."""
+        self.call("set_max_lanes", int(n))
+
     def total_linearizations(self):
         n = C.c_uint64()
         self.call("total_linearizations", C.byref(n))

@@ -94,12 +94,12 @@ struct Lane {
   unsigned k6_seq = 0;             // warp_residual launches of this lane since bpvo_hip_profiling (event sampling)
   std::string err;
 };
-// Estimation lanes (streams driven by host threads) of a batch.  8-channel descriptors: 1 — a second lane gains 3.5 % at 1024
-// pairs but makes the per-launch timings of the two lanes overlap, and the roofline of warp_residual<8> is quoted per
-// launch.  Narrower descriptors: 2 — their launches are short, the one-workgroup-per-pair kernels (median_finish, gn_step)
-// are a third of an iteration, and a second lane hides them behind the other lane's wide kernels (+7 % at 1024 pairs of
-// 640x480 intensity).  BPVO_HIP_LANES overrides either.  Results do not depend on the number of lanes (test_gpu_parity.py).
-constexpr int kDefaultLanes = 1;
+// Estimation lanes (streams driven by host threads) of a batch: the narrow per-pair kernels (median_finish, gn_step: one
+// workgroup / wave per pair) of one lane overlap the chip-filling kernels of the other.  Two lanes: +2 % at 1024 pairs of
+// 1241x376 bit-planes, +3.7 % at 128, +7 % for 640x480 intensity; four lanes lose at every size.  Per-launch durations of
+// overlapping lanes include the time shared with the other lane: measurements that need clean per-kernel times run with
+// bpvo_hip_set_max_lanes(ctx, 1) / BPVO_HIP_LANES=1.  Results do not depend on the number of lanes (test_gpu_parity.py).
+constexpr int kDefaultLanes = 2;
 constexpr int kDefaultLanesNarrow = 2;
 constexpr int kMinPairsPerLane = 8;
 
@@ -145,7 +145,11 @@ struct bpvo_hip_ctx {
   int dspace = 0;              // BPVO_WARP_DISPARITY_SPACE_F32: DisparitySpaceWarp as the warp (implies fast_warp)
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  BPVO_HIP_FUSE_FROZEN=0 turns it off.
-  int irls_merge_below = 384;  // fuse_frozen: fewer active workspaces than this -> one merged irls_reduce launch; BPVO_HIP_IRLS_MERGE_BELOW
+  int irls_merge_below = 1 << 30;   // fuse_frozen: fewer active workspaces than this -> ONE irls_reduce launch with a per-workspace branch
+                               // instead of two instantiations sharing the slot.  Measured faster at every batch size (1 pair +6 %, 8 / 32
+                               // pairs +13 %, 128 +7 %, 1024 +3.7 %: the second, half-empty launch costs more than the fourth wave per SIMD
+                               // buys the plain form), so it is always on; BPVO_HIP_IRLS_MERGE_BELOW=0 restores the two launches
+  int max_lanes_now = 1 << 30; // bpvo_hip_set_max_lanes: measurement runs that need per-launch timings without overlap
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
@@ -629,7 +633,7 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   }
   HIP_CK(c, hipStreamSynchronize(c->stream));   // frame stages run on the ctx stream; lanes start from a quiet device
-  const int nl = std::max(1, std::min((int) c->lanes.size(), n / kMinPairsPerLane));
+  const int nl = std::max(1, std::min(std::min((int) c->lanes.size(), c->max_lanes_now), n / kMinPairsPerLane));
   std::vector<int> rcs(nl, BPVO_OK);
   auto run = [&](int k) {
     const int lo = (int) ((long long) n * k / nl), hi = (int) ((long long) n * (k + 1) / nl);
@@ -1629,6 +1633,12 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
   int rc = refresh_counters(c);
   if(rc) return rc;
   for(int k = 0; k < 4; ++k) out[k] = c->tap_counts[k];
+  return BPVO_OK;
+}
+int bpvo_hip_set_max_lanes(bpvo_hip_ctx* c, int n)
+{
+  CHECK_CTX(c);
+  c->max_lanes_now = n >= 1 ? n : (1 << 30);
   return BPVO_OK;
 }
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* c, uint64_t* n)

@@ -128,6 +128,19 @@ def make_pair(rows: int, cols: int, index: int = 0, max_rot: float = 0.01, max_t
     return dict(K=K, b=b, imgA=imgA, dispA=dispA, imgB=imgB, dispB=dispB, T_gt=T_gt, seed=seed, twist=twist)
 
 
+def make_stereo_pair(rows: int, cols: int, index: int = 0, z0: float = 10.0):
+    """A rectified stereo pair of the plane scene: left image, right image (camera shifted by the baseline along +x), and the
+    true disparity of the left image.  Returns dict(K, b, left, right, disp)."""
+    seed = 1000 + int(index)
+    K, b = calibration(rows, cols)
+    plane = (0.1, -0.15)
+    left, disp = _render(K, b, rows, cols, np.eye(4), seed, z0, plane)
+    T_right = np.eye(4)
+    T_right[0, 3] = -b                     # X_right = X_left - (b, 0, 0)
+    right, _ = _render(K, b, rows, cols, T_right, seed, z0, plane)
+    return dict(K=K, b=b, left=left, right=right, disp=disp, seed=seed)
+
+
 def make_sequence(rows: int, cols: int, n_frames: int, index: int = 0, step_rot: float = 0.004, step_trans: float = 0.03):
     """A short camera trajectory over the same plane for addFrame tests: list of (img, disp) and absolute poses."""
     seed = 1000 + int(index)

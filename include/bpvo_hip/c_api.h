@@ -249,6 +249,10 @@ int bpvo_hip_fused_point_counts(bpvo_hip_ctx* ctx, uint64_t* fused, uint64_t* to
 /* tap cache of warp_residual since the last counter reset: out[0] hits, out[1] lookups (= valid points), out[2] / out[3] the same over
  * the first 8 linearisations of every level (the moving-pose regime) */
 int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
+/* estimation lanes (streams) later batch calls may use: n >= 1 caps them, n <= 0 lifts the cap.  Batches are split over up to two
+ * lanes by default so that the narrow per-pair kernels of one overlap the wide kernels of the other; per-launch timings are only
+ * clean with one lane.  Results never depend on it. */
+int bpvo_hip_set_max_lanes(bpvo_hip_ctx* ctx, int n);
 
 #ifdef __cplusplus
 }

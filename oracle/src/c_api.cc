@@ -423,6 +423,18 @@ float bpvo_orc_median(const float* data, size_t n)
 { std::vector<float> v(data, data + n); return medianOf(v); }
 int bpvo_orc_solve(const float H[36], const float G[6], float dp[6]) { return solveSystem(H, G, dp) ? 1 : 0; }
 void bpvo_orc_twist_to_matrix(const float p[6], float T[16]) { M44 m = twistToMatrix(p); std::memcpy(T, m.m, 64); }
+// StereoAlgorithm::run (BlockMatching): params = {preFilterCap, SADWindowSize, minDisparity, numberOfDisparities, textureThreshold, uniquenessRatio}
+int bpvo_orc_stereo_bm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int params[6], float* dmap)
+{
+  StereoParams sp;
+  sp.preFilterCap = params[0]; sp.SADWindowSize = params[1]; sp.minDisparity = params[2]; sp.numberOfDisparities = params[3];
+  sp.textureThreshold = params[4]; sp.uniquenessRatio = params[5];
+  if(sp.SADWindowSize < 5 || sp.SADWindowSize > 255 || sp.SADWindowSize % 2 == 0 || sp.numberOfDisparities <= 0 || sp.numberOfDisparities % 16 != 0 ||
+     sp.preFilterCap < 1 || sp.preFilterCap > 63) return 1;     // the argument checks of cvFindStereoCorrespondenceBM
+  stereoBM(left, right, rows, cols, sp, dmap);
+  return 0;
+}
+int bpvo_orc_stereo_prefilter(const uint8_t* src, int rows, int cols, int cap, uint8_t* dst) { stereoPrefilterXSobel(src, rows, cols, cap, dst); return 0; }
 // MEstimator::ComputeWeights on raw arrays (r [n], valid [n] u16 -> w [n]); n a multiple of 16 runs the SIMD body only
 int bpvo_orc_compute_weights(int loss, const float* r, const uint16_t* valid, size_t n, float sigma, float* w)
 {

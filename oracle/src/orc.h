@@ -83,6 +83,15 @@ void gradientAbsoluteMagnitude(const float* src, int rows, int cols, float* dst)
 void gradientAbsoluteMagnitudeAcc(const float* src, int rows, int cols, float* dst);        // bpvo/imgproc.cc:104-127
 bool isLocalMax(const float* ptr, int stride, int radius, int row, int col);                // bpvo/imgproc.h:117-160
 
+// stereo.cc — the stereo front-end: OpenCV 2.4 block matching with the reference's parameters
+// (utils/stereo_algorithm.cc:63-82); defaults = cvCreateStereoBMState(CV_STEREO_BM_BASIC) as the reference overrides them
+struct StereoParams {
+  int preFilterCap = 31, SADWindowSize = 15, minDisparity = 0, numberOfDisparities = 64, textureThreshold = 10, uniquenessRatio = 15;
+};
+void stereoPrefilterXSobel(const uint8_t* src, int rows, int cols, int ftzero, uint8_t* dst);
+void stereoBlockMatching(const uint8_t* left, const uint8_t* right, int rows, int cols, const StereoParams& sp, int16_t* disp);
+void stereoBM(const uint8_t* left, const uint8_t* right, int rows, int cols, const StereoParams& sp, float* dmap);
+
 // ---- descriptor (dense_descriptor.*, intensity_descriptor.cc, bitplanes_descriptor.cc)
 struct Descriptor {
   int rows = 0, cols = 0;
