@@ -53,6 +53,12 @@ class Result(C.Structure):
                 ("numLevels", C.c_int), ("isKeyFrame", C.c_int), ("keyFramingReason", C.c_int), ("hasPointCloud", C.c_int)]
 
 
+class StereoParams(C.Structure):
+    """bpvo_hip_stereo_params: the CvStereoBMState fields the reference sets (utils/stereo_algorithm.cc:63-82)."""
+    _fields_ = [("preFilterCap", C.c_int), ("SADWindowSize", C.c_int), ("minDisparity", C.c_int), ("numberOfDisparities", C.c_int),
+                ("textureThreshold", C.c_int), ("uniquenessRatio", C.c_int)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("units", C.c_double),
                 ("bytes_per_unit", C.c_double)]
@@ -282,6 +288,30 @@ class Context:
                     stats=[dict(numIterations=s.numIterations, finalError=s.finalError,
                                 firstOrderOptimality=s.firstOrderOptimality, status=s.status)
                            for s in r.optimizerStatistics[: r.numLevels]],
+                    isKeyFrame=bool(r.isKeyFrame), keyFramingReason=r.keyFramingReason, hasPointCloud=bool(r.hasPointCloud))
+
+    def default_stereo_params(self, ndisp=64):
+        sp = StereoParams()
+        self.b.fn("default_stereo_params", None)(C.byref(sp))
+        sp.numberOfDisparities = int(ndisp)
+        return sp
+
+    def stereo_bm(self, left, right, sp):
+        """StereoAlgorithm::run (block matching) on one pair or a stack [n, rows, cols]: f32 disparities, invalid = minDisparity - 1."""
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        n = 1 if left.ndim == 2 else left.shape[0]
+        out = np.empty(left.shape, np.float32)
+        self.call("stereo_bm", n, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), 0, C.byref(sp), out.ctypes.data_as(C.c_void_p), 0)
+        return out
+
+    def add_frame_stereo(self, left, right, sp):
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        r = Result()
+        self.call("add_frame_stereo", left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), C.byref(sp), C.byref(r))
+        return dict(pose=np.array(r.pose, np.float32).reshape(4, 4), stats=[dict(numIterations=s.numIterations, finalError=s.finalError,
+                    firstOrderOptimality=s.firstOrderOptimality, status=s.status) for s in r.optimizerStatistics[: r.numLevels]],
                     isKeyFrame=bool(r.isKeyFrame), keyFramingReason=r.keyFramingReason, hasPointCloud=bool(r.hasPointCloud))
 
     def add_frame_null(self):

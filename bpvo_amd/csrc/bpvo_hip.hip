@@ -150,6 +150,10 @@ struct bpvo_hip_ctx {
                                // pairs +13 %, 128 +7 %, 1024 +3.7 %: the second, half-empty launch costs more than the fourth wave per SIMD
                                // buys the plain form), so it is always on; BPVO_HIP_IRLS_MERGE_BELOW=0 restores the two launches
   int max_lanes_now = 1 << 30; // bpvo_hip_set_max_lanes: measurement runs that need per-launch timings without overlap
+  // stereo front-end scratch (lazily sized for the largest frame count seen): raw and pre-filtered u8 pairs, f32 disparities
+  uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
+  float* st_disp = nullptr;
+  int st_frames = 0;
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
@@ -1034,6 +1038,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
+  (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
   (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
@@ -1414,10 +1419,103 @@ static int build_point_cloud(bpvo_hip_ctx* c)
   return BPVO_OK;
 }
 
+// ---- stereo front-end (reference: utils/stereo_algorithm.cc:63-82,98-111 -> OpenCV 2.4 cvFindStereoCorrespondenceBM) ----
+static int stereo_check(bpvo_hip_ctx* c, const bpvo_hip_stereo_params* sp)
+{
+  // the argument checks of cvFindStereoCorrespondenceBM (stereobm.cpp) + what the kernel serves
+  if(!sp) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr stereo parameters");
+  if(sp->preFilterCap < 1 || sp->preFilterCap > 63) return fail(c, BPVO_ERR_INVALID_ARG, "preFilterCap must be within 1..63");
+  if(sp->SADWindowSize < 5 || sp->SADWindowSize > 255 || sp->SADWindowSize % 2 == 0 || sp->SADWindowSize >= std::min(c->cols, c->rows))
+    return fail(c, BPVO_ERR_INVALID_ARG, "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height");
+  if(sp->numberOfDisparities <= 0 || sp->numberOfDisparities % 16 != 0) return fail(c, BPVO_ERR_INVALID_ARG, "numberOfDisparities must be positive and divisble by 16");
+  if(sp->textureThreshold < 0) return fail(c, BPVO_ERR_INVALID_ARG, "texture threshold must be non-negative");
+  if(sp->uniquenessRatio < 0) return fail(c, BPVO_ERR_INVALID_ARG, "uniqueness ratio must be non-negative");
+  if(sp->SADWindowSize > 21) return fail(c, BPVO_ERR_UNSUPPORTED, "SADWindowSize: 5..21 are on the device path");
+  if(sp->minDisparity < 0 || sp->numberOfDisparities > 256) return fail(c, BPVO_ERR_UNSUPPORTED, "minDisparity >= 0 and numberOfDisparities <= 256 are on the device path");
+  return BPVO_OK;
+}
+static int stereo_reserve(bpvo_hip_ctx* c, int count)
+{
+  if(count <= c->st_frames) return BPVO_OK;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
+  c->st_left = c->st_right = c->st_left_pre = c->st_right_pre = nullptr; c->st_disp = nullptr; c->st_frames = 0;
+  const size_t npix = c->geom[0].npix * (size_t) count;
+  HIP_CK(c, hipMalloc((void**) &c->st_left, npix)); HIP_CK(c, hipMalloc((void**) &c->st_right, npix));
+  HIP_CK(c, hipMalloc((void**) &c->st_left_pre, npix)); HIP_CK(c, hipMalloc((void**) &c->st_right_pre, npix));
+  HIP_CK(c, hipMalloc((void**) &c->st_disp, npix * sizeof(float)));
+  c->st_frames = count;
+  return BPVO_OK;
+}
+// disparities of `count` rectified pairs into c->st_disp (device); d_left: where the left images are on the device afterwards
+static int stereo_run(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, bool on_device, const bpvo_hip_stereo_params* sp,
+                      const uint8_t** d_left)
+{
+  int rc = stereo_check(c, sp);
+  if(rc) return rc;
+  if(count <= 0 || !left || !right) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image");
+  rc = stereo_reserve(c, count);
+  if(rc) return rc;
+  const size_t npix = c->geom[0].npix * (size_t) count;
+  const uint8_t* dl = left;
+  const uint8_t* dr = right;
+  if(!on_device) {
+    HIP_CK(c, hipMemcpyAsync(c->st_left, left, npix, hipMemcpyHostToDevice, c->stream));
+    HIP_CK(c, hipMemcpyAsync(c->st_right, right, npix, hipMemcpyHostToDevice, c->stream));
+    dl = c->st_left; dr = c->st_right;
+  }
+  launch_stereo_prefilter(c->stream, dl, c->st_left_pre, c->rows, c->cols, sp->preFilterCap, count);
+  launch_stereo_prefilter(c->stream, dr, c->st_right_pre, c->rows, c->cols, sp->preFilterCap, count);
+  StereoLaunch g;
+  g.left_pre = c->st_left_pre; g.right_pre = c->st_right_pre; g.disp = c->st_disp;
+  g.rows = c->rows; g.cols = c->cols; g.nframes = count;
+  g.wsz = sp->SADWindowSize; g.ndisp = sp->numberOfDisparities; g.mindisp = sp->minDisparity; g.cap = sp->preFilterCap;
+  g.texture_threshold = sp->textureThreshold; g.uniqueness_ratio = sp->uniquenessRatio;
+  if(!launch_stereo_bm(c->stream, g)) return fail(c, BPVO_ERR_UNSUPPORTED, "stereo block matching: window / disparity range not served by the kernel");
+  HIP_CK(c, hipGetLastError());
+  if(d_left) *d_left = dl;
+  return BPVO_OK;
+}
+
+void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p)   // utils/stereo_algorithm.cc:63-82 (numberOfDisparities has no default there)
+{
+  p->preFilterCap = 31; p->SADWindowSize = 15; p->minDisparity = 0; p->numberOfDisparities = 64; p->textureThreshold = 10; p->uniquenessRatio = 15;
+}
+int bpvo_hip_stereo_bm(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, int on_device, const bpvo_hip_stereo_params* sp,
+                       float* disparity, int disparity_on_device)
+{
+  CHECK_CTX(c);
+  if(!disparity) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr disparity");
+  (void) hipSetDevice(c->device);
+  int rc = stereo_run(c, count, left, right, on_device != 0, sp, nullptr);
+  if(rc) return rc;
+  HIP_CK(c, hipMemcpyAsync(disparity, c->st_disp, c->geom[0].npix * (size_t) count * sizeof(float),
+                           disparity_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+
+static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bool on_device, bpvo_hip_result* ret);
 int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bpvo_hip_result* ret)
 {
   CHECK_CTX(c);
   if(!image || !disparity) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");   // bpvo/vo.cc:68-69
+  return add_frame_impl(c, image, disparity, false, ret);
+}
+// addFrame fed by the stereo front-end: the reference's apps run StereoAlgorithm::run on the rectified pair and hand the f32
+// disparity to VisualOdometry::addFrame (apps/vo_app.cc, utils/dataset.h); here the disparity never leaves the device
+int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* c, const uint8_t* left, const uint8_t* right, const bpvo_hip_stereo_params* sp, bpvo_hip_result* ret)
+{
+  CHECK_CTX(c);
+  if(!left || !right) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image");
+  (void) hipSetDevice(c->device);
+  const uint8_t* d_left = nullptr;
+  int rc = stereo_run(c, 1, left, right, false, sp, &d_left);
+  if(rc) return rc;
+  return add_frame_impl(c, d_left, c->st_disp, true, ret);
+}
+static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bool on_device, bpvo_hip_result* ret)
+{
   if(!ret) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr result");
   if(c->n_frames < 3) return fail(c, BPVO_ERR_INVALID_ARG, "add_frame needs a ctx with n_frames >= 3");
   (void) hipSetDevice(c->device);
@@ -1433,7 +1531,7 @@ int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* dispa
   c->cloud.clear();                 // the point cloud belongs to one Result (bpvo/types.h:549-563)
   c->cloud_pose = I;
 
-  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, false);   // _cur_frame->setData (vo.cc:131)
+  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, on_device);   // _cur_frame->setData (vo.cc:131)
   if(rc) return rc;
   HIP_CK(c, hipStreamSynchronize(c->stream));
 

@@ -54,6 +54,17 @@ void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
 
+// stereo front-end (kernels_stereo.hip): OpenCV 2.4 block matching with the reference's parameters, batched over frames
+struct StereoLaunch {
+  const uint8_t* left_pre;    // [nframes][rows*cols] pre-filtered images
+  const uint8_t* right_pre;
+  float* disp;                // [nframes][rows*cols]
+  int rows, cols, nframes;
+  int wsz, ndisp, mindisp, cap, texture_threshold, uniqueness_ratio;
+};
+void launch_stereo_prefilter(hipStream_t s, const uint8_t* src, uint8_t* dst, int rows, int cols, int cap, int nframes);
+bool launch_stereo_bm(hipStream_t s, const StereoLaunch& g);   // false: window size / disparity range outside what the kernel serves
+
 // Gauss-Newton stage (batched over workspaces / pairs)
 // Compacted list of the workspaces of a launch that are still iterating (estimate loops).  The host rebuilds it (on the
 // device) once per round of kItersPerSync iterations, together with the read-back of the count, and sizes the workspace

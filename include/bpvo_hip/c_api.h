@@ -228,6 +228,26 @@ int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* ctx, const float** d_reco
  * the RCCL gather), complete on return */
 int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* ctx, float* d_dst, int n_pairs);
 
+/* ---- stereo front-end.  reference: StereoAlgorithm (utils/stereo_algorithm.{h,cc}), BlockMatching branch:
+ * cvFindStereoCorrespondenceBM with the state of utils/stereo_algorithm.cc:63-82, then disp16.convertTo(CV_32F, 1/16) (:98-111).
+ * The matcher is OpenCV 2.4's (third party): restated, parity unpinned.  Invalid pixels carry minDisparity - 1 (getInvalidValue). */
+typedef struct bpvo_hip_stereo_params {
+  int preFilterCap;          /* 31 */
+  int SADWindowSize;         /* 15; odd, 5..21 on the device path */
+  int minDisparity;          /* 0 */
+  int numberOfDisparities;   /* no default in the reference ("must be provided"); multiple of 16, <= 256 */
+  int textureThreshold;      /* 10 */
+  int uniquenessRatio;       /* 15 */
+} bpvo_hip_stereo_params;
+void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p);
+/* StereoAlgorithm::run for `count` rectified pairs of the ctx's image size ([count][rows*cols] u8 each, host or device) ->
+ * f32 disparities [count][rows*cols] (host or device) */
+int bpvo_hip_stereo_bm(bpvo_hip_ctx* ctx, int count, const uint8_t* left, const uint8_t* right, int on_device,
+                       const bpvo_hip_stereo_params* sp, float* disparity, int disparity_on_device);
+/* VisualOdometry::addFrame(left, StereoAlgorithm::run(left, right)): the disparity map stays on the device */
+int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* ctx, const uint8_t* left, const uint8_t* right, const bpvo_hip_stereo_params* sp,
+                              bpvo_hip_result* result);
+
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx's own stream */
 typedef struct bpvo_hip_kernel_stat {
   char     name[48];

@@ -253,6 +253,16 @@ class VisualOdometryPoseEstimator {
   mutable WeightsVector _weights;
 };
 
+/* Block-matching parameters of the reference's StereoAlgorithm (utils/stereo_algorithm.cc:63-82: the CvStereoBMState fields it sets,
+ * with its defaults; numberOfDisparities "must be provided") */
+struct StereoParameters : bpvo_hip_stereo_params {
+  explicit StereoParameters(int number_of_disparities)
+  {
+    bpvo_hip_default_stereo_params(this);
+    numberOfDisparities = number_of_disparities;
+  }
+};
+
 /* bpvo::VisualOdometry (bpvo/vo.h:31-105).  The keyframe state machine of bpvo/vo.cc:125-224 runs inside the library
  * on three device-resident frames. */
 class VisualOdometry {
@@ -287,6 +297,36 @@ class VisualOdometry {
     if(image == nullptr || disparity == nullptr) throw Error("nullptr image/disparity");
     bpvo_hip_result r;
     _dev->check(bpvo_hip_add_frame(_dev->ctx(), image, disparity, &r));
+    return makeResult(r);
+  }
+
+  /* The reference's apps compute the disparity with StereoAlgorithm::run(left, right, dmap) (utils/stereo_algorithm.h:24-30; block
+   * matching by default) and pass it to addFrame.  Here both steps run on the device and the f32 map never crosses the bus. */
+  Result addFrame(const uint8_t* left, const uint8_t* right, const StereoParameters& stereo)
+  {
+    if(left == nullptr || right == nullptr) throw Error("nullptr image");
+    bpvo_hip_result r;
+    _dev->check(bpvo_hip_add_frame_stereo(_dev->ctx(), left, right, &stereo, &r));
+    return makeResult(r);
+  }
+
+  int numPointsAtLevel(int level = -1) const                     // bpvo/vo.h:86
+  {
+    int n = 0;
+    _dev->check(bpvo_hip_vo_num_points_at_level(_dev->ctx(), level, &n));
+    return n;
+  }
+  const PointVector& pointsAtLevel(int level = -1) const         // bpvo/vo.h:92
+  {
+    _points.resize(numPointsAtLevel(level));
+    if(!_points.empty()) _dev->check(bpvo_hip_vo_points_at_level(_dev->ctx(), level, _points[0].data()));
+    return _points;
+  }
+  const Trajectory& trajectory() const { return _trajectory; }   // bpvo/vo.h:98
+
+ private:
+  Result makeResult(const bpvo_hip_result& r)
+  {
     Result ret;
     std::memcpy(ret.pose.data(), r.pose, sizeof(r.pose));
     std::memcpy(ret.covariance.data(), r.covariance, sizeof(r.covariance));
@@ -306,22 +346,6 @@ class VisualOdometry {
     if(nt) _dev->check(bpvo_hip_get_trajectory(_dev->ctx(), _trajectory._poses[0].data()));
     return ret;
   }
-
-  int numPointsAtLevel(int level = -1) const                     // bpvo/vo.h:86
-  {
-    int n = 0;
-    _dev->check(bpvo_hip_vo_num_points_at_level(_dev->ctx(), level, &n));
-    return n;
-  }
-  const PointVector& pointsAtLevel(int level = -1) const         // bpvo/vo.h:92
-  {
-    _points.resize(numPointsAtLevel(level));
-    if(!_points.empty()) _dev->check(bpvo_hip_vo_points_at_level(_dev->ctx(), level, _points[0].data()));
-    return _points;
-  }
-  const Trajectory& trajectory() const { return _trajectory; }   // bpvo/vo.h:98
-
- private:
   std::shared_ptr<detail::Device> _dev;
   int _max_test_level;
   Trajectory _trajectory;

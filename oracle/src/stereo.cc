@@ -10,6 +10,8 @@
 //   * the SAD window of the last output columns reads the right image up to SADWindowSize/2 pixels past the end of its row
 //     (rptr[d] with the window column clamped, not the sum): linear addressing as in the original (the next row's pixels);
 //     past the end of the image the index is clamped to the last pixel (the original reads whatever follows the buffer).
+//   * minDisparity > 0: the original's column loop runs minDisparity columns past the end of the row (left image and
+//     output): the loop is cut at the last column.
 #include "orc.h"
 
 #include <algorithm>
@@ -54,7 +56,9 @@ void stereoBlockMatching(const uint8_t* left, const uint8_t* right, int rows, in
   const int wsz = sp.SADWindowSize, wsz2 = wsz / 2;
   const int ndisp = sp.numberOfDisparities, mindisp = sp.minDisparity;
   const int lofs = std::max(ndisp - 1 + mindisp, 0), rofs = -std::min(ndisp - 1 + mindisp, 0);
-  const int width1 = cols - rofs - ndisp + 1;
+  // width1 = width - rofs - ndisp + 1 in the original; for minDisparity > 0 that range overruns the row by minDisparity columns
+  // (it writes the first columns of the next row): cut at the last column here (documented choice, header)
+  const int width1 = std::min(cols - rofs - ndisp + 1, cols - lofs);
   const int ftzero = sp.preFilterCap;
   const int16_t FILTERED = (int16_t) ((mindisp - 1) << 4);
   if(lofs >= cols || rofs >= cols || width1 < 1) {

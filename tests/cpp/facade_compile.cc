@@ -41,6 +41,8 @@ int facade_surface()
   const bpvo::Matrix33 K = {{100.f, 0.f, 32.f, 0.f, 100.f, 32.f, 0.f, 0.f, 1.f}};
   bpvo::VisualOdometry vo(K, 0.1f, bpvo::ImageSize(64, 64), p);
   bpvo::Result r = vo.addFrame(nullptr, nullptr);
+  bpvo::Result rs = vo.addFrame(nullptr, nullptr, bpvo::StereoParameters(64));   // stereo front-end on the device
+  (void) rs;
   (void) vo.numPointsAtLevel();
   (void) vo.pointsAtLevel(-1).size();
   (void) vo.trajectory().size();
