@@ -129,7 +129,7 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
     d_d = torch.from_numpy(batch["disparities"][: 2 * n]).to(dev)
     for _ in range(warmup):
         ctx.batch_run_device(n, d_i.data_ptr(), d_d.data_ptr())
-    ctx.profiling(1)          # events around the frame stages only cost a few launches' gaps; warp_residual is sampled 1 in 5
+    ctx.profiling(int(os.environ.get("BPVO_BENCH_OTHER_PROFILING", "1")))   # events around the frame stages + 1 in 5 warp_residual launches
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -154,6 +154,7 @@ struct bpvo_hip_ctx {
   uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
   float* st_disp = nullptr;
   int st_frames = 0;
+  bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
@@ -557,7 +558,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
     g.fuse_frozen = c->fuse_frozen;
-    launch_level_begin(ln->stream, g.jobs, n, l);
+    // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
+    const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+    launch_level_begin(ln->stream, g.jobs, n, l, l2_moot ? 1 : 0);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); the state machine on the device
@@ -599,6 +602,13 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + slot);
       LANE_CK(ln, hipMemcpyAsync(ln->h_active + slot, ln->d_active + slot, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
       LANE_CK(ln, hipEventRecord(ln->round_ev[slot], ln->stream));
+      if(c->sync_rounds) {                  // A/B: one synchronisation per round, the round's own list feeds the next
+        LANE_CK(ln, hipStreamSynchronize(ln->stream));
+        if(ln->h_active[slot] <= 0) break;
+        n_cur = ln->h_active[slot];
+        g.active.list = lists[slot];
+        continue;
+      }
       if(round == 0) continue;              // nothing to learn yet: queue the second round behind the first
       const int prev = (round - 1) % 3;
       LANE_CK(ln, hipEventSynchronize(ln->round_ev[prev]));
@@ -996,6 +1006,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
+    if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }

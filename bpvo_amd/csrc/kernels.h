@@ -90,7 +90,7 @@ struct GNLaunch {
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
-void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level);
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level, int scale_is_moot = 0);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 // out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);

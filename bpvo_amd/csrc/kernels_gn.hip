@@ -1291,13 +1291,18 @@ __global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
 }
 
 // PoseEstimatorBase::reset + the head of run() (bpvo/pose_estimator_base.h:287-293,327-335)
-__global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level)
+// scale_is_moot (kL2 with the fused path available): MEstimator::ComputeWeights gives w = 1 whatever the scale
+// (bpvo/mestimator.cc:390-415), so the estimate loops never look at it: the level starts with the scale "frozen" at 1 and
+// every linearisation takes the fused residual + reduction path — two launches per iteration, no median.  (The reference still
+// runs estimateScale for kL2; its value is unobservable through estimatePose / addFrame.  bpvo_hip_linearize, which reports
+// sigma, computes it.)
+__global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level, int scale_is_moot)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if(p >= npairs) return;
   GNState* st = jobs[p].st;
   st->scale = 1.0f;
-  st->delta_scale = 1e10f;
+  st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
   st->f_norm_prev = 0.0f;
   st->g_tol = 0.0f;
   st->g_norm = 0.0f;
@@ -1414,9 +1419,9 @@ void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, in
 {
   hipLaunchKernelGGL(set_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, T_init, n);
 }
-void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level)
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level, int scale_is_moot)
 {
-  hipLaunchKernelGGL(level_begin_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, jobs, npairs, level);
+  hipLaunchKernelGGL(level_begin_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, jobs, npairs, level, scale_is_moot);
 }
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
 {
