@@ -19,22 +19,24 @@ def db_of(sub):
     return sqlite3.connect(fs[-1]) if fs else None
 
 
-db = db_of("trace")
-if db:
+for sub, suffix, env in (("trace", "", ""), ("trace1", "_1lane", "BPVO_HIP_LANES=1 ")):
+    db = db_of(sub)
+    if not db:
+        continue
     rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
-    lines = ["rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs   (durations in us)",
-             "%-100s %8s %14s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
+    lines = [env + "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs   (durations in us)",
+             "%-100s %8s %16s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "%")]
     for r in rows:
-        lines.append("%-100s %8d %14.1f %10.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
+        lines.append("%-100s %8d %16.1f %12.2f %7.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
     try:
-        bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+        bench = json.loads([l for l in open(os.path.join(src, sub + "_bench.json")) if l.startswith("{")][-1])
         lines.append("")
-        lines.append("bench.py line of the same run: value=%.1f %s, ms_per_step=%.3f, roofline=%s" %
-                     (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"])))
+        lines.append("bench.py line of the same run: value=%.1f %s, ms_per_step=%.3f, roofline=%s, roofline_timed_region=%s" %
+                     (bench["value"], bench["unit"], bench["ms_per_step"], json.dumps(bench["roofline"]), json.dumps(bench.get("roofline_timed_region"))))
     except Exception as e:  # noqa: BLE001
         lines.append("(no bench json: %s)" % e)
-    open(os.path.join(src, f"{tag}_kernel_trace_stats.txt"), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:12]))
+    open(os.path.join(src, f"{tag}_kernel_trace_stats{suffix}.txt"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:10]))
 
 per = {}
 for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
@@ -49,8 +51,8 @@ for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
         if "bpvo_hip" not in k:
             continue
         per.setdefault(k, {})[c] = dict(launches=n, avg=v, avg_duration_ns=dur)
-lines = ["PMC averages per launch; bounded config: bench.py --pairs-per-gpu 64 --fixed-iters 20 --steps 1 (all pairs active in",
-         "every launch: 64 x mean N = points per launch).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them."]
+lines = ["PMC averages per launch on the benched workload: BPVO_HIP_LANES=1 bench.py --steps 2 --warmup 0 (1024 pairs, converge mode, AlgorithmParameters()",
+         "tolerances; the launches shrink as pairs converge: averages are over all launches).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them."]
 for k in sorted(per):
     lines.append("")
     lines.append(k[:120])
@@ -74,7 +76,7 @@ for k, cs in per.items():
             traffic["fetch_size_kib_raw"] = cs["FETCH_SIZE"]["avg"]
             traffic["write_size_kib_raw"] = cs["WRITE_SIZE"]["avg"]
 try:
-    pj = json.loads(open(os.path.join(src, "pmc3.json")).read().strip().splitlines()[-1])
+    pj = json.loads([l for l in open(os.path.join(src, "pmc3.json")) if l.startswith("{")][-1])
     k6 = [k for k in per if "warp_residual_kernel<8" in k][0]
     launches = per[k6]["TCC_EA0_RDREQ_128B_sum"]["launches"]
     # points warp_residual itself processed (linearisations with a frozen scale go through irls_reduce's fused path)
@@ -90,5 +92,25 @@ try:
     traffic["algorithmic_bytes_per_point"] = 210
 except Exception as e:  # noqa: BLE001
     traffic["error"] = str(e)
+# the same for the timing-tolerance batch (tpmc1 / tpmc2)
+tper = {}
+for sub in sorted(glob.glob(os.path.join(src, "tpmc*"))):
+    if os.path.isdir(sub):
+        d = db_of(os.path.basename(sub))
+        if d:
+            for k, c, n, v, dur, grid in d.execute("select kernel_name, counter_name, count(*), avg(value), avg(duration), avg(grid_size) from counters_collection group by kernel_name, counter_name"):
+                if "warp_residual_kernel<8" in k:
+                    tper[c] = dict(launches=n, avg=v)
+try:
+    tj = json.loads([l for l in open(os.path.join(src, "tpmc1.json")) if l.startswith("{")][-1])
+    rd = 128 * tper["TCC_EA0_RDREQ_128B_sum"]["avg"] + 64 * tper["TCC_EA0_RDREQ_64B_sum"]["avg"] + 32 * tper["TCC_EA0_RDREQ_32B_sum"]["avg"]
+    wr64 = tper["TCC_EA0_WRREQ_64B_sum"]["avg"]; wr = tper["TCC_EA0_WRREQ_sum"]["avg"]
+    fp = tj["fused_path"]
+    ppl = (fp["of"] - fp["points"]) / tper["TCC_EA0_RDREQ_128B_sum"]["launches"]
+    traffic["timing_tolerance_batch"] = {"config": tj["config"]["workload"], "points_per_launch": ppl,
+                                         "warp_residual_hbm_bytes_per_point": (rd + 64 * wr64 + 32 * max(0.0, wr - wr64)) / ppl,
+                                         "tap_cache": tj.get("tap_cache")}
+except Exception as e:  # noqa: BLE001
+    traffic["timing_tolerance_batch"] = {"error": str(e)}
 open(os.path.join(src, f"{tag}_traffic.json"), "w").write(json.dumps(traffic, indent=1) + "\n")
 print(json.dumps(traffic))

@@ -19,7 +19,7 @@ try:
     print("bench: value %.0f, ms_per_step %.3f, steps %d -> wall %.1f ms; kernel time total %.1f ms" % (b["value"], b["ms_per_step"], b["steps"], b["ms_per_step"] * b["steps"], tot / 1e6))
 except Exception as e:
     print("no bench json", e)
-print("%-90s %8s %12s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+print("%-90s %8s %12s %10s %6s" % ("kernel", "calls", "total_ms", "avg_ms", "%"))
 for r in rows[:24]:
     print("%-90s %8d %12.1f %10.2f %6.2f" % (r[0][:90], r[1], r[2] / 1e3, r[3] / 1e3, r[4]))
 PY
