@@ -34,6 +34,7 @@ int bpvo_orc_create(bpvo_orc_ctx** out, const float K[9], float baseline, int ro
 void bpvo_orc_destroy(bpvo_orc_ctx* ctx);
 const char* bpvo_orc_last_error(const bpvo_orc_ctx* ctx);
 int bpvo_orc_set_num_threads(bpvo_orc_ctx* ctx, int n);
+int bpvo_orc_set_reduction(bpvo_orc_ctx* ctx, int mode);   /* 0: reference (f32 accumulation); 1: f64 accumulation — test instrument only */
 int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* ctx, int mode);   /* 0: PhotoError f64 (active), 1: projectPoints f32 (inactive branch) */
 int bpvo_orc_num_levels(const bpvo_orc_ctx* ctx);
 int bpvo_orc_num_channels(const bpvo_orc_ctx* ctx);

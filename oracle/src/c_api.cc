@@ -96,6 +96,13 @@ int bpvo_orc_set_num_threads(bpvo_orc_ctx* c, int n)
   return 0;
 }
 
+// 0: the reference's f32 accumulation of the normal equations; 1: the same terms accumulated in f64 (test instrument, orc.h)
+int bpvo_orc_set_reduction(bpvo_orc_ctx* c, int mode)
+{
+  for(auto& w : c->ws) w.est.reduction = mode;
+  c->vo.vo_pose.est.reduction = mode;
+  return 0;
+}
 int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* c, int mode)
 {
   if(mode != 0 && mode != 1 && mode != 2) return fail(c, "unknown warp formulation");

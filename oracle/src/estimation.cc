@@ -91,6 +91,36 @@ float linearSystemRun(const std::vector<float>& J, const std::vector<float>& r, 
                       const std::vector<uint16_t>& valid, float H[36], float G[6], int nthreads)
 {
   const size_t n = r.size();
+  if(nthreads == -1) {      // test instrument (orc.h, PoseEstimator::reduction): the same terms, accumulated in f64
+    double h[24] = {0}, g[6] = {0}, e = 0.0;
+    for(size_t i = 0; i < n; ++i) {
+      const float wi = w[i] * (float) valid[i];
+      const float wR = wi * r[i];
+      const float* j = J.data() + 6 * i;
+      int ii = 0;
+      for(int a = 0; a < 6; a += 2)
+        for(int b = a; b < 6; b += 2) {
+          h[ii++] += (double) ((wi * j[a]) * j[b]);
+          h[ii++] += (double) ((wi * j[a]) * j[b + 1]);
+          h[ii++] += (double) ((wi * j[a + 1]) * j[b]);
+          h[ii++] += (double) ((wi * j[a + 1]) * j[b + 1]);
+        }
+      for(int a = 0; a < 6; ++a) g[a] += (double) ((wi * r[i]) * j[a]);
+      e += (double) (wR * r[i]);
+    }
+    int ii = 0;
+    for(int a = 0; a < 6; a += 2)
+      for(int b = a; b < 6; b += 2) {
+        H[a * 6 + b] = (float) h[ii++];
+        H[a * 6 + b + 1] = (float) h[ii++];
+        H[(a + 1) * 6 + b] = (float) h[ii++];
+        H[(a + 1) * 6 + b + 1] = (float) h[ii++];
+      }
+    for(int a = 0; a < 6; ++a)
+      for(int b = a + 1; b < 6; ++b) H[b * 6 + a] = H[a * 6 + b];
+    for(int a = 0; a < 6; ++a) G[a] = (float) g[a];
+    return (float) std::sqrt(e);
+  }
   const int nchunks = std::max(1, nthreads);
   std::vector<float> part((size_t) nchunks * 32, 0.0f);
 #pragma omp parallel for num_threads(nthreads) if(nthreads > 1)

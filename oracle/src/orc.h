@@ -161,6 +161,10 @@ struct PoseEstimator {
   float functionTolerance = 1e-6f, parameterTolerance = 1e-6f, gradientTolerance = 1e-6f;
   int lossFunction = kHuber;
   int nthreads = 1;
+  // 0: the reference's f32 accumulation (serial, or range-split with nthreads > 1).  1: the same sums accumulated in f64 — NOT a
+  // mode of the reference: a test instrument that shows what a reduction without f32 accumulation noise (the GPU's tree +
+  // f64 combine is within 4e-6 of it) does to the termination tests (tests/test_oracle_cpu.py, tests/tools/fuzz_regressions.txt)
+  int reduction = 0;
   AutoScaleEstimator scale_estimator;
   std::vector<float> residuals, weights;
   std::vector<uint16_t> valid;        // replicated to C*N after linearize (Q12 / base.h:307-320)

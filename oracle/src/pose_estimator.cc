@@ -38,7 +38,7 @@ float PoseEstimator::linearize(TemplateData* tdata, const Descriptor& desc, cons
   last_sigma = sigma;
   computeWeights(lossFunction, residuals, valid, sigma, weights);
   num_fun_evals += 1;
-  return linearSystemRun(tdata->jacobians, residuals, weights, valid, H, G, nthreads);
+  return linearSystemRun(tdata->jacobians, residuals, weights, valid, H, G, reduction == 1 ? -1 : nthreads);
 }
 
 static inline float infNorm6(const float* g)
