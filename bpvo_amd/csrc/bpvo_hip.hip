@@ -1744,6 +1744,20 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* c, uint64_t out[4])
   for(int k = 0; k < 4; ++k) out[k] = c->tap_counts[k];
   return BPVO_OK;
 }
+// diagnostics: the Gauss-Newton state of a workspace after its last call — out[0..15] T, [16..51] H, [52..57] G, [58..63] dp,
+// [64] f_norm, [65] scale, [66] delta_scale, [67] g_norm, [68..83] T_lin (pose of the last linearisation)
+int bpvo_hip_debug_gn_state(bpvo_hip_ctx* c, int ws, float out[84])
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  (void) hipSetDevice(c->device);
+  GNState st;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  HIP_CK(c, hipMemcpy(&st, c->d_states + ws, sizeof(st), hipMemcpyDeviceToHost));
+  std::memcpy(out, st.T, 64); std::memcpy(out + 16, st.H, 144); std::memcpy(out + 52, st.G, 24); std::memcpy(out + 58, st.dp, 24);
+  out[64] = st.f_norm; out[65] = st.scale; out[66] = st.delta_scale; out[67] = st.g_norm;
+  std::memcpy(out + 68, st.T_lin, 64);
+  return BPVO_OK;
+}
 int bpvo_hip_set_max_lanes(bpvo_hip_ctx* c, int n)
 {
   CHECK_CTX(c);

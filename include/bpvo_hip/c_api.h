@@ -273,6 +273,9 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  * lanes by default so that the narrow per-pair kernels of one overlap the wide kernels of the other; per-launch timings are only
  * clean with one lane.  Results never depend on it. */
 int bpvo_hip_set_max_lanes(bpvo_hip_ctx* ctx, int n);
+/* diagnostics: Gauss-Newton state of a workspace after its last call: T (16), H (36), G (6), dp (6), f_norm, scale, delta_scale,
+ * g_norm, pose of the last linearisation (16) */
+int bpvo_hip_debug_gn_state(bpvo_hip_ctx* ctx, int ws, float out[84]);
 
 #ifdef __cplusplus
 }
