@@ -36,3 +36,20 @@ a = ch.linearize(0, 0, 1, lv, np.eye(4, dtype=np.float32)); bb = co.linearize(0,
 print("linearize at I: G hip", a["G"], "G orc", bb["G"])
 nT, nTi = ch.get_normalization(0, lv)
 print("normalisation hip", nT.reshape(-1)[[0, 3, 7, 11]], " orc", co.get_normalization(0, lv)[0].reshape(-1)[[0, 3, 7, 11]])
+# second linearisation: the oracle's solver on HIP's and on the oracle's H, G at the oracle's pose; sensitivity of its fallback decision
+rec = tr[1]
+T1 = rec[:16].reshape(4, 4)
+a = ch.linearize(0, 0, 1, lv, T1, reset_scale=False)
+Ho, Go = np.ascontiguousarray(rec[16:52].reshape(6, 6), np.float32), np.ascontiguousarray(rec[52:58], np.float32)
+def solve(H, G):
+    H = np.ascontiguousarray(H, np.float32); G = np.ascontiguousarray(G, np.float32); dp = np.zeros(6, np.float32)
+    orc.fn("solve")(H.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), dp.ctypes.data_as(C.c_void_p))
+    return dp
+print("second linearisation: cond(H) %.2e" % np.linalg.cond(Ho.astype(np.float64)))
+print("  solver on the oracle's H, G: |dp| %.4f" % np.linalg.norm(solve(Ho, Go)), " on HIP's H, G (sigma %.6f vs %.6f): |dp| %.4f" % (a["sigma"], rec[59], np.linalg.norm(solve(a["H"], a["G"]))))
+rng = np.random.default_rng(0)
+big = 0
+for k in range(200):
+    E = 1.0 + 2e-7 * rng.standard_normal((6, 6)); E = (E + E.T) / 2
+    big += np.linalg.norm(solve(Ho * E, Go * (1.0 + 2e-7 * rng.standard_normal(6)))) > 0.1
+print("  200 relative perturbations of 2e-7 of the oracle's system: the undamped step (|dp| > 0.1) in %d, the damped fallback in %d" % (big, 200 - big))
