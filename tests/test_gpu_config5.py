@@ -9,7 +9,7 @@ tree of the GPU and the serial f32 loop of the oracle then stop at 
 What the tests pin: identical valid counts and robust scales wherever both sides linearise at the same pose (first
 linearisation of every level included), poses within the bar, and the *distribution* of iteration counts / statuses; with
 the tolerances of the reference's own timing runs (conf/perf_*.cfg: 1e-6 / 1e-4 / 1e-6) most counts agree cell by cell and
-the one systematic difference (FunctionTol firing earlier on the noise-free GPU sum) is documented in that test.
+the one pair that differs (a chance stop of FunctionTol on a level whose f still fluctuates) is documented in that test.
 """
 import json
 import os
@@ -131,14 +131,14 @@ def test_config5_shard_iteration_statistics_default_tolerances(shard):
 def test_config5_shard_iteration_counts_with_the_reference_timing_tolerances(hip, orc, shard):
     """The same shard with the tolerances of the reference's own timing runs (conf/perf_bitplanes.cfg: 1e-6 / 1e-4 / 1e-6).
     Most cells agree exactly (equal iteration count in ~70 %, +-1 in ~80 %, same status in ~85 %), and 31 of the 32 pairs
-    agree in pose to 1e-5 rad.  What differs is systematic, not noise: `|f - f_prev| < 1e-4` (FunctionTol) is tested on
-    f = sqrt(sum w r^2); the reference (and the oracle) sums the ~2e5 terms serially in f32, which leaves ~1e-3 of rounding
-    noise on f, so on a slowly drifting level that test never fires and the loop runs on to ParameterTol / the iteration
-    limit; the GPU reduction (tree + f64 combine) has no such noise and stops as soon as the true decrease per
-    iteration is below 1e-4 — earlier, at a pose that can be > 1e-4 rad away (pair 80: level 0 stops at iteration 12 with
-    FunctionTol instead of 50; 1.7e-4 rad, 9.6e-4 m).  With the AlgorithmParameters() tolerances (functionTolerance 1e-6,
-    the benchmark configuration) both sides run to the noise floor and agree to 5e-6 rad (tests above).  Asserted here:
-    >= 90 % of the pairs within the north-star bar, every pair within 1e-3 rad / 5e-3 m, the cell statistics."""
+    agree in pose to 1e-5 rad.  The exception is a lottery, not a defect: on a level whose f = sqrt(sum w r^2) still
+    fluctuates by ~1e-2 from one iteration to the next (the robust scale moves, the pose drifts by ~1e-5 per step), the test
+    `|f - f_prev| < functionTolerance = 1e-4` fires whenever two consecutive values happen to fall within 1e-4 of each other
+    — about 1 % per iteration.  Pair 80: the GPU run draws it at iteration 12 of level 0, the oracle never in 50 iterations
+    (neither with its f32 sums nor with f64 accumulation, bpvo_orc_set_reduction), so the GPU pose is the one 38 drifting
+    iterations earlier: 1.7e-4 rad, 9.6e-4 m apart.  With the AlgorithmParameters() tolerances (functionTolerance 1e-6, the
+    benchmark configuration) both sides run to the noise floor and agree to 5e-6 rad (tests above).  Asserted here: >= 90 % of
+    the pairs within the north-star bar, every pair within 1e-3 rad / 5e-3 m, the cell statistics."""
     kw = dict(shard["kw"], parameterTolerance=1e-6, functionTolerance=1e-4, gradientTolerance=1e-6)
     batch = shard["batch"]
     ctx = hip.create(batch["K"], batch["b"], ROWS, COLS, make_params(hip, **kw), n_frames=2 * SHARD, n_pairs=SHARD)
