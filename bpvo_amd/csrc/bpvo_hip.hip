@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,10 @@ using namespace bpvo_hip;
 
 namespace {
 
+// live contexts per device: the estimation lanes of one context are streams = hardware queues, of which a process has a handful;
+// a second context's lanes end up multiplexed on the same queues and LOSE (measured: 505 k instead of 666 k GN it/s for a
+// 128-pair batch next to a second context), so batches only fan out over lanes while theirs is the only context on the device
+std::atomic<int> g_live_ctx[64];
 thread_local std::string g_create_error;   // bpvo_hip_last_error(nullptr): the failed create of THIS thread (contexts are created
                                            // concurrently by the per-GPU host threads of multi_gpu.hip)
 
@@ -154,6 +159,7 @@ struct bpvo_hip_ctx {
   uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
   float* st_disp = nullptr;
   int st_frames = 0;
+  bool counted_live = false;   // this context is in g_live_ctx
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
@@ -647,7 +653,8 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   }
   HIP_CK(c, hipStreamSynchronize(c->stream));   // frame stages run on the ctx stream; lanes start from a quiet device
-  const int nl = std::max(1, std::min(std::min((int) c->lanes.size(), c->max_lanes_now), n / kMinPairsPerLane));
+  const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
+  const int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
   std::vector<int> rcs(nl, BPVO_OK);
   auto run = [&](int k) {
     const int lo = (int) ((long long) n * k / nl), hi = (int) ((long long) n * (k + 1) / nl);
@@ -1035,6 +1042,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
 #undef CREATE_CK
   cp->T_kf = m44_identity();
   cp->cloud_pose = m44_identity();
+  g_live_ctx[device & 63].fetch_add(1);
+  cp->counted_live = true;
   *out = c.release();
   return BPVO_OK;
 }
@@ -1042,6 +1051,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
 void bpvo_hip_destroy(bpvo_hip_ctx* c)
 {
   if(!c) return;
+  if(c->counted_live) g_live_ctx[c->device & 63].fetch_sub(1);
   (void) hipSetDevice(c->device);
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
