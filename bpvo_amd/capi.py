@@ -418,6 +418,12 @@ class Context:
         self.call("tap_cache_counts", a)
         return tuple(int(x) for x in a)
 
+    def persistent_counts(self):
+        """(pyramid levels run by the persistent single-launch GN kernel, 1 if such a launch ever gave up) (HIP library only)."""
+        a, b = C.c_uint64(), C.c_int()
+        self.call("persistent_counts", C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def set_max_lanes(self, n):
         """Cap (n >= 1) or uncap (n <= 0) the estimation lanes of later batch calls (HIP library only)."""
         self.call("set_max_lanes", int(n))

@@ -93,6 +93,8 @@ struct Lane {
   int* d_list = nullptr;           // [3][n_pairs] active-workspace lists of the host rounds in flight (ActiveSet)
   int* h_active = nullptr;         // pinned [4]
   hipEvent_t round_ev[3] = {};     // "compaction of round r and its count have landed"
+  unsigned* d_pk_ctl = nullptr;    // [kMaxLevels][kPkCtlWords] {arrivals, abort} of the persistent kernel, one slot per level
+  unsigned* h_pk_ctl = nullptr;    // pinned copy
   GNState* h_states = nullptr;     // pinned [n_pairs]
   std::vector<EventPair> ev_pending;
   std::vector<hipEvent_t> ev_pool;
@@ -107,6 +109,7 @@ struct Lane {
 constexpr int kDefaultLanes = 2;
 constexpr int kDefaultLanesNarrow = 2;
 constexpr int kMinPairsPerLane = 8;
+constexpr int kPkCtlWords = 32;    // one 128-byte line per level
 
 }  // namespace
 
@@ -154,6 +157,14 @@ struct bpvo_hip_ctx {
                                // instead of two instantiations sharing the slot.  Measured faster at every batch size (1 pair +6 %, 8 / 32
                                // pairs +13 %, 128 +7 %, 1024 +3.7 %: the second, half-empty launch costs more than the fourth wave per SIMD
                                // buys the plain form), so it is always on; BPVO_HIP_IRLS_MERGE_BELOW=0 restores the two launches
+  // Groups of at most persist_max_ws workspaces (a single pair: sequential addFrame) run every pyramid level in ONE persistent
+  // launch (kernels_gn.hip, gn_persistent_kernel) instead of rounds of four kernels per iteration; bit-identical results.
+  // BPVO_HIP_PERSISTENT=0 turns it off, BPVO_HIP_PERSIST_MAX_WS / _GRID size it.  persistent_failed: a launch gave up at a barrier
+  // (workgroups not co-resident) — the context stays on the four-kernel chain from then on.
+  int persistent = 1, persist_max_ws = 1, persist_grid = 64;
+  long long persist_timeout = 50000000ll;   // ticks of the 100 MHz wall clock a grid barrier waits before it gives up (0.5 s)
+  bool persistent_failed = false;
+  uint64_t persistent_levels = 0;   // levels run by the persistent kernel (measurement)
   int max_lanes_now = 1 << 30; // bpvo_hip_set_max_lanes: measurement runs that need per-launch timings without overlap
   // stereo front-end scratch (lazily sized for the largest frame count seen): raw and pre-filtered u8 pairs, f32 disparities
   uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
@@ -550,6 +561,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     dT = ln->d_Tinit;
   }
   launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
+  const bool pk_group = c->persistent && !c->persistent_failed && n <= c->persist_max_ws && !c->profile_all;
+  bool persistent = pk_group;
+  if(persistent) LANE_CK(ln, hipMemsetAsync(ln->d_pk_ctl, 0, sizeof(unsigned) * kPkCtlWords * kMaxLevels, ln->stream));
 
   // PoseEstimatorParameters(AlgorithmParameters) (bpvo/pose_estimator_params.cc:27-33): maxFuncEvals stays 6*200 (Q4);
   // the low-res parameter set equals the full-res one (Q3).
@@ -569,6 +583,14 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     launch_level_begin(ln->stream, g.jobs, n, l, l2_moot ? 1 : 0);
     if(g.max_points <= 0) continue;
     launch_reset_tapkeys(ln->stream, g);
+    if(persistent && gn_persistent_serves(g)) {
+      // the whole level in one launch
+      LANE_CK(ln, launch_gn_persistent(ln->stream, g, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance,
+                                       ln->d_pk_ctl + (size_t) l * kPkCtlWords, gn_persistent_grid(g, c->persist_grid), c->persist_timeout));
+      c->persistent_levels += 1;
+      continue;
+    }
+    persistent = false;     // (a level the kernel does not serve: the rest of the pyramid takes the chain as well)
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); the state machine on the device
     // enforces the limits, the host queues rounds of kItersPerSync iterations until the device reports no active workspace.
     // Every round ends with a compaction of the list of still-active workspaces (ActiveSet, kernels.h) and the copy of its
@@ -629,8 +651,30 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   int ws_lo = wss[0], ws_hi = wss[0];
   for(int i = 1; i < n; ++i) { ws_lo = std::min(ws_lo, wss[i]); ws_hi = std::max(ws_hi, wss[i]); }
   LANE_CK(ln, hipMemcpyAsync(ln->h_states + ws_lo, c->d_states + ws_lo, sizeof(GNState) * (size_t) (ws_hi - ws_lo + 1), hipMemcpyDeviceToHost, ln->stream));
+  if(pk_group)
+    LANE_CK(ln, hipMemcpyAsync(ln->h_pk_ctl, ln->d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels, hipMemcpyDeviceToHost, ln->stream));
   LANE_CK(ln, hipStreamSynchronize(ln->stream));
   LANE_CK(ln, hipGetLastError());
+  if(pk_group && std::getenv("BPVO_HIP_PK_TIMING")) {     // library built with -DBPVO_PK_TIMING: per-phase ticks (10 ns) of workgroup 0
+    static const char* names[6] = {"warp", "barrier1", "median", "irls", "barrier2", "step"};
+    for(int l = c->L - 1; l >= 0; --l) {
+      const unsigned* t = ln->h_pk_ctl + (size_t) l * kPkCtlWords;
+      if(!t[15]) continue;
+      std::fprintf(stderr, "pk level %d: %u iterations;", l, t[15]);
+      for(int k = 0; k < 6; ++k) std::fprintf(stderr, " %s %.2f", names[k], 0.01 * t[8 + k] / t[15]);
+      std::fprintf(stderr, " us per iteration\n");
+    }
+  }
+  if(pk_group) {
+    bool gave_up = false;
+    for(int l = 0; l < c->L; ++l) gave_up = gave_up || ln->h_pk_ctl[(size_t) l * kPkCtlWords + 1] != 0;
+    if(gave_up) {
+      // a barrier timed out: the states of that level were not written back.  Rerun the group through the four-kernel chain
+      // (same results) and keep this context on it.
+      c->persistent_failed = true;
+      return estimate_group(c, ln, n, wss, refs, curs, T_init, poses, stats, d_records_out);
+    }
+  }
   for(int i = 0; i < n; ++i) {
     const GNState& st = ln->h_states[wss[i]];
     if(poses) std::memcpy(poses + 16 * (size_t) i, st.T_out, 16 * sizeof(float));
@@ -1015,6 +1059,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_PERSISTENT")) cp->persistent = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_PERSIST_GRID")) cp->persist_grid = std::max(1, std::min(128, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS")) cp->persist_timeout = std::max(1ll, std::atoll(e));   // tests of the give-up path
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
   for(size_t k = 0; k < cp->lanes.size(); ++k) {
@@ -1029,6 +1077,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
@@ -1065,6 +1115,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
     (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active); (void) hipFree(ln.d_list);
     (void) hipHostFree(ln.h_pjobs); (void) hipHostFree(ln.h_T); (void) hipHostFree(ln.h_active); (void) hipHostFree(ln.h_states);
+    (void) hipFree(ln.d_pk_ctl); (void) hipHostFree(ln.h_pk_ctl);
     for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
     for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
     for(auto e : ln.round_ev) if(e) (void) hipEventDestroy(e);
@@ -1733,6 +1784,14 @@ int bpvo_hip_fused_point_counts(bpvo_hip_ctx* c, uint64_t* fused, uint64_t* tota
   *total = (uint64_t) c->kc_units[KC_IRLS_REDUCE];
   return BPVO_OK;
 }
+int bpvo_hip_persistent_counts(bpvo_hip_ctx* c, uint64_t* levels, int* gave_up)
+{
+  if(!c) return BPVO_ERR_INVALID_ARG;
+  if(levels) *levels = c->persistent_levels;
+  if(gave_up) *gave_up = c->persistent_failed ? 1 : 0;
+  return BPVO_OK;
+}
+
 int bpvo_hip_median_path_counts(bpvo_hip_ctx* c, uint64_t* bracketed, uint64_t* full)
 {
   CHECK_CTX(c);

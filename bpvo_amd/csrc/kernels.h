@@ -101,6 +101,13 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol);
+// Persistent kernel for small groups: one launch runs a whole level of up to kPersistMaxWs workspaces (kernels_gn.hip).  ctl: two
+// zeroed words {arrivals, abort}; after the launch ctl[1] != 0 says the kernel gave up (states untouched: rerun the chain).
+constexpr int kPersistMaxWs = 8;
+bool gn_persistent_serves(const GNLaunch& g);
+int  gn_persistent_grid(const GNLaunch& g, int max_grid);
+hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol,
+                                unsigned* ctl, int grid, long long timeout_ticks);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
 int  gn_pts_per_block(int C);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);

@@ -11,6 +11,8 @@
 // No MFMA anywhere: ~1 flop/byte, HBM-bound gather + rank-1 accumulate.
 #include <float.h>
 
+#include <algorithm>
+
 #include <mutex>
 
 #include "kernels.h"
@@ -36,8 +38,13 @@ __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { ret
 // inside it.  No global atomics: block b of a workspace owns med_blk[b] = {#below, #inside, #valid points} and the
 // candidate segment cand[b * 256 * C ...]; the in-block compaction is a wave scan + LDS offsets.  All 256 threads of the
 // block must call it.
+// Generalised form: `blk` is the chunk (the blockIdx.x of warp_residual), `wave` the wavefront inside the 256-thread chunk, `s` the
+// chunk's LDS scratch; `write` = false for a chunk past the end that only keeps its threads in step (persistent kernel).  All
+// threads of the WORKGROUP must call it (it holds a __syncthreads).
+struct BracketLds { unsigned in[K6_WAVES], below[K6_WAVES], valid[K6_WAVES]; };
 template <int C>
-__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C])
+__device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C],
+                                              unsigned blk, int wave, BracketLds& s, bool write)
 {
   // one "inside the bracket" bit per channel: 64 bits once a point has more than 32 channels (central difference, 48)
   using mask_t = typename std::conditional<(C > 32), unsigned long long, unsigned>::type;
@@ -54,7 +61,7 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
     cnt += in ? 1u : 0u;
     mask |= (mask_t) (in ? 1u : 0u) << c;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   unsigned incl = cnt, sum_below = below, sum_valid = (v ? 1u : 0u) | (hit ? 0x10000u : 0u);   // valid points | tap-cache hits << 16
 #pragma unroll
   for(int o = 1; o < 64; o <<= 1) {
@@ -69,26 +76,33 @@ __device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, uns
   unsigned woff = 0;
   if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
     const unsigned t_in = __shfl(incl, 63);
-    if(lane == 0) reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
+    if(lane == 0 && write) reinterpret_cast<uint4*>(j.med_blk)[blk] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
   } else {
-    __shared__ unsigned s_in[K6_WAVES], s_below[K6_WAVES], s_valid[K6_WAVES];
-    if(lane == 63) s_in[wave] = incl;
-    if(lane == 0) { s_below[wave] = sum_below; s_valid[wave] = sum_valid; }
+    if(lane == 63) s.in[wave] = incl;
+    if(lane == 0) { s.below[wave] = sum_below; s.valid[wave] = sum_valid; }
     __syncthreads();
-    for(int w = 0; w < wave; ++w) woff += s_in[w];
-    if(threadIdx.x == 0) {
+    for(int w = 0; w < wave; ++w) woff += s.in[w];
+    if(wave == 0 && lane == 0 && write) {
       uint4 o = make_uint4(0u, 0u, 0u, 0u);
-      for(int w = 0; w < K6_WAVES; ++w) { o.x += s_below[w]; o.y += s_in[w]; o.z += s_valid[w] & 0xffffu; o.w += s_valid[w] >> 16; }
-      reinterpret_cast<uint4*>(j.med_blk)[blockIdx.x] = o;
+      for(int w = 0; w < K6_WAVES; ++w) { o.x += s.below[w]; o.y += s.in[w]; o.z += s.valid[w] & 0xffffu; o.w += s.valid[w] >> 16; }
+      reinterpret_cast<uint4*>(j.med_blk)[blk] = o;
     }
   }
   if(cnt) {
-    unsigned* seg = j.cand + (size_t) blockIdx.x * K6_BLOCK * C;
+    unsigned* seg = j.cand + (size_t) blk * K6_BLOCK * C;
     unsigned pos = woff + incl - cnt;
 #pragma unroll
     for(int c = 0; c < C; ++c)
       if(mask & ((mask_t) 1u << c)) seg[pos++] = keys[c];
   }
+}
+
+// the form warp_residual uses: one 256-thread workgroup = one chunk
+template <int C>
+__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C])
+{
+  __shared__ BracketLds s;
+  bracket_chunk<C>(j, lo, hi, v, hit, res, blockIdx.x, (int) (threadIdx.x >> 6), s, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -554,13 +568,14 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 //  full (first linearisation of a level, bracket miss): 3 passes over all keys, bits [30:20], [19:9], [8:0], one
 //    1024-thread workgroup per workspace with LDS histograms (4 privatised copies in pass 1 to cut same-bin atomic
 //    serialisation); keys surviving pass 1 are cached in LDS so pass 3 never touches HBM again.
-constexpr int MED_THREADS = 1024;
+constexpr int MED_THREADS = 1024;     // median_finish_kernel; the persistent kernel runs the same code with 512 (template parameter NT)
 constexpr int MED_COPIES = 4;
 constexpr int MED_BINS = 2048;
 constexpr int MED_CACHE = 20480;
 
 struct MedCursor { unsigned prefix; unsigned rank; };
 
+template <int NT = 1024>
 __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s_wave /*[16]*/, unsigned& total)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -575,7 +590,7 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s
   __syncthreads();
   unsigned woff = 0, tot = 0;
 #pragma unroll
-  for(int w = 0; w < 16; ++w) {
+  for(int w = 0; w < NT / 64; ++w) {
     const unsigned t = s_wave[w];
     if(w < wave) woff += t;
     tot += t;
@@ -584,29 +599,33 @@ __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s
   return woff + incl - v;
 }
 
-// every thread owns bins 2t, 2t+1 of a (<= 2048)-bin histogram: find the bins holding ranks k_lo / k_hi
-__device__ __forceinline__ void find_ranks(unsigned h0, unsigned h1, unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2]*/)
+// every thread owns BPT = 2048 / NT consecutive bins (2t, 2t+1 for 1024 threads) of a (<= 2048)-bin histogram, h[] their counts,
+// excl the number of keys in the bins before them: find the bins holding ranks k_lo / k_hi
+template <int BPT>
+__device__ __forceinline__ void find_ranks(const unsigned (&h)[BPT], unsigned excl, unsigned k_lo, unsigned k_hi, MedCursor* out /*[2]*/)
 {
-  const unsigned b = 2u * threadIdx.x;
-  if(k_lo >= excl && k_lo < excl + h0) { out[0].prefix = b; out[0].rank = k_lo - excl; }
-  else if(k_lo >= excl + h0 && k_lo < excl + h0 + h1) { out[0].prefix = b + 1; out[0].rank = k_lo - excl - h0; }
-  if(k_hi >= excl && k_hi < excl + h0) { out[1].prefix = b; out[1].rank = k_hi - excl; }
-  else if(k_hi >= excl + h0 && k_hi < excl + h0 + h1) { out[1].prefix = b + 1; out[1].rank = k_hi - excl - h0; }
+  unsigned b = (unsigned) BPT * threadIdx.x, e = excl;
+#pragma unroll
+  for(int q = 0; q < BPT; ++q) {
+    if(k_lo >= e && k_lo < e + h[q]) { out[0].prefix = b + q; out[0].rank = k_lo - e; }
+    if(k_hi >= e && k_hi < e + h[q]) { out[1].prefix = b + q; out[1].rank = k_hi - e; }
+    e += h[q];
+  }
 }
 
-template <int C, typename F>
+template <int C, int NT, typename F>
 __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
 {
   const int n = j.n;
   if constexpr(C == 8) {
     const float4* q = reinterpret_cast<const float4*>(j.r);
     constexpr int U = 4;   // points in flight per thread: all loads of a round are issued before any is consumed
-    for(int base = threadIdx.x; base < n; base += MED_THREADS * U) {
+    for(int base = threadIdx.x; base < n; base += NT * U) {
       unsigned char v[U];
       float4 a[U], b[U];
 #pragma unroll
       for(int u = 0; u < U; ++u) {
-        const int pt = base + u * MED_THREADS;
+        const int pt = base + u * NT;
         const bool in = pt < n;
         v[u] = in ? j.valid[pt] : (unsigned char) 0;
         a[u] = in ? load_stream(q + tile_index<2>(pt, 0)) : make_float4(0, 0, 0, 0);
@@ -615,7 +634,7 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
 #pragma unroll
       for(int u = 0; u < U; ++u) {
         if(!v[u]) continue;
-        const int pt = base + u * MED_THREADS;
+        const int pt = base + u * NT;
         f(__float_as_uint(a[u].x) & 0x7fffffffu, pt); f(__float_as_uint(a[u].y) & 0x7fffffffu, pt);
         f(__float_as_uint(a[u].z) & 0x7fffffffu, pt); f(__float_as_uint(a[u].w) & 0x7fffffffu, pt);
         f(__float_as_uint(b[u].x) & 0x7fffffffu, pt); f(__float_as_uint(b[u].y) & 0x7fffffffu, pt);
@@ -623,13 +642,13 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
       }
     }
   } else if constexpr(C != 1) {   // generic C: point-major records
-    for(int pt = threadIdx.x; pt < n; pt += MED_THREADS) {
+    for(int pt = threadIdx.x; pt < n; pt += NT) {
       if(!j.valid[pt]) continue;
 #pragma unroll
       for(int c = 0; c < C; ++c) f(__float_as_uint(j.r[(size_t) pt * C + c]) & 0x7fffffffu, pt);
     }
   } else {
-    for(int p4 = threadIdx.x * 4; p4 < n; p4 += MED_THREADS * 4) {   // n is a multiple of 16
+    for(int p4 = threadIdx.x * 4; p4 < n; p4 += NT * 4) {   // n is a multiple of 16
       const uchar4 v = *reinterpret_cast<const uchar4*>(j.valid + p4);
       const float4 a = *reinterpret_cast<const float4*>(j.r + p4);
       if(v.x) f(__float_as_uint(a.x) & 0x7fffffffu, p4 + 0);
@@ -643,7 +662,7 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
 // One refinement pass of the two-cursor radix select.  A key takes part in cursor X iff its bits above (shift + width)
 // equal X.prefix; its digit is (key >> shift) & (2^width - 1), width <= 11.  On return the cursors carry the extended
 // prefix and the rank inside the selected digit bin.  Block-wide (1024 threads); `src(f)` calls f(key) for every key.
-template <typename Src>
+template <int NT, typename Src>
 __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned width, MedCursor& lo, MedCursor& hi, unsigned* hist_lo,
                                             unsigned* hist_hi, unsigned* s_wave, MedCursor* cur)
 {
@@ -651,7 +670,7 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
   const bool split = lo.prefix != hi.prefix;
   const unsigned nbins = 1u << width, up = shift + width;
   __syncthreads();
-  for(unsigned i = tid; i < nbins; i += MED_THREADS) { hist_lo[i] = 0; hist_hi[i] = 0; }
+  for(unsigned i = tid; i < nbins; i += NT) { hist_lo[i] = 0; hist_hi[i] = 0; }
   __syncthreads();
   src([&](unsigned key) {
     const unsigned top = (up >= 32u) ? 0u : (key >> up);
@@ -661,23 +680,27 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
   });
   __syncthreads();
   unsigned dummy;
-  const bool own = 2u * tid < nbins;
-  const unsigned a0 = own ? hist_lo[2 * tid] : 0u, a1 = own ? hist_lo[2 * tid + 1] : 0u;
-  const unsigned ea = block_excl_scan_1024(a0 + a1, s_wave, dummy);
-  unsigned b0 = a0, b1 = a1, eb = ea;
+  constexpr int BPT = MED_BINS / NT;
+  const bool own = (unsigned) BPT * tid < nbins;        // nbins is a power of two >= BPT or smaller than it: bins past nbins read as 0
+  unsigned ha[BPT], hb[BPT], sa = 0, sb = 0;
+#pragma unroll
+  for(int q = 0; q < BPT; ++q) { ha[q] = (own && (unsigned) BPT * tid + q < nbins) ? hist_lo[BPT * tid + q] : 0u; sa += ha[q]; }
+  const unsigned ea = block_excl_scan_1024<NT>(sa, s_wave, dummy);
+  unsigned eb = ea;
   if(split) {
-    b0 = own ? hist_hi[2 * tid] : 0u; b1 = own ? hist_hi[2 * tid + 1] : 0u;
-    eb = block_excl_scan_1024(b0 + b1, s_wave, dummy);
+#pragma unroll
+    for(int q = 0; q < BPT; ++q) { hb[q] = (own && (unsigned) BPT * tid + q < nbins) ? hist_hi[BPT * tid + q] : 0u; sb += hb[q]; }
+    eb = block_excl_scan_1024<NT>(sb, s_wave, dummy);
   }
   MedCursor tmp[2];
   tmp[0].prefix = 0xffffffffu; tmp[1].prefix = 0xffffffffu; tmp[0].rank = tmp[1].rank = 0;
   if(own) {
-    find_ranks(a0, a1, ea, lo.rank, split ? 0xffffffffu : hi.rank, tmp);
+    find_ranks<BPT>(ha, ea, lo.rank, split ? 0xffffffffu : hi.rank, tmp);
     if(tmp[0].prefix != 0xffffffffu) { cur[0].prefix = (lo.prefix << width) | tmp[0].prefix; cur[0].rank = tmp[0].rank; }
     if(!split && tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
     if(split) {
       tmp[1].prefix = 0xffffffffu;
-      find_ranks(b0, b1, eb, 0xffffffffu, hi.rank, tmp);
+      find_ranks<BPT>(hb, eb, 0xffffffffu, hi.rank, tmp);
       if(tmp[1].prefix != 0xffffffffu) { cur[1].prefix = (hi.prefix << width) | tmp[1].prefix; cur[1].rank = tmp[1].rank; }
     }
   }
@@ -687,16 +710,12 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
   __syncthreads();
 }
 
-// K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
-template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+// The work of one 1024-thread workgroup on workspace j; `st` is the state it reads and (thread 0, at the very end) updates — the
+// workspace's own in HBM, or a workgroup-local copy (persistent kernel, where every workgroup runs the selection redundantly and
+// `stats` is true for one of them only).
+template <int C, int NT>
+__device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsigned char* smem_raw, bool stats)
 {
-  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
-  GNState* st = j.st;
-  if(!st->active) return;
-  if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
   unsigned* hist_hi = hist_lo + MED_COPIES * MED_BINS;                    // [MED_BINS]
   unsigned* cache = hist_hi + MED_BINS;                                   // [MED_CACHE]
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
     // totals of the per-block counters written by the bracket step of warp_residual (bracket_block)
     const int nblk = (j.n + K6_BLOCK - 1) / K6_BLOCK;
     unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0;
-    for(int b = tid; b < nblk; b += MED_THREADS) {
+    for(int b = tid; b < nblk; b += NT) {
       const uint4 o = reinterpret_cast<const uint4*>(j.med_blk)[b];
       c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
     }
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
       __syncthreads();
       t_below = t_in = t_valid = 0;
 #pragma unroll
-      for(int w = 0; w < 16; ++w) { t_below += cache[w * 4 + 0]; t_in += cache[w * 4 + 1]; t_valid += cache[w * 4 + 2]; tap_hits += cache[w * 4 + 3]; }
+      for(int w = 0; w < NT / 64; ++w) { t_below += cache[w * 4 + 0]; t_in += cache[w * 4 + 1]; t_valid += cache[w * 4 + 2]; tap_hits += cache[w * 4 + 3]; }
       tap_lookups = t_valid;
       __syncthreads();
     }
@@ -747,7 +766,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
       // candidates sit in per-block segments of 256*C slots; wave w walks segments w, w+16, ...
       auto src = [&](auto f) {
         const int lane = tid & 63, wave = tid >> 6;
-        for(int b = wave; b < nblk; b += MED_THREADS / 64) {
+        for(int b = wave; b < nblk; b += NT / 64) {
           const unsigned mb = reinterpret_cast<const uint4*>(j.med_blk)[b].y;
           const unsigned* seg = j.cand + (size_t) b * K6_BLOCK * C;
           for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
@@ -759,7 +778,7 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
         const unsigned width = remaining > 11u ? 11u : remaining;
         const bool was_split = lo.prefix != hi.prefix;
         remaining -= width;
-        refine_pass(src, remaining, width, lo, hi, hist_lo, hist_hi, s_wave, cur);
+        refine_pass<NT>(src, remaining, width, lo, hi, hist_lo, hist_hi, s_wave, cur);
         if(!first || remaining == 0) continue;
         first = false;
         // After the first digit the selected bins usually hold a handful of keys: finish by direct ranking (each thread
@@ -767,9 +786,9 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
         const unsigned dmask = (1u << width) - 1u;
         const unsigned n_lo = hist_lo[lo.prefix & dmask];
         const unsigned n_hi = was_split ? hist_hi[hi.prefix & dmask] : hist_lo[hi.prefix & dmask];
-        if(n_lo > (unsigned) MED_THREADS || n_hi > (unsigned) MED_THREADS) continue;
-        unsigned* list_lo = cache;                    // [MED_THREADS]
-        unsigned* list_hi = cache + MED_THREADS;      // [MED_THREADS]
+        if(n_lo > (unsigned) NT || n_hi > (unsigned) NT) continue;
+        unsigned* list_lo = cache;                    // [NT]
+        unsigned* list_hi = cache + NT;               // [NT]
         const bool same_bin = lo.prefix == hi.prefix;
         __syncthreads();
         if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0; }
@@ -810,33 +829,39 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
 
   // ---- full path
   if(!done) {
-    for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += MED_THREADS) hist_lo[i] = 0;
+    for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += NT) hist_lo[i] = 0;
     if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
     __syncthreads();
     {   // pass 1: bits [30:20], privatised histogram copies
       unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
       unsigned first = 0xffffffffu;
-      for_each_valid_key<C>(j, [&](unsigned key, int pt) {
+      for_each_valid_key<C, NT>(j, [&](unsigned key, int pt) {
         atomicAdd(&h[key >> 20], 1u);
         first = min(first, (unsigned) pt);
       });
       if(C == 1 && first != 0xffffffffu) atomicMin(&s_misc[1], first);
     }
     __syncthreads();
-    unsigned h0 = 0, h1 = 0;
+    constexpr int BPT = MED_BINS / NT;
+    unsigned hh[BPT], hsum = 0;
 #pragma unroll
-    for(int c = 0; c < MED_COPIES; ++c) { h0 += hist_lo[c * MED_BINS + 2 * tid]; h1 += hist_lo[c * MED_BINS + 2 * tid + 1]; }
-    const unsigned excl = block_excl_scan_1024(h0 + h1, s_wave, n_total);
+    for(int q = 0; q < BPT; ++q) {
+      hh[q] = 0;
+#pragma unroll
+      for(int c = 0; c < MED_COPIES; ++c) hh[q] += hist_lo[c * MED_BINS + BPT * tid + q];
+      hsum += hh[q];
+    }
+    const unsigned excl = block_excl_scan_1024<NT>(hsum, s_wave, n_total);
     if(n_total >= 3) {
       const unsigned k_hi = n_total / 2, k_lo = (n_total % 2 == 0) ? k_hi - 1 : k_hi;
-      find_ranks(h0, h1, excl, k_lo, k_hi, cur);
+      find_ranks<BPT>(hh, excl, k_lo, k_hi, cur);
       __syncthreads();
       MedCursor lo = cur[0], hi = cur[1];
       __syncthreads();
       // pass 2: bits [19:9] of the keys in the selected pass-1 bucket(s); survivors cached in LDS
       const unsigned p_lo = lo.prefix, p_hi = hi.prefix;
-      refine_pass([&](auto f) {
-        for_each_valid_key<C>(j, [&](unsigned key, int) {
+      refine_pass<NT>([&](auto f) {
+        for_each_valid_key<C, NT>(j, [&](unsigned key, int) {
           const unsigned top = key >> 20;
           if(top == p_lo || top == p_hi) {
             const unsigned idx = atomicAdd(&s_misc[0], 1u);
@@ -847,9 +872,9 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
       }, 9u, 11u, lo, hi, hist_lo, hist_hi, s_wave, cur);
       const unsigned ncache = s_misc[0];
       // pass 3: bits [8:0]
-      refine_pass([&](auto f) {
-        if(ncache <= MED_CACHE) { for(unsigned i = tid; i < ncache; i += MED_THREADS) f(cache[i]); }
-        else for_each_valid_key<C>(j, [&](unsigned key, int) { f(key); });
+      refine_pass<NT>([&](auto f) {
+        if(ncache <= MED_CACHE) { for(unsigned i = tid; i < ncache; i += NT) f(cache[i]); }
+        else for_each_valid_key<C, NT>(j, [&](unsigned key, int) { f(key); });
       }, 0u, 9u, lo, hi, hist_lo, hist_hi, s_wave, cur);
       const float v_lo = __uint_as_float(lo.prefix), v_hi = __uint_as_float(hi.prefix);
       median = (n_total % 2 != 0) ? v_hi : (float) (((double) (v_lo + v_hi)) / 2.0);   // (*m + *middle) / 2.0, utils.h:236
@@ -862,11 +887,13 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
   }
 
   if(tid == 0) {
-    j.cnt[done ? 2 : 3] += 1ull;                                            // measurement: bracketed vs full selections
-    // tap cache: a linearisation without bracket counters is the first of a level (keys reset: no hits, every valid point looks up)
-    if(!st->median_valid) tap_lookups = n_total / (unsigned) C;
-    j.cnt[5] += tap_hits; j.cnt[6] += tap_lookups;
-    if(st->num_fun_evals < 8) { j.cnt[7] += tap_hits; j.cnt[8] += tap_lookups; }
+    if(stats) {
+      j.cnt[done ? 2 : 3] += 1ull;                                          // measurement: bracketed vs full selections
+      // tap cache: a linearisation without bracket counters is the first of a level (keys reset: no hits, every valid point looks up)
+      if(!st->median_valid) tap_lookups = n_total / (unsigned) C;
+      j.cnt[5] += tap_hits; j.cnt[6] += tap_lookups;
+      if(st->num_fun_evals < 8) { j.cnt[7] += tap_hits; j.cnt[8] += tap_lookups; }
+    }
     const unsigned long long nm6 = (unsigned long long) n_total - 6ull;     // size_t wrap for n < 6 (Q5)
     float s = (1.4826f * (1.0f + 5.0f / (float) nm6)) * median;
     if((double) s < 1e-6) s = 1.0f;
@@ -885,6 +912,18 @@ __global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJo
       st->median_valid = 0;
     }
   }
+}
+
+// K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
+template <int C>
+__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+{
+  const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
+  GNState* st = j.st;
+  if(!st->active) return;
+  if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  median_block<C, MED_THREADS>(j, st, smem_raw, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -916,8 +955,13 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
 }
 
 // the work of one workgroup of irls_reduce on workspace j
+// `tile` is the run of pts_per_block points (the blockIdx.x of irls_reduce), `vtid` the thread's index among the 256 that share the
+// tile, `s_part` their LDS scratch.  `has` = false: a tile past the end whose threads only keep in step (persistent kernel); all
+// threads of the WORKGROUP must call the function (it holds a __syncthreads).
+typedef float IrlsPartLds[4][kPartialStride];
 template <int C, int LOSS, bool FUSED>
-__device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __restrict__ st, int pts_per_block)
+__device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
+                                          IrlsPartLds& s_part, bool has)
 {
   // Fused path (C = 8): the robust scale is frozen for the rest of the level, so nothing separates the residuals from
   // their weights any more — they are recomputed here exactly as warp_residual does (same warp_point, same tap cache) and
@@ -932,9 +976,8 @@ __device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __re
     for(int k = 0; k < 12; ++k) P[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(P[k])));
   }
   const int n = j.n;
-  const int p_begin = blockIdx.x * pts_per_block;
-  if(p_begin >= n) return;
-  const int p_end = min(n, p_begin + pts_per_block);
+  const int p_begin = tile * pts_per_block;
+  const int p_end = has ? min(n, p_begin + pts_per_block) : p_begin;
   const float sigma_inv = 1.0f / st->scale;
   const float s_nrm[4] = {j.nrm[0], j.nrm[1], j.nrm[2], j.nrm[3]};
   const bool dspace = j.dspace != 0;      // uniform over the launch
@@ -944,7 +987,7 @@ __device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __re
 #pragma unroll
   for(int k = 0; k < kNumAcc; ++k) acc[k] = 0.0f;
 
-  for(int i = p_begin + threadIdx.x; i < p_end; i += GN_BLOCK) {
+  for(int i = p_begin + vtid; i < p_end; i += GN_BLOCK) {
     float rr[C], Ix[C], Iy[C];
     float v;
     if constexpr(fused) {
@@ -1038,16 +1081,213 @@ __device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __re
     for(int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
     acc[k] = v;
   }
-  __shared__ float s_part[4][kPartialStride];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = vtid & 63, wave = vtid >> 6;
   if(lane == 0) {
 #pragma unroll
     for(int k = 0; k < kNumAcc; ++k) s_part[wave][k] = acc[k];
   }
   __syncthreads();
-  if(threadIdx.x < kNumAcc) {
-    const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-    j.partials[(size_t) blockIdx.x * kPartialStride + threadIdx.x] = v;
+  if(vtid < kNumAcc && has) {
+    const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
+    j.partials[(size_t) tile * kPartialStride + vtid] = v;
+  }
+}
+
+// the form irls_reduce uses: one 256-thread workgroup = one tile
+template <int C, int LOSS, bool FUSED>
+__device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __restrict__ st, int pts_per_block)
+{
+  if((int) blockIdx.x * pts_per_block >= j.n) return;
+  __shared__ IrlsPartLds s_part;
+  irls_tile<C, LOSS, FUSED>(j, st, pts_per_block, blockIdx.x, threadIdx.x, s_part, true);
+}
+
+// irls_tile for LATENCY-bound launches (persistent kernel, C = 8): the same per-point arithmetic and the same accumulation order
+// (a thread's points in ascending order, then the wave tree, then the four waves), but a thread handles its points two at a time
+// and requests EVERYTHING both need — point, tap-cache key, the eight cached tap vectors, template pixels, gradients (fused
+// path); point, valid byte, residuals, gradients (plain) — before the first use: one memory round trip per pair of points instead
+// of four or five dependent ones per point (point -> projection -> key -> taps, in two halves).  The cached taps are loaded
+// speculatively: on a miss (3 % of the lookups) they are discarded and the footprint is gathered as usual.  The throughput
+// kernels do the opposite on purpose — there the speculative bytes cost more than the latency they hide.
+struct IrlsPointLat {
+  float4 Pt, tc[8], px[2], g[4], r[2];
+  unsigned key;
+  float v;
+};
+template <bool FUSED>
+__device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPointLat& d)
+{
+  d.Pt = load_stream(j.pts + i);
+  const float4* qg = reinterpret_cast<const float4*>(j.grad);
+  if constexpr(FUSED) {
+    d.key = j.tapkey[i];
+    const float4* tc = reinterpret_cast<const float4*>(j.tapcache);
+#pragma unroll
+    for(int k = 0; k < 8; ++k) d.tc[k] = load_stream(tc + tile_index<8>(i, k));
+    const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+    d.px[0] = load_stream(p0 + tile_index<2>(i, 0)); d.px[1] = load_stream(p0 + tile_index<2>(i, 1));
+  } else {
+    d.v = (float) j.valid[i];
+    const float4* qr = reinterpret_cast<const float4*>(j.r);
+    d.r[0] = load_stream(qr + tile_index<2>(i, 0)); d.r[1] = load_stream(qr + tile_index<2>(i, 1));
+  }
+#pragma unroll
+  for(int k = 0; k < 4; ++k) d.g[k] = load_stream(qg + tile_index<4>(i, k));
+}
+
+template <int LOSS, bool FUSED>
+__device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
+                                              IrlsPartLds& s_part, bool has)
+{
+  float P[12];
+  if constexpr(FUSED) {
+    projection_matrix(j, st->T, P);
+#pragma unroll
+    for(int k = 0; k < 12; ++k) P[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(P[k])));
+  }
+  const int n = j.n, W = j.cols, R = j.rows;
+  const int p_begin = tile * pts_per_block;
+  const int p_end = has ? min(n, p_begin + pts_per_block) : p_begin;
+  const float sigma_inv = 1.0f / st->scale;
+  const float s_nrm[4] = {j.nrm[0], j.nrm[1], j.nrm[2], j.nrm[3]};
+  const bool dspace = j.dspace != 0;
+  const float ds_fx = j.K[0], ds_fy = j.K[4], ds_fx_i = 1.0f / j.K[0], ds_fy_i = 1.0f / j.K[4], ds_b_i = 1.0f / j.b;
+
+  float acc[kNumAcc];
+#pragma unroll
+  for(int k = 0; k < kNumAcc; ++k) acc[k] = 0.0f;
+
+  // one point: residuals (fused: warp_point's arithmetic on the preloaded taps), weights, rank-2 update — as in irls_tile
+  auto point = [&](int i, const IrlsPointLat& d) {
+    float rr[8], Ix[8], Iy[8];
+    float v;
+    if constexpr(FUSED) {
+      const double X0 = (double) d.Pt.x, X1 = (double) d.Pt.y, X2 = (double) d.Pt.z, X3 = (double) d.Pt.w;
+      double u[3];
+#pragma unroll
+      for(int r = 0; r < 3; ++r) {
+        double s = (double) P[r * 4 + 0] * X0;
+        s += (double) P[r * 4 + 1] * X1;
+        s += (double) P[r * 4 + 2] * X2;
+        s += (double) P[r * 4 + 3] * X3;
+        u[r] = s;
+      }
+      const double zi = 1.0 / u[2];
+      const double x = zi * u[0], y = zi * u[1];
+      const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+      int xi = 0, yi = 0;
+      if(in_range) {
+        xi = (int) x; xi -= (xi > x);
+        yi = (int) y; yi -= (yi > y);
+      }
+      const bool valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+      const double xf = x - (double) xi, yf = y - (double) yi;
+      bool hit = false;
+      if(valid) {
+        const double wx = 1.0 - xf, wy = 1.0 - yf;
+        const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+        hit = d.key == key;
+        float4 t[8];
+#pragma unroll
+        for(int k = 0; k < 8; ++k) t[k] = d.tc[k];
+        if(!hit) {
+          const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
+          const float4* q1 = q0 + (size_t) W * 2;
+          t[0] = q0[0]; t[1] = q0[1]; t[2] = q0[2]; t[3] = q0[3];
+          t[4] = q1[0]; t[5] = q1[1]; t[6] = q1[2]; t[7] = q1[3];
+          float4* tcw = reinterpret_cast<float4*>(j.tapcache);
+#pragma unroll
+          for(int k = 0; k < 8; ++k) store_stream(tcw + tile_index<8>(i, k), t[k]);
+          j.tapkey[i] = key;
+        }
+        // pieces 0, 1: I00 of channels 0-3 / 4-7; 2, 3: I01; 4, 5: I10; 6, 7: I11 (warp_point)
+        const float i00[8] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w};
+        const float i01[8] = {t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, t[3].z, t[3].w};
+        const float i10[8] = {t[4].x, t[4].y, t[4].z, t[4].w, t[5].x, t[5].y, t[5].z, t[5].w};
+        const float i11[8] = {t[6].x, t[6].y, t[6].z, t[6].w, t[7].x, t[7].y, t[7].z, t[7].w};
+        const float i0[8] = {d.px[0].x, d.px[0].y, d.px[0].z, d.px[0].w, d.px[1].x, d.px[1].y, d.px[1].z, d.px[1].w};
+#pragma unroll
+        for(int c = 0; c < 8; ++c) {
+          const double Iw = wy * ((double) i00[c] * wx + (double) i01[c] * xf) + yf * ((double) i10[c] * wx + (double) i11[c] * xf);
+          rr[c] = (float) (Iw - (double) i0[c]);
+        }
+      } else {
+#pragma unroll
+        for(int c = 0; c < 8; ++c) rr[c] = 0.0f;
+      }
+      v = valid ? 1.0f : 0.0f;
+      acc[29] += hit ? 1.0f : 0.0f;
+    } else {
+      v = d.v;
+      rr[0] = d.r[0].x; rr[1] = d.r[0].y; rr[2] = d.r[0].z; rr[3] = d.r[0].w; rr[4] = d.r[1].x; rr[5] = d.r[1].y; rr[6] = d.r[1].z; rr[7] = d.r[1].w;
+    }
+    acc[28] += v;
+    Ix[0] = d.g[0].x; Ix[1] = d.g[0].y; Ix[2] = d.g[0].z; Ix[3] = d.g[0].w; Ix[4] = d.g[1].x; Ix[5] = d.g[1].y; Ix[6] = d.g[1].z; Ix[7] = d.g[1].w;
+    Iy[0] = d.g[2].x; Iy[1] = d.g[2].y; Iy[2] = d.g[2].z; Iy[3] = d.g[2].w; Iy[4] = d.g[3].x; Iy[5] = d.g[3].y; Iy[6] = d.g[3].z; Iy[7] = d.g[3].w;
+    float Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, Gx = 0.0f, Gy = 0.0f;
+#pragma unroll
+    for(int c = 0; c < 8; ++c) {
+      const float r = rr[c];
+      const float w = mest_weight<LOSS>(r, sigma_inv) * v;
+      const float wx = w * Ix[c], wy = w * Iy[c];
+      Sxx += wx * Ix[c];
+      Sxy += wx * Iy[c];
+      Syy += wy * Iy[c];
+      Gx += wx * r;
+      Gy += wy * r;
+      acc[27] += (w * r) * r;
+    }
+    const float4 Pt = d.Pt;
+    float A[6], B[6];
+    if(!dspace) {
+      const JacPoint jp = jac_point(Pt.x, Pt.y, Pt.z, s_nrm);
+      const float t_xz2 = jp.x * jp.rz2, t_yz2 = jp.y * jp.rz2;
+      A[0] = -(t_xz2 * jp.yc2); A[1] = jp.zc3 * jp.rz + t_xz2 * jp.xc1; A[2] = -(jp.yc2 * jp.rz); A[3] = jp.rzs; A[4] = 0.0f; A[5] = -(jp.s_i * t_xz2);
+      B[0] = -(jp.zc3 * jp.rz) - t_yz2 * jp.yc2; B[1] = t_yz2 * jp.xc1; B[2] = jp.xc1 * jp.rz; B[3] = 0.0f; B[4] = jp.rzs; B[5] = -(jp.s_i * t_yz2);
+    } else {
+      const float x = Pt.x, y = Pt.y, dd = Pt.z;
+      const float xfi = x * ds_fx_i, yfi = y * ds_fy_i, dbi = dd * ds_b_i;
+      A[0] = -(x * yfi); A[1] = ds_fx + x * xfi; A[2] = -(ds_fx * yfi); A[3] = dbi; A[4] = 0.0f; A[5] = -(dbi * xfi);
+      B[0] = -ds_fy - y * yfi; B[1] = y * xfi; B[2] = ds_fy * xfi; B[3] = 0.0f; B[4] = dbi * (ds_fy * ds_fx_i); B[5] = -(dbi * (y * ds_fx_i));
+    }
+    int idx = 0;
+#pragma unroll
+    for(int a = 0; a < 6; ++a) {
+      const float pa = Sxx * A[a] + Sxy * B[a];
+      const float qa = Sxy * A[a] + Syy * B[a];
+#pragma unroll
+      for(int b = a; b < 6; ++b) acc[idx++] += pa * A[b] + qa * B[b];
+    }
+#pragma unroll
+    for(int a = 0; a < 6; ++a) acc[21 + a] += Gx * A[a] + Gy * B[a];
+  };
+
+  for(int i0 = p_begin + vtid; i0 < p_end; i0 += 2 * GN_BLOCK) {
+    const int i1 = i0 + GN_BLOCK;
+    const bool has1 = i1 < p_end;
+    IrlsPointLat d0, d1;
+    irls_lat_load<FUSED>(j, i0, d0);
+    irls_lat_load<FUSED>(j, has1 ? i1 : i0, d1);
+    point(i0, d0);
+    if(has1) point(i1, d1);
+  }
+
+#pragma unroll
+  for(int k = 0; k < kNumAcc; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for(int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
+    acc[k] = v;
+  }
+  const int lane = vtid & 63, wave = vtid >> 6;
+  if(lane == 0) {
+#pragma unroll
+    for(int k = 0; k < kNumAcc; ++k) s_part[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if(vtid < kNumAcc && has) {
+    const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
+    j.partials[(size_t) tile * kPartialStride + vtid] = v;
   }
 }
 
@@ -1198,6 +1438,41 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
   return false;
 }
 
+// lanes 0 .. kNumAcc-1 of one wave: deterministic sum (tile order, f64) of the tile partials of workspace j
+__device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/)
+{
+  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
+  if(lane < kNumAcc) {
+    double s = 0.0;
+    const float* __restrict__ pp = j.partials + lane;
+#pragma unroll 8
+    for(int b = 0; b < nblk; ++b) s += (double) pp[(size_t) b * kPartialStride];
+    s_sum[lane] = (float) s;
+  }
+}
+
+// one thread, on an LDS copy `st` of the state: the step that consumes the linearisation summed in s_sum.  `stats`: this copy
+// is the one that keeps the workspace's measurement counters (the persistent kernel runs the step redundantly in every workgroup)
+__device__ __forceinline__ void gn_serial_step(const PairJob& j, GNState* st, const float* s_nrm, const float* s_sum, SolveScratch* scratch,
+                                               int mode, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol_param,
+                                               int fuse_frozen, bool stats)
+{
+  // the linearisation consumed here was taken at st->T; with the fused path its residuals were never written
+  for(int i = 0; i < 16; ++i) st->T_lin[i] = st->T[i];
+  const bool fused_lin = fuse_frozen && !(st->delta_scale > 1e-6f);
+  st->r_stale = fused_lin ? 1 : 0;
+  const bool again = gn_logic(st, s_nrm, s_sum, scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
+  (void) again;   // who is still active is read from st->active (compact_active_kernel once per host round / the persistent loop)
+  if(stats) {
+    j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
+    j.cnt[1] += 1ull;
+    if(fused_lin) {                           // the fused path keeps its own tap-cache statistics (the others: median_finish)
+      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += (unsigned long long) s_sum[28];
+      j.cnt[10] += (unsigned long long) j.n;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
                                                      int max_iterations, int max_fun_evals, float p_tol, float f_tol,
                                                      float g_tol_param, ActiveSet act, int fuse_frozen)
@@ -1217,32 +1492,11 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
   if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
   if(threadIdx.x == 4) s_nrm[4] = j.dspace ? 1.0f : 0.0f;
-
-  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
-  if(threadIdx.x < kNumAcc) {                        // deterministic: block order, f64
-    double s = 0.0;
-    const float* __restrict__ pp = j.partials + threadIdx.x;
-#pragma unroll 8
-    for(int b = 0; b < nblk; ++b) s += (double) pp[(size_t) b * kPartialStride];
-    s_sum[threadIdx.x] = (float) s;
-  }
+  gn_sum_partials(j, pts_per_block, threadIdx.x, s_sum);
   __syncthreads();
-
-  if(threadIdx.x == 0) {
-    GNState* st = reinterpret_cast<GNState*>(s_state);
-    // the linearisation consumed here was taken at st->T; with the fused path its residuals were never written
-    for(int i = 0; i < 16; ++i) st->T_lin[i] = st->T[i];
-    const bool fused_lin = fuse_frozen && !(st->delta_scale > 1e-6f);
-    st->r_stale = fused_lin ? 1 : 0;
-    const bool again = gn_logic(st, s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
-    (void) again;   // who is still active is read from st->active by compact_active_kernel once per host round
-    j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
-    j.cnt[1] += 1ull;
-    if(fused_lin) {                           // the fused path keeps its own tap-cache statistics (the others: median_finish)
-      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += (unsigned long long) s_sum[28];
-      j.cnt[10] += (unsigned long long) j.n;
-    }
-  }
+  if(threadIdx.x == 0)
+    gn_serial_step(j, reinterpret_cast<GNState*>(s_state), s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol,
+                   g_tol_param, fuse_frozen, true);
   __syncthreads();
   for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
 }
@@ -1273,6 +1527,241 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __r
     __syncthreads();
   }
   if(threadIdx.x == 0) *out_count = (int) s_base;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent Gauss-Newton kernel for SMALL groups (a single pair: sequential addFrame; up to kPersistMaxWs pairs): a whole
+// pyramid level — every linearisation, median, reduction, solve and pose update until the last workspace of the group has
+// finished — in ONE launch.  The four-kernel chain spends a single pair's iteration on four dependent launches of 5 - 9 us
+// each, every one of which re-reads the job and the state from HBM; here
+//   * the state of every workspace lives in LDS for the whole level, one copy per workgroup, all copies identical: the serial
+//     steps (robust scale, 6x6 solve, pose update, convergence tests) are executed REDUNDANTLY by every workgroup on its own
+//     copy — deterministic arithmetic on identical inputs — so nothing has to be broadcast and two of the four
+//     synchronisation points of an iteration disappear;
+//   * the two that remain (all residual chunks before the median, all tile partials before the solve) are grid barriers: one
+//     agent-scope release + arrive + poll + acquire per workgroup (guide: "barrier-counter"), a frozen robust scale needs only
+//     the second;
+//   * a 512-thread workgroup works as two 256-thread chunks of warp_residual / tiles of irls_reduce side by side, calling the
+//     very device functions of the four kernels (warp_point, bracket_chunk, median_block, irls_tile, gn_sum_partials,
+//     gn_serial_step) with the same chunk / tile indices, so every value — residuals, median, partials, their f64 sum — is
+//     bit-identical to the chain's.
+// Residency: the grid (at most kPersistMaxGrid workgroups, one per CU: 123 KB of LDS) is far below the chip's 256 CUs and the
+// launcher checks the occupancy query; should the workgroups still not become co-resident (another process holding the CUs), the
+// poll of a barrier gives up after `timeout` ticks of the 100 MHz wall clock, raises ctl[1] and every workgroup leaves WITHOUT
+// writing the states back — the host then reruns the group through the four-kernel chain (bpvo_hip.hip).  The GPU cannot hang.
+// 512 threads: two waves per SIMD, i.e. 256 VGPRs — a 1024-thread workgroup leaves 128, and the fused irls_tile (136 as a kernel)
+// then spills inside its point loop (measured: 23 us per iteration for that phase instead of 8)
+constexpr int PK_THREADS = 512;
+constexpr int PK_VB = PK_THREADS / 256;      // 256-thread chunks / tiles per workgroup
+static_assert(K6_BLOCK == 256 && GN_BLOCK == 256, "the persistent kernel's virtual blocks are 256 threads");
+static_assert(PK_THREADS / 64 >= kPersistMaxWs, "pk_step_phase: one wave per workspace");
+
+struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
+
+// The phases are separate NON-inlined functions: inlined into one body the compiler hoists every workspace's addresses and job
+// fields across all of them and spills hundreds of bytes per lane; as functions each gets its own register allocation.  Their
+// LDS is declared at namespace scope for that reason.
+constexpr int kStateWords = (int) (sizeof(GNState) / sizeof(uint32_t));
+__shared__ uint32_t pk_state[kPersistMaxWs][kStateWords];
+__shared__ float pk_sum[kPersistMaxWs][kPartialStride];
+__shared__ float pk_nrm[kPersistMaxWs][8];
+__shared__ SolveScratch pk_scratch[kPersistMaxWs];
+__shared__ BracketLds pk_br[PK_VB];
+__shared__ IrlsPartLds pk_part[PK_VB];
+__shared__ int pk_ok;
+__device__ __forceinline__ GNState* pk_st(int ws) { return reinterpret_cast<GNState*>(pk_state[ws]); }
+
+// warp_residual (+ bracket step) of workspace ws: chunk c goes to workgroup c % nwg, virtual block (c / nwg) % PK_VB
+template <int C>
+__device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const GNState* st = pk_st(ws);
+  const PairJob& j = jobs[ws];
+  const int n = j.n;
+  const int nchunks = (n + K6_BLOCK - 1) / K6_BLOCK;
+  float P[12];
+  projection_matrix(j, st->T, P);
+  const bool bracket = (st->delta_scale > 1e-6f) && st->median_valid;
+  const unsigned lo_key = st->lo_key, hi_key = st->hi_key;
+  if(stats_wg && tid == 0) j.cnt[4] += (unsigned long long) n;
+  for(int base = 0; base < nchunks; base += nwg * PK_VB) {
+    const int chunk = base + vsub * nwg + (int) blockIdx.x;
+    const bool has = chunk < nchunks;
+    const int i_raw = chunk * K6_BLOCK + vtid;
+    const bool in_block = has && i_raw < n;
+    const int i = in_block ? i_raw : n - 1;
+    float res[C];
+    bool hit;
+    const bool valid = warp_point<C, false>(j, P, i, in_block, res, hit);
+    if(in_block) {
+      j.valid[i] = valid ? 1 : 0;
+      if constexpr(C == 8) {
+        float4* o = reinterpret_cast<float4*>(j.r);
+        store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
+        store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
+      } else {
+#pragma unroll
+        for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
+      }
+    }
+    if(bracket) bracket_chunk<C>(j, lo_key, hi_key, valid && in_block, hit && valid && in_block, res, (unsigned) chunk, vtid >> 6, pk_br[vsub], has);
+  }
+}
+
+template <int C>
+__device__ __attribute__((noinline)) void pk_median_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // median_block's histograms and key cache
+  median_block<C, PK_THREADS>(jobs[ws], pk_st(ws), smem_raw, stats_wg);
+  __syncthreads();
+}
+
+// irls_reduce of workspace ws: tile t goes to workgroup t % nwg, virtual block (t / nwg) % PK_VB
+template <int C, int LOSS, bool FUSED>
+__device__ __attribute__((noinline)) void pk_irls_phase(const PairJob* __restrict__ jobs, int ws, int pts_per_block)
+{
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const PairJob& j = jobs[ws];
+  const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
+  for(int base = 0; base < ntiles; base += nwg * PK_VB) {
+    const int tile = base + vsub * nwg + (int) blockIdx.x;
+    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles);
+    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles);
+    __syncthreads();
+  }
+}
+
+// gn_step: wave w sums the partials of workspace w, its lane 0 runs the serial step on this workgroup's copy of the state
+__device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm, int fuse, bool stats_wg)
+{
+  const int ws = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool mine = ws < nws && pk_st(ws < nws ? ws : 0)->active;
+  if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws]);
+  __syncthreads();
+  if(mine && lane == 0)
+    gn_serial_step(jobs[ws], pk_st(ws), pk_nrm[ws], pk_sum[ws], &pk_scratch[ws], 0, prm.max_iterations, prm.max_fun_evals, prm.p_tol, prm.f_tol,
+                   prm.g_tol, fuse, stats_wg);
+  __syncthreads();
+}
+
+// returns false when the barrier gave up (timeout, or another workgroup's abort)
+__device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigned epoch, long long timeout)
+{
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned target = epoch * gridDim.x;
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while(__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 63u) == 0u || timeout < 64) {     // (tiny budgets: the tests of this path)
+        if(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pk_ok = ok;
+  }
+  __syncthreads();
+  return pk_ok != 0;
+}
+
+template <int C, int LOSS>
+__global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm,
+                                                                   int fuse_frozen, unsigned* ctl, long long timeout)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  const bool stats_wg = blockIdx.x == 0;
+  const bool fuse = kCanFuse && fuse_frozen;
+
+  for(int ws = 0; ws < nws; ++ws) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs[ws].st);
+    for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[ws][i] = g[i];
+    if(tid < 4) pk_nrm[ws][tid] = jobs[ws].nrm[tid];
+    if(tid == 4) pk_nrm[ws][4] = jobs[ws].dspace ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+
+  unsigned epoch = 0;
+  bool ok = true;
+  // BPVO_PK_TIMING: workgroup 0 accumulates the 100 MHz wall-clock ticks of every phase in ctl[8..13] and the iterations in ctl[15]
+#ifdef BPVO_PK_TIMING
+  long long tk = wall_clock64();
+  unsigned acc_t[6] = {0, 0, 0, 0, 0, 0}, iters = 0;
+#define PK_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[k] += (unsigned) (t_ - tk); tk = t_; } while(0)
+#else
+#define PK_TICK(k) do { } while(0)
+#endif
+  for(;;) {
+    // who does what in this iteration: the same answer in every workgroup (identical state copies)
+    bool any_active = false, any_warp = false;
+    for(int ws = 0; ws < nws; ++ws) {
+      const GNState* st = pk_st(ws);
+      if(!st->active) continue;
+      any_active = true;
+      if(!fuse || st->delta_scale > 1e-6f) any_warp = true;
+    }
+    if(!any_active) break;
+#ifdef BPVO_PK_TIMING
+    tk = wall_clock64(); ++iters;
+#endif
+
+    if(any_warp) {
+      // warp_residual of the workspaces whose robust scale still moves (all of them without the fused path) ...
+      for(int ws = 0; ws < nws; ++ws) {
+        const GNState* st = pk_st(ws);
+        if(st->active && (!fuse || st->delta_scale > 1e-6f)) pk_warp_phase<C>(jobs, ws, stats_wg);
+      }
+      PK_TICK(0);
+      ok = pk_grid_barrier(ctl, ++epoch, timeout);
+      PK_TICK(1);
+      if(!ok) break;
+      // ... and their exact median + robust scale, every workgroup on its own copy of the state
+      for(int ws = 0; ws < nws; ++ws) {
+        const GNState* st = pk_st(ws);
+        if(st->active && st->delta_scale > 1e-6f) pk_median_phase<C>(jobs, ws, stats_wg);
+      }
+      PK_TICK(2);
+    }
+    // weights + normal equations per tile (frozen scale with the fused path: residuals recomputed there)
+    for(int ws = 0; ws < nws; ++ws) {
+      const GNState* st = pk_st(ws);
+      if(!st->active) continue;
+      if constexpr(kCanFuse) {
+        if(fuse && !(st->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, ws, pts_per_block);
+        else pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block);
+      } else {
+        pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block);
+      }
+    }
+    PK_TICK(3);
+    ok = pk_grid_barrier(ctl, ++epoch, timeout);
+    PK_TICK(4);
+    if(!ok) break;
+    pk_step_phase(jobs, nws, pts_per_block, prm, fuse ? 1 : 0, stats_wg);
+    PK_TICK(5);
+  }
+#ifdef BPVO_PK_TIMING
+  if(blockIdx.x == 0 && tid == 0) {
+    for(int k = 0; k < 6; ++k) ctl[8 + k] = acc_t[k];
+    ctl[15] = iters;
+  }
+#endif
+
+  if(ok && blockIdx.x == 0) {
+    for(int ws = 0; ws < nws; ++ws) {
+      uint32_t* g = reinterpret_cast<uint32_t*>(jobs[ws].st);
+      for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[ws][i];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1522,6 +2011,54 @@ void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iteratio
   const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
                      f_tol, g_tol, g.active, fuse);
+}
+// ---- persistent kernel for small groups
+bool gn_persistent_serves(const GNLaunch& g)
+{
+  return (g.C == 8 || g.C == 1) && g.interp == BPVO_INTERP_LINEAR && !g.fast_warp && g.npairs >= 1 && g.npairs <= kPersistMaxWs && !g.active.list;
+}
+int gn_persistent_grid(const GNLaunch& g, int max_grid)
+{
+  const int chunks = (g.max_points + K6_BLOCK - 1) / K6_BLOCK;
+  return std::max(1, std::min(max_grid, (chunks + PK_VB - 1) / PK_VB));
+}
+template <int C>
+static hipError_t launch_gn_persistent_c(hipStream_t s, const GNLaunch& g, const GNParams& prm, unsigned* ctl, int grid, long long timeout)
+{
+  const int ppb = gn_pts_per_block(C);
+  const int fuse = (C == 8 && g.fuse_frozen) ? 1 : 0;
+  auto go = [&](auto kern) -> hipError_t {
+    // once per kernel and device (the lanes' host threads may race here): the opt-in for the 123 KB of median_block's LDS and the
+    // residency check — one workgroup per CU must fit, the grid itself (<= 128) is far below the number of CUs
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev &= 63;
+    std::call_once(once[dev], [&] {
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      int per_cu = 0;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, kMedianLds);
+      if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
+    });
+    if(status[dev] != hipSuccess) return status[dev];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PK_THREADS), kMedianLds, s, g.jobs, g.npairs, ppb, prm, fuse, ctl, timeout);
+    return hipGetLastError();
+  };
+  switch(g.loss) {
+    case BPVO_LOSS_HUBER: return go(gn_persistent_kernel<C, BPVO_LOSS_HUBER>);
+    case BPVO_LOSS_TUKEY: return go(gn_persistent_kernel<C, BPVO_LOSS_TUKEY>);
+    default: return go(gn_persistent_kernel<C, BPVO_LOSS_L2>);
+  }
+}
+hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol,
+                                unsigned* ctl, int grid, long long timeout_ticks)
+{
+  if(g.max_points <= 0) return hipSuccess;
+  GNParams prm;
+  prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
+  if(g.C == 8) return launch_gn_persistent_c<8>(s, g, prm, ctl, grid, timeout_ticks);
+  return launch_gn_persistent_c<1>(s, g, prm, ctl, grid, timeout_ticks);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {

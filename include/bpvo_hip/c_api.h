@@ -248,6 +248,11 @@ int bpvo_hip_stereo_bm(bpvo_hip_ctx* ctx, int count, const uint8_t* left, const 
 int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* ctx, const uint8_t* left, const uint8_t* right, const bpvo_hip_stereo_params* sp,
                               bpvo_hip_result* result);
 
+/* Pyramid levels that were run by the persistent single-launch Gauss-Newton kernel (groups of BPVO_HIP_PERSIST_MAX_WS or fewer
+ * pairs) since the context was created, and whether such a launch ever gave up at a grid barrier (the
+ * context then stays on the four-kernel chain; results are the same either way). */
+int bpvo_hip_persistent_counts(bpvo_hip_ctx* ctx, uint64_t* levels, int* gave_up);
+
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx's own stream */
 typedef struct bpvo_hip_kernel_stat {
   char     name[48];

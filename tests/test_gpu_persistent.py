@@ -1,0 +1,99 @@
+"""The persistent single-launch Gauss-Newton kernel (small groups: sequential addFrame, a handful of pairs) against the
+four-kernel chain it replaces: same device functions, same chunk / tile indices, so everything observable must be equal BIT
+FOR BIT — poses, statistics, residuals, valid masks, weights, robust scale — and the kernel must really have run
+(bpvo_hip_persistent_counts).  reference path: PoseEstimatorBase::run, bpvo/pose_estimator_base.h:324-407."""
+import numpy as np
+import pytest
+
+from bpvo_amd import synth
+from util import bits_equal, make_params, setup_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def run_single(hip, rows, cols, levels, descriptor, loss, **kw):
+    ctx, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor=descriptor, loss=loss, **kw)
+    T, st = ctx.estimate_pose(0, 0, 1)
+    rec = dict(T=T, st=st, frac=ctx.fraction_good(0, 0.85), r=ctx.get_residuals(0), v=ctx.get_valid(0), w=ctx.get_weights(0),
+               fused=ctx.fused_point_counts(), med=ctx.median_path_counts(), taps=ctx.tap_cache_counts(), lin=ctx.total_linearizations())
+    # a second estimate from the first one's pose (a warm start: few iterations, early exits)
+    T2, st2 = ctx.estimate_pose(0, 0, 1, T)
+    rec["T2"], rec["st2"], rec["pk"] = T2, st2, ctx.persistent_counts()
+    return rec
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4")])
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("bitplanes", "huber"), ("bitplanes", "l2"), ("intensity", "huber"),
+                                             ("intensity", "tukey")])
+def test_persistent_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, descriptor, loss, monkeypatch):
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
+        out.append(run_single(hip, rows, cols, levels, descriptor, loss))
+    a, b = out
+    assert a["pk"] == (0, 0)
+    assert b["pk"][0] >= 2 * levels and b["pk"][1] == 0, b["pk"]        # every level of both estimates, never gave up
+    assert bits_equal(a["T"], b["T"]) and bits_equal(a["T2"], b["T2"])
+    assert a["st"] == b["st"] and a["st2"] == b["st2"]
+    assert a["frac"] == b["frac"]
+    assert np.array_equal(a["v"], b["v"]) and bits_equal(a["r"], b["r"]) and bits_equal(a["w"], b["w"])
+    # the same work was done: linearisations, median selections by path, fused points, tap-cache lookups and hits
+    assert a["lin"] == b["lin"] and a["med"] == b["med"] and a["fused"] == b["fused"] and a["taps"] == b["taps"]
+
+
+@pytest.mark.parametrize("n_pairs", [2, 5, 8])
+def test_persistent_kernel_groups_of_pairs(hip, n_pairs, monkeypatch):
+    """Groups of up to 8 pairs in one persistent launch (BPVO_HIP_PERSIST_MAX_WS): pairs converge after different numbers of
+    iterations, so workspaces drop out of the loop one by one while the others go on."""
+    rows, cols, levels = 120, 160, 3
+    b = synth.make_batch(rows, cols, n_pairs, first_index=11)
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
+        monkeypatch.setenv("BPVO_HIP_PERSIST_MAX_WS", "8")
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels),
+                         n_frames=2 * n_pairs, n_pairs=n_pairs)
+        poses, stats = ctx.batch_run(b["images"], b["disparities"])
+        out.append(dict(poses=poses, stats=stats, r=ctx.get_residuals(n_pairs - 1), w=ctx.get_weights(n_pairs - 1), pk=ctx.persistent_counts(),
+                        lin=ctx.total_linearizations()))
+    a, c = out
+    assert a["pk"] == (0, 0) and c["pk"] == (levels, 0)
+    assert bits_equal(a["poses"], c["poses"]) and a["stats"].tobytes() == c["stats"].tobytes()
+    assert bits_equal(a["r"], c["r"]) and bits_equal(a["w"], c["w"])
+    assert a["lin"] == c["lin"]
+    if n_pairs > 2:
+        assert len(np.unique(a["stats"]["numIterations"][:, 0])) > 1          # the pairs really finish at different iterations
+
+
+def test_persistent_kernel_small_grid_and_sequence(hip, monkeypatch):
+    """A grid of ONE workgroup (every chunk and tile looped over by the same four virtual blocks) and of 3 (ragged split), and a
+    short addFrame sequence (key-framing, warm starts) through the persistent path."""
+    rows, cols, levels = 120, 160, 3
+    ref = None
+    for on, grid in (("0", "64"), ("1", "1"), ("1", "3"), ("1", "64")):
+        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
+        monkeypatch.setenv("BPVO_HIP_PERSIST_GRID", grid)
+        rec = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
+        seq = synth.make_sequence(rows, cols, 6)
+        vo = hip.create(seq["K"], seq["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels), n_frames=3, n_pairs=1)
+        rec["traj"] = np.stack([vo.add_frame(img, disp)["pose"] for img, disp in seq["frames"]])
+        if ref is None:
+            ref = rec
+            continue
+        assert rec["pk"][1] == 0 and rec["pk"][0] > 0
+        assert bits_equal(ref["T"], rec["T"]) and ref["st"] == rec["st"] and bits_equal(ref["r"], rec["r"]) and bits_equal(ref["w"], rec["w"])
+        assert bits_equal(ref["traj"], rec["traj"])
+
+
+def test_persistent_kernel_gives_up_cleanly(hip, monkeypatch):
+    """A grid barrier that cannot complete in time (here: a 10 ns budget) makes every workgroup leave without writing the states
+    back; the library reruns the group through the four-kernel chain and stays on it.  Same results, no hang."""
+    rows, cols, levels = 376, 1241, 4
+    monkeypatch.setenv("BPVO_HIP_PERSISTENT", "0")
+    ref = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
+    monkeypatch.setenv("BPVO_HIP_PERSISTENT", "1")
+    monkeypatch.setenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS", "1")
+    rec = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
+    assert rec["pk"][1] == 1 and rec["pk"][0] <= levels          # gave up during the first estimate, never tried again
+    assert bits_equal(ref["T"], rec["T"]) and bits_equal(ref["T2"], rec["T2"]) and ref["st"] == rec["st"] and ref["st2"] == rec["st2"]
+    assert bits_equal(ref["r"], rec["r"]) and bits_equal(ref["w"], rec["w"]) and np.array_equal(ref["v"], rec["v"])
