@@ -153,19 +153,19 @@ __device__ __forceinline__ void dspace_matrix(const PairJob& j, const float* __r
 // `in_block` gates the tap-cache update (lanes past the end of a block redo the last point, loads only).  Returns valid.
 // HALF (C = 8, f64 formulation): the taps are fetched and consumed in two groups of four channels, which halves the
 // registers they occupy — for the fused path of irls_reduce, where the 29 accumulators are live as well.
-template <int C, bool FAST, bool HALF = false>
+template <int C, bool FAST, bool HALF = false, bool NT = true>
 __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12], int i, bool in_block, float (&res)[C], bool& cache_hit)
 {
   cache_hit = false;
   const int W = j.cols, R = j.rows;
-  const float4 X = load_stream(j.pts + i);
+  const float4 X = load_v4<NT>(j.pts + i);
   // C = 1: the launches are short and latency-bound, so the key, the cached taps and the template pixel are requested
   // together with the point instead of after the projection (16 speculative bytes per point; for C = 8 the same
   // speculation costs 128 bytes and was measured slower)
   unsigned spec_key = 0; float4 spec_taps = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float spec_pix = 0.0f;
   if constexpr(C == 1) {
     spec_key = j.tapkey[i];
-    spec_taps = load_stream(reinterpret_cast<const float4*>(j.tapcache) + i);
+    spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache) + i);
     spec_pix = j.pix[i];
   }
   int xi = 0, yi = 0;
@@ -230,16 +230,16 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       for(int h = 0; h < 2; ++h) {
         float4 a, b, c, d;      // I00, I01, I10, I11 of channels 4h .. 4h+3
         if(hit) {
-          a = load_stream(tc + tile_index<8>(i, h)); b = load_stream(tc + tile_index<8>(i, 2 + h));
-          c = load_stream(tc + tile_index<8>(i, 4 + h)); d = load_stream(tc + tile_index<8>(i, 6 + h));
+          a = load_v4<NT>(tc + tile_index<8>(i, h)); b = load_v4<NT>(tc + tile_index<8>(i, 2 + h));
+          c = load_v4<NT>(tc + tile_index<8>(i, 4 + h)); d = load_v4<NT>(tc + tile_index<8>(i, 6 + h));
         } else {
           a = q0[h]; b = q0[2 + h]; c = q1[h]; d = q1[2 + h];
           if(in_block) {
-            store_stream(tc + tile_index<8>(i, h), a); store_stream(tc + tile_index<8>(i, 2 + h), b);
-            store_stream(tc + tile_index<8>(i, 4 + h), c); store_stream(tc + tile_index<8>(i, 6 + h), d);
+            store_v4<NT>(tc + tile_index<8>(i, h), a); store_v4<NT>(tc + tile_index<8>(i, 2 + h), b);
+            store_v4<NT>(tc + tile_index<8>(i, 4 + h), c); store_v4<NT>(tc + tile_index<8>(i, 6 + h), d);
           }
         }
-        const float4 t = load_stream(p0 + tile_index<2>(i, h));
+        const float4 t = load_v4<NT>(p0 + tile_index<2>(i, h));
         const float i00[4] = {a.x, a.y, a.z, a.w}, i01[4] = {b.x, b.y, b.z, b.w}, i10[4] = {c.x, c.y, c.z, c.w},
                     i11[4] = {d.x, d.y, d.z, d.w}, i0[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -273,25 +273,25 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       float4 a0, a1, a2, a3, b0, b1, b2, b3;
       float4* tc = reinterpret_cast<float4*>(j.tapcache);
       if(hit) {
-        a0 = load_stream(tc + tile_index<8>(i, 0)); a1 = load_stream(tc + tile_index<8>(i, 1));
-        a2 = load_stream(tc + tile_index<8>(i, 2)); a3 = load_stream(tc + tile_index<8>(i, 3));
-        b0 = load_stream(tc + tile_index<8>(i, 4)); b1 = load_stream(tc + tile_index<8>(i, 5));
-        b2 = load_stream(tc + tile_index<8>(i, 6)); b3 = load_stream(tc + tile_index<8>(i, 7));
+        a0 = load_v4<NT>(tc + tile_index<8>(i, 0)); a1 = load_v4<NT>(tc + tile_index<8>(i, 1));
+        a2 = load_v4<NT>(tc + tile_index<8>(i, 2)); a3 = load_v4<NT>(tc + tile_index<8>(i, 3));
+        b0 = load_v4<NT>(tc + tile_index<8>(i, 4)); b1 = load_v4<NT>(tc + tile_index<8>(i, 5));
+        b2 = load_v4<NT>(tc + tile_index<8>(i, 6)); b3 = load_v4<NT>(tc + tile_index<8>(i, 7));
       } else {
         const float4* q0 = reinterpret_cast<const float4*>(d0);
         const float4* q1 = reinterpret_cast<const float4*>(d1);
         a0 = q0[0]; a1 = q0[1]; a2 = q0[2]; a3 = q0[3];
         b0 = q1[0]; b1 = q1[1]; b2 = q1[2]; b3 = q1[3];
         if(in_block) {
-          store_stream(tc + tile_index<8>(i, 0), a0); store_stream(tc + tile_index<8>(i, 1), a1);
-          store_stream(tc + tile_index<8>(i, 2), a2); store_stream(tc + tile_index<8>(i, 3), a3);
-          store_stream(tc + tile_index<8>(i, 4), b0); store_stream(tc + tile_index<8>(i, 5), b1);
-          store_stream(tc + tile_index<8>(i, 6), b2); store_stream(tc + tile_index<8>(i, 7), b3);
+          store_v4<NT>(tc + tile_index<8>(i, 0), a0); store_v4<NT>(tc + tile_index<8>(i, 1), a1);
+          store_v4<NT>(tc + tile_index<8>(i, 2), a2); store_v4<NT>(tc + tile_index<8>(i, 3), a3);
+          store_v4<NT>(tc + tile_index<8>(i, 4), b0); store_v4<NT>(tc + tile_index<8>(i, 5), b1);
+          store_v4<NT>(tc + tile_index<8>(i, 6), b2); store_v4<NT>(tc + tile_index<8>(i, 7), b3);
           j.tapkey[i] = key;
         }
       }
       const float4* p0 = reinterpret_cast<const float4*>(j.pix);
-      const float4 t0 = load_stream(p0 + tile_index<2>(i, 0)), t1 = load_stream(p0 + tile_index<2>(i, 1));
+      const float4 t0 = load_v4<NT>(p0 + tile_index<2>(i, 0)), t1 = load_v4<NT>(p0 + tile_index<2>(i, 1));
       I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
       I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
       I10[0] = b0.x; I10[1] = b0.y; I10[2] = b0.z; I10[3] = b0.w; I10[4] = b1.x; I10[5] = b1.y; I10[6] = b1.z; I10[7] = b1.w;
@@ -306,7 +306,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       cache_hit = spec_key == key;
       if(spec_key != key) {
         t = make_float4(d0[0], d0[1], d1[0], d1[1]);
-        if(in_block) { store_stream(tc + i, t); j.tapkey[i] = key; }
+        if(in_block) { store_v4<NT>(tc + i, t); j.tapkey[i] = key; }
       }
       I00[0] = t.x; I01[0] = t.y; I10[0] = t.z; I11[0] = t.w;
       I0[0] = spec_pix;
@@ -1108,7 +1108,8 @@ __device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __re
 // path); point, valid byte, residuals, gradients (plain) — before the first use: one memory round trip per pair of points instead
 // of four or five dependent ones per point (point -> projection -> key -> taps, in two halves).  The cached taps are loaded
 // speculatively: on a miss (3 % of the lookups) they are discarded and the footprint is gathered as usual.  The throughput
-// kernels do the opposite on purpose — there the speculative bytes cost more than the latency they hide.
+// kernels do the opposite on purpose — there the speculative bytes cost more than the latency they hide.  Cached
+// accesses instead of the streaming ones for the same reason: a single pair's working set stays in the L2s between iterations.
 struct IrlsPointLat {
   float4 Pt, tc[8], px[2], g[4], r[2];
   unsigned key;
@@ -1117,22 +1118,22 @@ struct IrlsPointLat {
 template <bool FUSED>
 __device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPointLat& d)
 {
-  d.Pt = load_stream(j.pts + i);
+  d.Pt = load_v4<false>(j.pts + i);
   const float4* qg = reinterpret_cast<const float4*>(j.grad);
   if constexpr(FUSED) {
     d.key = j.tapkey[i];
     const float4* tc = reinterpret_cast<const float4*>(j.tapcache);
 #pragma unroll
-    for(int k = 0; k < 8; ++k) d.tc[k] = load_stream(tc + tile_index<8>(i, k));
+    for(int k = 0; k < 8; ++k) d.tc[k] = load_v4<false>(tc + tile_index<8>(i, k));
     const float4* p0 = reinterpret_cast<const float4*>(j.pix);
-    d.px[0] = load_stream(p0 + tile_index<2>(i, 0)); d.px[1] = load_stream(p0 + tile_index<2>(i, 1));
+    d.px[0] = load_v4<false>(p0 + tile_index<2>(i, 0)); d.px[1] = load_v4<false>(p0 + tile_index<2>(i, 1));
   } else {
     d.v = (float) j.valid[i];
     const float4* qr = reinterpret_cast<const float4*>(j.r);
-    d.r[0] = load_stream(qr + tile_index<2>(i, 0)); d.r[1] = load_stream(qr + tile_index<2>(i, 1));
+    d.r[0] = load_v4<false>(qr + tile_index<2>(i, 0)); d.r[1] = load_v4<false>(qr + tile_index<2>(i, 1));
   }
 #pragma unroll
-  for(int k = 0; k < 4; ++k) d.g[k] = load_stream(qg + tile_index<4>(i, k));
+  for(int k = 0; k < 4; ++k) d.g[k] = load_v4<false>(qg + tile_index<4>(i, k));
 }
 
 template <int LOSS, bool FUSED>
@@ -1197,7 +1198,7 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
           t[4] = q1[0]; t[5] = q1[1]; t[6] = q1[2]; t[7] = q1[3];
           float4* tcw = reinterpret_cast<float4*>(j.tapcache);
 #pragma unroll
-          for(int k = 0; k < 8; ++k) store_stream(tcw + tile_index<8>(i, k), t[k]);
+          for(int k = 0; k < 8; ++k) store_v4<false>(tcw + tile_index<8>(i, k), t[k]);
           j.tapkey[i] = key;
         }
         // pieces 0, 1: I00 of channels 0-3 / 4-7; 2, 3: I01; 4, 5: I10; 6, 7: I11 (warp_point)
@@ -1594,13 +1595,13 @@ __device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restric
     const int i = in_block ? i_raw : n - 1;
     float res[C];
     bool hit;
-    const bool valid = warp_point<C, false>(j, P, i, in_block, res, hit);
+    const bool valid = warp_point<C, false, false, false>(j, P, i, in_block, res, hit);      // cached (not streaming) accesses
     if(in_block) {
       j.valid[i] = valid ? 1 : 0;
       if constexpr(C == 8) {
         float4* o = reinterpret_cast<float4*>(j.r);
-        store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
-        store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
+        o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
+        o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
       } else {
 #pragma unroll
         for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];

@@ -125,6 +125,13 @@ __device__ __forceinline__ void store_stream(float4* p, const float4& a)
   bpvo_v4f v; v.x = a.x; v.y = a.y; v.z = a.z; v.w = a.w;
   __builtin_nontemporal_store(v, reinterpret_cast<bpvo_v4f*>(p));
 }
+// ... and the choice as a template parameter: launches that are latency-bound on a working set that fits the L2s (the persistent
+// single-pair kernel: 6 MB at the finest level of a 1241x376 pair) want the lines kept — non-temporal accesses there cost 8 % of an
+// estimatePose (profiles/r02_persistent_phases.txt)
+template <bool NT>
+__device__ __forceinline__ float4 load_v4(const float4* p) { if constexpr(NT) return load_stream(p); else return *p; }
+template <bool NT>
+__device__ __forceinline__ void store_v4(float4* p, const float4& a) { if constexpr(NT) store_stream(p, a); else *p = a; }
 #endif
 
 // everything a kernel needs to know about one (workspace, level) linearisation
