@@ -5,6 +5,7 @@
 // channels of one pixel are one 32-byte record (C = 8): a bilinear gather touches 2 x 64 contiguous bytes instead
 // of 32 scattered dwords, and every kernel below writes/reads full records with 16-byte accesses.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -84,6 +85,48 @@ __global__ __launch_bounds__(256) void pyrdown_u8_kernel(const FrameJob* src_job
     const int y = y0 + r;
     if(y >= dj.rows) break;
     const int acc = h[2 * r] + 4 * h[2 * r + 1] + 6 * h[2 * r + 2] + 4 * h[2 * r + 3] + h[2 * r + 4];
+    ((uint8_t*) dj.img)[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
+  }
+}
+
+// The same through LDS (the form launch_pyrdown uses): a workgroup stages the (2*64+3) x (2*16+3) source pixels of a 64 x 16 output
+// tile with row-contiguous byte loads (a wavefront reads 64 consecutive bytes per request instead of 64 bytes strided by two, eleven
+// rows of five per thread), forms the horizontal [1 4 6 4 1] sums once per (source row, output column) and the vertical ones from
+// those.  Integer arithmetic, same values.  1024 pairs of 1241x376: 2.5 -> see profiles/README.md ms per step for the three levels.
+constexpr int PDT_W = 64, PDT_H = 16;
+constexpr int PDS_W = 2 * PDT_W + 3, PDS_H = 2 * PDT_H + 3, PDS_PITCH = 2 * PDT_W + 4;
+__global__ __launch_bounds__(256) void pyrdown_u8_lds_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
+{
+  __shared__ uint8_t s_src[PDS_H][PDS_PITCH];
+  __shared__ uint16_t s_h[PDS_H][PDT_W];      // <= 16 * 255
+  const FrameJob& sj = src_jobs[blockIdx.z];
+  const FrameJob& dj = dst_jobs[blockIdx.z];
+  const int sw = sj.cols, sh = sj.rows;
+  const int dx0 = blockIdx.x * PDT_W, dy0 = blockIdx.y * PDT_H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint8_t* __restrict__ s = sj.img;
+  for(int r = wave; r < PDS_H; r += 4) {
+    const uint8_t* row = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw;
+#pragma unroll
+    for(int c0 = 0; c0 < PDS_W; c0 += 64) {
+      const int c = c0 + lane;
+      if(c < PDS_W) s_src[r][c] = row[reflect101(min(2 * dx0 - 2 + c, sw + 1), sw)];
+    }
+  }
+  __syncthreads();
+  for(int idx = threadIdx.x; idx < PDS_H * PDT_W; idx += 256) {
+    const int r = idx >> 6, x = idx & 63;
+    const uint8_t* q = &s_src[r][2 * x];
+    s_h[r][x] = (uint16_t) (q[2] * 6 + (q[1] + q[3]) * 4 + q[0] + q[4]);
+  }
+  __syncthreads();
+  const int x = dx0 + lane;
+  if(x >= dj.cols) return;
+#pragma unroll
+  for(int q = 0; q < PDT_H / 4; ++q) {
+    const int ty = wave * (PDT_H / 4) + q, y = dy0 + ty;
+    if(y >= dj.rows) break;
+    const int acc = s_h[2 * ty][lane] + 4 * s_h[2 * ty + 1][lane] + 6 * s_h[2 * ty + 2][lane] + 4 * s_h[2 * ty + 3][lane] + s_h[2 * ty + 4][lane];
     ((uint8_t*) dj.img)[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
   }
 }
@@ -995,7 +1038,9 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 }
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {
-  hipLaunchKernelGGL(pyrdown_u8_kernel, dim3((dW + 63) / 64, (dR + 4 * PD_ROWS - 1) / (4 * PD_ROWS), nframes), dim3(256), 0, s, src, dst);
+  static const bool direct = std::getenv("BPVO_HIP_PYRDOWN_DIRECT") != nullptr;     // A/B switch: the register-only form
+  if(direct) hipLaunchKernelGGL(pyrdown_u8_kernel, dim3((dW + 63) / 64, (dR + 4 * PD_ROWS - 1) / (4 * PD_ROWS), nframes), dim3(256), 0, s, src, dst);
+  else hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H - 1) / PDT_H, nframes), dim3(256), 0, s, src, dst);
 }
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {
