@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,10 +92,12 @@ struct Lane {
   PairJob* d_pjobs = nullptr;      // [L][n_pairs]
   float* h_T = nullptr;            // pinned [n_pairs][16]
   float* d_Tinit = nullptr;
-  int* d_active = nullptr;         // [3] counts of the active lists
+  int* d_active = nullptr;         // [3] counts of the active lists ([3][2] for a pipelined lane: one per group)
   int* d_list = nullptr;           // [3][n_pairs] active-workspace lists of the host rounds in flight (ActiveSet)
   int* h_active = nullptr;         // pinned [4]
   hipEvent_t round_ev[3] = {};     // "compaction of round r and its count have landed"
+  hipEvent_t staging_ev[2] = {};   // "the upload of this lane's rows of FrameJob table 0 / 1 has left the pinned staging"
+  hipEvent_t selected_ev = nullptr; // staggered batches: "the selection of this lane's templates has been queued" (FrameRun)
   unsigned* d_pk_ctl = nullptr;    // [kMaxLevels][kPkCtlWords] {arrivals, abort} of the persistent kernel, one slot per level
   unsigned* h_pk_ctl = nullptr;    // pinned copy
   GNState* h_states = nullptr;     // pinned [n_pairs]
@@ -129,7 +134,7 @@ struct bpvo_hip_ctx {
   std::vector<FrameSlot> frames;
   std::vector<Workspace> ws;
   GNState* d_states = nullptr;
-  FrameJob* d_fjobs = nullptr;     // [L][n_frames]
+  FrameJob* d_fjobs = nullptr;     // [2][L][n_frames]: the table of the setData stage, then the one of the setTemplate stage
   std::vector<Lane> lanes;         // lanes[0] shares the ctx stream
   PairJob* d_job1 = nullptr;       // scratch single job (linearize / weights)
   float* d_records = nullptr;      // [n_pairs][kRecordFloats]
@@ -171,6 +176,10 @@ struct bpvo_hip_ctx {
   float* st_disp = nullptr;
   int st_frames = 0;
   bool counted_live = false;   // this context is in g_live_ctx
+  // Batches: the pipelined chain (two groups per lane, wide + narrow kernel in one launch; kernels_gn.hip gn_pipe_kernel).  BPVO_HIP_PIPE=0
+  // turns it off, BPVO_HIP_PIPE_MIN_PAIRS / _HEAD_ROUNDS size it.
+  int pipe = 1, pipe_min_pairs = 16, pipe_head_rounds = 2;
+  bool stagger = true;         // BPVO_HIP_STAGGER=0: batches run stage by stage over all pairs (batch_run_staggered)
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
@@ -181,6 +190,7 @@ struct bpvo_hip_ctx {
   uint64_t kc_launches[KC_COUNT] = {};
   uint64_t total_lin = 0, median_bracketed = 0, median_full = 0;
   uint64_t tap_counts[4] = {};
+  std::mutex units_mu;         // kc_units updates of concurrent frame stages
   std::string err;
 };
 
@@ -407,124 +417,181 @@ void resolve_events(bpvo_hip_ctx* c)   // call from the API thread after the lan
 
 // ---- frame stages ---------------------------------------------------------------------------------------------------
 // slots: first, first+stride, ...; uploads the FrameJob table [L][count] and returns its device base
-int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count)
+// A frame stage runs either on the ctx stream (single frames, batches on one lane) or, for staggered batches, on a lane's own stream
+// with its own rows [tab, tab + count) of the job tables and count staging (FrameRun); errors of a lane go to the lane's string.
+struct FrameRun {
+  hipStream_t stream;
+  Lane* ln;          // timing events are taken from / queued on this lane
+  int tab;           // first row of the FrameJob table [L][n_frames] and of h_ints / d_ints [n_frames][kMaxLevels] used by this run
+  bool own_thread;   // run by a lane thread next to others: no resolve_events, errors into ln->err
+  hipEvent_t selected_ev;   // recorded once the selection of all levels has been queued (the next lane's frame stage starts behind it), or null
+  std::function<void()> on_selected;   // ... and called right after that record (releases the next lane's host thread)
+};
+#define FR_CK(c_, fr_, expr)                                                                \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if(e_ != hipSuccess) {                                                                  \
+      ((fr_).own_thread ? (fr_).ln->err : (c_)->err) = std::string(#expr) + ": " + hipGetErrorString(e_); \
+      return BPVO_ERR_DEVICE;                                                               \
+    }                                                                                       \
+  } while(0)
+FrameRun ctx_run(bpvo_hip_ctx* c) { return FrameRun{c->stream, &c->lanes[0], 0, false, nullptr, nullptr}; }
+
+// which: 0 = table of the setData stage, 1 = table of the setTemplate stage (two tables, so that queueing the template stage does not
+// have to wait for the descriptor kernels that still read the first).  Returns the device table through *tab (row fr.tab of level 0).
+int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const FrameRun& fr, int which, const FrameJob** tab)
 {
-  HIP_CK(c, hipStreamSynchronize(c->stream));   // the pinned staging table may still feed an earlier async copy
-  for(int l = 0; l < c->L; ++l)
-    for(int i = 0; i < count; ++i) c->h_fjobs[(size_t) l * c->n_frames + i] = make_frame_job(c, c->frames[first + i * stride], l);
-  HIP_CK(c, hipMemcpyAsync(c->d_fjobs, c->h_fjobs, sizeof(FrameJob) * (size_t) c->L * c->n_frames, hipMemcpyHostToDevice, c->stream));
+  const size_t table = (size_t) which * c->L * c->n_frames;
+  FR_CK(c, fr, hipEventSynchronize(fr.ln->staging_ev[which]));   // the pinned rows may still feed the copy of an earlier call
+  for(int l = 0; l < c->L; ++l) {
+    FrameJob* row = c->h_fjobs + table + (size_t) l * c->n_frames + fr.tab;
+    for(int i = 0; i < count; ++i) row[i] = make_frame_job(c, c->frames[first + i * stride], l);
+    FR_CK(c, fr, hipMemcpyAsync(c->d_fjobs + table + (size_t) l * c->n_frames + fr.tab, row, sizeof(FrameJob) * (size_t) count, hipMemcpyHostToDevice, fr.stream));
+  }
+  FR_CK(c, fr, hipEventRecord(fr.ln->staging_ev[which], fr.stream));
+  *tab = c->d_fjobs + table + fr.tab;
   return BPVO_OK;
 }
 
 // VisualOdometryFrame::setData (reference: bpvo/vo_frame.cc:48-55) for `count` frames at once
+int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device,
+                    const FrameRun& fr)
+{
+  if(count <= 0) return BPVO_OK;
+  const size_t npix = c->geom[0].npix;
+  hipStream_t s = fr.stream;
+  if(!on_device) {
+    for(int i = 0; i < count; ++i) {
+      FrameSlot& f = c->frames[first + i * stride];
+      FR_CK(c, fr, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, hipMemcpyHostToDevice, s));
+      FR_CK(c, fr, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+  }
+  const FrameJob* tab = nullptr;
+  int rc = upload_frame_jobs(c, first, stride, count, fr, 0, &tab);
+  if(rc) return rc;
+  const int NF = c->n_frames;
+  if(on_device) launch_ingest(s, tab, images, disps, npix, count);   // one launch instead of 2 copies per frame
+  {
+    double px = 0;
+    for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_PYRAMID, px, fr.ln);
+    for(int l = 1; l < c->L; ++l)   // ImagePyramid::compute (bpvo/image_pyramid.cc:43-50)
+      launch_pyrdown(s, tab + (size_t) (l - 1) * NF, tab + (size_t) l * NF, c->geom[l].cols, c->geom[l].rows, count);
+  }
+  {
+    double px = 0;
+    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_DESCRIPTOR, px, fr.ln);
+    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
+      const FrameJob* jobs = tab + (size_t) l * NF;
+      const LevelGeom& g = c->geom[l];
+      if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
+        launch_central_difference(s, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius, c->cd_before, c->cd_after);
+      } else if(c->C == 5 || c->C == 10) {
+        launch_descriptor_fields(s, jobs, g.cols, g.rows, count, c->C == 10, c->df_g1, c->df_g2);
+      } else if(c->C == 3) {
+        launch_gradient_descriptor(s, jobs, g.cols, g.rows, count, c->grad_pre);
+      } else if(c->C == 1) {
+        if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(s, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
+        else launch_intensity(s, jobs, g.cols, g.rows, count);
+      } else {
+        // census fused into the bit-planes kernel unless the census is taken of the smoothed image or the planes stay unsmoothed
+        const bool fused_census = !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f && !c->split_census;
+        if(!fused_census)
+          launch_census(s, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
+        launch_bitplanes(s, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k, fused_census ? 1 : 0);
+      }
+    }
+  }
+  FR_CK(c, fr, hipGetLastError());
+  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_data = true;
+  return BPVO_OK;
+}
 int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device)
 {
   if(count <= 0) return BPVO_OK;
   if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
   if(!images || !disps) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
-  const size_t npix = c->geom[0].npix;
-  if(!on_device) {
-    for(int i = 0; i < count; ++i) {
-      FrameSlot& f = c->frames[first + i * stride];
-      HIP_CK(c, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, hipMemcpyHostToDevice, c->stream));
-      HIP_CK(c, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    }
-  }
-  int rc = upload_frame_jobs(c, first, stride, count);
-  if(rc) return rc;
-  const int NF = c->n_frames;
-  if(on_device) launch_ingest(c->stream, c->d_fjobs, images, disps, npix, count);   // one launch instead of 2 copies per frame
-  {
-    double px = 0;
-    for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
-    ScopedTimer t(c, KC_PYRAMID, px);
-    for(int l = 1; l < c->L; ++l)   // ImagePyramid::compute (bpvo/image_pyramid.cc:43-50)
-      launch_pyrdown(c->stream, c->d_fjobs + (size_t) (l - 1) * NF, c->d_fjobs + (size_t) l * NF, c->geom[l].cols, c->geom[l].rows, count);
-  }
-  {
-    double px = 0;
-    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) px += (double) c->geom[l].npix * count;
-    ScopedTimer t(c, KC_DESCRIPTOR, px);
-    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
-      const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
-      const LevelGeom& g = c->geom[l];
-      if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
-        launch_central_difference(c->stream, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius, c->cd_before, c->cd_after);
-      } else if(c->C == 5 || c->C == 10) {
-        launch_descriptor_fields(c->stream, jobs, g.cols, g.rows, count, c->C == 10, c->df_g1, c->df_g2);
-      } else if(c->C == 3) {
-        launch_gradient_descriptor(c->stream, jobs, g.cols, g.rows, count, c->grad_pre);
-      } else if(c->C == 1) {
-        if(c->params.descriptor == BPVO_DESC_LAPLACIAN) launch_laplacian(c->stream, jobs, g.cols, g.rows, count, c->params.laplacianKernelSize);
-        else launch_intensity(c->stream, jobs, g.cols, g.rows, count);
-      } else {
-        // census fused into the bit-planes kernel unless the census is taken of the smoothed image or the planes stay unsmoothed
-        const bool fused_census = !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f && !c->split_census;
-        if(!fused_census)
-          launch_census(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaPriorToCensusTransform > 0.0f ? c->census_taps : nullptr);
-        launch_bitplanes(c->stream, jobs, g.cols, g.rows, count, c->params.sigmaBitPlanes, c->gauss_k, fused_census ? 1 : 0);
-      }
-    }
-  }
-  HIP_CK(c, hipGetLastError());
-  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_data = true;
-  return BPVO_OK;
+  return frames_set_data(c, first, stride, count, images, disps, on_device, ctx_run(c));
 }
 
 // VisualOdometryFrame::setTemplate (reference: bpvo/vo_frame.cc:61-93 -> bpvo/template_data.cc:37-142) for `count` frames
+int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const FrameRun& fr)
+{
+  if(count <= 0) return BPVO_OK;
+  hipStream_t s = fr.stream;
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    if(f.tmpl_slab) continue;
+    size_t total = 0;
+    FrameSlot tmp;
+    carve_frame_tmpl(c, tmp, nullptr, &total);
+    FR_CK(c, fr, hipMalloc(&f.tmpl_slab, total));
+    FR_CK(c, fr, hipMemsetAsync(f.tmpl_slab, 0, total, s));
+    carve_frame_tmpl(c, f, (unsigned char*) f.tmpl_slab, nullptr);
+  }
+  const FrameJob* tab = nullptr;
+  int rc = upload_frame_jobs(c, first, stride, count, fr, 1, &tab);
+  if(rc) return rc;
+  const int NF = c->n_frames;
+  int* const h_ints = c->h_ints + (size_t) fr.tab * kMaxLevels;
+  int* const d_ints = c->d_ints + (size_t) fr.tab * kMaxLevels;
+  const bpvo_hip_params& p = c->params;
+  const int border = std::max(p.nonMaxSuppRadius, 3);   // template_data.cc:51
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    const FrameJob* jobs = tab + (size_t) l * NF;
+    const LevelGeom& g = c->geom[l];
+    ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count, fr.ln);
+    launch_saliency(s, jobs, c->C, g.cols, g.rows, count);
+    launch_select(s, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
+  }
+  {
+    // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
+    ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln);
+    // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
+    launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, c->dspace ? 0 : p.withNormalization);
+  }
+  // one read-back of the point counts: the host needs them to size the template-build and GN grids
+  launch_gather_counts(s, tab, NF, count, p.maxTestLevel, c->L, d_ints);
+  FR_CK(c, fr, hipMemcpyAsync(h_ints, d_ints, sizeof(int) * kMaxLevels * (size_t) count, hipMemcpyDeviceToHost, s));
+  if(fr.selected_ev) FR_CK(c, fr, hipEventRecord(fr.selected_ev, s));
+  if(fr.on_selected) fr.on_selected();
+  FR_CK(c, fr, hipStreamSynchronize(s));
+  std::vector<int> max_n(c->L, 0);
+  double pts = 0;
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    for(int l = 0; l < c->L; ++l) {
+      f.n_host[l] = (l >= p.maxTestLevel) ? h_ints[(size_t) i * kMaxLevels + l] : 0;
+      max_n[l] = std::max(max_n[l], f.n_host[l]);
+      pts += f.n_host[l];
+    }
+  }
+  if(c->profiling) {
+    std::lock_guard<std::mutex> lk(c->units_mu);
+    c->kc_units[KC_TEMPLATE] += pts;
+    c->kc_units[KC_NORMALIZATION] += pts;
+  }
+  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+    ScopedTimer t(c, KC_TEMPLATE, 0.0, fr.ln);
+    launch_template_build(s, tab + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5);
+  }
+  if(!fr.own_thread) {      // (a lane thread goes straight on to its estimation on the same stream)
+    FR_CK(c, fr, hipStreamSynchronize(s));
+    FR_CK(c, fr, hipGetLastError());
+    resolve_events(c);
+  }
+  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_template = true;
+  return BPVO_OK;
+}
 int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 {
   if(count <= 0) return BPVO_OK;
   if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
-  for(int i = 0; i < count; ++i) {
-    FrameSlot& f = c->frames[first + i * stride];
-    if(!f.has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");   // vo_frame.cc:63
-    int rc = ensure_template_storage(c, f);
-    if(rc) return rc;
-  }
-  int rc = upload_frame_jobs(c, first, stride, count);
-  if(rc) return rc;
-  const int NF = c->n_frames;
-  const bpvo_hip_params& p = c->params;
-  const int border = std::max(p.nonMaxSuppRadius, 3);   // template_data.cc:51
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
-    const FrameJob* jobs = c->d_fjobs + (size_t) l * NF;
-    const LevelGeom& g = c->geom[l];
-    ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count);
-    launch_saliency(c->stream, jobs, c->C, g.cols, g.rows, count);
-    launch_select(c->stream, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
-  }
-  {
-    // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
-    ScopedTimer t(c, KC_NORMALIZATION, 0.0);
-    // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
-    launch_normalization(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, c->dspace ? 0 : p.withNormalization);
-  }
-  // one read-back of the point counts: the host needs them to size the template-build and GN grids
-  launch_gather_counts(c->stream, c->d_fjobs, NF, count, p.maxTestLevel, c->L, c->d_ints);
-  HIP_CK(c, hipMemcpyAsync(c->h_ints, c->d_ints, sizeof(int) * kMaxLevels * (size_t) count, hipMemcpyDeviceToHost, c->stream));
-  HIP_CK(c, hipStreamSynchronize(c->stream));
-  std::vector<int> max_n(c->L, 0);
-  for(int i = 0; i < count; ++i) {
-    FrameSlot& f = c->frames[first + i * stride];
-    double pts = 0;
-    for(int l = 0; l < c->L; ++l) {
-      f.n_host[l] = (l >= p.maxTestLevel) ? c->h_ints[(size_t) i * kMaxLevels + l] : 0;
-      max_n[l] = std::max(max_n[l], f.n_host[l]);
-      pts += f.n_host[l];
-    }
-    c->kc_units[KC_TEMPLATE] += c->profiling ? pts : 0.0;
-    c->kc_units[KC_NORMALIZATION] += c->profiling ? pts : 0.0;
-  }
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
-    ScopedTimer t(c, KC_TEMPLATE, 0.0);
-    launch_template_build(c->stream, c->d_fjobs + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5);
-  }
-  HIP_CK(c, hipStreamSynchronize(c->stream));
-  HIP_CK(c, hipGetLastError());
-  resolve_events(c);
-  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_template = true;
-  return BPVO_OK;
+  for(int i = 0; i < count; ++i)
+    if(!c->frames[first + i * stride].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");   // vo_frame.cc:63
+  return frames_set_template(c, first, stride, count, ctx_run(c));
 }
 
 // ---- estimatePose ---------------------------------------------------------------------------------------------------
@@ -602,6 +669,60 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     const int kItersPerSync = 4;
     const int max_rounds = (max_lin + kItersPerSync - 1) / kItersPerSync + 2;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
+    if(c->pipe && n >= c->pipe_min_pairs && gn_pipe_serves(g) && !c->profile_all && !c->sync_rounds) {
+      // PIPELINED chain (kernels_gn.hip, gn_pipe_kernel): the lane's pairs as two groups one kernel apart, every launch = a chip-filling
+      // kernel of one group + a narrow kernel of the other.  The first pipe_head_rounds rounds of a level run the four-kernel chain on
+      // all pairs: that is where every pair takes the full 3-pass median, which wants the 1024-thread workgroup.  Rounds are pipelined
+      // as below; the active lists are kept per group (compact_split).
+      const int nA0 = n / 2;
+      PipeSide A, B, none;
+      A.base = 0; A.n = nA0; B.base = nA0; B.n = n - nA0;
+      int* const listsA[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
+      auto pipe = [&](int wide_op, const PipeSide& wide, int narrow_op, const PipeSide& narrow) {
+        launch_gn_pipe(ln->stream, g, wide_op, wide, narrow_op, narrow, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
+                       p.gradientTolerance);
+      };
+      g.npairs = n;
+      g.active = ActiveSet();
+      g.merge_irls = 1;
+      for(int round = 0; round < max_rounds; ++round) {
+        if(round < c->pipe_head_rounds) {
+          for(int k = 0; k < kItersPerSync; ++k) {
+            const bool sampled = (ln->k6_seq++ % kProfileEvery) == 0;
+            { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
+            launch_median(ln->stream, g);
+            launch_irls_reduce(ln->stream, g);
+            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+          }
+        } else {
+          // W M I G of group A against - W M I of group B, then G of B alone (wide op 0 = warp_residual, 1 = irls_reduce; narrow op
+          // 0 = median, 1 = gn_step)
+          for(int k = 0; k < kItersPerSync; ++k) {
+            {
+              const bool sampled = (ln->k6_seq++ % kProfileEvery) == 0;
+              ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled);
+              pipe(0, A, 1, k == 0 ? none : B);
+            }
+            pipe(0, B, 0, A);
+            pipe(1, A, 0, B);
+            pipe(1, B, 1, A);
+          }
+          pipe(0, none, 1, B);
+        }
+        const int slot = round % 3;
+        launch_compact_split(ln->stream, g.jobs, A, B, listsA[slot], listsA[slot] + nA0, ln->d_active + 2 * slot);
+        LANE_CK(ln, hipMemcpyAsync(ln->h_active + 2 * slot, ln->d_active + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, ln->stream));
+        LANE_CK(ln, hipEventRecord(ln->round_ev[slot], ln->stream));
+        if(round == 0) continue;
+        const int prev = (round - 1) % 3;
+        LANE_CK(ln, hipEventSynchronize(ln->round_ev[prev]));
+        const int nA = ln->h_active[2 * prev], nB = ln->h_active[2 * prev + 1];
+        if(nA + nB <= 0) break;
+        A.list = listsA[prev]; A.base = 0; A.n = nA;
+        B.list = listsA[prev] + nA0; B.base = 0; B.n = nB;
+      }
+      continue;
+    }
     int* const lists[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
     int n_cur = n;
     g.active.list = nullptr;                // first rounds: every workspace of the group, in order
@@ -1050,7 +1171,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
-  CREATE_CK(hipMalloc((void**) &cp->d_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
+  CREATE_CK(hipMalloc((void**) &cp->d_fjobs, 2 * sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
   {
     int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
@@ -1058,6 +1179,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_FUSE_FROZEN")) cp->fuse_frozen = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_STAGGER")) cp->stagger = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_PIPE")) cp->pipe = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_PIPE_MIN_PAIRS")) cp->pipe_min_pairs = std::max(2, std::atoi(e));
+    if(const char* e = std::getenv("BPVO_HIP_PIPE_HEAD_ROUNDS")) cp->pipe_head_rounds = std::max(0, std::min(2, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSISTENT")) cp->persistent = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
@@ -1071,12 +1196,14 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     else { CREATE_CK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
     CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipMalloc((void**) &ln.d_active, 4 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_active, 8 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_list, 3 * sizeof(int) * (size_t) n_pairs));
     for(auto& e : ln.round_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    CREATE_CK(hipEventCreateWithFlags(&ln.selected_ev, hipEventDisableTiming));
+    for(auto& e : ln.staging_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 8 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
@@ -1086,7 +1213,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
   CREATE_CK(hipMalloc((void**) &cp->d_counters, kWsCounters * sizeof(unsigned long long) * n_pairs));
   CREATE_CK(hipMemset(cp->d_counters, 0, kWsCounters * sizeof(unsigned long long) * n_pairs));
-  CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, sizeof(FrameJob) * (size_t) cp->L * n_frames));
+  CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, 2 * sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipHostMalloc((void**) &cp->h_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
   CREATE_CK(hipMalloc((void**) &cp->d_ints, sizeof(int) * std::max((size_t) n_frames * kMaxLevels, (size_t) 16)));
 #undef CREATE_CK
@@ -1119,6 +1246,8 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
     for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
     for(auto e : ln.round_ev) if(e) (void) hipEventDestroy(e);
+    if(ln.selected_ev) (void) hipEventDestroy(ln.selected_ev);
+    for(auto e : ln.staging_ev) if(e) (void) hipEventDestroy(e);
     if(ln.owns_stream && ln.stream) (void) hipStreamDestroy(ln.stream);
   }
   if(c->stream) (void) hipStreamDestroy(c->stream);
@@ -1702,12 +1831,71 @@ int bpvo_hip_batch_estimate(bpvo_hip_ctx* c, int n_pairs, const float* T_init, f
   for(int p = 0; p < n_pairs; ++p) { wss[p] = p; refs[p] = 2 * p; curs[p] = 2 * p + 1; }
   return estimate_batch(c, n_pairs, wss.data(), refs.data(), curs.data(), T_init, poses, stats);
 }
+// Staggered lanes (round 2).  A batch whose frame stage ran as a whole before any estimation starts every lane at the coarsest
+// pyramid level at the same moment: for the first two levels (a few hundred points per pair) every launch is latency-bound and the
+// chip idles, whatever the number of lanes.  Here each lane runs ITS pairs end to end on its own stream — setData, setTemplate,
+// estimatePose — and lane k's frame stage is queued behind lane k-1's selection: the chip-filling frame kernels of one lane run
+// under the narrow coarse-level iterations of the previous one, and the coarse levels of lane k under the fine levels of lane k-1.
+// Same kernels on the same data per pair: results are bit-identical to the one-stage-at-a-time form (BPVO_HIP_STAGGER=0).
+int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* images, const float* disparities, bool on_device, float* poses,
+                        bpvo_hip_stats* stats)
+{
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  const size_t npix = c->geom[0].npix;
+  std::vector<int> rcs(nl, BPVO_OK);
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<int> selected(nl, 0);     // 1: the lane recorded its selected_ev (or failed before: nobody waits for ever)
+  auto run = [&](int k) {
+    Lane* ln = &c->lanes[k];
+    (void) hipSetDevice(c->device);
+    const int lo = (int) ((long long) n_pairs * k / nl), hi = (int) ((long long) n_pairs * (k + 1) / nl), n = hi - lo;
+    auto release_next = [&mu, &cv, &selected, k] { { std::lock_guard<std::mutex> lk(mu); selected[k] = 1; } cv.notify_all(); };
+    struct Release { std::function<void()> f; ~Release() { f(); } } always{release_next};   // whatever happens, nobody waits for ever
+    if(k > 0) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return selected[k - 1] != 0; }); }
+      if(hipStreamWaitEvent(ln->stream, c->lanes[k - 1].selected_ev, 0) != hipSuccess) { ln->err = "hipStreamWaitEvent"; rcs[k] = BPVO_ERR_DEVICE; return; }
+    }
+    FrameRun fr{ln->stream, ln, 2 * lo, true, nullptr, nullptr};
+    int rc = frames_set_data(c, 2 * lo, 1, 2 * n, images + (size_t) 2 * lo * npix, disparities + (size_t) 2 * lo * npix, on_device, fr);
+    if(rc) { rcs[k] = rc; return; }
+    fr.selected_ev = ln->selected_ev;     // recorded, and the next lane released, before the template stage waits for its point counts
+    fr.on_selected = release_next;
+    rc = frames_set_template(c, 2 * lo, 2, n, fr);
+    if(rc) { rcs[k] = rc; return; }
+    std::vector<int> wss(n), refs(n), curs(n);
+    for(int i = 0; i < n; ++i) { wss[i] = lo + i; refs[i] = 2 * (lo + i); curs[i] = 2 * (lo + i) + 1; }
+    rcs[k] = estimate_group(c, ln, n, wss.data(), refs.data(), curs.data(), nullptr, poses ? poses + 16 * (size_t) lo : nullptr,
+                            stats ? stats + (size_t) lo * c->L : nullptr, c->d_records + (size_t) kRecordFloats * lo);
+  };
+  {
+    std::vector<std::thread> th;
+    for(int k = 1; k < nl; ++k) th.emplace_back(run, k);
+    run(0);
+    for(auto& t : th) t.join();
+  }
+  for(int k = 0; k < nl; ++k)
+    if(rcs[k]) { c->err = c->lanes[k].err; return rcs[k]; }
+  resolve_events(c);
+  for(int i = 0; i < n_pairs; ++i) {
+    Workspace& w = c->ws[i];
+    w.last_ref = 2 * i;
+    w.last_cur = 2 * i + 1;
+    w.last_level = c->params.maxTestLevel;
+  }
+  return BPVO_OK;
+}
+
 int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, const float* disparities, int on_device,
                        float* poses, bpvo_hip_stats* stats)
 {
   CHECK_CTX(c);
   if(n_pairs < 0 || 2 * n_pairs > c->n_frames || n_pairs > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "batch exceeds ctx capacity");
   (void) hipSetDevice(c->device);
+  if(n_pairs > 0 && (!images || !disparities)) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
+  const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
+  const int nl = std::max(1, std::min(lanes_ok, n_pairs / kMinPairsPerLane));
+  if(c->stagger && nl > 1 && !c->profile_all) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats);
   int rc = frames_set_data(c, 0, 1, 2 * n_pairs, images, disparities, on_device != 0);
   if(rc) return rc;
   rc = frames_set_template(c, 0, 2, n_pairs);

@@ -25,5 +25,14 @@ def orc():
 @pytest.fixture(scope="session")
 def hip():
     """ctypes binding of the product library; the tests that use it are marked gpu."""
+    # Some GPU tests also use torch for device buffers.  This image's torch wheel carries its own copy of the HIP / HSA runtime, and
+    # that copy finds no GPU when it is initialised AFTER the system runtime the product library links (the other order works): bring
+    # torch's up first, so that the outcome does not depend on which tests were selected.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     import bpvo_amd
     return bpvo_amd.load()
