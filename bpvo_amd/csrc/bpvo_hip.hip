@@ -92,7 +92,7 @@ struct Lane {
   PairJob* d_pjobs = nullptr;      // [L][n_pairs]
   float* h_T = nullptr;            // pinned [n_pairs][16]
   float* d_Tinit = nullptr;
-  int* d_active = nullptr;         // [3] counts of the active lists ([3][2] for a pipelined lane: one per group)
+  int* d_active = nullptr;         // [3] counts of the active lists
   int* d_list = nullptr;           // [3][n_pairs] active-workspace lists of the host rounds in flight (ActiveSet)
   int* h_active = nullptr;         // pinned [4]
   hipEvent_t round_ev[3] = {};     // "compaction of round r and its count have landed"
@@ -176,9 +176,6 @@ struct bpvo_hip_ctx {
   float* st_disp = nullptr;
   int st_frames = 0;
   bool counted_live = false;   // this context is in g_live_ctx
-  // Batches: the pipelined chain (two groups per lane, wide + narrow kernel in one launch; kernels_gn.hip gn_pipe_kernel).  BPVO_HIP_PIPE=0
-  // turns it off, BPVO_HIP_PIPE_MIN_PAIRS / _HEAD_ROUNDS size it.
-  int pipe = 1, pipe_min_pairs = 16, pipe_head_rounds = 2;
   bool stagger = true;         // BPVO_HIP_STAGGER=0: batches run stage by stage over all pairs (batch_run_staggered)
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
@@ -446,8 +443,11 @@ int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const F
   for(int l = 0; l < c->L; ++l) {
     FrameJob* row = c->h_fjobs + table + (size_t) l * c->n_frames + fr.tab;
     for(int i = 0; i < count; ++i) row[i] = make_frame_job(c, c->frames[first + i * stride], l);
-    FR_CK(c, fr, hipMemcpyAsync(c->d_fjobs + table + (size_t) l * c->n_frames + fr.tab, row, sizeof(FrameJob) * (size_t) count, hipMemcpyHostToDevice, fr.stream));
   }
+  // rows [tab, tab + count) of every level in one copy
+  const size_t pitch = sizeof(FrameJob) * (size_t) c->n_frames;
+  FR_CK(c, fr, hipMemcpy2DAsync(c->d_fjobs + table + fr.tab, pitch, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, (size_t) c->L,
+                                hipMemcpyHostToDevice, fr.stream));
   FR_CK(c, fr, hipEventRecord(fr.ln->staging_ev[which], fr.stream));
   *tab = c->d_fjobs + table + fr.tab;
   return BPVO_OK;
@@ -647,9 +647,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fuse_frozen = c->fuse_frozen;
     // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
     const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
-    launch_level_begin(ln->stream, g.jobs, n, l, l2_moot ? 1 : 0);
+    launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
     if(g.max_points <= 0) continue;
-    launch_reset_tapkeys(ln->stream, g);
     if(persistent && gn_persistent_serves(g)) {
       // the whole level in one launch
       LANE_CK(ln, launch_gn_persistent(ln->stream, g, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance,
@@ -669,60 +668,6 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     const int kItersPerSync = 4;
     const int max_rounds = (max_lin + kItersPerSync - 1) / kItersPerSync + 2;
     constexpr unsigned kProfileEvery = 5;   // co-prime with kItersPerSync: no phase lock with the host round trips
-    if(c->pipe && n >= c->pipe_min_pairs && gn_pipe_serves(g) && !c->profile_all && !c->sync_rounds) {
-      // PIPELINED chain (kernels_gn.hip, gn_pipe_kernel): the lane's pairs as two groups one kernel apart, every launch = a chip-filling
-      // kernel of one group + a narrow kernel of the other.  The first pipe_head_rounds rounds of a level run the four-kernel chain on
-      // all pairs: that is where every pair takes the full 3-pass median, which wants the 1024-thread workgroup.  Rounds are pipelined
-      // as below; the active lists are kept per group (compact_split).
-      const int nA0 = n / 2;
-      PipeSide A, B, none;
-      A.base = 0; A.n = nA0; B.base = nA0; B.n = n - nA0;
-      int* const listsA[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
-      auto pipe = [&](int wide_op, const PipeSide& wide, int narrow_op, const PipeSide& narrow) {
-        launch_gn_pipe(ln->stream, g, wide_op, wide, narrow_op, narrow, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                       p.gradientTolerance);
-      };
-      g.npairs = n;
-      g.active = ActiveSet();
-      g.merge_irls = 1;
-      for(int round = 0; round < max_rounds; ++round) {
-        if(round < c->pipe_head_rounds) {
-          for(int k = 0; k < kItersPerSync; ++k) {
-            const bool sampled = (ln->k6_seq++ % kProfileEvery) == 0;
-            { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
-            launch_median(ln->stream, g);
-            launch_irls_reduce(ln->stream, g);
-            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
-          }
-        } else {
-          // W M I G of group A against - W M I of group B, then G of B alone (wide op 0 = warp_residual, 1 = irls_reduce; narrow op
-          // 0 = median, 1 = gn_step)
-          for(int k = 0; k < kItersPerSync; ++k) {
-            {
-              const bool sampled = (ln->k6_seq++ % kProfileEvery) == 0;
-              ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled);
-              pipe(0, A, 1, k == 0 ? none : B);
-            }
-            pipe(0, B, 0, A);
-            pipe(1, A, 0, B);
-            pipe(1, B, 1, A);
-          }
-          pipe(0, none, 1, B);
-        }
-        const int slot = round % 3;
-        launch_compact_split(ln->stream, g.jobs, A, B, listsA[slot], listsA[slot] + nA0, ln->d_active + 2 * slot);
-        LANE_CK(ln, hipMemcpyAsync(ln->h_active + 2 * slot, ln->d_active + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, ln->stream));
-        LANE_CK(ln, hipEventRecord(ln->round_ev[slot], ln->stream));
-        if(round == 0) continue;
-        const int prev = (round - 1) % 3;
-        LANE_CK(ln, hipEventSynchronize(ln->round_ev[prev]));
-        const int nA = ln->h_active[2 * prev], nB = ln->h_active[2 * prev + 1];
-        if(nA + nB <= 0) break;
-        A.list = listsA[prev]; A.base = 0; A.n = nA;
-        B.list = listsA[prev] + nA0; B.base = 0; B.n = nB;
-      }
-      continue;
-    }
     int* const lists[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
     int n_cur = n;
     g.active.list = nullptr;                // first rounds: every workspace of the group, in order
@@ -1180,9 +1125,6 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_STAGGER")) cp->stagger = std::atoi(e) != 0;
-    if(const char* e = std::getenv("BPVO_HIP_PIPE")) cp->pipe = std::atoi(e) != 0;
-    if(const char* e = std::getenv("BPVO_HIP_PIPE_MIN_PAIRS")) cp->pipe_min_pairs = std::max(2, std::atoi(e));
-    if(const char* e = std::getenv("BPVO_HIP_PIPE_HEAD_ROUNDS")) cp->pipe_head_rounds = std::max(0, std::min(2, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSISTENT")) cp->persistent = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
@@ -1196,14 +1138,14 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     else { CREATE_CK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
     CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipMalloc((void**) &ln.d_active, 8 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_active, 4 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_list, 3 * sizeof(int) * (size_t) n_pairs));
     for(auto& e : ln.round_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipEventCreateWithFlags(&ln.selected_ev, hipEventDisableTiming));
     for(auto& e : ln.staging_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 8 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));

@@ -73,13 +73,6 @@ bool launch_stereo_bm(hipStream_t s, const StereoLaunch& g);   // false: window 
 // of a level at 1024 pairs.  list == nullptr: every workspace of the launch, in order.
 struct ActiveSet {
   const int* list = nullptr;   // device [npairs]
-  int base = 0;                // no list: entry k is workspace base + k
-};
-// one group of a pipelined lane (gn_pipe_kernel): n entries of `list`, or workspaces base .. base + n - 1
-struct PipeSide {
-  const int* list = nullptr;
-  int base = 0;
-  int n = 0;
 };
 
 struct GNLaunch {
@@ -97,7 +90,8 @@ struct GNLaunch {
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
-void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level, int scale_is_moot = 0);
+// PoseEstimatorBase::reset of every workspace + invalidation of its tap-cache keys (max_points: the largest template of the launch)
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int max_points, int level, int scale_is_moot = 0);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
 // out_list / out_count <- the still-active workspaces among the n_in entries of `in` (or of 0..n_in-1), in order
 void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int n_in, int* out_list, int* out_count);
@@ -108,12 +102,6 @@ void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol);
-// Pipelined chain: one launch = a chip-filling kernel of one group (wide_op 0: warp_residual, 1: irls_reduce) + a narrow kernel of the
-// other group (narrow_op 0: median, 1: gn_step); kernels_gn.hip, gn_pipe_kernel.  g.jobs / max_points / loss as for the single kernels.
-bool gn_pipe_serves(const GNLaunch& g);
-void launch_gn_pipe(hipStream_t s, const GNLaunch& g, int wide_op, const PipeSide& wide, int narrow_op, const PipeSide& narrow, int max_iterations,
-                    int max_fun_evals, float p_tol, float f_tol, float g_tol);
-void launch_compact_split(hipStream_t s, const PairJob* jobs, const PipeSide& in_a, const PipeSide& in_b, int* out_a, int* out_b, int* counts);
 // Persistent kernel for small groups: one launch runs a whole level of up to kPersistMaxWs workspaces (kernels_gn.hip).  ctl: two
 // zeroed words {arrivals, abort}; after the launch ctl[1] != 0 says the kernel gave up (states untouched: rerun the chain).
 constexpr int kPersistMaxWs = 8;

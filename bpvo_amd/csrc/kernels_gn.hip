@@ -30,7 +30,7 @@ constexpr int K6_BLOCK = K6_BLOCK_VALUE;
 constexpr int K6_WAVES = K6_BLOCK / 64;
 
 // workspace of a workgroup: k-th entry of the active list, or k itself without a list
-__device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : a.base + k; }
+__device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
 
 // K7a (fused into warp_residual): bracket counting + candidate compaction for the exact median of the NEXT kernel.
 // The median moves little between GN iterations, so while the residuals are still in registers every block counts its
@@ -722,15 +722,13 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 // The work of one 1024-thread workgroup on workspace j; `st` is the state it reads and (thread 0, at the very end) updates — the
 // workspace's own in HBM, or a workgroup-local copy (persistent kernel, where every workgroup runs the selection redundantly and
 // `stats` is true for one of them only).
-// COPIES privatised pass-1 histograms (a power of two >= 2: the second one doubles as the segment-offset table of the bracketed path),
-// CACHE words of key cache: the LDS footprint is ((COPIES + 1) * MED_BINS + CACHE + 24) words.
-template <int C, int NT, int COPIES = MED_COPIES, int CACHE = MED_CACHE>
+template <int C, int NT>
 __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsigned char* smem_raw, bool stats)
 {
-  unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [COPIES][MED_BINS]
-  unsigned* hist_hi = hist_lo + COPIES * MED_BINS;                    // [MED_BINS]
-  unsigned* cache = hist_hi + MED_BINS;                                   // [CACHE]
-  unsigned* s_wave = cache + CACHE;                                   // [16]
+  unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
+  unsigned* hist_hi = hist_lo + MED_COPIES * MED_BINS;                    // [MED_BINS]
+  unsigned* cache = hist_hi + MED_BINS;                                   // [MED_CACHE]
+  unsigned* s_wave = cache + MED_CACHE;                                   // [16]
   MedCursor* cur = reinterpret_cast<MedCursor*>(s_wave + 16);             // [2]
   unsigned* s_misc = reinterpret_cast<unsigned*>(cur + 2);                // [0] cache count, [1] first valid point
 
@@ -783,7 +781,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       unsigned* s_off = hist_lo + MED_BINS;                              // [nblk + 1] — refine_pass only uses the first MED_BINS words of hist_lo
       constexpr unsigned kListRoom = 2u * (unsigned) NT;                  // cache[0 .. 2 NT): lists of the ranking step
       unsigned* dense = cache + kListRoom;
-      const bool in_lds = m <= (unsigned) CACHE - kListRoom && nblk < (COPIES - 1) * MED_BINS;
+      const bool in_lds = m <= (unsigned) MED_CACHE - kListRoom && nblk < (MED_COPIES - 1) * MED_BINS;
       if(in_lds) {
         unsigned run = 0;                                                  // running offset of the chunks of NT segments
         for(int b0 = 0; b0 < nblk; b0 += NT) {
@@ -891,11 +889,11 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
 
   // ---- full path
   if(!done) {
-    for(int i = tid; i < (COPIES + 1) * MED_BINS; i += NT) hist_lo[i] = 0;
+    for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += NT) hist_lo[i] = 0;
     if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
     __syncthreads();
     {   // pass 1: bits [30:20], privatised histogram copies
-      unsigned* h = hist_lo + (tid & (COPIES - 1)) * MED_BINS;
+      unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
       unsigned first = 0xffffffffu;
       for_each_valid_key<C, NT>(j, [&](unsigned key, int pt) {
         atomicAdd(&h[key >> 20], 1u);
@@ -910,7 +908,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     for(int q = 0; q < BPT; ++q) {
       hh[q] = 0;
 #pragma unroll
-      for(int c = 0; c < COPIES; ++c) hh[q] += hist_lo[c * MED_BINS + BPT * tid + q];
+      for(int c = 0; c < MED_COPIES; ++c) hh[q] += hist_lo[c * MED_BINS + BPT * tid + q];
       hsum += hh[q];
     }
     const unsigned excl = block_excl_scan_1024<NT>(hsum, s_wave, n_total);
@@ -927,7 +925,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
           const unsigned top = key >> 20;
           if(top == p_lo || top == p_hi) {
             const unsigned idx = atomicAdd(&s_misc[0], 1u);
-            if(idx < CACHE) cache[idx] = key;
+            if(idx < MED_CACHE) cache[idx] = key;
           }
           f(key);
         });
@@ -935,7 +933,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       const unsigned ncache = s_misc[0];
       // pass 3: bits [8:0]
       refine_pass<NT>([&](auto f) {
-        if(ncache <= CACHE) { for(unsigned i = tid; i < ncache; i += NT) f(cache[i]); }
+        if(ncache <= MED_CACHE) { for(unsigned i = tid; i < ncache; i += NT) f(cache[i]); }
         else for_each_valid_key<C, NT>(j, [&](unsigned key, int) { f(key); });
       }, 0u, 9u, lo, hi, hist_lo, hist_hi, s_wave, cur);
       const float v_lo = __uint_as_float(lo.prefix), v_hi = __uint_as_float(hi.prefix);
@@ -1593,104 +1591,6 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// PIPELINED chain for batches (round 2).  The pairs of a lane are split in two groups that run one kernel apart:
-//     launch k     : group A warp_residual     | group B gn_step
-//     launch k + 1 : group B warp_residual     | group A median
-//     launch k + 2 : group A irls_reduce       | group B median
-//     launch k + 3 : group B irls_reduce       | group A gn_step
-// so every launch pairs ONE chip-filling kernel (one workgroup per 256 / 1024 points) with ONE narrow kernel (one workgroup per
-// pair, bound by its chain of dependent steps: 9 - 13 us whatever the batch size).  As separate launches the narrow kernels
-// leave the chip idle — 21 % of the Gauss-Newton time of a 128-pair batch, 8 % at 1024 pairs — and two HIP streams hide little
-// of it (their workgroups only meet by chance and the 1024-thread / 123 KB median workgroup waits for a whole CU to drain).
-// Inside one grid the narrow workgroups come first and the wide ones fill the rest of the chip around them.  Every part calls
-// the device functions of the four kernels with the same chunk / tile indices: results are bit-identical to the chain.
-// The narrow median runs with 256 threads and a 48 KB footprint here (exact either way); its full 3-pass path is slow in that
-// shape, so the first linearisations of a level — where every pair takes it — stay on the four-kernel chain (bpvo_hip.hip).
-struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
-enum { PIPE_WARP = 0, PIPE_IRLS = 1, PIPE_MEDIAN = 0, PIPE_STEP = 1 };
-constexpr int PIPE_MED_COPIES = 2, PIPE_MED_CACHE = 6144;
-constexpr int kPipeMedWords = (PIPE_MED_COPIES + 1) * MED_BINS + PIPE_MED_CACHE + 24;
-struct PipeStepLds { uint32_t state[sizeof(GNState) / sizeof(uint32_t)]; float sum[kPartialStride]; float nrm[5]; SolveScratch scratch; };
-union PipeLds {
-  BracketLds bracket;
-  IrlsPartLds part;
-  unsigned med[kPipeMedWords];
-  PipeStepLds step;
-};
-
-template <int LOSS, int WIDE, int NARROW>
-__global__ __launch_bounds__(256) void gn_pipe_kernel(const PairJob* __restrict__ jobs, PipeSide wide, PipeSide narrow, int gx, int pts_per_block,
-                                                      GNParams prm)
-{
-  __shared__ __attribute__((aligned(16))) PipeLds lds;
-  const int b = blockIdx.x;
-  if(b < narrow.n) {
-    const PairJob& j = jobs[narrow.list ? narrow.list[b] : narrow.base + b];
-    GNState* gst = j.st;
-    if(!gst->active) return;
-    if constexpr(NARROW == PIPE_MEDIAN) {
-      if(!(gst->delta_scale > 1e-6f)) return;
-      median_block<8, 256, PIPE_MED_COPIES, PIPE_MED_CACHE>(j, gst, reinterpret_cast<unsigned char*>(lds.med), true);
-    } else {
-      if(threadIdx.x >= 64) return;                          // gn_step: one wavefront
-      constexpr int kWords = (int) (sizeof(GNState) / sizeof(uint32_t));
-      for(int i = threadIdx.x; i < kWords; i += 64) lds.step.state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
-      if(threadIdx.x < 4) lds.step.nrm[threadIdx.x] = j.nrm[threadIdx.x];
-      if(threadIdx.x == 4) lds.step.nrm[4] = j.dspace ? 1.0f : 0.0f;
-      gn_sum_partials(j, pts_per_block, threadIdx.x, lds.step.sum);
-      __builtin_amdgcn_s_barrier();     // (one wave: orders the LDS writes above; the other waves have left)
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      if(threadIdx.x == 0)
-        gn_serial_step(j, reinterpret_cast<GNState*>(lds.step.state), lds.step.nrm, lds.step.sum, &lds.step.scratch, 0, prm.max_iterations,
-                       prm.max_fun_evals, prm.p_tol, prm.f_tol, prm.g_tol, 1, true);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = lds.step.state[i];
-    }
-    return;
-  }
-  const int w = b - narrow.n;
-  const int k = w / gx, chunk = w - k * gx;
-  const PairJob& j = jobs[wide.list ? wide.list[k] : wide.base + k];
-  if constexpr(WIDE == PIPE_WARP) {
-    warp_chunk<8, false>(j, 1, (unsigned) chunk, lds.bracket);
-  } else {
-    const GNState* __restrict__ st = j.st;
-    if(!st->active) return;
-    if(chunk * pts_per_block >= j.n) return;
-    if(st->delta_scale > 1e-6f) irls_tile<8, LOSS, false>(j, st, pts_per_block, chunk, threadIdx.x, lds.part, true);
-    else irls_tile<8, LOSS, true>(j, st, pts_per_block, chunk, threadIdx.x, lds.part, true);
-  }
-}
-
-// the still-active workspaces of the two groups of a pipelined lane, each in order: block 0 -> (out_a, counts[0]), block 1 -> (out_b, counts[1])
-__global__ __launch_bounds__(1024) void compact_split_kernel(const PairJob* __restrict__ jobs, PipeSide in_a, PipeSide in_b, int* __restrict__ out_a,
-                                                             int* __restrict__ out_b, int* __restrict__ counts)
-{
-  const PipeSide in = blockIdx.x == 0 ? in_a : in_b;
-  int* __restrict__ out_list = blockIdx.x == 0 ? out_a : out_b;
-  __shared__ unsigned s_wave[16];
-  __shared__ unsigned s_base;
-  if(threadIdx.x == 0) s_base = 0;
-  __syncthreads();
-  for(int base = 0; base < in.n; base += 1024) {
-    const int k = base + threadIdx.x;
-    int ws = -1;
-    if(k < in.n) {
-      ws = in.list ? in.list[k] : in.base + k;
-      if(!jobs[ws].st->active) ws = -1;
-    }
-    unsigned total;
-    const unsigned off = block_excl_scan_1024(ws >= 0 ? 1u : 0u, s_wave, total);
-    const unsigned b = s_base;
-    if(ws >= 0) out_list[b + off] = ws;
-    __syncthreads();
-    if(threadIdx.x == 0) s_base = b + total;
-    __syncthreads();
-  }
-  if(threadIdx.x == 0) counts[blockIdx.x] = (int) s_base;
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Persistent Gauss-Newton kernel for SMALL groups (a single pair: sequential addFrame; up to kPersistMaxWs pairs): a whole
 // pyramid level — every linearisation, median, reduction, solve and pose update until the last workspace of the group has
 // finished — in ONE launch.  The four-kernel chain spends a single pair's iteration on four dependent launches of 5 - 9 us
@@ -1717,6 +1617,8 @@ constexpr int PK_VB = PK_THREADS / 256;      // 256-thread chunks / tiles per wo
 static_assert(K6_BLOCK == 256 && GN_BLOCK == 256, "the persistent kernel's virtual blocks are 256 threads");
 static_assert(PK_THREADS / 64 >= kPersistMaxWs, "pk_step_phase: one wave per workspace");
 
+
+struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
 
 // The phases are separate NON-inlined functions: inlined into one body the compiler hoists every workspace's addresses and job
 // fields across all of them and spills hundreds of bytes per lane; as functions each gets its own register allocation.  Their
@@ -1949,11 +1851,18 @@ __global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
 // every linearisation takes the fused residual + reduction path — two launches per iteration, no median.  (The reference still
 // runs estimateScale for kL2; its value is unobservable through estimatePose / addFrame.  bpvo_hip_linearize, which reports
 // sigma, computes it.)
-__global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level, int scale_is_moot)
+// One launch does both: workgroup (x, p) invalidates the tap-cache keys [256 x, 256 x + 256) of workspace p (reset_tapkeys_kernel below,
+// which the linearize seam still uses on its own), thread 0 of workgroup (0, p) resets the state.
+__global__ __launch_bounds__(GN_BLOCK) void level_begin_kernel(const PairJob* jobs, int npairs, int level, int scale_is_moot)
 {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if(p >= npairs) return;
-  GNState* st = jobs[p].st;
+  const int p = blockIdx.y;
+  const PairJob& j = jobs[p];
+  {
+    const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
+    if(i < j.n && j.tapkey) j.tapkey[i] = 0xffffffffu;
+  }
+  if(blockIdx.x != 0 || threadIdx.x != 0) return;
+  GNState* st = j.st;
   st->scale = 1.0f;
   st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
   st->f_norm_prev = 0.0f;
@@ -1969,7 +1878,7 @@ __global__ void level_begin_kernel(const PairJob* jobs, int npairs, int level, i
   st->last_median = 0.0f;
   for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
   for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
-  st->active = (jobs[p].n > 0) ? 1 : 0;
+  st->active = (j.n > 0) ? 1 : 0;
 }
 
 // invalidates the tap cache keys of every workspace of a launch (start of a level / of a linearize call)
@@ -2072,9 +1981,9 @@ void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, in
 {
   hipLaunchKernelGGL(set_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, T_init, n);
 }
-void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int level, int scale_is_moot)
+void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int max_points, int level, int scale_is_moot)
 {
-  hipLaunchKernelGGL(level_begin_kernel, dim3((npairs + 63) / 64), dim3(64), 0, s, jobs, npairs, level, scale_is_moot);
+  hipLaunchKernelGGL(level_begin_kernel, dim3(std::max(1, (max_points + GN_BLOCK - 1) / GN_BLOCK), npairs), dim3(GN_BLOCK), 0, s, jobs, npairs, level, scale_is_moot);
 }
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g)
 {
@@ -2223,41 +2132,6 @@ hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterat
   prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
   if(g.C == 8) return launch_gn_persistent_c<8>(s, g, prm, ctl, grid, timeout_ticks);
   return launch_gn_persistent_c<1>(s, g, prm, ctl, grid, timeout_ticks);
-}
-// ---- pipelined chain (gn_pipe_kernel)
-bool gn_pipe_serves(const GNLaunch& g)
-{
-  return g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR;
-}
-template <int WIDE, int NARROW>
-static void launch_gn_pipe_t(hipStream_t s, const GNLaunch& g, const PipeSide& wide, const PipeSide& narrow, int gx, int ppb, const GNParams& prm)
-{
-  const dim3 grid(narrow.n + wide.n * gx);
-  switch(g.loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((gn_pipe_kernel<BPVO_LOSS_HUBER, WIDE, NARROW>), grid, dim3(256), 0, s, g.jobs, wide, narrow, gx, ppb, prm); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((gn_pipe_kernel<BPVO_LOSS_TUKEY, WIDE, NARROW>), grid, dim3(256), 0, s, g.jobs, wide, narrow, gx, ppb, prm); break;
-    default: hipLaunchKernelGGL((gn_pipe_kernel<BPVO_LOSS_L2, WIDE, NARROW>), grid, dim3(256), 0, s, g.jobs, wide, narrow, gx, ppb, prm); break;
-  }
-}
-void launch_gn_pipe(hipStream_t s, const GNLaunch& g, int wide_op, const PipeSide& wide, int narrow_op, const PipeSide& narrow, int max_iterations,
-                    int max_fun_evals, float p_tol, float f_tol, float g_tol)
-{
-  if(g.max_points <= 0 || wide.n + narrow.n <= 0) return;
-  GNParams prm;
-  prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
-  const int ppb = gn_pts_per_block(8);
-  const int gx = wide_op == 0 ? (g.max_points + K6_BLOCK - 1) / K6_BLOCK : (g.max_points + ppb - 1) / ppb;
-  if(wide_op == 0) {
-    if(narrow_op == 0) launch_gn_pipe_t<PIPE_WARP, PIPE_MEDIAN>(s, g, wide, narrow, gx, ppb, prm);
-    else launch_gn_pipe_t<PIPE_WARP, PIPE_STEP>(s, g, wide, narrow, gx, ppb, prm);
-  } else {
-    if(narrow_op == 0) launch_gn_pipe_t<PIPE_IRLS, PIPE_MEDIAN>(s, g, wide, narrow, gx, ppb, prm);
-    else launch_gn_pipe_t<PIPE_IRLS, PIPE_STEP>(s, g, wide, narrow, gx, ppb, prm);
-  }
-}
-void launch_compact_split(hipStream_t s, const PairJob* jobs, const PipeSide& in_a, const PipeSide& in_b, int* out_a, int* out_b, int* counts)
-{
-  hipLaunchKernelGGL(compact_split_kernel, dim3(2), dim3(1024), 0, s, jobs, in_a, in_b, out_a, out_b, counts);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
 {
