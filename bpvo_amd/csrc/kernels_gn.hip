@@ -76,7 +76,7 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
   unsigned woff = 0;
   if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
     const unsigned t_in = __shfl(incl, 63);
-    if(lane == 0 && write) reinterpret_cast<uint4*>(j.med_blk)[blk] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
+    if(lane == 0 && write) reinterpret_cast<uint4*>(j.med_blk.get())[blk] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
   } else {
     if(lane == 63) s.in[wave] = incl;
     if(lane == 0) { s.below[wave] = sum_below; s.valid[wave] = sum_valid; }
@@ -85,7 +85,7 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
     if(wave == 0 && lane == 0 && write) {
       uint4 o = make_uint4(0u, 0u, 0u, 0u);
       for(int w = 0; w < K6_WAVES; ++w) { o.x += s.below[w]; o.y += s.in[w]; o.z += s.valid[w] & 0xffffu; o.w += s.valid[w] >> 16; }
-      reinterpret_cast<uint4*>(j.med_blk)[blk] = o;
+      reinterpret_cast<uint4*>(j.med_blk.get())[blk] = o;
     }
   }
   if(cnt) {
@@ -165,7 +165,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
   unsigned spec_key = 0; float4 spec_taps = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float spec_pix = 0.0f;
   if constexpr(C == 1) {
     spec_key = j.tapkey[i];
-    spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache) + i);
+    spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache.get()) + i);
     spec_pix = j.pix[i];
   }
   int xi = 0, yi = 0;
@@ -224,8 +224,8 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
       const bool hit = j.tapkey[i] == key;
       cache_hit = hit;
-      float4* tc = reinterpret_cast<float4*>(j.tapcache);
-      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+      float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
 #pragma unroll
       for(int h = 0; h < 2; ++h) {
         float4 a, b, c, d;      // I00, I01, I10, I11 of channels 4h .. 4h+3
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const bool hit = j.tapkey[i] == key;
       cache_hit = hit;
       float4 a0, a1, a2, a3, b0, b1, b2, b3;
-      float4* tc = reinterpret_cast<float4*>(j.tapcache);
+      float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
       if(hit) {
         a0 = load_v4<NT>(tc + tile_index<8>(i, 0)); a1 = load_v4<NT>(tc + tile_index<8>(i, 1));
         a2 = load_v4<NT>(tc + tile_index<8>(i, 2)); a3 = load_v4<NT>(tc + tile_index<8>(i, 3));
@@ -290,7 +290,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
           j.tapkey[i] = key;
         }
       }
-      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
       const float4 t0 = load_v4<NT>(p0 + tile_index<2>(i, 0)), t1 = load_v4<NT>(p0 + tile_index<2>(i, 1));
       I00[0] = a0.x; I00[1] = a0.y; I00[2] = a0.z; I00[3] = a0.w; I00[4] = a1.x; I00[5] = a1.y; I00[6] = a1.z; I00[7] = a1.w;
       I01[0] = a2.x; I01[1] = a2.y; I01[2] = a2.z; I01[3] = a2.w; I01[4] = a3.x; I01[5] = a3.y; I01[6] = a3.z; I01[7] = a3.w;
@@ -301,7 +301,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       // the same tap cache for single-channel descriptors: the four taps of a point are one 16-byte record.  The gather
       // costs two (mostly distinct) HBM lines per point at the sparse levels for 16 useful bytes; a hit is one coalesced load.
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-      float4* tc = reinterpret_cast<float4*>(j.tapcache);
+      float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
       float4 t = spec_taps;
       cache_hit = spec_key == key;
       if(spec_key != key) {
@@ -333,7 +333,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       for(int c = 0; c < C; ++c) res[c] = 0.0f;
     } else {   // operator() returns 0 for an invalid point and run() still subtracts I0 (photo_error.cc:203-210)
       if constexpr(C == 8) {
-        const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+        const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
         const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
         res[0] = 0.0f - t0.x; res[1] = 0.0f - t0.y; res[2] = 0.0f - t0.z; res[3] = 0.0f - t0.w;
         res[4] = 0.0f - t1.x; res[5] = 0.0f - t1.y; res[6] = 0.0f - t1.z; res[7] = 0.0f - t1.w;
@@ -380,7 +380,7 @@ __device__ __forceinline__ void warp_chunk(const PairJob& j, int mode, unsigned 
   if(in_block) j.valid[i] = valid ? 1 : 0;
   if(in_block) {
     if constexpr(C == 8) {     // tiled residual record: two fully coalesced 16-byte stores per lane
-      float4* o = reinterpret_cast<float4*>(j.r);
+      float4* o = reinterpret_cast<float4*>(j.r.get());
       store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
       store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
     } else {      // generic C: point-major records [N][C]
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
   if(valid) {
     float I0[C];
     if constexpr(C == 8) {
-      const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+      const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
       const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
       I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
     } else {
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
   }
   if(in_block) {
     if constexpr(C == 8) {
-      float4* o = reinterpret_cast<float4*>(j.r);
+      float4* o = reinterpret_cast<float4*>(j.r.get());
       o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
       o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
     } else {
@@ -627,7 +627,7 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
 {
   const int n = j.n;
   if constexpr(C == 8) {
-    const float4* q = reinterpret_cast<const float4*>(j.r);
+    const float4* q = reinterpret_cast<const float4*>(j.r.get());
     constexpr int U = 4;   // points in flight per thread: all loads of a round are issued before any is consumed
     for(int base = threadIdx.x; base < n; base += NT * U) {
       unsigned char v[U];
@@ -744,7 +744,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     const int nblk = (j.n + K6_BLOCK - 1) / K6_BLOCK;
     unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0, cnt_first = 0;    // cnt_first: candidates of segment `tid`
     for(int b = tid; b < nblk; b += NT) {
-      const uint4 o = reinterpret_cast<const uint4*>(j.med_blk)[b];
+      const uint4 o = reinterpret_cast<const uint4*>(j.med_blk.get())[b];
       if(b == tid) cnt_first = o.y;
       c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
     }
@@ -786,7 +786,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
         unsigned run = 0;                                                  // running offset of the chunks of NT segments
         for(int b0 = 0; b0 < nblk; b0 += NT) {
           const int b = b0 + tid;
-          const unsigned cnt = b0 == 0 ? cnt_first : (b < nblk ? reinterpret_cast<const uint4*>(j.med_blk)[b].y : 0u);
+          const unsigned cnt = b0 == 0 ? cnt_first : (b < nblk ? reinterpret_cast<const uint4*>(j.med_blk.get())[b].y : 0u);
           unsigned total;
           const unsigned off = block_excl_scan_1024<NT>(cnt, s_wave, total);
           if(b < nblk) s_off[b] = run + off;
@@ -827,7 +827,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
         }
         const int lane = tid & 63, wave = tid >> 6;
         for(int b = wave; b < nblk; b += NT / 64) {
-          const unsigned mb = reinterpret_cast<const uint4*>(j.med_blk)[b].y;
+          const unsigned mb = reinterpret_cast<const uint4*>(j.med_blk.get())[b].y;
           const unsigned* seg = j.cand + (size_t) b * K6_BLOCK * C;
           for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
         }
@@ -1070,8 +1070,8 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
     // summation order (H, G are tolerance-compared).
     const float4 Pt = load_stream(j.pts + i);
     if constexpr(C == 8) {
-      const float4* qr = reinterpret_cast<const float4*>(j.r);
-      const float4* qg = reinterpret_cast<const float4*>(j.grad);
+      const float4* qr = reinterpret_cast<const float4*>(j.r.get());
+      const float4* qg = reinterpret_cast<const float4*>(j.grad.get());
       if constexpr(!fused) {
         const float4 r0 = load_stream(qr + tile_index<2>(i, 0)), r1 = load_stream(qr + tile_index<2>(i, 1));
         rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
@@ -1082,7 +1082,7 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
       Iy[0] = gy0.x; Iy[1] = gy0.y; Iy[2] = gy0.z; Iy[3] = gy0.w; Iy[4] = gy1.x; Iy[5] = gy1.y; Iy[6] = gy1.z; Iy[7] = gy1.w;
     } else if constexpr(C == 1) {
       rr[0] = j.r[i];
-      const float2 g2 = reinterpret_cast<const float2*>(j.grad)[i];
+      const float2 g2 = reinterpret_cast<const float2*>(j.grad.get())[i];
       Ix[0] = g2.x; Iy[0] = g2.y;
     } else {      // generic C: point-major r[N][C], grad[N][2][C]
 #pragma unroll
@@ -1179,17 +1179,17 @@ template <bool FUSED>
 __device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPointLat& d)
 {
   d.Pt = load_v4<false>(j.pts + i);
-  const float4* qg = reinterpret_cast<const float4*>(j.grad);
+  const float4* qg = reinterpret_cast<const float4*>(j.grad.get());
   if constexpr(FUSED) {
     d.key = j.tapkey[i];
-    const float4* tc = reinterpret_cast<const float4*>(j.tapcache);
+    const float4* tc = reinterpret_cast<const float4*>(j.tapcache.get());
 #pragma unroll
     for(int k = 0; k < 8; ++k) d.tc[k] = load_v4<false>(tc + tile_index<8>(i, k));
-    const float4* p0 = reinterpret_cast<const float4*>(j.pix);
+    const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
     d.px[0] = load_v4<false>(p0 + tile_index<2>(i, 0)); d.px[1] = load_v4<false>(p0 + tile_index<2>(i, 1));
   } else {
     d.v = (float) j.valid[i];
-    const float4* qr = reinterpret_cast<const float4*>(j.r);
+    const float4* qr = reinterpret_cast<const float4*>(j.r.get());
     d.r[0] = load_v4<false>(qr + tile_index<2>(i, 0)); d.r[1] = load_v4<false>(qr + tile_index<2>(i, 1));
   }
 #pragma unroll
@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
           const float4* q1 = q0 + (size_t) W * 2;
           t[0] = q0[0]; t[1] = q0[1]; t[2] = q0[2]; t[3] = q0[3];
           t[4] = q1[0]; t[5] = q1[1]; t[6] = q1[2]; t[7] = q1[3];
-          float4* tcw = reinterpret_cast<float4*>(j.tapcache);
+          float4* tcw = reinterpret_cast<float4*>(j.tapcache.get());
 #pragma unroll
           for(int k = 0; k < 8; ++k) store_v4<false>(tcw + tile_index<8>(i, k), t[k]);
           j.tapkey[i] = key;
@@ -1660,7 +1660,7 @@ __device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restric
     if(in_block) {
       j.valid[i] = valid ? 1 : 0;
       if constexpr(C == 8) {
-        float4* o = reinterpret_cast<float4*>(j.r);
+        float4* o = reinterpret_cast<float4*>(j.r.get());
         o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
         o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
       } else {
@@ -1749,7 +1749,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
   const bool fuse = kCanFuse && fuse_frozen;
 
   for(int ws = 0; ws < nws; ++ws) {
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs[ws].st);
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs[ws].st.get());
     for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[ws][i] = g[i];
     if(tid < 4) pk_nrm[ws][tid] = jobs[ws].nrm[tid];
     if(tid == 4) pk_nrm[ws][4] = jobs[ws].dspace ? 1.0f : 0.0f;
@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
 
   if(ok && blockIdx.x == 0) {
     for(int ws = 0; ws < nws; ++ws) {
-      uint32_t* g = reinterpret_cast<uint32_t*>(jobs[ws].st);
+      uint32_t* g = reinterpret_cast<uint32_t*>(jobs[ws].st.get());
       for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[ws][i];
     }
   }
@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, float*
   if(i >= job->n) return;
   const float sigma_inv = 1.0f / job->st->scale;
   if constexpr(C == 8) {
-    const float4* q = reinterpret_cast<const float4*>(job->r);
+    const float4* q = reinterpret_cast<const float4*>(job->r.get());
     const float4 a = q[tile_index<2>(i, 0)], b = q[tile_index<2>(i, 1)];
     float* o = w_out + (size_t) i * 8;
     o[0] = mest_weight<LOSS>(a.x, sigma_inv); o[1] = mest_weight<LOSS>(a.y, sigma_inv);
@@ -1931,7 +1931,7 @@ __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, flo
   if(i < job->n) {
     const float sigma_inv = 1.0f / job->st->scale;
     if constexpr(C == 8) {
-      const float4* q = reinterpret_cast<const float4*>(job->r);
+      const float4* q = reinterpret_cast<const float4*>(job->r.get());
       const float4 a = q[tile_index<2>(i, 0)], b = q[tile_index<2>(i, 1)];
       good = (mest_weight<LOSS>(a.x, sigma_inv) > thr) + (mest_weight<LOSS>(a.y, sigma_inv) > thr) +
              (mest_weight<LOSS>(a.z, sigma_inv) > thr) + (mest_weight<LOSS>(a.w, sigma_inv) > thr) +

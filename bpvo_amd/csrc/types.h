@@ -134,55 +134,73 @@ template <bool NT>
 __device__ __forceinline__ void store_v4(float4* p, const float4& a) { if constexpr(NT) store_stream(p, a); else *p = a; }
 #endif
 
+// Pointer members of the job tables.  A pointer a kernel loads from memory is a GENERIC pointer to the compiler (it cannot know the
+// address space), and every access through it becomes a flat_load / flat_store: 64-bit address arithmetic in vector registers, a wait on
+// both memory counters, the LDS aperture check.  Declared as global-address-space pointers in the device pass (same eight bytes, same
+// layout as the host's plain pointer) the accesses are global_load / global_store — the whole Gauss-Newton and frame code was flat.
+template <class T>
+struct GPtr {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef T __attribute__((address_space(1)))* raw_t;
+#else
+  typedef T* raw_t;
+#endif
+  raw_t p;
+  __host__ __device__ operator T*() const { return (T*) p; }
+  __host__ __device__ T* get() const { return (T*) p; }
+  __host__ __device__ T* operator->() const { return (T*) p; }
+  __host__ __device__ GPtr& operator=(T* q) { p = (raw_t) q; return *this; }
+};
+
 // everything a kernel needs to know about one (workspace, level) linearisation
 struct PairJob {
   // template (reference frame) at this level
-  const float4* pts;      // [N] (X,Y,Z,1)
-  const float*  pix;      // [N][C] tiled (see tile_index)
-  const float*  grad;     // [N][2][C] tiled: (fx*Ix[c]), (fy*Iy[c]) — the 1x6 Jacobians are recomputed from these
-  const float*  nrm;      // (s, c1, c2, c3) Hartley normalisation of the level
+  GPtr<const float4> pts;      // [N] (X,Y,Z,1)
+  GPtr<const float> pix;      // [N][C] tiled (see tile_index)
+  GPtr<const float> grad;     // [N][2][C] tiled: (fx*Ix[c]), (fy*Iy[c]) — the 1x6 Jacobians are recomputed from these
+  GPtr<const float> nrm;      // (s, c1, c2, c3) Hartley normalisation of the level
   int           n;        // number of points (multiple of 16)
   // current frame descriptor at this level, pixel-interleaved [rows*cols][C]
-  const float*  desc;
+  GPtr<const float> desc;
   int           rows, cols;
   float         K[9];     // level intrinsics (K * 0.5^l, K(2,2) = 1)
   float         b;        // level baseline (b * 2^l)
   int           dspace;   // 1: DisparitySpaceWarp (BPVO_WARP_DISPARITY_SPACE_F32): pts = (x - cx, y - cy, d, 1), grad = raw (Ix, Iy)
   // workspace
-  float*        r;        // [N][C] residuals, tiled
-  uint8_t*      valid;    // [N]
-  uint32_t*     tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 and C = 1)
-  float*        tapcache; // C = 8: [N][32] tiled, the 4 taps x 8 channels of the footprint last gathered for the point; C = 1: [N] float4
-  uint32_t*     cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
-  uint32_t*     med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, tap-cache hits} of the bracket pass
-  float*        partials; // [nblocks][kPartialStride]
-  unsigned long long* cnt; // [kWsCounters] per-workspace measurement counters: [0] points linearised, [1] linearisations,
+  GPtr<float> r;        // [N][C] residuals, tiled
+  GPtr<uint8_t> valid;    // [N]
+  GPtr<uint32_t> tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 and C = 1)
+  GPtr<float> tapcache; // C = 8: [N][32] tiled, the 4 taps x 8 channels of the footprint last gathered for the point; C = 1: [N] float4
+  GPtr<uint32_t> cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
+  GPtr<uint32_t> med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, tap-cache hits} of the bracket pass
+  GPtr<float> partials; // [nblocks][kPartialStride]
+  GPtr<unsigned long long> cnt; // [kWsCounters] per-workspace measurement counters: [0] points linearised, [1] linearisations,
                            // [2] bracketed / [3] full median selections, [4] points processed by warp_residual (the rest
                            // went through the fused path of irls_reduce), [5] tap-cache hits / [6] lookups (= valid points),
                            // [7] / [8] the same over the first 8 linearisations of a level, [10] points linearised through the
                            // fused path; written by one thread each: no atomics
-  GNState*      st;
+  GPtr<GNState> st;
 };
 
 // selection / template-build job for one (frame, level)
 constexpr int kDfPlanes = 7;
 struct FrameJob {
-  const uint8_t* img;       // level image u8
-  uint8_t*       cen;       // census scratch u8 (BitPlanes)
-  float*         desc;      // [rows*cols][C]
-  float*         ch0;       // [rows*cols] copy of descriptor channel 0 (C = 8): the saliency map needs little else (Q7), and a
+  GPtr<const uint8_t> img;       // level image u8
+  GPtr<uint8_t> cen;       // census scratch u8 (BitPlanes)
+  GPtr<float> desc;      // [rows*cols][C]
+  GPtr<float> ch0;       // [rows*cols] copy of descriptor channel 0 (C = 8): the saliency map needs little else (Q7), and a
                             // compact plane spares it a strided pass over the 32-byte records
-  float*         scratch;   // descriptor fields: kDfPlanes work planes of the level-0 size
-  float*         sal;       // [rows*cols]
-  uint8_t*       flag;      // [rows*cols] candidate flags
-  int*           blk_count; // [nblk] then exclusive offsets
-  int*           n_out;     // device: number of points kept (multiple of 16)
-  const float*   disp;      // full-resolution disparity
-  float4*        pts;
-  int*           inds;
-  float*         pix;
-  float*         grad;
-  float*         nrm;       // (s, c1, c2, c3)
+  GPtr<float> scratch;   // descriptor fields: kDfPlanes work planes of the level-0 size
+  GPtr<float> sal;       // [rows*cols]
+  GPtr<uint8_t> flag;      // [rows*cols] candidate flags
+  GPtr<int> blk_count; // [nblk] then exclusive offsets
+  GPtr<int> n_out;     // device: number of points kept (multiple of 16)
+  GPtr<const float> disp;      // full-resolution disparity
+  GPtr<float4> pts;
+  GPtr<int> inds;
+  GPtr<float> pix;
+  GPtr<float> grad;
+  GPtr<float> nrm;       // (s, c1, c2, c3)
   int            rows, cols, level, disp_cols;
   int            cap;       // capacity of pts/inds
   int            nms_radius;   // <= 0: NMS off for this level

@@ -40,6 +40,14 @@ for s, e in iv[1:]:
     else: ce = max(ce, e)
 tot += ce - cs
 print("some kernel running: %.2f ms of %.2f" % (tot / 1e6, (max(r[2] for r in rows) - t0) / 1e6))
+# frame stage (everything before the first level_begin of a queue): time per kernel
+for q, rs in byq.items():
+    acc = collections.OrderedDict()
+    for n, s, e, _ in rs:
+        sn = short(n).replace("_kernel", "")
+        if sn == "level_begin": break
+        a = acc.setdefault(sn, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
+    if acc: print("queue", q, "frame stage:", " ".join("%s %dx=%.0fus" % (k, v[0], v[1]) for k, v in acc.items()), "| total %.2f ms" % (sum(v[1] for v in acc.values()) / 1e3))
 # per queue and level: launches, mean duration per kernel, summed gaps (end -> next start on the same queue)
 for q, rs in byq.items():
     lvl = -1; acc = collections.OrderedDict()
