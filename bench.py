@@ -309,7 +309,7 @@ def main():
     kstats_1lane = {}
     if not args.no_profile:
         ctx.set_max_lanes(1)
-        ctx.profiling(2 if args.profile_all else 1)
+        ctx.profiling(2 if args.profile_all else 3)     # 3: every warp_residual launch, so that the average is rocprofv3's average
         ctx.batch_run_device(P, d_images.data_ptr(), d_disps.data_ptr())
         torch.cuda.synchronize()
         kstats_1lane = {k["name"]: k for k in ctx.kernel_stats()}
@@ -377,7 +377,7 @@ def main():
                         "frac": k["algorithmic_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
                         "bytes_per_point": 18 + 24 * (8 if args.descriptor == "bitplanes" else 1),
                         "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"],
-                        "measured": "one untimed step of the same workload on a single estimation lane, HIP events around every 5th launch on the "
+                        "measured": "one untimed step of the same workload on a single estimation lane, HIP events around EVERY launch on the "
                                     "library's stream (the timed steps overlap two lanes: roofline_timed_region)"}
 
         # the whole Gauss-Newton loop against the HBM roofline: algorithmic bytes of one iteration (20 + 56 C per point)

@@ -391,7 +391,8 @@ class Context:
 
     # -- measurement
     def profiling(self, level=1):
-        """0 off, 1 = HIP events around warp_residual + frame stages, 2 = around every kernel. Resets the counters."""
+        """0 off, 1 = HIP events around the frame stages + every 5th warp_residual launch, 2 = around every kernel, 3 = as 1 with every
+        warp_residual launch. Resets the counters."""
         self.call("profiling", int(level))
 
     def kernel_stats(self):

@@ -182,6 +182,7 @@ struct bpvo_hip_ctx {
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)
+  bool profile_k6_all = false; // level 3: events around EVERY warp_residual launch (and nothing else in the loop): bench.py's roofline pass
   double kc_ms[KC_COUNT] = {};
   double kc_units[KC_COUNT] = {};
   uint64_t kc_launches[KC_COUNT] = {};
@@ -677,7 +678,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       for(int k = 0; k < kItersPerSync; ++k) {
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
-        const bool sampled = c->profile_all || (ln->k6_seq++ % kProfileEvery) == 0;
+        const bool sampled = c->profile_all || c->profile_k6_all || (ln->k6_seq++ % kProfileEvery) == 0;
         { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
         if(c->profile_all) {
           { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
@@ -824,7 +825,7 @@ int refresh_counters(bpvo_hip_ctx* c)
   // the sampled launches so that units / launches stays the points of an average launch
   double all_k6 = 0;
   for(const auto& ln : c->lanes) all_k6 += ln.k6_seq;
-  const bool sampled = c->profiling && !c->profile_all && all_k6 > 0;
+  const bool sampled = c->profiling && !c->profile_all && !c->profile_k6_all && all_k6 > 0;
   // (h[4]: the points warp_residual itself processed; workspaces with a frozen scale go through irls_reduce's fused path)
   c->kc_units[KC_WARP_RESIDUAL] = sampled ? (double) h[4] * (double) c->kc_launches[KC_WARP_RESIDUAL] / all_k6 : (double) h[4];
   c->points_fused = (double) h[10];
@@ -1870,7 +1871,8 @@ int bpvo_hip_profiling(bpvo_hip_ctx* c, int enable)
   HIP_CK(c, hipStreamSynchronize(c->stream));
   resolve_events(c);
   c->profiling = enable != 0;
-  c->profile_all = enable >= 2;
+  c->profile_all = enable == 2;
+  c->profile_k6_all = enable == 3;
   for(int k = 0; k < KC_COUNT; ++k) { c->kc_ms[k] = 0; c->kc_units[k] = 0; c->kc_launches[k] = 0; }
   HIP_CK(c, hipMemset(c->d_counters, 0, kWsCounters * sizeof(unsigned long long) * c->n_pairs));
   c->total_lin = 0;

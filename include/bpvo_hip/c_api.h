@@ -262,7 +262,8 @@ typedef struct bpvo_hip_kernel_stat {
   double   bytes_per_unit;    /* algorithmic bytes per unit */
 } bpvo_hip_kernel_stat;
 /* 0 off; 1: HIP events around the frame stages and around every 5th warp_residual launch of a batch estimate (the
- * reported units are scaled to the sampled launches); 2: around every launch of every kernel.  Resets the counters. */
+ * reported units are scaled to the sampled launches); 2: around every launch of every kernel; 3: as 1, but around EVERY
+ * warp_residual launch (the average is then over the same launches as a rocprofv3 kernel trace's).  Resets the counters. */
 int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);
 int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int max_out, int* n_out);
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */
