@@ -152,6 +152,8 @@ struct GPtr {
   __host__ __device__ GPtr& operator=(T* q) { p = (raw_t) q; return *this; }
 };
 
+static_assert(sizeof(GPtr<float>) == sizeof(float*) && alignof(GPtr<float>) == alignof(float*), "GPtr must be layout-compatible with a plain pointer: the host fills the tables the device reads");
+
 // everything a kernel needs to know about one (workspace, level) linearisation
 struct PairJob {
   // template (reference frame) at this level
