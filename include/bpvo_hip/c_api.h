@@ -215,7 +215,12 @@ int bpvo_hip_get_trajectory(bpvo_hip_ctx* ctx, float* poses /*[n][16]*/);
  * Pair p uses frame slots 2p (reference/template frame A) and 2p+1 (current frame B) and workspace p.
  * For each pair: A.setData, A.setTemplate, B.setData, estimatePose(A, B, Identity) -> poses[p].
  * images = [A0,B0,A1,B1,...] (2*n_pairs images), disparities likewise (B's disparity is stored but unused).
- * stats = [n_pairs][numLevels]. */
+ * stats = [n_pairs][numLevels].
+ * A pyramid level of a pair whose template keeps no point does not fail the batch (the reference's computeResiduals throws there,
+ * bpvo/template_data.cc:177, and so do the single-pair entry points: BPVO_ERR_NO_TEMPLATE): that level of that pair is skipped, its
+ * statistics stay at the OptimizerStatistics() defaults {0, -1, -1, BPVO_STATUS_SOLVER_ERROR} and its pose passes through.
+ * With two or more estimation lanes each lane runs its share of the pairs end to end on its own stream (frame stages queued one behind
+ * the other): same results, bit for bit, as the three stages called one after the other. */
 int bpvo_hip_batch_run(bpvo_hip_ctx* ctx, int n_pairs, const uint8_t* images, const float* disparities,
                        int on_device, float* poses /*[n_pairs][16]*/, bpvo_hip_stats* stats);
 /* same, but only the estimatePose stage on already prepared slots */

@@ -401,6 +401,12 @@ def test_full_size_batch_properties(hip):
     poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
     poses2, stats2 = ctx.batch_run(batch["images"], batch["disparities"])
     assert np.array_equal(poses, poses2) and np.array_equal(stats["numIterations"], stats2["numIterations"])   # deterministic
+    # batch_run runs every estimation lane's pairs end to end on the lane's stream (staggered frame stages); the three stages called
+    # one after the other over all pairs give the same results bit for bit
+    ctx.frames_set_data(0, 1, batch["images"], batch["disparities"])
+    ctx.frames_set_template(0, 2, n)
+    poses3, stats3 = ctx.batch_estimate(n)
+    assert np.array_equal(poses3, poses) and np.array_equal(stats3["numIterations"], stats["numIterations"])
     # reversed pair order in a second context: every pair's result is unchanged bit for bit
     perm = np.arange(n)[::-1]
     idx = np.stack([2 * perm, 2 * perm + 1], axis=1).reshape(-1)
