@@ -92,9 +92,9 @@ struct Lane {
   PairJob* d_pjobs = nullptr;      // [L][n_pairs]
   float* h_T = nullptr;            // pinned [n_pairs][16]
   float* d_Tinit = nullptr;
-  int* d_active = nullptr;         // [3] counts of the active lists
+  int* d_active = nullptr;         // [3][2] per round in flight: entries of the active list, and how many of them still estimate their scale
   int* d_list = nullptr;           // [3][n_pairs] active-workspace lists of the host rounds in flight (ActiveSet)
-  int* h_active = nullptr;         // pinned [4]
+  int* h_active = nullptr;         // pinned [3][2]
   hipEvent_t round_ev[3] = {};     // "compaction of round r and its count have landed"
   hipEvent_t staging_ev[2] = {};   // "the upload of this lane's rows of FrameJob table 0 / 1 has left the pinned staging"
   hipEvent_t selected_ev = nullptr; // staggered batches: "the selection of this lane's templates has been queued" (FrameRun)
@@ -176,6 +176,7 @@ struct bpvo_hip_ctx {
   float* st_disp = nullptr;
   int st_frames = 0;
   bool counted_live = false;   // this context is in g_live_ctx
+  bool skip_frozen_launches = true;   // BPVO_HIP_SKIP_FROZEN=0: keep launching warp_residual / median when every active scale is frozen (A/B)
   bool stagger = true;         // BPVO_HIP_STAGGER=0: batches run stage by stage over all pairs (batch_run_staggered)
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
   bool split_census = false;   // BPVO_HIP_SPLIT_CENSUS=1: census as its own kernel even where it can be fused (A/B measurements)
@@ -672,44 +673,56 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     int* const lists[3] = {ln->d_list, ln->d_list + NP, ln->d_list + 2 * (size_t) NP};
     int n_cur = n;
     g.active.list = nullptr;                // first rounds: every workspace of the group, in order
+    // Once NO active workspace of the list estimates its robust scale any more (a frozen scale stays frozen for the level, and the
+    // list only shrinks), the median has nothing to do and — with the fused path, where irls_reduce recomputes the residuals of
+    // frozen workspaces itself — neither has warp_residual: their launches are dropped for the rest of the level.  (Each would
+    // still cost its floor of ~5 us per iteration in the tail of a level.)  l2_moot: true from the first linearisation.
+    const bool fused_path = c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+    bool none_moving = l2_moot && c->skip_frozen_launches;
     for(int round = 0; round < max_rounds; ++round) {
       g.npairs = n_cur;
       g.merge_irls = n_cur < c->irls_merge_below ? 1 : 0;
+      const bool launch_median_k = !none_moving, launch_warp_k = !(none_moving && fused_path);
       for(int k = 0; k < kItersPerSync; ++k) {
         // level 1 brackets every kProfileEvery-th warp_residual launch of the lane with events (a running counter, so the
         // sampled launches rotate through all iterations and levels): an event pair costs a few µs of dispatch gap
-        const bool sampled = c->profile_all || c->profile_k6_all || (ln->k6_seq++ % kProfileEvery) == 0;
-        { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled); launch_warp_residual(ln->stream, g); }
+        if(launch_warp_k) {
+          const bool sampled = c->profile_all || c->profile_k6_all || (ln->k6_seq++ % kProfileEvery) == 0;
+          ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled);
+          launch_warp_residual(ln->stream, g);
+        }
         if(c->profile_all) {
-          { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
+          if(launch_median_k) { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
           { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
           { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
             launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
                            p.gradientTolerance); }
         } else {
-          launch_median(ln->stream, g);
+          if(launch_median_k) launch_median(ln->stream, g);
           launch_irls_reduce(ln->stream, g);
           launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
                          p.gradientTolerance);
         }
       }
       const int slot = round % 3;
-      launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + slot);
-      LANE_CK(ln, hipMemcpyAsync(ln->h_active + slot, ln->d_active + slot, sizeof(int), hipMemcpyDeviceToHost, ln->stream));
+      launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + 2 * slot);
+      LANE_CK(ln, hipMemcpyAsync(ln->h_active + 2 * slot, ln->d_active + 2 * slot, 2 * sizeof(int), hipMemcpyDeviceToHost, ln->stream));
       LANE_CK(ln, hipEventRecord(ln->round_ev[slot], ln->stream));
       if(c->sync_rounds) {                  // A/B: one synchronisation per round, the round's own list feeds the next
         LANE_CK(ln, hipStreamSynchronize(ln->stream));
-        if(ln->h_active[slot] <= 0) break;
-        n_cur = ln->h_active[slot];
+        if(ln->h_active[2 * slot] <= 0) break;
+        n_cur = ln->h_active[2 * slot];
+        none_moving = none_moving || (c->skip_frozen_launches && ln->h_active[2 * slot + 1] == 0);
         g.active.list = lists[slot];
         continue;
       }
       if(round == 0) continue;              // nothing to learn yet: queue the second round behind the first
       const int prev = (round - 1) % 3;
       LANE_CK(ln, hipEventSynchronize(ln->round_ev[prev]));
-      const int n_prev = ln->h_active[prev];
+      const int n_prev = ln->h_active[2 * prev];
       if(n_prev <= 0) break;                // (the round just queued runs empty)
       n_cur = n_prev;
+      none_moving = none_moving || (c->skip_frozen_launches && ln->h_active[2 * prev + 1] == 0);
       g.active.list = lists[prev];
     }
   }
@@ -1126,6 +1139,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_IRLS_MERGE_BELOW")) cp->irls_merge_below = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_STAGGER")) cp->stagger = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_SKIP_FROZEN")) cp->skip_frozen_launches = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSISTENT")) cp->persistent = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
@@ -1139,14 +1153,14 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     else { CREATE_CK(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
     CREATE_CK(hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipMalloc((void**) &ln.d_active, 4 * sizeof(int)));
+    CREATE_CK(hipMalloc((void**) &ln.d_active, 8 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_list, 3 * sizeof(int) * (size_t) n_pairs));
     for(auto& e : ln.round_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipEventCreateWithFlags(&ln.selected_ev, hipEventDisableTiming));
     for(auto& e : ln.staging_ev) CREATE_CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) cp->L * n_pairs));
     CREATE_CK(hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
-    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 4 * sizeof(int)));
+    CREATE_CK(hipHostMalloc((void**) &ln.h_active, 8 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));

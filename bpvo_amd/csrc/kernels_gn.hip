@@ -1568,16 +1568,21 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
 __global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __restrict__ jobs, ActiveSet in, int n_in,
                                                               int* __restrict__ out_list, int* __restrict__ out_count)
 {
+  // out_count[0]: entries of the new list; out_count[1]: how many of them still estimate their robust scale (delta_scale > 1e-6).  A
+  // frozen scale stays frozen for the rest of the level, so once [1] is 0 the host stops launching warp_residual (fused path) and median.
   __shared__ unsigned s_wave[16];
-  __shared__ unsigned s_base;
-  if(threadIdx.x == 0) s_base = 0;
+  __shared__ unsigned s_base, s_moving;
+  if(threadIdx.x == 0) { s_base = 0; s_moving = 0; }
   __syncthreads();
+  unsigned moving = 0;
   for(int base = 0; base < n_in; base += 1024) {
     const int k = base + threadIdx.x;
     int ws = -1;
     if(k < n_in) {
       ws = in.list ? in.list[k] : k;
-      if(!jobs[ws].st->active) ws = -1;
+      const GNState* st = jobs[ws].st;
+      if(!st->active) ws = -1;
+      else if(st->delta_scale > 1e-6f) moving += 1u;
     }
     unsigned total;
     const unsigned off = block_excl_scan_1024(ws >= 0 ? 1u : 0u, s_wave, total);
@@ -1587,7 +1592,9 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __r
     if(threadIdx.x == 0) s_base = b + total;
     __syncthreads();
   }
-  if(threadIdx.x == 0) *out_count = (int) s_base;
+  if(moving) atomicAdd(&s_moving, moving);
+  __syncthreads();
+  if(threadIdx.x == 0) { out_count[0] = (int) s_base; out_count[1] = (int) s_moving; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
