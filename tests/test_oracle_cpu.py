@@ -513,6 +513,121 @@ def test_interpolation_variants_against_numpy(orc, interp):
     assert rot < 2e-2 and trans < 0.5, (rot, trans)
 
 
+@pytest.mark.parametrize("descriptor", ["intensity", "bitplanes"])
+def test_linear_interpolation_against_numpy(orc, descriptor):
+    """The hot path's residual, restated a second time in numpy straight from PhotoError::Impl::init / run kLinear
+    (bpvo/photo_error.cc:343-389,446-449): f64 projection with the f32 P = K T, Floor, valid = 0 <= xi < cols-1 && 0 <= yi < rows-1,
+    Iw = (1-yf) (I00 wx + I01 xf) + yf (I10 wx + I11 xf) in double with wx = 1 - xf, r = float(Iw - double(I0)), 0 where invalid —
+    every channel, bit for bit."""
+    rows, cols = 96, 128
+    ctx, d, _ = setup_pair(orc, rows, cols, descriptor=descriptor, levels=1)
+    T = synth.twist_to_matrix([0.01, -0.02, 0.03, 0.3, -0.2, 0.1]).astype(np.float32)
+    ctx.linearize(0, 0, 1, 0, T)
+    n = ctx.num_points(0, 0)
+    C = ctx.Cn
+    v = ctx.get_valid(0).astype(bool).reshape(-1)
+    v = v.reshape(C, n) if v.size == C * n else np.tile(v[:n], (C, 1))     # per point, or replicated per channel (replicateValidFlags)
+    r = ctx.get_residuals(0).reshape(C, n)
+    x, y = _np_project(ctx, d, T)
+    xi, yi = np.floor(x).astype(np.int64), np.floor(y).astype(np.int64)
+    ref_valid = (xi >= 0) & (xi < cols - 1) & (yi >= 0) & (yi < rows - 1)
+    assert 0 < ref_valid.sum() < n
+    xf, yf = (x - xi)[ref_valid], (y - yi)[ref_valid]
+    xv, yv = xi[ref_valid], yi[ref_valid]
+    wx = 1.0 - xf
+    I0 = ctx.get_pixels(0, 0)
+    for c in range(C):
+        assert np.array_equal(v[c], ref_valid)                       # replicateValidFlags: the same mask for every channel
+        I1 = ctx.get_descriptor_channel(1, 0, c).astype(np.float64)
+        Iw = (1.0 - yf) * (I1[yv, xv] * wx + I1[yv, xv + 1] * xf) + yf * (I1[yv + 1, xv] * wx + I1[yv + 1, xv + 1] * xf)
+        assert bits_equal((Iw - I0[c][ref_valid].astype(np.float64)).astype(np.float32), r[c][ref_valid]), c
+        assert np.all(r[c][~ref_valid] == 0.0)
+
+
+def test_jacobian_is_the_derivative_of_the_warp(orc):
+    """An independent check of RigidBodyWarp::computeJacobian (bpvo/rigid_body_warp.cc:60-315) together with paramsToPose
+    (bpvo/rigid_body_warp.h:130-138): row k of a point's Jacobian must be Ix du/dp_k + Iy dv/dp_k of the projection
+    (u, v) = normHomog(K [T_inv exp(p) T] X) at p = 0, T the Hartley normalisation of the level — here by central finite
+    differences in float64 on the oracle's own points, gradients and normalisation.  (The SSE code's reciprocal is the exact one
+    here, Q13; 1e-3 relative covers f32 rounding of the rows.)"""
+    rows, cols = 96, 128
+    ctx, d, _ = setup_pair(orc, rows, cols, descriptor="intensity", levels=1)
+    X = ctx.get_points(0, 0).astype(np.float64)
+    J = ctx.get_jacobians(0, 0)[0].astype(np.float64)                 # [n][6]
+    Tn, Tni = (m.astype(np.float64) for m in ctx.get_normalization(0, 0))
+    K = np.eye(4); K[:3, :3] = d["K"].astype(np.float64)
+    inds = ctx.get_point_indices(0, 0)
+    I = ctx.get_descriptor_channel(0, 0, 0).astype(np.float64)
+    yy, xx = inds // cols, inds % cols
+    Ix = 0.5 * (I[yy, xx + 1] - I[yy, xx - 1])                       # the central differences of TemplateData::setData (CD3)
+    Iy = 0.5 * (I[yy + 1, xx] - I[yy - 1, xx])
+
+    def project(p):
+        M = K @ Tni @ synth.twist_to_matrix(p).astype(np.float64) @ Tn
+        u = X @ M.T
+        return u[:, 0] / u[:, 2], u[:, 1] / u[:, 2]
+
+    h = 1e-6
+    assert np.abs(J).max() > 1.0
+    for k in range(6):
+        e = np.zeros(6); e[k] = h
+        (up, vp), (um, vm) = project(e), project(-e)
+        fd = Ix * (up - um) / (2 * h) + Iy * (vp - vm) / (2 * h)
+        scale = np.abs(fd).max()
+        assert scale > 0
+        assert np.abs(fd - J[:, k]).max() <= 1e-3 * scale, (k, np.abs(fd - J[:, k]).max(), scale)
+
+
+def test_points_gradients_and_normalization_against_numpy(orc):
+    """Three more pieces of the template restated independently in numpy from the reference's text:
+    makePoint (bpvo/rigid_body_warp.h:47-60: Z = Bf * (1.0 / d) through double, X = (x - cx) * Z * (1.0f / fx)) — bit for bit;
+    the template pixels and the Jacobian's gradients (bpvo/template_data.cc:111-131: CD3 0.5f * (I[+1] - I[-1]), CD5
+    (1/18) (I[-2] - 8 I[-1] + 8 I[+1] - I[+2])) through the rows the oracle builds from them; HartlyNormalization
+    (bpvo/warps.cc:27-48: c = mean point, m = mean |p - c|, s = sqrt(3.0) / max(m, 1e-6f), T = [s I, -s c; 0 1]) — to 5e-5
+    against an f64 evaluation (the reference adds the N points one after the other in f32; the order in which Eigen adds the four
+    squares of a norm is third-party)."""
+    rows, cols = 96, 128
+    for grad in (capi.GRAD_CD3, capi.GRAD_CD5):
+        ctx, d, _ = setup_pair(orc, rows, cols, descriptor="intensity", levels=1, gradientEstimation=grad)
+        inds = ctx.get_point_indices(0, 0)
+        yy, xx = inds // cols, inds % cols
+        K = d["K"].astype(np.float32)
+        fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+        disp = d["dispA"].astype(np.float32)[yy, xx]
+        Bf = np.float32(np.float32(d["b"]) * fx)
+        Z = (Bf.astype(np.float64) * (1.0 / disp.astype(np.float64))).astype(np.float32)
+        Xp = ((xx.astype(np.float32) - cx) * Z) * np.float32(np.float32(1.0) / fx)
+        Yp = ((yy.astype(np.float32) - cy) * Z) * np.float32(np.float32(1.0) / fy)
+        P = ctx.get_points(0, 0)
+        assert bits_equal(P[:, 0], Xp) and bits_equal(P[:, 1], Yp) and bits_equal(P[:, 2], Z) and np.all(P[:, 3] == 1.0)
+        # pixels and gradients
+        I = ctx.get_descriptor_channel(0, 0, 0)
+        assert bits_equal(ctx.get_pixels(0, 0)[0], I[yy, xx])
+        if grad == capi.GRAD_CD3:
+            Ix = np.float32(0.5) * (I[yy, xx + 1] - I[yy, xx - 1])
+            Iy = np.float32(0.5) * (I[yy + 1, xx] - I[yy - 1, xx])
+        else:
+            NN = np.float32(np.float32(1.0) / np.float32(18.0))
+            e = np.float32(8.0)
+            Ix = NN * (((I[yy, xx - 2] - e * I[yy, xx - 1]) + e * I[yy, xx + 1]) - I[yy, xx + 2])
+            Iy = NN * (((I[yy - 2, xx] - e * I[yy - 1, xx]) + e * I[yy + 1, xx]) - I[yy + 2, xx])
+        # columns 3 and 4 of a Jacobian row are (fx Ix) / (z s) and (fy Iy) / (z s) (bpvo/rigid_body_warp.cc:205-233): the gradients
+        # can be read back from them
+        Tn, _ = ctx.get_normalization(0, 0)
+        J = ctx.get_jacobians(0, 0)[0].astype(np.float64)
+        zs = Z.astype(np.float64) * float(Tn[0, 0])
+        assert np.abs(J[:, 3] * zs - float(fx) * Ix.astype(np.float64)).max() <= 2e-6 * np.abs(float(fx) * Ix).max()
+        assert np.abs(J[:, 4] * zs - float(fy) * Iy.astype(np.float64)).max() <= 2e-6 * np.abs(float(fy) * Iy).max()
+        # Hartley normalisation
+        P64 = P.astype(np.float64)
+        c = P64.mean(axis=0)
+        m = np.linalg.norm(P64 - c, axis=1).mean()
+        sN = np.sqrt(3.0) / max(m, 1e-6)
+        assert abs(float(Tn[0, 0]) - sN) <= 5e-5 * sN and Tn[0, 0] == Tn[1, 1] == Tn[2, 2] and Tn[3, 3] == 1.0
+        assert np.abs(Tn[:3, 3].astype(np.float64) + sN * c[:3]).max() <= 5e-5 * np.abs(sN * c[:3]).max()
+        assert np.all(Tn[3, :3] == 0.0) and np.all(Tn[:3, :3] - np.diag(np.diag(Tn[:3, :3])) == 0.0)
+
+
 @pytest.mark.parametrize("ksize", [1, 3, 5, 7])
 def test_laplacian_descriptor_against_scipy(orc, ksize):
     """cv::Laplacian(u8 -> f32, ksize 1 / 3) = correlation with {0,1,0,1,-4,1,0,1,0} / {2,0,2,0,-8,0,2,0,2}; ksize 5 / 7 = Sobel
