@@ -12,6 +12,7 @@
 #include <float.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include <mutex>
 
@@ -722,13 +723,15 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 // The work of one 1024-thread workgroup on workspace j; `st` is the state it reads and (thread 0, at the very end) updates — the
 // workspace's own in HBM, or a workgroup-local copy (persistent kernel, where every workgroup runs the selection redundantly and
 // `stats` is true for one of them only).
-template <int C, int NT>
+// COPIES privatised pass-1 histograms (a power of two >= 2: the second one doubles as the segment-offset table of the bracketed path),
+// CACHE words of key cache: the LDS footprint is ((COPIES + 1) * MED_BINS + CACHE + 24) words.
+template <int C, int NT, int COPIES = MED_COPIES, int CACHE = MED_CACHE>
 __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsigned char* smem_raw, bool stats)
 {
-  unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [MED_COPIES][MED_BINS]
-  unsigned* hist_hi = hist_lo + MED_COPIES * MED_BINS;                    // [MED_BINS]
-  unsigned* cache = hist_hi + MED_BINS;                                   // [MED_CACHE]
-  unsigned* s_wave = cache + MED_CACHE;                                   // [16]
+  unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [COPIES][MED_BINS]
+  unsigned* hist_hi = hist_lo + COPIES * MED_BINS;                    // [MED_BINS]
+  unsigned* cache = hist_hi + MED_BINS;                                   // [CACHE]
+  unsigned* s_wave = cache + CACHE;                                   // [16]
   MedCursor* cur = reinterpret_cast<MedCursor*>(s_wave + 16);             // [2]
   unsigned* s_misc = reinterpret_cast<unsigned*>(cur + 2);                // [0] cache count, [1] first valid point
 
@@ -781,7 +784,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       unsigned* s_off = hist_lo + MED_BINS;                              // [nblk + 1] — refine_pass only uses the first MED_BINS words of hist_lo
       constexpr unsigned kListRoom = 2u * (unsigned) NT;                  // cache[0 .. 2 NT): lists of the ranking step
       unsigned* dense = cache + kListRoom;
-      const bool in_lds = m <= (unsigned) MED_CACHE - kListRoom && nblk < (MED_COPIES - 1) * MED_BINS;
+      const bool in_lds = m <= (unsigned) CACHE - kListRoom && nblk < (COPIES - 1) * MED_BINS;
       if(in_lds) {
         unsigned run = 0;                                                  // running offset of the chunks of NT segments
         for(int b0 = 0; b0 < nblk; b0 += NT) {
@@ -889,11 +892,11 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
 
   // ---- full path
   if(!done) {
-    for(int i = tid; i < (MED_COPIES + 1) * MED_BINS; i += NT) hist_lo[i] = 0;
+    for(int i = tid; i < (COPIES + 1) * MED_BINS; i += NT) hist_lo[i] = 0;
     if(tid == 0) { s_misc[0] = 0; s_misc[1] = 0xffffffffu; }
     __syncthreads();
     {   // pass 1: bits [30:20], privatised histogram copies
-      unsigned* h = hist_lo + (tid & (MED_COPIES - 1)) * MED_BINS;
+      unsigned* h = hist_lo + (tid & (COPIES - 1)) * MED_BINS;
       unsigned first = 0xffffffffu;
       for_each_valid_key<C, NT>(j, [&](unsigned key, int pt) {
         atomicAdd(&h[key >> 20], 1u);
@@ -908,7 +911,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     for(int q = 0; q < BPT; ++q) {
       hh[q] = 0;
 #pragma unroll
-      for(int c = 0; c < MED_COPIES; ++c) hh[q] += hist_lo[c * MED_BINS + BPT * tid + q];
+      for(int c = 0; c < COPIES; ++c) hh[q] += hist_lo[c * MED_BINS + BPT * tid + q];
       hsum += hh[q];
     }
     const unsigned excl = block_excl_scan_1024<NT>(hsum, s_wave, n_total);
@@ -925,7 +928,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
           const unsigned top = key >> 20;
           if(top == p_lo || top == p_hi) {
             const unsigned idx = atomicAdd(&s_misc[0], 1u);
-            if(idx < MED_CACHE) cache[idx] = key;
+            if(idx < CACHE) cache[idx] = key;
           }
           f(key);
         });
@@ -933,7 +936,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       const unsigned ncache = s_misc[0];
       // pass 3: bits [8:0]
       refine_pass<NT>([&](auto f) {
-        if(ncache <= MED_CACHE) { for(unsigned i = tid; i < ncache; i += NT) f(cache[i]); }
+        if(ncache <= CACHE) { for(unsigned i = tid; i < ncache; i += NT) f(cache[i]); }
         else for_each_valid_key<C, NT>(j, [&](unsigned key, int) { f(key); });
       }, 0u, 9u, lo, hi, hist_lo, hist_hi, s_wave, cur);
       const float v_lo = __uint_as_float(lo.prefix), v_hi = __uint_as_float(hi.prefix);
@@ -975,15 +978,20 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
 }
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
-template <int C>
-__global__ __launch_bounds__(MED_THREADS) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+// Two shapes.  1024 threads with the full 123 KB (one workgroup per CU): the fastest single selection — launches of up to one
+// workgroup per CU.  512 threads with 53 KB (three workgroups per CU): launches of MORE workgroups
+// than CUs, which with the first shape run in waves of 256 workgroups at ~10 us each (1024 pairs: 41 / 32 / 22 / 12 us per launch as
+// the pairs converge).  The selection is exact in either shape.
+constexpr int MED_THREADS_B = 512, MED_COPIES_B = 2, MED_CACHE_B = 7168;   // 53 KB: three workgroups per CU
+template <int C, int NT, int COPIES, int CACHE>
+__global__ __launch_bounds__(NT) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  median_block<C, MED_THREADS>(j, st, smem_raw, true);
+  median_block<C, NT, COPIES, CACHE>(j, st, smem_raw, true);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2027,6 +2035,7 @@ void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 static constexpr size_t kMedianLds = ((MED_COPIES + 1) * MED_BINS + MED_CACHE + 16 + 4 + 4) * sizeof(unsigned);
+static constexpr size_t kMedianLdsB = ((MED_COPIES_B + 1) * MED_BINS + MED_CACHE_B + 16 + 4 + 4) * sizeof(unsigned);
 void launch_median(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
@@ -2037,11 +2046,18 @@ void launch_median(hipStream_t s, const GNLaunch& g)
   std::call_once(attr_once[dev & 63], [] {
     for(int C : {1, 3, 5, 8, 10, 24, 48})
       dispatch_channels(C, [&](auto c) {
-        (void) hipFuncSetAttribute((const void*) median_finish_kernel<decltype(c)::value>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+        constexpr int CC = decltype(c)::value;
+        (void) hipFuncSetAttribute((const void*) median_finish_kernel<CC, MED_THREADS, MED_COPIES, MED_CACHE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+        (void) hipFuncSetAttribute((const void*) median_finish_kernel<CC, MED_THREADS_B, MED_COPIES_B, MED_CACHE_B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLdsB);
       });
   });
+  static const int wide_from = std::getenv("BPVO_HIP_MEDIAN_WIDE_FROM") ? std::atoi(std::getenv("BPVO_HIP_MEDIAN_WIDE_FROM")) : 257;   // A/B
   dispatch_channels(g.C, [&](auto c) {
-    hipLaunchKernelGGL(median_finish_kernel<decltype(c)::value>, dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+    constexpr int CC = decltype(c)::value;
+    if(g.npairs >= wide_from)
+      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS_B, MED_COPIES_B, MED_CACHE_B>), dim3(g.npairs), dim3(MED_THREADS_B), kMedianLdsB, s, g.jobs, g.active);
+    else
+      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS, MED_COPIES, MED_CACHE>), dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
   });
 }
 
