@@ -300,6 +300,27 @@ def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
         assert np.array_equal(out[lanes][1]["status"], out[1][1]["status"])
 
 
+def test_wide_launches_take_the_second_median_shape_and_change_nothing(hip):
+    """Launches of more than 256 workspaces run median_finish in its 512-thread / 53 KB shape (three workgroups per CU), smaller ones
+    in the 1024-thread shape (kernels_gn.hip): the selection is exact in either, so a 288-pair batch on ONE lane (one launch covers
+    all 288) equals, pair for pair, the same pairs run as batches of 48."""
+    rows, cols, levels, n, sub = 96, 128, 2, 288, 48
+    batch = synth.make_batch(rows, cols, n, first_index=300, workers=8)
+    p = make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels)
+    ctx = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    ctx.set_max_lanes(1)
+    poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
+    ctx.close()
+    small = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=2 * sub, n_pairs=sub)
+    small.set_max_lanes(1)
+    for k in range(0, n, sub):
+        ps, ss = small.batch_run(batch["images"][2 * k: 2 * (k + sub)], batch["disparities"][2 * k: 2 * (k + sub)])
+        assert bits_equal(ps, poses[k: k + sub]), k
+        assert np.array_equal(ss["numIterations"], stats["numIterations"][k: k + sub])
+        assert np.array_equal(ss["status"], stats["status"][k: k + sub])
+    small.close()
+
+
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
