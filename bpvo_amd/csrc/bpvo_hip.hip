@@ -742,6 +742,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       if(!t[15]) continue;
       std::fprintf(stderr, "pk level %d: %u iterations;", l, t[15]);
       for(int k = 0; k < 6; ++k) std::fprintf(stderr, " %s %.2f", names[k], 0.01 * t[8 + k] / t[15]);
+      std::fprintf(stderr, " | step: sum_partials %.2f unpack %.2f solve %.2f pose %.2f tests %.2f", 0.01 * t[20] / t[15], 0.01 * t[16] / t[15], 0.01 * t[17] / t[15],
+                   0.01 * t[18] / t[15], 0.01 * t[19] / t[15]);
       std::fprintf(stderr, " us per iteration\n");
     }
   }

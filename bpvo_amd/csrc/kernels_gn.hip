@@ -1424,9 +1424,18 @@ __device__ void gn_finalize(GNState* st)
 
 // the serial part of gn_step, executed by lane 0 on the LDS copy of the state; returns true if another linearisation
 // is requested (the workspace stays active)
+#ifdef BPVO_PK_TIMING
+__shared__ unsigned pk_sub[8];      // timing build: 10-ns ticks of the serial step's parts (unpack, solve, pose update, tests), summed
+#define GN_SUBTICK(k) do { const long long t_ = wall_clock64(); pk_sub[k] += (unsigned) (t_ - sub_t); sub_t = t_; } while(0)
+#else
+#define GN_SUBTICK(k) do { } while(0)
+#endif
 __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, SolveScratch* scratch, int mode, int max_iterations,
                          int max_fun_evals, float p_tol, float f_tol, float g_tol_param)
 {
+#ifdef BPVO_PK_TIMING
+  long long sub_t = wall_clock64();
+#endif
   // unpack: upper triangle -> symmetric H (toEigen + selfadjointView<Upper>, linear_system_builder.cc:207-221)
   {
     int idx = 0;
@@ -1443,6 +1452,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
   st->n_valid = (uint32_t) s_sum[28];
   st->num_fun_evals += 1;
   if(mode == 1) return true;
+  GN_SUBTICK(0);
 
   const float sqrt_eps = sqrtf(FLT_EPSILON);
 
@@ -1475,7 +1485,9 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
       gn_finalize(st);                                  // `break`: no ++ on the way out
       return false;
     }
+    GN_SUBTICK(1);
     gn_update_pose(st, nrm);                            // :390
+    GN_SUBTICK(2);
     const bool cont = (st->num_iterations++ < max_iterations) && !st->has_converged && (st->num_fun_evals < max_fun_evals);
     if(!cont) { gn_finalize(st); return false; }
   }
@@ -1497,6 +1509,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
   st->has_converged = conv ? 1 : 0;
   st->dp_norm_prev = dp_norm;
   st->f_norm_prev = f_norm;
+  GN_SUBTICK(3);
   if(!conv) {
     st->phase = PHASE_LOOP;                             // next launch: linearize at the updated pose
     return true;
@@ -1507,15 +1520,31 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
   return false;
 }
 
-// lanes 0 .. kNumAcc-1 of one wave: deterministic sum (tile order, f64) of the tile partials of workspace j
+// lanes 0 .. kNumAcc-1 of one wave: deterministic sum (tile order, f64) of the tile partials of workspace j.
+// The loads of 32 tiles are issued back to back, UNCONDITIONALLY (the tile index is clamped, the add is what the bound selects: a
+// conditional load makes the compiler wait per branch), so a level costs one global-memory round trip per 32 tiles instead of one per
+// 8: 2.2 -> 1.3 us of the serial step at the finest level of a 1241x376 pair (profiles/r02_persistent_phases.txt).  Same order of additions.
 __device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/)
 {
   const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
   if(lane < kNumAcc) {
     double s = 0.0;
     const float* __restrict__ pp = j.partials + lane;
-#pragma unroll 8
-    for(int b = 0; b < nblk; ++b) s += (double) pp[(size_t) b * kPartialStride];
+    auto chunked = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      for(int b0 = 0; b0 < nblk; b0 += U) {
+        float v[U];
+#pragma unroll
+        for(int u = 0; u < U; ++u) v[u] = pp[(size_t) min(b0 + u, nblk - 1) * kPartialStride];
+#pragma unroll
+        for(int u = 0; u < U; ++u) {
+          const double t = s + (double) v[u];
+          s = (b0 + u < nblk) ? t : s;
+        }
+      }
+    };
+    if(nblk <= 8) chunked(std::integral_constant<int, 8>());      // (coarse levels: no point in 32 loads for 6 tiles)
+    else chunked(std::integral_constant<int, 32>());
     s_sum[lane] = (float) s;
   }
 }
@@ -1720,8 +1749,14 @@ __device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restric
 {
   const int ws = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool mine = ws < nws && pk_st(ws < nws ? ws : 0)->active;
+#ifdef BPVO_PK_TIMING
+  long long sub_t = wall_clock64();
+#endif
   if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws]);
   __syncthreads();
+#ifdef BPVO_PK_TIMING
+  if(threadIdx.x == 0) GN_SUBTICK(4);
+#endif
   if(mine && lane == 0)
     gn_serial_step(jobs[ws], pk_st(ws), pk_nrm[ws], pk_sum[ws], &pk_scratch[ws], 0, prm.max_iterations, prm.max_fun_evals, prm.p_tol, prm.f_tol,
                    prm.g_tol, fuse, stats_wg);
@@ -1777,6 +1812,8 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
 #ifdef BPVO_PK_TIMING
   long long tk = wall_clock64();
   unsigned acc_t[6] = {0, 0, 0, 0, 0, 0}, iters = 0;
+  if(tid < 8) pk_sub[tid] = 0;
+  __syncthreads();
 #define PK_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[k] += (unsigned) (t_ - tk); tk = t_; } while(0)
 #else
 #define PK_TICK(k) do { } while(0)
@@ -1834,6 +1871,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
   if(blockIdx.x == 0 && tid == 0) {
     for(int k = 0; k < 6; ++k) ctl[8 + k] = acc_t[k];
     ctl[15] = iters;
+    for(int k = 0; k < 5; ++k) ctl[16 + k] = pk_sub[k];
   }
 #endif
 
