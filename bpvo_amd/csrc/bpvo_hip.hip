@@ -615,7 +615,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   (void) hipSetDevice(c->device);
   const bpvo_hip_params& p = c->params;
   const int NP = c->n_pairs;
-  LANE_CK(ln, hipStreamSynchronize(ln->stream));   // pinned staging reuse
+  // (the pinned staging of a lane is free here: every call that uses it ends with a synchronisation of the lane's stream)
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < n; ++i) {
@@ -778,9 +778,11 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[refs[i]].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   }
-  HIP_CK(c, hipStreamSynchronize(c->stream));   // frame stages run on the ctx stream; lanes start from a quiet device
   const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
   const int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
+  // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
+  // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
+  if(nl > 1) HIP_CK(c, hipStreamSynchronize(c->stream));
   std::vector<int> rcs(nl, BPVO_OK);
   auto run = [&](int k) {
     const int lo = (int) ((long long) n * k / nl), hi = (int) ((long long) n * (k + 1) / nl);
