@@ -176,6 +176,10 @@ struct bpvo_hip_ctx {
   float* st_disp = nullptr;
   int st_frames = 0;
   bool counted_live = false;   // this context is in g_live_ctx
+  // addFrame: the fraction of good points (should_keyframe's last criterion) is queued right behind the estimation, before the host
+  // waits for the pose, instead of in a second round trip; frac_* hold it for fraction_good (same kernels, same count)
+  float prefetch_frac_thr = -1.0f;    // >= 0 while bpvo_hip_add_frame runs its estimate
+  bool frac_valid = false; int frac_ws = -1; float frac_thr = 0.0f; unsigned frac_cnt = 0; int frac_n = 0;
   bool skip_frozen_launches = true;   // BPVO_HIP_SKIP_FROZEN=0: keep launching warp_residual / median when every active scale is frozen (A/B)
   bool stagger = true;         // BPVO_HIP_STAGGER=0: batches run stage by stage over all pairs (batch_run_staggered)
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
@@ -615,6 +619,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   (void) hipSetDevice(c->device);
   const bpvo_hip_params& p = c->params;
   const int NP = c->n_pairs;
+  c->frac_valid = false;
   // (the pinned staging of a lane is free here: every call that uses it ends with a synchronisation of the lane's stream)
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
@@ -727,6 +732,22 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     }
   }
   launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
+  bool frac_queued = false;
+  if(n == 1 && c->prefetch_frac_thr >= 0.0f && ln == &c->lanes[0]) {
+    // fraction_good of this workspace at the level the estimate ended on, from the job already on the device
+    const PairJob* job = ln->d_pjobs + (size_t) p.maxTestLevel * NP;
+    const int npts = ln->h_pjobs[(size_t) p.maxTestLevel * NP].n;
+    if(npts > 0) {
+      GNLaunch gr;
+      gr.jobs = job; gr.npairs = 1; gr.max_points = npts; gr.C = c->C;
+      launch_refresh_residuals(ln->stream, gr);
+      LANE_CK(ln, hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), ln->stream));
+      launch_count_good(ln->stream, job, npts, c->C, p.lossFunction, c->prefetch_frac_thr, c->d_count);
+      LANE_CK(ln, hipMemcpyAsync(c->h_ints, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ln->stream));
+      frac_queued = true;
+      c->frac_n = npts;
+    }
+  }
   // only this group's states: other lanes may still be writing theirs
   int ws_lo = wss[0], ws_hi = wss[0];
   for(int i = 1; i < n; ++i) { ws_lo = std::min(ws_lo, wss[i]); ws_hi = std::max(ws_hi, wss[i]); }
@@ -735,6 +756,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     LANE_CK(ln, hipMemcpyAsync(ln->h_pk_ctl, ln->d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels, hipMemcpyDeviceToHost, ln->stream));
   LANE_CK(ln, hipStreamSynchronize(ln->stream));
   LANE_CK(ln, hipGetLastError());
+  if(frac_queued) { c->frac_valid = true; c->frac_ws = wss[0]; c->frac_thr = c->prefetch_frac_thr; c->frac_cnt = (unsigned) c->h_ints[0]; }
   if(pk_group && std::getenv("BPVO_HIP_PK_TIMING")) {     // library built with -DBPVO_PK_TIMING: per-phase ticks (10 ns) of workgroup 0
     static const char* names[6] = {"warp", "barrier1", "median", "irls", "barrier2", "step"};
     for(int l = c->L - 1; l >= 0; --l) {
@@ -894,6 +916,10 @@ int fraction_good(bpvo_hip_ctx* c, int ws, float thr, float* frac)
   Workspace& w = c->ws[ws];
   if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
   const int n = c->frames[w.last_ref].n_host[w.last_level];
+  if(c->frac_valid && c->frac_ws == ws && c->frac_thr == thr && c->frac_n == n) {      // queued behind the estimate by addFrame
+    *frac = c->frac_cnt / static_cast<float>((size_t) n * c->C);
+    return BPVO_OK;
+  }
   int rc = ensure_residuals(c, ws);
   if(rc) return rc;
   rc = upload_single_job(c, ws, w.last_ref, w.last_cur, w.last_level);
@@ -1399,6 +1425,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   if(!c->frames[ref_slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
   if(!c->frames[cur_slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   if(c->frames[ref_slot].n_host[level] <= 0) return fail(c, BPVO_ERR_NO_TEMPLATE, "you should call setData before calling computeResiduals");
+  c->frac_valid = false;
   (void) hipSetDevice(c->device);
   int rc = upload_single_job(c, ws, ref_slot, cur_slot, level);
   if(rc) return rc;
@@ -1711,7 +1738,9 @@ static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* di
   const int ws0 = 0;
   rc = check_template_not_empty(c, c->vo_ref);
   if(rc) return rc;
+  c->prefetch_frac_thr = c->params.goodPointThreshold;      // should_keyframe's fraction of good points rides behind the estimate
   rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, c->T_kf.m, T_est.m, ret->optimizerStatistics);
+  c->prefetch_frac_thr = -1.0f;
   if(rc) return rc;
   int reason = BPVO_KF_NO_KEYFRAMING;
   rc = should_keyframe(c, T_est, &reason);
