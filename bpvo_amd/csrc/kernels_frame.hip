@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, 
 // ---- K1b: 8 bit-planes + cv::GaussianBlur 5x5 (reference: bpvo/bitplanes_descriptor.cc:37-57).
 // One 256-thread workgroup produces a 64 x 8 tile of 32-byte pixel records.  The census bytes of the tile + 2-px halo
 // (REFLECT_101 on the coordinates) are staged in LDS, the horizontal pass is written to LDS for all 8 planes
-// (12 rows x 64 cols x 8 f32 = 24 KB, 6 workgroups per CU), the vertical pass streams full records to HBM with two 16-byte
+// (12 rows x 64 cols x 8 f32 = 24 KB; with the spread census tile 32 KB: 5 workgroups per CU), the vertical pass streams full records to HBM with two 16-byte
 // stores per pixel.
 // Arithmetic per plane, f32, no fusing, exactly OpenCV's symmetric 5-tap filters:
 //   row: t = S0*k0 + (S-1 + S+1)*k1 + (S-2 + S+2)*k2        column: s = k0*T0; s += k1*(T+1 + T-1); s += k2*(T+2 + T-2)

@@ -576,8 +576,9 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 //    then selects among the candidates only.  If the wanted ranks fall outside the bracket the full path runs — the
 //    result is exact either way; the bracket width adapts to the last observed change.
 //  full (first linearisation of a level, bracket miss): 3 passes over all keys, bits [30:20], [19:9], [8:0], one
-//    1024-thread workgroup per workspace with LDS histograms (4 privatised copies in pass 1 to cut same-bin atomic
-//    serialisation); keys surviving pass 1 are cached in LDS so pass 3 never touches HBM again.
+//    workgroup per workspace (1024 threads, or 512 in launches wider than the chip: median_finish_kernel) with LDS histograms
+//    (privatised copies in pass 1 to cut same-bin atomic serialisation); keys surviving pass 1 are cached in LDS so pass 3
+//    never touches HBM again.
 constexpr int MED_THREADS = 1024;     // median_finish_kernel; the persistent kernel runs the same code with 512 (template parameter NT)
 constexpr int MED_COPIES = 4;
 constexpr int MED_BINS = 2048;
@@ -720,7 +721,7 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
   __syncthreads();
 }
 
-// The work of one 1024-thread workgroup on workspace j; `st` is the state it reads and (thread 0, at the very end) updates — the
+// The work of one NT-thread workgroup on workspace j; `st` is the state it reads and (thread 0, at the very end) updates — the
 // workspace's own in HBM, or a workgroup-local copy (persistent kernel, where every workgroup runs the selection redundantly and
 // `stats` is true for one of them only).
 // COPIES privatised pass-1 histograms (a power of two >= 2: the second one doubles as the segment-offset table of the bracketed path),
