@@ -180,6 +180,7 @@ struct bpvo_hip_ctx {
   // waits for the pose, instead of in a second round trip; frac_* hold it for fraction_good (same kernels, same count)
   float prefetch_frac_thr = -1.0f;    // >= 0 while bpvo_hip_add_frame runs its estimate
   bool frac_valid = false; int frac_ws = -1; float frac_thr = 0.0f; unsigned frac_cnt = 0; int frac_n = 0;
+  double tapcache_max_density = 0.5;   // BPVO_HIP_TAPCACHE_MAX_DENSITY: levels with more template points per pixel than this run without the tap cache (batches)
   bool skip_frozen_launches = true;   // BPVO_HIP_SKIP_FROZEN=0: keep launching warp_residual / median when every active scale is frozen (A/B)
   bool stagger = true;         // BPVO_HIP_STAGGER=0: batches run stage by stage over all pairs (batch_run_staggered)
   bool sync_rounds = false;    // BPVO_HIP_SYNC_ROUNDS=1: no pipelining of the host rounds (A/B measurements)
@@ -624,8 +625,18 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < n; ++i) {
-      ln->h_pjobs[(size_t) l * NP + i] = make_pair_job(c, wss[i], refs[i], curs[i], l);
-      max_pts[l] = std::max(max_pts[l], ln->h_pjobs[(size_t) l * NP + i].n);
+      PairJob& pj = ln->h_pjobs[(size_t) l * NP + i];
+      pj = make_pair_job(c, wss[i], refs[i], curs[i], l);
+      // Dense levels (no non-maximum suppression: most pixels are template points) gather their taps straight from the descriptor:
+      // neighbouring points share three quarters of their footprints, so the 32-byte records are fetched about once per pixel
+      // from HBM, where the per-point tap cache reads 128 bytes per point whatever the neighbours do.  The cache pays at the
+      // sparse levels (one point in ~25 pixels: every footprint its own two or three lines).  Batches only: the persistent
+      // single-pair kernel keeps its (L2-resident) cache.
+      if(c->C == 8 && n > c->persist_max_ws && (double) pj.n > c->tapcache_max_density * (double) c->geom[l].npix) {
+        pj.tapkey = nullptr;
+        pj.tapcache = nullptr;
+      }
+      max_pts[l] = std::max(max_pts[l], pj.n);
     }
   LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
   const float* dT = nullptr;
@@ -1170,6 +1181,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_SYNC_ROUNDS")) cp->sync_rounds = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_STAGGER")) cp->stagger = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_SKIP_FROZEN")) cp->skip_frozen_launches = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_TAPCACHE_MAX_DENSITY")) cp->tapcache_max_density = std::atof(e);
     if(const char* e = std::getenv("BPVO_HIP_SPLIT_CENSUS")) cp->split_census = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSISTENT")) cp->persistent = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));

@@ -223,7 +223,8 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
       const float4* q1 = q0 + (size_t) W * 2;
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-      const bool hit = j.tapkey[i] == key;
+      const bool cached = j.tapkey != nullptr;      // (uniform over the workspace) dense levels gather straight from the descriptor
+      const bool hit = cached && j.tapkey[i] == key;
       cache_hit = hit;
       float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
       const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
           c = load_v4<NT>(tc + tile_index<8>(i, 4 + h)); d = load_v4<NT>(tc + tile_index<8>(i, 6 + h));
         } else {
           a = q0[h]; b = q0[2 + h]; c = q1[h]; d = q1[2 + h];
-          if(in_block) {
+          if(in_block && cached) {
             store_v4<NT>(tc + tile_index<8>(i, h), a); store_v4<NT>(tc + tile_index<8>(i, 2 + h), b);
             store_v4<NT>(tc + tile_index<8>(i, 4 + h), c); store_v4<NT>(tc + tile_index<8>(i, 6 + h), d);
           }
@@ -250,7 +251,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
         }
         if(h == 0) __builtin_amdgcn_sched_barrier(0);   // keep the second group's loads behind the first group's arithmetic
       }
-      if(!hit && in_block) j.tapkey[i] = key;
+      if(!hit && in_block && cached) j.tapkey[i] = key;
     } else {
 #pragma unroll
       for(int c = 0; c < 8; ++c) res[c] = 0.0f;
@@ -269,7 +270,8 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       // fully coalesced buffer keyed by (yi << 16 | xi): a hit replaces the gather — two 64-byte segments that cost
       // 2.3 128-byte HBM lines on average (profiles/r01_pmc_summary.txt) — by one coalesced 128-byte read.
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-      const bool hit = j.tapkey[i] == key;
+      const bool cached = j.tapkey != nullptr;      // (uniform over the workspace) dense levels gather straight from the descriptor
+      const bool hit = cached && j.tapkey[i] == key;
       cache_hit = hit;
       float4 a0, a1, a2, a3, b0, b1, b2, b3;
       float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
@@ -283,7 +285,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
         const float4* q1 = reinterpret_cast<const float4*>(d1);
         a0 = q0[0]; a1 = q0[1]; a2 = q0[2]; a3 = q0[3];
         b0 = q1[0]; b1 = q1[1]; b2 = q1[2]; b3 = q1[3];
-        if(in_block) {
+        if(in_block && cached) {
           store_v4<NT>(tc + tile_index<8>(i, 0), a0); store_v4<NT>(tc + tile_index<8>(i, 1), a1);
           store_v4<NT>(tc + tile_index<8>(i, 2), a2); store_v4<NT>(tc + tile_index<8>(i, 3), a3);
           store_v4<NT>(tc + tile_index<8>(i, 4), b0); store_v4<NT>(tc + tile_index<8>(i, 5), b1);
@@ -767,7 +769,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       t_below = t_in = t_valid = 0;
 #pragma unroll
       for(int w = 0; w < NT / 64; ++w) { t_below += cache[w * 4 + 0]; t_in += cache[w * 4 + 1]; t_valid += cache[w * 4 + 2]; tap_hits += cache[w * 4 + 3]; }
-      tap_lookups = t_valid;
+      tap_lookups = j.tapkey ? t_valid : 0u;      // (no tap cache at dense levels: nothing looked up)
       __syncthreads();
     }
     const unsigned nt = (unsigned) C * t_valid, below = t_below, m = t_in;
@@ -954,7 +956,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     if(stats) {
       j.cnt[done ? 2 : 3] += 1ull;                                          // measurement: bracketed vs full selections
       // tap cache: a linearisation without bracket counters is the first of a level (keys reset: no hits, every valid point looks up)
-      if(!st->median_valid) tap_lookups = n_total / (unsigned) C;
+      if(!st->median_valid) tap_lookups = j.tapkey ? n_total / (unsigned) C : 0u;
       j.cnt[5] += tap_hits; j.cnt[6] += tap_lookups;
       if(st->num_fun_evals < 8) { j.cnt[7] += tap_hits; j.cnt[8] += tap_lookups; }
     }
@@ -1566,7 +1568,7 @@ __device__ __forceinline__ void gn_serial_step(const PairJob& j, GNState* st, co
     j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
     j.cnt[1] += 1ull;
     if(fused_lin) {                           // the fused path keeps its own tap-cache statistics (the others: median_finish)
-      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += (unsigned long long) s_sum[28];
+      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += j.tapkey ? (unsigned long long) s_sum[28] : 0ull;
       j.cnt[10] += (unsigned long long) j.n;
     }
   }
