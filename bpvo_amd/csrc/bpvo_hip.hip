@@ -632,7 +632,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       // from HBM, where the per-point tap cache reads 128 bytes per point whatever the neighbours do.  The cache pays at the
       // sparse levels (one point in ~25 pixels: every footprint its own two or three lines).  Batches only: the persistent
       // single-pair kernel keeps its (L2-resident) cache.
-      if(c->C == 8 && n > c->persist_max_ws && (double) pj.n > c->tapcache_max_density * (double) c->geom[l].npix) {
+      if((c->C == 8 || c->C == 1) && n > c->persist_max_ws && (double) pj.n > c->tapcache_max_density * (double) c->geom[l].npix) {
         pj.tapkey = nullptr;
         pj.tapcache = nullptr;
       }

@@ -165,8 +165,10 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
   // speculation costs 128 bytes and was measured slower)
   unsigned spec_key = 0; float4 spec_taps = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float spec_pix = 0.0f;
   if constexpr(C == 1) {
-    spec_key = j.tapkey[i];
-    spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache.get()) + i);
+    if(j.tapkey) {      // (uniform over the workspace: dense levels run without the cache)
+      spec_key = j.tapkey[i];
+      spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache.get()) + i);
+    }
     spec_pix = j.pix[i];
   }
   int xi = 0, yi = 0;
@@ -306,10 +308,11 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
       float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
       float4 t = spec_taps;
-      cache_hit = spec_key == key;
-      if(spec_key != key) {
+      const bool cached = j.tapkey != nullptr;
+      cache_hit = cached && spec_key == key;
+      if(!cache_hit) {
         t = make_float4(d0[0], d0[1], d1[0], d1[1]);
-        if(in_block) { store_v4<NT>(tc + i, t); j.tapkey[i] = key; }
+        if(in_block && cached) { store_v4<NT>(tc + i, t); j.tapkey[i] = key; }
       }
       I00[0] = t.x; I01[0] = t.y; I10[0] = t.z; I11[0] = t.w;
       I0[0] = spec_pix;
