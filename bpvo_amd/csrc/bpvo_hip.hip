@@ -363,6 +363,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.valid = c->ws[ws].valid;
   j.cand = c->ws[ws].cand;
   j.tapkey = c->ws[ws].tapkey;
+  j.tapcache_on = c->ws[ws].tapkey != nullptr;
   j.tapcache = c->ws[ws].tapcache;
   j.med_blk = c->ws[ws].med_blk;
   j.partials = c->ws[ws].partials;
@@ -633,8 +634,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       // sparse levels (one point in ~25 pixels: every footprint its own two or three lines).  Batches only: the persistent
       // single-pair kernel keeps its (L2-resident) cache.
       if((c->C == 8 || c->C == 1) && n > c->persist_max_ws && (double) pj.n > c->tapcache_max_density * (double) c->geom[l].npix) {
-        pj.tapkey = nullptr;
-        pj.tapcache = nullptr;
+        pj.tapcache_on = 0;
       }
       max_pts[l] = std::max(max_pts[l], pj.n);
     }

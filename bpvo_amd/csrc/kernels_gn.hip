@@ -165,7 +165,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
   // speculation costs 128 bytes and was measured slower)
   unsigned spec_key = 0; float4 spec_taps = make_float4(0.0f, 0.0f, 0.0f, 0.0f); float spec_pix = 0.0f;
   if constexpr(C == 1) {
-    if(j.tapkey) {      // (uniform over the workspace: dense levels run without the cache)
+    if(j.tapcache_on) {      // (uniform over the workspace: dense levels run without the cache)
       spec_key = j.tapkey[i];
       spec_taps = load_v4<NT>(reinterpret_cast<const float4*>(j.tapcache.get()) + i);
     }
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
       const float4* q1 = q0 + (size_t) W * 2;
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-      const bool cached = j.tapkey != nullptr;      // (uniform over the workspace) dense levels gather straight from the descriptor
+      const bool cached = j.tapcache_on != 0;       // (uniform over the workspace) dense levels gather straight from the descriptor
       const bool hit = cached && j.tapkey[i] == key;
       cache_hit = hit;
       float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
@@ -272,7 +272,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       // fully coalesced buffer keyed by (yi << 16 | xi): a hit replaces the gather — two 64-byte segments that cost
       // 2.3 128-byte HBM lines on average (profiles/r01_pmc_summary.txt) — by one coalesced 128-byte read.
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-      const bool cached = j.tapkey != nullptr;      // (uniform over the workspace) dense levels gather straight from the descriptor
+      const bool cached = j.tapcache_on != 0;       // (uniform over the workspace) dense levels gather straight from the descriptor
       const bool hit = cached && j.tapkey[i] == key;
       cache_hit = hit;
       float4 a0, a1, a2, a3, b0, b1, b2, b3;
@@ -308,7 +308,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
       const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
       float4* tc = reinterpret_cast<float4*>(j.tapcache.get());
       float4 t = spec_taps;
-      const bool cached = j.tapkey != nullptr;
+      const bool cached = j.tapcache_on != 0;
       cache_hit = cached && spec_key == key;
       if(!cache_hit) {
         t = make_float4(d0[0], d0[1], d1[0], d1[1]);
@@ -772,7 +772,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       t_below = t_in = t_valid = 0;
 #pragma unroll
       for(int w = 0; w < NT / 64; ++w) { t_below += cache[w * 4 + 0]; t_in += cache[w * 4 + 1]; t_valid += cache[w * 4 + 2]; tap_hits += cache[w * 4 + 3]; }
-      tap_lookups = j.tapkey ? t_valid : 0u;      // (no tap cache at dense levels: nothing looked up)
+      tap_lookups = j.tapcache_on ? t_valid : 0u;      // (no tap cache at dense levels: nothing looked up)
       __syncthreads();
     }
     const unsigned nt = (unsigned) C * t_valid, below = t_below, m = t_in;
@@ -959,7 +959,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     if(stats) {
       j.cnt[done ? 2 : 3] += 1ull;                                          // measurement: bracketed vs full selections
       // tap cache: a linearisation without bracket counters is the first of a level (keys reset: no hits, every valid point looks up)
-      if(!st->median_valid) tap_lookups = j.tapkey ? n_total / (unsigned) C : 0u;
+      if(!st->median_valid) tap_lookups = j.tapcache_on ? n_total / (unsigned) C : 0u;
       j.cnt[5] += tap_hits; j.cnt[6] += tap_lookups;
       if(st->num_fun_evals < 8) { j.cnt[7] += tap_hits; j.cnt[8] += tap_lookups; }
     }
@@ -1571,7 +1571,7 @@ __device__ __forceinline__ void gn_serial_step(const PairJob& j, GNState* st, co
     j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
     j.cnt[1] += 1ull;
     if(fused_lin) {                           // the fused path keeps its own tap-cache statistics (the others: median_finish)
-      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += j.tapkey ? (unsigned long long) s_sum[28] : 0ull;
+      j.cnt[5] += (unsigned long long) s_sum[29]; j.cnt[6] += j.tapcache_on ? (unsigned long long) s_sum[28] : 0ull;
       j.cnt[10] += (unsigned long long) j.n;
     }
   }

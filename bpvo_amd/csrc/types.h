@@ -172,6 +172,8 @@ struct PairJob {
   GPtr<float> r;        // [N][C] residuals, tiled
   GPtr<uint8_t> valid;    // [N]
   GPtr<uint32_t> tapkey;   // [N] (yi << 16 | xi) of the footprint held in tapcache, 0xffffffff = none (C = 8 and C = 1)
+  int           tapcache_on; // 0: this (workspace, level) gathers its taps straight from the descriptor (dense levels of a batch); the keys are
+                           // still reset at the start of the level, so that a later call that does use the cache finds no stale entry
   GPtr<float> tapcache; // C = 8: [N][32] tiled, the 4 taps x 8 channels of the footprint last gathered for the point; C = 1: [N] float4
   GPtr<uint32_t> cand;     // [N*C] candidate keys of the bracketed median selection, one 256*C segment per block
   GPtr<uint32_t> med_blk;  // [ceil(N/256)][4] per-block {below, inside, valid points, tap-cache hits} of the bracket pass

@@ -321,6 +321,31 @@ def test_wide_launches_take_the_second_median_shape_and_change_nothing(hip):
     small.close()
 
 
+def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch):
+    """Batches run their dense pyramid levels without the per-point tap cache (PairJob::tapcache_on).  Calls that do use it afterwards
+    on the same workspace — the on-demand refresh behind get_residuals / get_weights — must not find entries an EARLIER cached run left
+    there: the keys are reset at the start of every level whether the cache is used or not.  160 x 120: no level reaches
+    minNumPixelsForNonMaximaSuppression, every level is dense."""
+    rows, cols, levels, n = 120, 160, 3, 3
+    b1 = synth.make_batch(rows, cols, n, first_index=40)
+    b2 = synth.make_batch(rows, cols, n, first_index=50)
+    p = make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels)
+    ctx = hip.create(b1["K"], b1["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    # a cached single-pair estimate on OTHER images fills the tap cache of workspace 2 (same geometry: the same footprints recur)
+    ctx.frames_set_data(0, 1, b2["images"], b2["disparities"])
+    ctx.frame_set_template(4)
+    ctx.estimate_pose(2, 4, 5)
+    poses, stats = ctx.batch_run(b1["images"], b1["disparities"])
+    r, w, v = ctx.get_residuals(2), ctx.get_weights(2), ctx.get_valid(2)
+    ctx.close()
+    monkeypatch.setenv("BPVO_HIP_TAPCACHE_MAX_DENSITY", "2.0")        # the cache at every level, as before
+    ref = hip.create(b1["K"], b1["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    poses_ref, stats_ref = ref.batch_run(b1["images"], b1["disparities"])
+    assert bits_equal(poses, poses_ref) and stats.tobytes() == stats_ref.tobytes()
+    assert np.array_equal(v, ref.get_valid(2)) and bits_equal(r, ref.get_residuals(2)) and bits_equal(w, ref.get_weights(2))
+    ref.close()
+
+
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
