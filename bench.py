@@ -446,7 +446,7 @@ def main():
             "tap_cache": {"hits": tap[0], "lookups": tap[1], "hit_rate": (tap[0] / tap[1]) if tap[1] else None,
                           "first_8_linearisations_of_a_level": {"hits": tap[2], "lookups": tap[3], "hit_rate": (tap[2] / tap[3]) if tap[3] else None},
                           "later_linearisations": {"hit_rate": ((tap[0] - tap[2]) / (tap[1] - tap[3])) if tap[1] > tap[3] else None},
-                          "note": "lookups = valid template points"},
+                          "note": "lookups = valid template points of the (workspace, level) linearisations that use the tap cache: the dense pyramid levels of a batch gather straight from the descriptor"},
             "fused_path": {"points": fused_pts[0], "of": fused_pts[1],
                            "note": "linearisations with a frozen robust scale: residuals recomputed inside irls_reduce, warp_residual skips them"},
             "roofline": roofline,
