@@ -321,7 +321,8 @@ def test_wide_launches_take_the_second_median_shape_and_change_nothing(hip):
     small.close()
 
 
-def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch):
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
+def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch, descriptor, loss):
     """Batches run their dense pyramid levels without the per-point tap cache (PairJob::tapcache_on).  Calls that do use it afterwards
     on the same workspace — the on-demand refresh behind get_residuals / get_weights — must not find entries an EARLIER cached run left
     there: the keys are reset at the start of every level whether the cache is used or not.  160 x 120: no level reaches
@@ -329,7 +330,7 @@ def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch)
     rows, cols, levels, n = 120, 160, 3, 3
     b1 = synth.make_batch(rows, cols, n, first_index=40)
     b2 = synth.make_batch(rows, cols, n, first_index=50)
-    p = make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels)
+    p = make_params(hip, descriptor=descriptor, loss=loss, levels=levels)
     ctx = hip.create(b1["K"], b1["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
     # a cached single-pair estimate on OTHER images fills the tap cache of workspace 2 (same geometry: the same footprints recur)
     ctx.frames_set_data(0, 1, b2["images"], b2["disparities"])
