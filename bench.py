@@ -8,9 +8,10 @@ one pass of the hot path over the rank's batch with the inputs already resident 
     setTemplate(A)          (saliency, NMS selection, points, Jacobians)  for every pair
     estimatePose(A, B, I)   (coarse-to-fine GN / IRLS to convergence)     for every pair
     + for N > 1: ONE RCCL gather of the 32-float result records to rank 0.
-Pairs are sharded across ranks (weak scaling: --pairs-per-gpu each, seeds 1000 + global pair index); there is no
-data-path collective.  value = GN iterations (linearise + solve + pose update, counted like the reference's
-_num_fun_evals, bpvo/pose_estimator_gn.h:78) of the whole job per second of step time.
+The job is BASELINE.json config 5: ONE batch of --pairs (1024) pairs, seeds 1000 + pair index, split contiguously over the
+ranks — strong scaling: `--gpus N` gives every rank 1024 / N pairs (N = 1: the whole batch on one GPU).  `--weak` instead runs
+--pairs on EVERY rank.  There is no data-path collective.  value = GN iterations (linearise + solve + pose update, counted
+like the reference's _num_fun_evals, bpvo/pose_estimator_gn.h:78) of the whole job per second of step time.
 
 Launch: `python bench.py` (1 GPU) or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
@@ -37,14 +38,15 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs-per-gpu", type=int, default=1024, help="pairs per GPU (default: the whole 1024-pair batch of BASELINE.json config 5 on every GPU)")
+    ap.add_argument("--pairs", type=int, default=1024, help="pairs of the job (BASELINE.json config 5: 1024), split over the ranks; with --weak: pairs per rank")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: every rank runs --pairs pairs (the job grows with N)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=0, help="shorthand for --weak --pairs P")
     ap.add_argument("--rows", type=int, default=376)
     ap.add_argument("--cols", type=int, default=1241)
     ap.add_argument("--descriptor", default="bitplanes", choices=["bitplanes", "intensity"])
     ap.add_argument("--loss", default="tukey", choices=["tukey", "huber", "l2"])
     ap.add_argument("--levels", type=int, default=4)
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: --pairs-per-gpu is the TOTAL batch (BASELINE config 5: 1024 pairs), every rank runs total / N of it")
+    ap.add_argument("--strong", action="store_true", help="(the default; kept so that older command lines still parse)")
     ap.add_argument("--tolerances", default="default", choices=["default", "timing"],
                     help="default = AlgorithmParameters() (1e-7 / 1e-6 / 1e-8); timing = the reference's conf/perf_*.cfg (1e-6 / 1e-4 / 1e-6)")
     ap.add_argument("--fixed-iters", type=int, default=0,
@@ -190,8 +192,8 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
     }
     npairs = batch["images"].shape[0] // 2
     if npairs >= 128:
-        # BASELINE config 5 as it is really sharded: 1024 pairs over 8 GPUs = 128 pairs per GPU (strong scaling; `--strong --gpus 8`
-        # runs exactly this on every rank)
+        # BASELINE config 5 as it is really sharded: 1024 pairs over 8 GPUs = 128 pairs per GPU (strong scaling; `--gpus 8` runs
+        # exactly this on every rank)
         out["config-5 shard: 128 of the 1024 pairs (1241x376 bitplanes, 4 levels, tukey) on one GPU"] = \
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 128, args.descriptor, args.levels, args.loss, steps=10, warmup=2)
     if npairs >= 1024:
@@ -215,15 +217,17 @@ def main():
     from bpvo_amd.distributed import RECORD_FLOATS, gather_records, records_to_poses, shard_range
 
     # ---- synthetic inputs for this rank's shard (rendered on the CPU before anything touches the GPU)
-    if args.strong:
-        total = args.pairs_per_gpu
+    if args.pairs_per_gpu > 0:
+        args.weak, args.pairs = True, args.pairs_per_gpu
+    if args.weak:
+        P = args.pairs
+        lo, hi = shard_range(P * world, rank, world)
+    else:
+        total = args.pairs
         lo, hi = shard_range(total, rank, world)
         P = hi - lo
         if P <= 0 or total % world:
-            raise SystemExit("--strong needs the total batch to divide by the number of ranks")
-    else:
-        P = args.pairs_per_gpu
-        lo, hi = shard_range(P * world, rank, world)
+            raise SystemExit("the batch must divide by the number of ranks (strong scaling: --pairs / --gpus pairs per rank)")
     workers = args.gen_workers or max(1, min(16, (os.cpu_count() or 1) // max(1, world)))
     t0 = time.perf_counter()
     cache = os.path.join(args.input_cache, f"synth_{args.rows}x{args.cols}_{lo}_{hi}") if args.input_cache else ""
@@ -307,12 +311,14 @@ def main():
     # untimed step of the same workload on a single lane (same kernels, same launches, HIP events on the library's stream);
     # what the events saw inside the timed region is reported next to it (roofline_timed_region).
     kstats_1lane = {}
+    fused_1lane = (0, 0)
     if not args.no_profile:
         ctx.set_max_lanes(1)
-        ctx.profiling(2 if args.profile_all else 3)     # 3: every warp_residual launch, so that the average is rocprofv3's average
+        ctx.profiling(2 if args.profile_all else 3)     # 3: every warp_residual and irls_reduce launch, so that the averages are rocprofv3's
         ctx.batch_run_device(P, d_images.data_ptr(), d_disps.data_ptr())
         torch.cuda.synchronize()
         kstats_1lane = {k["name"]: k for k in ctx.kernel_stats()}
+        fused_1lane = ctx.fused_point_counts()
         ctx.set_max_lanes(0)
     # the reference's own iteration counter (OptimizerStatistics::numIterations, bpvo/pose_estimator_base.h:392-398) summed over
     # pairs and levels of the LAST step; `gn_local` counts linearisations (= _num_fun_evals, pose_estimator_gn.h:78), 1-2 more per level
@@ -380,16 +386,48 @@ def main():
                         "measured": "one untimed step of the same workload on a single estimation lane, HIP events around EVERY launch on the "
                                     "library's stream (the timed steps overlap two lanes: roofline_timed_region)"}
 
-        # the whole Gauss-Newton loop against the HBM roofline: algorithmic bytes of one iteration (20 + 56 C per point)
-        # x points linearised, over the step time that is not spent in the per-frame stages (HIP events around those)
-        gn_loop = None
-        if not args.no_profile and points_linearized > 0:
-            C_ = 8 if args.descriptor == "bitplanes" else 1
-            gn_s = elapsed - frame_ms_local * 1e-3
-            gbps = (20 + 56 * C_) * points_linearized / gn_s / 1e9
-            gn_loop = {"bytes_per_point": 20 + 56 * C_, "points_linearized": points_linearized, "seconds": gn_s,
-                       "frame_stage_seconds": frame_ms_local * 1e-3, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS,
-                       "note": "rank 0; everything between the frame stages and the end of the step counts as loop time (launch gaps, host round trips, the narrow per-pair work)"}
+        # The second chip-filling kernel, irls_reduce (since round 2 the larger share of the GPU time), in MOVED bytes: what its
+        # loads request.  SURVEY.md 8d's algorithmic 2 + 28 C does not describe it — the Jacobian rows are recomputed, not read,
+        # and a workspace with a frozen scale takes the fused path (residuals recomputed from the taps):
+        #   plain  point 16 + valid 1 + residuals 4 C + gradients 8 C                       = 17 + 12 C  (113 B at C = 8)
+        #   fused  point 16 + template pixels 4 C + gradients 8 C + taps 16 C (+ 4 B key)   = 16 + 28 C (+ 4) (244 / 240 B)
+        # Next to it the HBM bytes per point the PMC passes counted on this workload (profiles/traffic.json).
+        roofline_irls = None
+        tjson = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tjson = json.load(open(tpath))
+            except Exception:
+                tjson = {}
+        if "irls_reduce" in kernels_1lane and args.descriptor == "bitplanes":
+            k = kernels_1lane["irls_reduce"]
+            C_ = 8
+            fused_1, total_1 = fused_1lane
+            frac_fused = fused_1 / total_1 if total_1 else 0.0
+            moved_per_point = (17 + 12 * C_) * (1.0 - frac_fused) + (16 + 28 * C_ + 4) * frac_fused
+            gbps = moved_per_point * k["units_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
+            t_pp = tjson.get("irls_reduce_hbm_bytes_per_point")
+            roofline_irls = {"bound": "hbm", "kernel": "irls_reduce_both_kernel<" + args.loss + ">", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": gbps / HBM_PEAK_GBS, "traffic": (t_pp * k["units_per_launch"]) if t_pp else None,
+                             "bytes_per_point": moved_per_point, "bytes_per_point_plain": 17 + 12 * C_, "bytes_per_point_fused": 16 + 28 * C_ + 4,
+                             "fused_fraction_of_points": frac_fused, "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"],
+                             "launches": k["launches"], "accounting": "moved (requested) bytes, not SURVEY 8d's algorithmic 226 B: Jacobians are recomputed, a third of the points recompute their residuals",
+                             "measured": "the same single-lane pass, HIP events around EVERY launch"}
+
+        # Both chip-filling kernels of the Gauss-Newton loop together, in HBM bytes the counters saw (PMC passes on this workload, bytes per
+        # point from profiles/traffic.json) over the sum of their launch durations in the single-lane pass
+        gn_kernels = None
+        if roofline is not None and roofline_irls is not None and tjson.get("warp_residual_hbm_bytes_per_point") and tjson.get("irls_reduce_hbm_bytes_per_point"):
+            k6, k8 = kernels_1lane["warp_residual"], kernels_1lane["irls_reduce"]
+            hbm_bytes = tjson["warp_residual_hbm_bytes_per_point"] * k6["units_per_launch"] * k6["launches"] + \
+                tjson["irls_reduce_hbm_bytes_per_point"] * k8["units_per_launch"] * k8["launches"]
+            secs = (k6["total_ms"] + k8["total_ms"]) * 1e-3
+            gn_kernels = {"kernels": ["warp_residual", "irls_reduce"], "hbm_bytes": hbm_bytes, "kernel_seconds": secs, "achieved": hbm_bytes / secs / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                          "share_of_step": secs / (elapsed / args.steps),
+                          "note": "HBM traffic by the PMC counters over the summed launch durations of the two kernels (single-lane pass); "
+                                  "share_of_step compares that sum with one timed two-lane step"}
 
         cpu = None
         pose_vs_cpu = None
@@ -422,7 +460,7 @@ def main():
             if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s",
             "value": gn_total / elapsed_max, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "dist_backend": (args.dist_backend if world > 1 else None),
-            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32 (+f64 projection/interpolation)", "data": "synthetic",
             "config": {"workload": f"batch of {n_pairs_total} independent {args.cols}x{args.rows} stereo pairs "
                                    f"({P} per GPU), {args.descriptor} descriptor, {args.levels} pyramid levels, {args.loss} loss, "
@@ -437,7 +475,8 @@ def main():
             "numIterations_per_s": numit_total * args.steps / elapsed_max,
             "numIterations_note": "sum over pairs and levels of OptimizerStatistics::numIterations (the reference's reported count: 1-2 below "
                                   "the linearisations of a level) per second — the like-for-like figure next to `value`",
-            "gn_loop_roofline": gn_loop,
+            "roofline_irls_reduce": roofline_irls,
+            "gn_kernels_hbm": gn_kernels,
             "points_linearized_rank0": points_linearized,
             "mean_iterations_per_level": [float(x) for x in iters.mean(axis=0)],
             "pose_check": pose_err,

@@ -236,6 +236,15 @@ class Context:
                   H.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), C.byref(f), C.byref(s), C.byref(nv))
         return dict(H=H, G=G, f_norm=f.value, sigma=s.value, num_valid=nv.value)
 
+    def linearize_at_scale(self, ws, ref, cur, level, T, sigma):
+        """computeResiduals at T, then ComputeWeights / LinearSystemBuilder::Run with the GIVEN robust scale (HIP library only)."""
+        T = _f32(T).reshape(16)
+        H, G = np.empty((6, 6), np.float32), np.empty(6, np.float32)
+        f, nv = C.c_float(), C.c_int()
+        self.call("linearize_at_scale", int(ws), int(ref), int(cur), int(level), T.ctypes.data_as(C.c_void_p), C.c_float(sigma),
+                  H.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), C.byref(f), C.byref(nv))
+        return dict(H=H, G=G, f_norm=f.value, sigma=float(np.float32(sigma)), num_valid=nv.value)
+
     def _get_vec(self, name, ws, dtype):
         n = C.c_size_t()
         self.call(name, int(ws), None, C.byref(n))

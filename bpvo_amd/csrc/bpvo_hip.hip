@@ -168,8 +168,11 @@ struct bpvo_hip_ctx {
   // (workgroups not co-resident) — the context stays on the four-kernel chain from then on.
   int persistent = 1, persist_max_ws = 1, persist_grid = 64;
   long long persist_timeout = 50000000ll;   // ticks of the 100 MHz wall clock a grid barrier waits before it gives up (0.5 s)
-  bool persistent_failed = false;
-  uint64_t persistent_levels = 0;   // levels run by the persistent kernel (measurement)
+  std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
+  std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)
+  // bpvo_hip_estimate_pose_trace: while trace_ws >= 0 the jobs of that workspace carry the device trace buffer
+  float* d_trace = nullptr;
+  int trace_cap = 0, trace_ws = -1;
   int max_lanes_now = 1 << 30; // bpvo_hip_set_max_lanes: measurement runs that need per-launch timings without overlap
   // stereo front-end scratch (lazily sized for the largest frame count seen): raw and pre-filtered u8 pairs, f32 disparities
   uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
@@ -369,6 +372,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
   j.cnt = c->d_counters + kWsCounters * (size_t) ws;
+  if(ws == c->trace_ws) { j.trace = c->d_trace; j.trace_cap = c->trace_cap; }
   return j;
 }
 
@@ -603,25 +607,28 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 }
 
 // ---- estimatePose ---------------------------------------------------------------------------------------------------
+// (an early return must not leave work in flight that still reads the lane's pinned staging: drain the stream first)
 #define LANE_CK(ln_, expr)                                                                  \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
     if(e_ != hipSuccess) {                                                                  \
       (ln_)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+      (void) hipStreamSynchronize((ln_)->stream);                                           \
       return BPVO_ERR_DEVICE;                                                               \
     }                                                                                       \
   } while(0)
 
 // VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93) for a group of `n` workspaces on one
 // lane.  wss[i]: workspace, refs[i] / curs[i]: frame slots.  T_init host [n][16] or null (Identity).
+// allow_persistent: only a group that has the device to itself (a batch on ONE lane) may take the persistent kernel — two
+// hand-barrier grids of concurrent lanes must not be co-scheduled.
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init,
-                   float* poses, bpvo_hip_stats* stats, float* d_records_out)
+                   float* poses, bpvo_hip_stats* stats, float* d_records_out, bool allow_persistent)
 {
   if(n <= 0) return BPVO_OK;
   (void) hipSetDevice(c->device);
   const bpvo_hip_params& p = c->params;
   const int NP = c->n_pairs;
-  c->frac_valid = false;
   // (the pinned staging of a lane is free here: every call that uses it ends with a synchronisation of the lane's stream)
   std::vector<int> max_pts(c->L, 0);
   for(int l = 0; l < c->L; ++l)
@@ -646,7 +653,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     dT = ln->d_Tinit;
   }
   launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
-  const bool pk_group = c->persistent && !c->persistent_failed && n <= c->persist_max_ws && !c->profile_all;
+  const bool pk_group = allow_persistent && c->persistent && !c->persistent_failed.load() && n <= c->persist_max_ws && !c->profile_all;
   bool persistent = pk_group;
   if(persistent) LANE_CK(ln, hipMemsetAsync(ln->d_pk_ctl, 0, sizeof(unsigned) * kPkCtlWords * kMaxLevels, ln->stream));
 
@@ -669,10 +676,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     if(g.max_points <= 0) continue;
     if(persistent && gn_persistent_serves(g)) {
       // the whole level in one launch
-      LANE_CK(ln, launch_gn_persistent(ln->stream, g, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance,
-                                       ln->d_pk_ctl + (size_t) l * kPkCtlWords, gn_persistent_grid(g, c->persist_grid), c->persist_timeout));
-      c->persistent_levels += 1;
-      continue;
+      const hipError_t pe = launch_gn_persistent(ln->stream, g, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance,
+                                                 ln->d_pk_ctl + (size_t) l * kPkCtlWords, gn_persistent_grid(g, c->persist_grid), c->persist_timeout);
+      if(pe == hipSuccess) {
+        c->persistent_levels.fetch_add(1);
+        continue;
+      }
+      // the device cannot grant the kernel its LDS / residency (or the launch failed): degrade to the four-kernel chain — this level,
+      // the rest of the pyramid and every later call of the context — instead of failing the estimate
+      (void) hipGetLastError();
+      c->persistent_failed.store(true);
     }
     persistent = false;     // (a level the kernel does not serve: the rest of the pyramid takes the chain as well)
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); the state machine on the device
@@ -707,18 +720,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
           ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled);
           launch_warp_residual(ln->stream, g);
         }
-        if(c->profile_all) {
-          if(launch_median_k) { ScopedTimer t(c, KC_MEDIAN, 0.0, ln); launch_median(ln->stream, g); }
-          { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln); launch_irls_reduce(ln->stream, g); }
-          { ScopedTimer t(c, KC_GN_STEP, 0.0, ln);
-            launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                           p.gradientTolerance); }
-        } else {
-          if(launch_median_k) launch_median(ln->stream, g);
-          launch_irls_reduce(ln->stream, g);
-          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance,
-                         p.gradientTolerance);
-        }
+        // level 2 times every kernel; level 3 (bench.py's single-lane roofline pass) every warp_residual AND every irls_reduce launch
+        { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all && launch_median_k); if(launch_median_k) launch_median(ln->stream, g); }
+        { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all || c->profile_k6_all); launch_irls_reduce(ln->stream, g); }
+        { ScopedTimer t(c, KC_GN_STEP, 0.0, ln, c->profile_all);
+          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance); }
       }
       const int slot = round % 3;
       launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + 2 * slot);
@@ -786,8 +792,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     if(gave_up) {
       // a barrier timed out: the states of that level were not written back.  Rerun the group through the four-kernel chain
       // (same results) and keep this context on it.
-      c->persistent_failed = true;
-      return estimate_group(c, ln, n, wss, refs, curs, T_init, poses, stats, d_records_out);
+      c->persistent_failed.store(true);
+      return estimate_group(c, ln, n, wss, refs, curs, T_init, poses, stats, d_records_out, false);
     }
   }
   for(int i = 0; i < n; ++i) {
@@ -817,11 +823,12 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
   if(nl > 1) HIP_CK(c, hipStreamSynchronize(c->stream));
   std::vector<int> rcs(nl, BPVO_OK);
+  c->frac_valid = false;      // (on the API thread: the lane threads only read the context's settings)
   auto run = [&](int k) {
     const int lo = (int) ((long long) n * k / nl), hi = (int) ((long long) n * (k + 1) / nl);
     rcs[k] = estimate_group(c, &c->lanes[k], hi - lo, wss + lo, refs + lo, curs + lo, T_init ? T_init + 16 * (size_t) lo : nullptr,
                             poses ? poses + 16 * (size_t) lo : nullptr, stats ? stats + (size_t) lo * c->L : nullptr,
-                            c->d_records + (size_t) kRecordFloats * lo);
+                            c->d_records + (size_t) kRecordFloats * lo, nl == 1);
   };
   if(nl == 1) {
     run(0);
@@ -1234,7 +1241,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
-  (void) hipFree(c->d_count); (void) hipFree(c->d_counters);
+  (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
   (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
@@ -1430,8 +1437,8 @@ int bpvo_hip_get_normalization(bpvo_hip_ctx* c, int slot, int level, float T[16]
 }
 
 // ---- operator-level seam --------------------------------------------------------------------------------------------
-int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int level, const float T[16], int reset_scale,
-                       float H[36], float G[6], float* f_norm, float* sigma, int* num_valid)
+static int linearize_impl(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int level, const float T[16], int reset_scale, float given_scale,
+                          float H[36], float G[6], float* f_norm, float* sigma, int* num_valid)
 {
   CHECK_CTX(c); CHECK_WS(c, ws); CHECK_SLOT(c, ref_slot); CHECK_SLOT(c, cur_slot); CHECK_LEVEL(c, level);
   if(!c->frames[ref_slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
@@ -1444,7 +1451,7 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   Lane& l0 = c->lanes[0];
   std::memcpy(l0.h_T, T, 16 * sizeof(float));
   HIP_CK(c, hipMemcpyAsync(l0.d_Tinit, l0.h_T, 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  launch_prepare_linearize(c->stream, c->d_job1, l0.d_Tinit, reset_scale, level);
+  launch_prepare_linearize(c->stream, c->d_job1, l0.d_Tinit, reset_scale, level, given_scale);
   GNLaunch g;
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   g.fast_warp = c->fast_warp;
@@ -1462,10 +1469,21 @@ int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int 
   std::memcpy(H, st.H, sizeof(st.H));
   std::memcpy(G, st.G, sizeof(st.G));
   *f_norm = st.f_norm;
-  *sigma = st.scale;
+  if(sigma) *sigma = st.scale;
   *num_valid = (int) st.n_valid;
   c->ws[ws].last_ref = ref_slot; c->ws[ws].last_cur = cur_slot; c->ws[ws].last_level = level;
   return BPVO_OK;
+}
+int bpvo_hip_linearize(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int level, const float T[16], int reset_scale,
+                       float H[36], float G[6], float* f_norm, float* sigma, int* num_valid)
+{
+  return linearize_impl(c, ws, ref_slot, cur_slot, level, T, reset_scale ? 1 : 0, 0.0f, H, G, f_norm, sigma, num_valid);
+}
+int bpvo_hip_linearize_at_scale(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, int level, const float T[16], float sigma,
+                                float H[36], float G[6], float* f_norm, int* num_valid)
+{
+  if(c && !(sigma > 0.0f)) return fail(c, BPVO_ERR_INVALID_ARG, "sigma must be positive");
+  return linearize_impl(c, ws, ref_slot, cur_slot, level, T, 2, sigma, H, G, f_norm, nullptr, num_valid);
 }
 
 int bpvo_hip_get_residuals(bpvo_hip_ctx* c, int ws, float* r, size_t* n_out)
@@ -1558,6 +1576,33 @@ int bpvo_hip_estimate_pose(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, 
   if(int rc = check_template_not_empty(c, ref_slot)) return rc;
   (void) hipSetDevice(c->device);
   return estimate_batch(c, 1, &ws, &ref_slot, &cur_slot, T_init, T_est, stats);
+}
+
+int bpvo_hip_estimate_pose_trace(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, const float T_init[16], float T_est[16],
+                                 bpvo_hip_stats* stats, float* records, int max_records, int* n_records)
+{
+  CHECK_CTX(c); CHECK_WS(c, ws);
+  if(!T_init || !T_est || !n_records || max_records < 0 || (max_records > 0 && !records)) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr pose / records");
+  if(int rc = check_template_not_empty(c, ref_slot)) return rc;
+  (void) hipSetDevice(c->device);
+  // at most min(maxIterations + 2, maxFuncEvals) linearisations per level (pose_estimator_base.h:373-393)
+  const int cap = c->L * (std::min(std::max(c->params.maxIterations, 0) + 2, 6 * 200) + 1);
+  if(cap > c->trace_cap) {
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    (void) hipFree(c->d_trace);
+    c->d_trace = nullptr; c->trace_cap = 0;
+    HIP_CK(c, hipMalloc((void**) &c->d_trace, sizeof(float) * kTraceFloats * (size_t) cap));
+    c->trace_cap = cap;
+  }
+  c->trace_ws = ws;
+  const int rc = estimate_batch(c, 1, &ws, &ref_slot, &cur_slot, T_init, T_est, stats);
+  c->trace_ws = -1;
+  if(rc) return rc;
+  const int n = c->lanes[0].h_states[ws].trace_n;
+  *n_records = n;
+  const int ncopy = std::min(std::min(n, max_records), c->trace_cap);
+  if(ncopy > 0) HIP_CK(c, hipMemcpy(records, c->d_trace, sizeof(float) * kTraceFloats * (size_t) ncopy, hipMemcpyDeviceToHost));
+  return BPVO_OK;
 }
 
 // ---- VisualOdometry -------------------------------------------------------------------------------------------------
@@ -1843,6 +1888,7 @@ int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* ima
                         bpvo_hip_stats* stats)
 {
   HIP_CK(c, hipStreamSynchronize(c->stream));
+  c->frac_valid = false;
   const size_t npix = c->geom[0].npix;
   std::vector<int> rcs(nl, BPVO_OK);
   std::mutex mu;
@@ -1868,7 +1914,7 @@ int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* ima
     std::vector<int> wss(n), refs(n), curs(n);
     for(int i = 0; i < n; ++i) { wss[i] = lo + i; refs[i] = 2 * (lo + i); curs[i] = 2 * (lo + i) + 1; }
     rcs[k] = estimate_group(c, ln, n, wss.data(), refs.data(), curs.data(), nullptr, poses ? poses + 16 * (size_t) lo : nullptr,
-                            stats ? stats + (size_t) lo * c->L : nullptr, c->d_records + (size_t) kRecordFloats * lo);
+                            stats ? stats + (size_t) lo * c->L : nullptr, c->d_records + (size_t) kRecordFloats * lo, false);
   };
   {
     std::vector<std::thread> th;
@@ -1978,8 +2024,8 @@ int bpvo_hip_fused_point_counts(bpvo_hip_ctx* c, uint64_t* fused, uint64_t* tota
 int bpvo_hip_persistent_counts(bpvo_hip_ctx* c, uint64_t* levels, int* gave_up)
 {
   if(!c) return BPVO_ERR_INVALID_ARG;
-  if(levels) *levels = c->persistent_levels;
-  if(gave_up) *gave_up = c->persistent_failed ? 1 : 0;
+  if(levels) *levels = c->persistent_levels.load();
+  if(gave_up) *gave_up = c->persistent_failed.load() ? 1 : 0;
   return BPVO_OK;
 }
 

@@ -109,7 +109,7 @@ bool gn_persistent_serves(const GNLaunch& g);
 int  gn_persistent_grid(const GNLaunch& g, int max_grid);
 hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol,
                                 unsigned* ctl, int grid, long long timeout_ticks);
-void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level);
+void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);
 int  gn_pts_per_block(int C);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);

@@ -1035,7 +1035,7 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
 typedef float IrlsPartLds[4][kPartialStride];
 template <int C, int LOSS, bool FUSED>
 __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
-                                          IrlsPartLds& s_part, bool has)
+                                          IrlsPartLds& s_part, bool has, float* __restrict__ partials)
 {
   // Fused path (C = 8): the robust scale is frozen for the rest of the level, so nothing separates the residuals from
   // their weights any more — they are recomputed here exactly as warp_residual does (same warp_point, same tap cache) and
@@ -1163,7 +1163,7 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
   __syncthreads();
   if(vtid < kNumAcc && has) {
     const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
-    j.partials[(size_t) tile * kPartialStride + vtid] = v;
+    partials[(size_t) tile * kPartialStride + vtid] = v;
   }
 }
 
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __re
 {
   if((int) blockIdx.x * pts_per_block >= j.n) return;
   __shared__ IrlsPartLds s_part;
-  irls_tile<C, LOSS, FUSED>(j, st, pts_per_block, blockIdx.x, threadIdx.x, s_part, true);
+  irls_tile<C, LOSS, FUSED>(j, st, pts_per_block, blockIdx.x, threadIdx.x, s_part, true, j.partials);
 }
 
 // irls_tile for LATENCY-bound launches (persistent kernel, C = 8): the same per-point arithmetic and the same accumulation order
@@ -1212,7 +1212,7 @@ __device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPoint
 
 template <int LOSS, bool FUSED>
 __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
-                                              IrlsPartLds& s_part, bool has)
+                                              IrlsPartLds& s_part, bool has, float* __restrict__ partials)
 {
   float P[12];
   if constexpr(FUSED) {
@@ -1362,7 +1362,7 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
   __syncthreads();
   if(vtid < kNumAcc && has) {
     const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
-    j.partials[(size_t) tile * kPartialStride + vtid] = v;
+    partials[(size_t) tile * kPartialStride + vtid] = v;
   }
 }
 
@@ -1530,12 +1530,13 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 // The loads of 32 tiles are issued back to back, UNCONDITIONALLY (the tile index is clamped, the add is what the bound selects: a
 // conditional load makes the compiler wait per branch), so a level costs one global-memory round trip per 32 tiles instead of one per
 // 8: 2.2 -> 1.3 us of the serial step at the finest level of a 1241x376 pair (profiles/r02_persistent_phases.txt).  Same order of additions.
-__device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/)
+__device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/,
+                                                const float* __restrict__ partials)
 {
   const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
   if(lane < kNumAcc) {
     double s = 0.0;
-    const float* __restrict__ pp = j.partials + lane;
+    const float* __restrict__ pp = partials + lane;
     auto chunked = [&](auto uc) {
       constexpr int U = decltype(uc)::value;
       for(int b0 = 0; b0 < nblk; b0 += U) {
@@ -1567,6 +1568,18 @@ __device__ __forceinline__ void gn_serial_step(const PairJob& j, GNState* st, co
   st->r_stale = fused_lin ? 1 : 0;
   const bool again = gn_logic(st, s_nrm, s_sum, scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param);
   (void) again;   // who is still active is read from st->active (compact_active_kernel once per host round / the persistent loop)
+  if(stats && mode == 0 && j.trace) {
+    // bpvo_hip_estimate_pose_trace: the linearisation just consumed (pose, system, function value, scale, valid count) and the step
+    // solved from it; record layout: BPVO_HIP_TRACE_FLOATS in c_api.h
+    if(st->trace_n < j.trace_cap) {
+      float* o = j.trace + (size_t) st->trace_n * kTraceFloats;
+      for(int i = 0; i < 16; ++i) o[i] = st->T_lin[i];
+      for(int i = 0; i < 36; ++i) o[16 + i] = st->H[i];
+      for(int i = 0; i < 6; ++i) { o[52 + i] = st->G[i]; o[61 + i] = st->dp[i]; }
+      o[58] = st->f_norm; o[59] = st->scale; o[60] = (float) st->n_valid; o[67] = (float) st->level;
+    }
+    st->trace_n += 1;
+  }
   if(stats) {
     j.cnt[0] += (unsigned long long) j.n;     // measurement: points and linearisations processed (bench.py roofline)
     j.cnt[1] += 1ull;
@@ -1596,7 +1609,7 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
   if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
   if(threadIdx.x == 4) s_nrm[4] = j.dspace ? 1.0f : 0.0f;
-  gn_sum_partials(j, pts_per_block, threadIdx.x, s_sum);
+  gn_sum_partials(j, pts_per_block, threadIdx.x, s_sum, j.partials);
   __syncthreads();
   if(threadIdx.x == 0)
     gn_serial_step(j, reinterpret_cast<GNState*>(s_state), s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol,
@@ -1735,30 +1748,44 @@ __device__ __attribute__((noinline)) void pk_median_phase(const PairJob* __restr
 // callee-saved registers per call through scratch — 250 KB per workgroup each way: measured 12.6 instead of 9.2 us per iteration.
 // Splitting a tile's points over the workgroup's two virtual blocks, contributions exchanged through LDS and added in point
 // order, was measured as well: 10.2 us — the exchange costs more than the halved arithmetic saves.)
+// The tile partials are DOUBLE-BUFFERED by iteration parity.  An iteration whose active workspaces all have a frozen scale (fused
+// path) or a moot one (kL2) has no warp / median phase and hence no grid barrier between the step of iteration k and the reduction
+// of iteration k + 1: a workgroup that finishes its step early would overwrite partials a slower workgroup is still summing (every
+// workgroup sums all tiles for its own copy of the state).  With two buffers the writes of iteration k + 1 go to the other one; the
+// buffer of iteration k is written again in iteration k + 2 at the earliest, i.e. after the barrier of iteration k + 1, which every
+// workgroup only reaches after its step of iteration k.  The second buffer starts right behind the ntiles entries of the first (the
+// allocation holds cap / 256 entries, the reduction uses at most cap / 1024).
+__device__ __forceinline__ float* pk_partials(const PairJob& j, int pts_per_block, unsigned parity)
+{
+  const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
+  return j.partials + (size_t) (parity & 1u) * (size_t) ntiles * kPartialStride;
+}
 template <int C, int LOSS, bool FUSED>
-__device__ __forceinline__ void pk_irls_phase(const PairJob* __restrict__ jobs, int ws, int pts_per_block)
+__device__ __forceinline__ void pk_irls_phase(const PairJob* __restrict__ jobs, int ws, int pts_per_block, unsigned parity)
 {
   const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
   const int nwg = (int) gridDim.x;
   const PairJob& j = jobs[ws];
   const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
+  float* const partials = pk_partials(j, pts_per_block, parity);
   for(int base = 0; base < ntiles; base += nwg * PK_VB) {
     const int tile = base + vsub * nwg + (int) blockIdx.x;
-    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles);
-    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles);
+    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
+    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
     __syncthreads();
   }
 }
 
 // gn_step: wave w sums the partials of workspace w, its lane 0 runs the serial step on this workgroup's copy of the state
-__device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm, int fuse, bool stats_wg)
+__device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm, int fuse, bool stats_wg,
+                                                        unsigned parity)
 {
   const int ws = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool mine = ws < nws && pk_st(ws < nws ? ws : 0)->active;
 #ifdef BPVO_PK_TIMING
   long long sub_t = wall_clock64();
 #endif
-  if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws]);
+  if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws], pk_partials(jobs[ws], pts_per_block, parity));
   __syncthreads();
 #ifdef BPVO_PK_TIMING
   if(threadIdx.x == 0) GN_SUBTICK(4);
@@ -1812,7 +1839,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
   }
   __syncthreads();
 
-  unsigned epoch = 0;
+  unsigned epoch = 0, epoch_it = 0;     // grid barriers passed; iterations done (parity of the partials buffer)
   bool ok = true;
   // BPVO_PK_TIMING: workgroup 0 accumulates the 100 MHz wall-clock ticks of every phase in ctl[8..13] and the iterations in ctl[15]
 #ifdef BPVO_PK_TIMING
@@ -1860,18 +1887,19 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
       const GNState* st = pk_st(ws);
       if(!st->active) continue;
       if constexpr(kCanFuse) {
-        if(fuse && !(st->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, ws, pts_per_block);
-        else pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block);
+        if(fuse && !(st->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, ws, pts_per_block, epoch_it);
+        else pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block, epoch_it);
       } else {
-        pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block);
+        pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block, epoch_it);
       }
     }
     PK_TICK(3);
     ok = pk_grid_barrier(ctl, ++epoch, timeout);
     PK_TICK(4);
     if(!ok) break;
-    pk_step_phase(jobs, nws, pts_per_block, prm, fuse ? 1 : 0, stats_wg);
+    pk_step_phase(jobs, nws, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
     PK_TICK(5);
+    ++epoch_it;
   }
 #ifdef BPVO_PK_TIMING
   if(blockIdx.x == 0 && tid == 0) {
@@ -1896,6 +1924,7 @@ __global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
   if(p >= n) return;
   GNState* st = jobs[p].st;
   for(int i = 0; i < 16; ++i) st->T_out[i] = T_init ? T_init[p * 16 + i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+  st->trace_n = 0;
   for(int l = 0; l < kMaxLevels; ++l) {                 // OptimizerStatistics() defaults (bpvo/types.cc:306-310)
     st->stats[l].numIterations = 0;
     st->stats[l].finalError = -1.0f;
@@ -1949,12 +1978,15 @@ __global__ __launch_bounds__(GN_BLOCK) void reset_tapkeys_kernel(const PairJob* 
 }
 
 // operator-level seam (bpvo_hip_linearize): pose in, optional AutoScaleEstimator::reset
-__global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int reset_scale, int level)
+// reset_scale 2: the scale is GIVEN (bpvo_hip_linearize_at_scale) — the estimator is left frozen at it, so the median kernel and
+// the bracket step leave the workspace alone and irls_reduce weighs with exactly this value
+__global__ void prepare_linearize_kernel(const PairJob* job, const float* T, int reset_scale, int level, float given_scale)
 {
   if(threadIdx.x != 0 || blockIdx.x != 0) return;
   GNState* st = job->st;
   for(int i = 0; i < 16; ++i) st->T[i] = T[i];
-  if(reset_scale) { st->scale = 1.0f; st->delta_scale = 1e10f; }
+  if(reset_scale == 2) { st->scale = given_scale; st->delta_scale = 0.0f; }
+  else if(reset_scale) { st->scale = 1.0f; st->delta_scale = 1e10f; }
   if(reset_scale || st->level != level) { st->median_valid = 0; st->last_median = 0.0f; }
   st->level = level;
   st->active = 1;
@@ -2200,9 +2232,9 @@ hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterat
   if(g.C == 8) return launch_gn_persistent_c<8>(s, g, prm, ctl, grid, timeout_ticks);
   return launch_gn_persistent_c<1>(s, g, prm, ctl, grid, timeout_ticks);
 }
-void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level)
+void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level, float given_scale)
 {
-  hipLaunchKernelGGL(prepare_linearize_kernel, dim3(1), dim3(64), 0, s, job, T, reset_scale, level);
+  hipLaunchKernelGGL(prepare_linearize_kernel, dim3(1), dim3(64), 0, s, job, T, reset_scale, level, given_scale);
 }
 template <int C>
 static void launch_weights_c(hipStream_t s, const PairJob* job, int n, int loss, float* w_out)

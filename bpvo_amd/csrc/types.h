@@ -14,6 +14,7 @@ constexpr int kReduceVals = 28;    // 21 upper-triangular H + 6 G + sum w r^2
 constexpr int kPartialStride = 32;
 constexpr int kWsCounters = 12;
 constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hip_batch_result_records_device)
+constexpr int kTraceFloats = BPVO_HIP_TRACE_FLOATS;   // one record per linearisation (c_api.h)
 
 // TILED per-point layout.  Template pixels, Jacobians and residuals are records of W floats per point
 // (W = C, 6*C, C).  A record is cut into V-float vector pieces (V = 4 for C = 8; 1 or 2 for C = 1) and points are grouped
@@ -108,6 +109,7 @@ struct GNState {
   // and r_stale says that the buffers have to be refreshed from it before anything reads them (done on demand).
   float T_lin[16];
   int   r_stale;
+  int   trace_n;                             // records written to PairJob::trace since set_pose (bpvo_hip_estimate_pose_trace)
 };
 
 // Streaming (non-temporal) 16-byte accesses for data that is read or written exactly once per launch and is far larger
@@ -184,6 +186,11 @@ struct PairJob {
                            // [7] / [8] the same over the first 8 linearisations of a level, [10] points linearised through the
                            // fused path; written by one thread each: no atomics
   GPtr<GNState> st;
+  // per-linearisation trace of the Gauss-Newton run (bpvo_hip_estimate_pose_trace; null otherwise): trace_cap records of
+  // kTraceFloats floats, written by the thread that runs the serial step — the table the reference prints per iteration at
+  // kIteration verbosity (bpvo/pose_estimator_base.h:231-247), with the pose, H, G and dp added
+  GPtr<float> trace;
+  int           trace_cap;
 };
 
 // selection / template-build job for one (frame, level)

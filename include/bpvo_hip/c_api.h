@@ -175,6 +175,12 @@ int bpvo_hip_get_normalization(bpvo_hip_ctx* ctx, int slot, int level, float T[1
  * Outputs: H (6x6 row-major, symmetric), G, f_norm = sqrt(sum w v r^2), sigma, number of valid points. */
 int bpvo_hip_linearize(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, int level, const float T[16],
                        int reset_scale, float H[36], float G[6], float* f_norm, float* sigma, int* num_valid);
+/* The same seam with the robust scale GIVEN instead of estimated: computeResiduals at T, then MEstimator::ComputeWeights(r, sigma) and
+ * LinearSystemBuilder::Run (bpvo/pose_estimator_gn.h:72,76-79 without :74).  The scale estimator of the workspace is left frozen at
+ * sigma.  For comparing H, G and f_norm with a reference run at a pose where that run's sigma is known (its freeze history, Q6, is
+ * not reproducible from the pose alone). */
+int bpvo_hip_linearize_at_scale(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, int level, const float T[16],
+                                float sigma, float H[36], float G[6], float* f_norm, int* num_valid);
 int bpvo_hip_get_residuals(bpvo_hip_ctx* ctx, int ws, float* r /*[C*N]*/, size_t* n);
 int bpvo_hip_get_valid(bpvo_hip_ctx* ctx, int ws, uint16_t* v /*[N]*/, size_t* n);
 int bpvo_hip_get_weights(bpvo_hip_ctx* ctx, int ws, float* w /*[C*N]*/, size_t* n);          /* vo_pose_estimator.cc:95-99 */
@@ -201,6 +207,18 @@ int bpvo_hip_set_warp_formulation(bpvo_hip_ctx* ctx, int mode);
  * coarse-to-fine PoseEstimatorGN::run (pose_estimator_base.h:324-407). stats[numLevels]. */
 int bpvo_hip_estimate_pose(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, const float T_init[16],
                            float T_est[16], bpvo_hip_stats* stats);
+
+/* The same estimate with one record per linearisation of the Gauss-Newton runs, in the order they happen (coarse to fine) — what the
+ * reference prints per iteration at Verbosity kIteration (PoseEstimatorBase::run, bpvo/pose_estimator_base.h:231-247,373-393: iteration,
+ * function value, first-order optimality, step size), with the pose of the linearisation and the system that was solved added:
+ *   [0..15] T the linearisation was taken at (row-major)   [16..51] H   [52..57] G   [58] f_norm = sqrt(sum w v r^2)
+ *   [59] robust scale sigma the weights used   [60] valid points   [61..66] dp solved from (H, G)   [67] pyramid level
+ * Written on the device by the thread that runs the solve / pose update (gn_step, or the persistent single-pair kernel); the
+ * estimate itself is the one bpvo_hip_estimate_pose gives, bit for bit.  *n_records = records written (may exceed max_records:
+ * only the first max_records are copied). */
+#define BPVO_HIP_TRACE_FLOATS 68
+int bpvo_hip_estimate_pose_trace(bpvo_hip_ctx* ctx, int ws, int ref_slot, int cur_slot, const float T_init[16], float T_est[16],
+                                 bpvo_hip_stats* stats, float* records /*[max_records][68]*/, int max_records, int* n_records);
 
 /* ---- VisualOdometry (reference: bpvo/vo.h:42-100, bpvo/vo.cc:125-224). Uses frame slots 0..2 and
  * workspace 0 of the ctx (needs n_frames >= 3). */
@@ -235,7 +253,11 @@ int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* ctx, float* d_dst, int n_pa
 
 /* ---- stereo front-end.  reference: StereoAlgorithm (utils/stereo_algorithm.{h,cc}), BlockMatching branch:
  * cvFindStereoCorrespondenceBM with the state of utils/stereo_algorithm.cc:63-82, then disp16.convertTo(CV_32F, 1/16) (:98-111).
- * The matcher is OpenCV 2.4's (third party): restated, parity unpinned.  Invalid pixels carry minDisparity - 1 (getInvalidValue). */
+ * The matcher is OpenCV 2.4's (third party): restated, parity unpinned.  Invalid pixels carry minDisparity - 1 (getInvalidValue).
+ * Two documented deviations where the original depends on memory layout: right-image window columns past the row end are read by
+ * linear addressing, clamped at the end of the image; and for minDisparity > 0 the original's column loop runs past the end of the
+ * row (its results there depend on the next row's bytes) — here and in the oracle that overrun is CUT at the last column, not
+ * reproduced. */
 typedef struct bpvo_hip_stereo_params {
   int preFilterCap;          /* 31 */
   int SADWindowSize;         /* 15; odd, 5..21 on the device path */
@@ -268,7 +290,8 @@ typedef struct bpvo_hip_kernel_stat {
 } bpvo_hip_kernel_stat;
 /* 0 off; 1: HIP events around the frame stages and around every 5th warp_residual launch of a batch estimate (the
  * reported units are scaled to the sampled launches); 2: around every launch of every kernel; 3: as 1, but around EVERY
- * warp_residual launch (the average is then over the same launches as a rocprofv3 kernel trace's).  Resets the counters. */
+ * warp_residual and EVERY irls_reduce launch (the averages are then over the same launches as a rocprofv3 kernel trace's).
+ * Resets the counters. */
 int bpvo_hip_profiling(bpvo_hip_ctx* ctx, int enable);
 int bpvo_hip_get_kernel_stats(bpvo_hip_ctx* ctx, bpvo_hip_kernel_stat* out, int max_out, int* n_out);
 int bpvo_hip_total_linearizations(bpvo_hip_ctx* ctx, uint64_t* n);  /* GN iterations done since create/reset */

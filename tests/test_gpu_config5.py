@@ -31,11 +31,15 @@ SHARD = 128            # pairs per GPU of config 5 at G = 8
 N_ORACLE = 32          # pairs of the shard also run through the CPU oracle (every 4th)
 
 
-def _oracle_pairs(orc, batch, picks, p_kw, trace=False):
-    """The picked pairs of `batch`, one at a time through the oracle (single-threaded = the reference's default build)."""
+def _oracle_pairs(orc, batch, picks, p_kw, trace=False, chunks=1, f64=0):
+    """The picked pairs of `batch`, one at a time through the oracle.  chunks = 1: the serial sums of the reference's default build;
+    chunks = n: the normal equations summed as n contiguous chunks, the decomposition of the reference's tbb::parallel_reduce
+    (WITH_TBB, bpvo/linear_system_builder.cc:91-131,233-237); f64: the same terms accumulated in double (an instrument)."""
     out = []
     p = make_params(orc, **p_kw)
     ctx = orc.create(batch["K"], batch["b"], ROWS, COLS, p, n_frames=2, n_pairs=1)
+    ctx.call("set_num_threads", chunks)
+    ctx.call("set_reduction", f64)
     for k in picks:
         ctx.frame_set_data(0, batch["images"][2 * k], batch["disparities"][2 * k])
         ctx.frame_set_template(0)
@@ -128,39 +132,69 @@ def test_config5_shard_iteration_statistics_default_tolerances(shard):
     assert np.all(np.isin(st_h, [capi.STATUS_PARAMETER_TOL, capi.STATUS_FUNCTION_TOL, capi.STATUS_GRADIENT_TOL, capi.STATUS_MAX_ITERATIONS]))
 
 
+ENVELOPE = [("serial", 1, 0), ("2 chunks", 2, 0), ("4 chunks", 4, 0), ("8 chunks", 8, 0), ("f64", 1, 1)]
+
+
+def _envelope_check(poses, picks, runs):
+    """Every GPU pose within the bar of SOME run of the reference path (its serial sums, its 2 / 4 / 8-chunk parallel reduction, the f64
+    instrument) — or, said with the serial run as the centre: no further from it than the reference's own runs are, plus the bar."""
+    rows = []
+    for i, k in enumerate(picks):
+        d = np.array([pose_error(poses[k], r[i]["T"]) for r in runs])                     # [variant][rot, trans]
+        spread = np.array([pose_error(r[i]["T"], runs[0][i]["T"]) for r in runs])          # the reference against itself
+        near = int(np.argmin(d[:, 0] / ROT_TOL + d[:, 1] / TRANS_TOL))
+        rows.append(dict(pair=k, rot=float(d[0, 0]), trans=float(d[0, 1]), spread_rot=float(spread[:, 0].max()), spread_trans=float(spread[:, 1].max()),
+                         nearest=ENVELOPE[near][0], near_rot=float(d[near, 0]), near_trans=float(d[near, 1])))
+    return rows
+
+
 def test_config5_shard_iteration_counts_with_the_reference_timing_tolerances(hip, orc, shard):
     """The same shard with the tolerances of the reference's own timing runs (conf/perf_bitplanes.cfg: 1e-6 / 1e-4 / 1e-6).
-    Most cells agree exactly (equal iteration count in ~70 %, +-1 in ~80 %, same status in ~85 %), and 31 of the 32 pairs
-    agree in pose to 1e-5 rad.  The exception is a lottery, not a defect: on a level whose f = sqrt(sum w r^2) still
-    fluctuates by ~1e-2 from one iteration to the next (the robust scale moves, the pose drifts by ~1e-5 per step), the test
-    `|f - f_prev| < functionTolerance = 1e-4` fires whenever two consecutive values happen to fall within 1e-4 of each other
-    — about 1 % per iteration.  Pair 80: the GPU run draws it at iteration 12 of level 0, the oracle never in 50 iterations
-    (neither with its f32 sums nor with f64 accumulation, bpvo_orc_set_reduction), so the GPU pose is the one 38 drifting
-    iterations earlier: 1.7e-4 rad, 9.6e-4 m apart.  With the AlgorithmParameters() tolerances (functionTolerance 1e-6, the
-    benchmark configuration) both sides run to the noise floor and agree to 5e-6 rad (tests above).  Asserted here: >= 90 % of
-    the pairs within the north-star bar, every pair within 1e-3 rad / 5e-3 m, the cell statistics."""
+    Most cells agree exactly (equal iteration count in ~70 %, +-1 in ~80 %, same status in ~85 %), and 31 of the 32 pairs agree
+    with the single-threaded oracle to 1e-5 rad.  On a level whose f = sqrt(sum w r^2) still fluctuates by ~1e-2 from one iteration
+    to the next, `|f - f_prev| < functionTolerance = 1e-4` fires whenever two consecutive values happen to fall within 1e-4 (3 ulp at
+    f ~ 300) of each other: a lottery drawn by the rounding of the sums.  Pair 80: the GPU draws it at iteration 12 of level 0 and
+    ends 1.7e-4 rad / 9.6e-4 m from the serial oracle — and so does the REFERENCE's own parallel reduction with 4 chunks (same
+    iteration, same pose to 1e-6; serial, 2, 8 chunks and the f64 instrument never draw it: tests/tools/oracle_envelope.py).  The
+    assertion is therefore made against the reference's envelope, for EVERY pair: within 1e-4 rad / 1e-3 m of one of the runs
+    {serial, 2, 4, 8 chunks, f64}, and no further from the serial run than those runs are from it (+ the bar)."""
     kw = dict(shard["kw"], parameterTolerance=1e-6, functionTolerance=1e-4, gradientTolerance=1e-6)
     batch = shard["batch"]
     ctx = hip.create(batch["K"], batch["b"], ROWS, COLS, make_params(hip, **kw), n_frames=2 * SHARD, n_pairs=SHARD)
     poses, stats = ctx.batch_run(batch["images"], batch["disparities"])
     ctx.close()
     picks = shard["picks"]
-    ref = _oracle_pairs(orc, batch, picks, kw)
+    runs = [_oracle_pairs(orc, batch, picks, kw, chunks=c, f64=f) for _, c, f in ENVELOPE]
+    ref = runs[0]
     t = _iteration_table(stats["numIterations"][picks], stats["status"][picks], np.array([r["its"] for r in ref]),
                          np.array([r["status"] for r in ref]))
-    errs = np.array([pose_error(poses[k], r["T"]) for k, r in zip(picks, ref)])
     print("\nconfig-5 shard iteration statistics (timing tolerances):", json.dumps(t))
-    print("pose disagreement (rad, m) per pair:", np.array2string(errs, precision=2, max_line_width=200))
-    for k, r, e in zip(picks, ref, errs):
-        print(k, "hip", stats["numIterations"][k].tolist(), [hex(x) for x in stats["status"][k].tolist()], "orc", r["its"], [hex(x) for x in r["status"]],
-              "err %.2e %.2e" % tuple(e))
+    env = _envelope_check(poses, picks, runs)
+    for e, k in zip(env, picks):
+        print(k, "hip", stats["numIterations"][k].tolist(), "its per run", [r[picks.index(k)]["its"] for r in runs], json.dumps(e))
     assert t["equal_cells"] >= 0.55 and t["within_1"] >= 0.7 and t["same_status"] >= 0.75, t
     assert t["abs_delta_mean"] <= 3.0, t
     for mh, mo in zip(t["mean_hip"], t["mean_orc"]):
         assert abs(mh - mo) <= 0.15 * max(mh, mo) + 1.0, t
-    within = (errs[:, 0] <= ROT_TOL) & (errs[:, 1] <= TRANS_TOL)
-    assert within.mean() >= 0.9, (within.mean(), errs[~within])
-    assert errs[:, 0].max() <= 1e-3 and errs[:, 1].max() <= 5e-3, (errs[:, 0].max(), errs[:, 1].max())
+    for e in env:
+        assert e["near_rot"] <= ROT_TOL and e["near_trans"] <= TRANS_TOL, e
+        assert e["rot"] <= e["spread_rot"] + ROT_TOL and e["trans"] <= e["spread_trans"] + TRANS_TOL, e
+    # and the reference's spread is real: at least one pair whose own runs lie further apart than the bar (pair 80, 4 chunks)
+    assert max(e["spread_rot"] for e in env) > ROT_TOL
+
+
+def test_config5_shard_default_tolerances_inside_the_reference_envelope(orc, shard):
+    """AlgorithmParameters() tolerances (the benchmark configuration): every pose of the 32 pairs within the bar of EVERY run of the
+    reference path {serial, 2, 4, 8 chunks, f64} — at the noise floor the summation order no longer moves the pose."""
+    picks = shard["picks"]
+    runs = [shard["ref"]] + [_oracle_pairs(orc, shard["batch"], picks, shard["kw"], chunks=c, f64=f) for _, c, f in ENVELOPE[1:]]
+    env = _envelope_check(shard["poses"], picks, runs)
+    worst = (max(e["rot"] for e in env), max(e["trans"] for e in env), max(e["spread_rot"] for e in env), max(e["spread_trans"] for e in env))
+    print("\nconfig-5 shard, default tolerances: worst GPU-vs-serial %.2e rad %.2e m; the reference against itself %.2e rad %.2e m" % worst)
+    for i, k in enumerate(picks):
+        for r in runs:
+            rot, tr = pose_error(shard["poses"][k], r[i]["T"])
+            assert rot <= ROT_TOL and tr <= TRANS_TOL, (k, rot, tr)
 
 
 # ---- multi-rank: bench.py under torch.distributed.run ---------------------------------------------------------------
@@ -177,8 +211,8 @@ def _device_count_without_touching_the_gpu():
     return torch.cuda.device_count()
 
 
-@pytest.mark.parametrize("pairs_per_rank", [5])
-def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_rank):
+@pytest.mark.parametrize("pairs_per_rank,mode", [pytest.param(5, "strong", id="strong-default"), pytest.param(3, "weak", id="weak")])
+def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_rank, mode):
     """bench.py launched exactly as the driver launches it (python -m torch.distributed.run --nproc-per-node N): the records
     rank 0 gathers equal, bit for bit, the same pairs run on ONE context in this process, and every rank took part.  With more
     than one GPU the ranks sit on different devices and the gather is RCCL; on a one-GPU box two ranks share the device and
@@ -188,8 +222,9 @@ def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_
     dump = str(tmp_path / "records.npy")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0",
-           "--pairs-per-gpu", str(pairs_per_rank), "--cpu-pairs", "0", "--other-configs", "0", "--gen-workers", "2",
-           "--dump-records", dump]
+           "--cpu-pairs", "0", "--other-configs", "0", "--gen-workers", "2", "--dump-records", dump]
+    # the default is BASELINE config 5's shape: ONE batch (--pairs) split over the ranks; --weak gives every rank --pairs pairs
+    cmd += ["--pairs", str(world * pairs_per_rank)] if mode == "strong" else ["--weak", "--pairs", str(pairs_per_rank)]
     if ndev <= 1:
         cmd += ["--dist-backend", "gloo", "--single-device"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -197,7 +232,7 @@ def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == world and out["config"]["pairs_per_gpu"] == pairs_per_rank
+    assert out["n_gpus"] == world and out["config"]["pairs_per_gpu"] == pairs_per_rank and out["scaling"] == mode
     rec = np.load(dump)
     n = world * pairs_per_rank
     assert rec.shape == (n, 32)

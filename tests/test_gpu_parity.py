@@ -125,22 +125,29 @@ def test_estimate_pose_parity(hip, orc, rows, cols, levels, descriptor, loss):
     # against ground truth both must be reasonable (sanity of the synthetic scene, not a parity bar)
     rg, tg = pose_error(Th, d["T_gt"])
     assert rg < 1e-2 and tg < 1e-1, (rg, tg)
-    # per-iteration trace: linearise the HIP path at every pose the oracle visited
+    # per-iteration trace: linearise the HIP path at the poses the oracle visited.  The robust scale of a later linearisation of a level
+    # depends on the estimator's freeze history (Q6), which a pose alone does not reproduce — so the oracle's OWN sigma of that
+    # linearisation is handed to the HIP side (bpvo_hip_linearize_at_scale): valid count, H, G and f_norm are then compared at
+    # EVERY sampled pose; on the first linearisation of each level sigma itself is estimated on both sides and must be equal.
     step = max(1, len(trace) // 24)
-    prev_level = -1
-    for rec in trace[::step]:
+    first_of_level = {int(l): int(np.flatnonzero(trace[:, 67] == l)[0]) for l in np.unique(trace[:, 67])}
+    picks = sorted(set(range(0, len(trace), step)) | set(first_of_level.values()))
+    for i in picks:
+        rec = trace[i]
         T = rec[:16].reshape(4, 4)
         level = int(rec[67])
-        a = ch.linearize(0, 0, 1, level, T, reset_scale=True)
-        assert a["num_valid"] == int(rec[60]), (level, a["num_valid"], rec[60])
+        if i == first_of_level[level]:
+            a = ch.linearize(0, 0, 1, level, T, reset_scale=True)
+            assert a["sigma"] == rec[59], (level, a["sigma"], rec[59])          # exact median, both sides from sigma = 1
+        else:
+            a = ch.linearize_at_scale(0, 0, 1, level, T, float(rec[59]))
+        assert a["num_valid"] == int(rec[60]), (level, i, a["num_valid"], rec[60])
         Ho, Go = rec[16:52].reshape(6, 6), rec[52:58]
         scale = np.abs(Ho).max()
-        if level != prev_level:   # sigma of the oracle record is only comparable on the first linearisation of a level
-            prev_level = level
-        assert abs(a["f_norm"] - rec[58]) <= 1e-3 * max(rec[58], 1e-6) or a["sigma"] != rec[59]
-        if a["sigma"] == rec[59]:
-            assert np.abs(a["H"] - Ho).max() <= 2e-4 * scale
-            assert np.abs(a["G"] - Go).max() <= 2e-4 * max(np.abs(Go).max(), 1e-3 * scale)
+        # the oracle sums serially in f32 (within 2e-4 of an f64 evaluation, test_linearize_parity); the GPU within 4e-6
+        assert abs(a["f_norm"] - rec[58]) <= 1e-3 * max(rec[58], 1e-6), (level, i, a["f_norm"], rec[58])
+        assert np.abs(a["H"] - Ho).max() <= 2e-4 * scale, (level, i)
+        assert np.abs(a["G"] - Go).max() <= 2e-4 * max(np.abs(Go).max(), 1e-3 * scale), (level, i)
 
 
 def test_estimate_pose_nonzero_workspace_and_init(hip, orc):
