@@ -92,6 +92,24 @@ try:
     traffic["algorithmic_bytes_per_point"] = 210
 except Exception as e:  # noqa: BLE001
     traffic["error"] = str(e)
+# ... and of irls_reduce (one launch serves the plain and the fused path): bytes per linearised point, for bench.py's second roofline block
+try:
+    k8 = [k for k in per if "irls_reduce_both_kernel" in k and "TCC_EA0_RDREQ_128B_sum" in per[k]][0]
+    cs = per[k8]
+    rd = 128 * cs["TCC_EA0_RDREQ_128B_sum"]["avg"] + 64 * cs["TCC_EA0_RDREQ_64B_sum"]["avg"] + 32 * cs["TCC_EA0_RDREQ_32B_sum"]["avg"]
+    wr64 = cs.get("TCC_EA0_WRREQ_64B_sum", {}).get("avg", 0.0)
+    wr = cs.get("TCC_EA0_WRREQ_sum", {}).get("avg", 0.0)
+    wbytes = 64 * wr64 + 32 * max(0.0, wr - wr64)
+    pj = json.loads([l for l in open(os.path.join(src, "pmc3.json")) if l.startswith("{")][-1])
+    ppl = pj["points_linearized_rank0"] / cs["TCC_EA0_RDREQ_128B_sum"]["launches"]
+    traffic["irls_reduce_read_bytes_per_launch"] = rd
+    traffic["irls_reduce_write_bytes_per_launch"] = wbytes
+    traffic["irls_reduce_points_per_launch"] = ppl
+    traffic["irls_reduce_hbm_bytes_per_point"] = (rd + wbytes) / ppl
+    if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        traffic["irls_reduce_guide_corrected_bytes_per_point"] = 1024.0 * (2.0 * cs["FETCH_SIZE"]["avg"] + cs["WRITE_SIZE"]["avg"]) / ppl
+except Exception as e:  # noqa: BLE001
+    traffic["irls_reduce_error"] = str(e)
 # the same for the timing-tolerance batch (tpmc1 / tpmc2)
 tper = {}
 for sub in sorted(glob.glob(os.path.join(src, "tpmc*"))):

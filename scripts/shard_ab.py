@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""A/B of run-time settings on one batch size, every variant in a process of its own (several settings are read once per process).
+
+  python scripts/shard_ab.py --pairs 128 --steps 10 -- "" "BPVO_HIP_MEDIAN_WIDE_FROM=1" "BPVO_HIP_LANES=1,BPVO_HIP_STAGGER=0"
+
+The parent renders the synthetic inputs once (no GPU in the parent: children are plain child processes), every child loads them, runs
+`warmup` + `steps` steps of bpvo_hip_batch_run on device-resident inputs and prints GN iterations/s — bench.py's step, nothing else
+around it.  `--ref-pairs N` also measures an N-pair batch (the 1024-pair headline) with every variant, for the shard / headline ratio.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(a):
+    import numpy as np
+    import torch
+    import bpvo_amd
+    from bpvo_amd import capi
+    d = np.load(a.child)
+    hip = bpvo_amd.load()
+    p = hip.default_params()
+    p.numPyramidLevels = a.levels
+    p.descriptor = capi.DESC_BITPLANES if a.descriptor == "bitplanes" else capi.DESC_INTENSITY
+    p.lossFunction = {"tukey": capi.LOSS_TUKEY, "huber": capi.LOSS_HUBER, "l2": capi.LOSS_L2}[a.loss]
+    p.verbosity = capi.VERB_SILENT
+    if a.tolerances == "timing":
+        p.parameterTolerance, p.functionTolerance, p.gradientTolerance = 1e-6, 1e-4, 1e-6
+    n = a.pairs
+    rows, cols = d["images"].shape[1:]
+    ctx = hip.create(d["K"], float(d["b"]), rows, cols, p, device=0, n_frames=2 * n, n_pairs=n)
+    dev = torch.device("cuda", 0)
+    di = torch.from_numpy(d["images"][: 2 * n]).to(dev)
+    dd = torch.from_numpy(d["disparities"][: 2 * n]).to(dev)
+    for _ in range(a.warmup):
+        ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr())
+    ctx.profiling(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        poses, stats = ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gn = ctx.total_linearizations()
+    print(json.dumps(dict(pairs=n, value=gn / dt, ms_per_step=1e3 * dt / a.steps, gn_per_step=gn / a.steps,
+                          checksum=float(np.abs(poses.astype(np.float64)).sum()))))
+    ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=128)
+    ap.add_argument("--ref-pairs", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=376)
+    ap.add_argument("--cols", type=int, default=1241)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--descriptor", default="bitplanes")
+    ap.add_argument("--loss", default="tukey")
+    ap.add_argument("--tolerances", default="default")
+    ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--child", default="")
+    ap.add_argument("variants", nargs="*")
+    a = ap.parse_args()
+    if a.child:
+        return child(a)
+    import numpy as np
+    from bpvo_amd import synth
+    nmax = max(a.pairs, a.ref_pairs)
+    path = f"/tmp/shard_ab_{a.rows}x{a.cols}_{nmax}.npz"
+    if not os.path.exists(path):
+        b = synth.make_batch(a.rows, a.cols, nmax, first_index=0, workers=min(16, os.cpu_count() or 1))
+        np.savez(path, images=b["images"], disparities=b["disparities"], K=b["K"], b=b["b"])
+    variants = a.variants or [""]
+    sizes = [a.pairs] + ([a.ref_pairs] if a.ref_pairs else [])
+    for rep in range(a.repeat):
+        for v in variants:
+            env = dict(os.environ)
+            for kv in filter(None, v.split(",")):
+                k, val = kv.split("=", 1)
+                env[k] = val
+            out = []
+            for n in sizes:
+                steps = a.steps if n == a.pairs else max(2, a.steps // 4)
+                cmd = [sys.executable, os.path.abspath(__file__), "--child", path, "--pairs", str(n), "--steps", str(steps), "--warmup", str(a.warmup),
+                       "--levels", str(a.levels), "--descriptor", a.descriptor, "--loss", a.loss, "--tolerances", a.tolerances]
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out.append(json.loads(line[-1]) if line else dict(error=(r.stdout + r.stderr)[-400:]))
+            msg = " | ".join(f"{o.get('pairs')}: {o.get('value', 0) / 1e3:8.1f} k GN it/s {o.get('ms_per_step', 0):7.2f} ms" if "value" in o else str(o) for o in out)
+            if len(out) == 2 and "value" in out[0] and "value" in out[1]:
+                msg += f" | ratio {out[0]['value'] / out[1]['value']:.3f}"
+            print(f"[{rep}] {v or 'default':60s} {msg}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -125,13 +125,13 @@ def test_gpu_iterates_follow_the_reference_iteration_by_iteration(hip, orc, rows
             if parted is None:
                 if rot > IT_ROT or tr > it_trans:
                     parted = (k, "pose")
-                elif d_sigma > 1e-4:
+                elif d_sigma > 5e-4:
                     parted = (k, "scale")      # a different branch of the freeze rule (Q6): |sigma - sigma_prev| <= 1e-6 on one side only
             if parted is None:
                 # still together: same valid set up to the points a 1e-6 pose difference moves across the border, function values
                 # differing by the rounding of the sums only
                 assert abs(gl[k, 60] - ol[k, 60]) <= max(2.0, 1e-3 * ol[k, 60]), (l, k, gl[k, 60], ol[k, 60])
-                assert abs(gl[k, 58] - ol[k, 58]) <= max(2.0 * env_f, 5e-4 * ol[k, 58]), (l, k, gl[k, 58], ol[k, 58], env_f)
+                assert abs(gl[k, 58] - ol[k, 58]) <= max(2.0 * env_f, 1e-3 * ol[k, 58]), (l, k, gl[k, 58], ol[k, 58], env_f)
             else:
                 # apart: inside what the reference's own decompositions show at this iterate, or inside the bound of its branches
                 assert (rot <= max(IT_ROT, 3.0 * env_rot) and tr <= max(it_trans, 3.0 * env_tr)) or (rot <= BRANCH_ROT and tr <= BRANCH_TRANS * it_trans / IT_TRANS), \
