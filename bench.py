@@ -180,6 +180,54 @@ def add_frame_latency(hip, dev_index, seq, which):
             "keyframes": n_key, "note": "host image + disparity buffers per call (PCIe included), one frame at a time"}
 
 
+def stereo_lines(hip, torch, dev, dev_index, stereo_in):
+    """Stereo front-end: the block matcher of the reference's default StereoAlgorithm on batches of rectified pairs
+    resident in HBM (disparities written to HBM), and sequential addFrame(left, right) from host buffers.  The matcher is integer
+    SAD over a 15 x 15 window for every (pixel, disparity): VALU-bound (wave prefix sums + compares), not HBM-bound — two u8 images
+    in, one f32 map out."""
+    out = {}
+    for name, (rows, cols, ndisp, pairs) in stereo_in["batches"].items():
+        left, right, K, b = pairs
+        n = left.shape[0]
+        p = hip.default_params(); p.numPyramidLevels = 1
+        ctx = hip.create(K, b, rows, cols, p, device=dev_index, n_frames=1, n_pairs=1)
+        sp = ctx.default_stereo_params(ndisp)
+        dl, dr = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
+        dd = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            ctx.stereo_bm_device(n, dl.data_ptr(), dr.data_ptr(), sp, dd.data_ptr())
+        torch.cuda.synchronize()
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.stereo_bm_device(n, dl.data_ptr(), dr.data_ptr(), sp, dd.data_ptr())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        valid = float((dd[0] >= 0).float().mean().item())
+        sums = float(n) * rows * (cols - ndisp + 1) * ndisp
+        out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "window_sums_per_s": sums / dt,
+                     "valid_fraction_frame0": valid, "disparities": ndisp, "SADWindowSize": sp.SADWindowSize,
+                     "bound": "VALU (integer SAD, wave prefix sums): 2 u8 images in + 1 f32 map out are " + "%.1f" % ((2 + 4) * rows * cols * n / dt / 1e9) + " GB/s of HBM traffic"}
+        ctx.close()
+    seq = stereo_in.get("sequence")
+    if seq is not None:
+        rows, cols, ndisp, frames, K, b = seq
+        p = hip.default_params(); p.numPyramidLevels = 3; p.verbosity = 0x22
+        p.parameterTolerance, p.functionTolerance, p.gradientTolerance = 1e-6, 1e-4, 1e-6
+        ctx = hip.create(K, b, rows, cols, p, device=dev_index, n_frames=3, n_pairs=1)
+        sp = ctx.default_stereo_params(ndisp)
+        ctx.add_frame_stereo(frames[0][0], frames[0][1], sp)
+        t0 = time.perf_counter()
+        for l, r in frames[1:]:
+            ctx.add_frame_stereo(l, r, sp)
+        dt = time.perf_counter() - t0
+        out[f"addFrame(left, right) {cols}x{rows}, {ndisp} disparities, intensity / 3 levels"] = {
+            "frames": len(frames) - 1, "ms_per_frame": 1e3 * dt / (len(frames) - 1),
+            "note": "two u8 host images per call; block matching, setData, estimatePose on the device, the f32 disparity never crosses the bus"}
+        ctx.close()
+    return out
+
+
 def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=None):
     """BASELINE.json configs[1], [2] (640x480) as batches, and configs[3] (one KITTI-shaped pair at a time: the latency-bound
     B = 1 case the roofline section of SURVEY.md asks to report next to the batched one)."""
@@ -201,6 +249,8 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
         # AlgorithmParameters() defaults, so the per-frame stages are about half of the step
         out["1241x376 bitplanes, 3 levels, tukey, tolerances of conf/perf_bitplanes.cfg (1e-6/1e-4/1e-6), 1024 pairs"] = \
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1024, args.descriptor, 3, args.loss, steps=3, warmup=1, tolerances="timing", want_stages=True)
+    if seq640 is not None and seq640.get("stereo") is not None:
+        out["stereo front-end"] = stereo_lines(hip, torch, dev, dev_index, seq640["stereo"])
     if seq640 is not None:
         out["addFrame 640x480, parameters of conf/perf_intensity.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_intensity")
         out["addFrame 640x480, parameters of conf/perf_bitplanes.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_bitplanes")
@@ -247,6 +297,14 @@ def main():
     if world == 1 and args.other_configs > 0 and (args.rows, args.cols) == (376, 1241):
         other_batch = synth.make_batch(480, 640, args.other_configs, first_index=0, workers=workers)
         seq640 = synth.make_sequence(480, 640, 25, index=21, step_rot=0.004, step_trans=0.03)
+        # rectified pairs for the stereo front-end lines (rendered now: no CPU rendering after the GPU is up)
+        def stereo_stack(rows_, cols_, n_):
+            ps = [synth.make_stereo_pair(rows_, cols_, i) for i in range(n_)]
+            return (np.stack([q["left"] for q in ps]), np.stack([q["right"] for q in ps]), ps[0]["K"], ps[0]["b"])
+        st_seq = synth.make_stereo_sequence(480, 640, 9, index=23, step_rot=0.004, step_trans=0.03)
+        seq640["stereo"] = {"batches": {"block matching 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, stereo_stack(376, 1241, 16)),
+                                        "block matching 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, stereo_stack(480, 640, 16))},
+                            "sequence": (480, 640, 64, st_seq["frames"], st_seq["K"], st_seq["b"])}
 
     import torch
     import torch.distributed as dist

@@ -314,6 +314,10 @@ class Context:
         self.call("stereo_bm", n, left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), 0, C.byref(sp), out.ctypes.data_as(C.c_void_p), 0)
         return out
 
+    def stereo_bm_device(self, count, d_left_ptr, d_right_ptr, sp, d_disp_ptr):
+        """StereoAlgorithm::run on `count` pairs already in device memory, f32 disparities written to device memory."""
+        self.call("stereo_bm", int(count), C.c_void_p(d_left_ptr), C.c_void_p(d_right_ptr), 1, C.byref(sp), C.c_void_p(d_disp_ptr), 1)
+
     def add_frame_stereo(self, left, right, sp):
         left = np.ascontiguousarray(left, dtype=np.uint8)
         right = np.ascontiguousarray(right, dtype=np.uint8)
@@ -433,6 +437,12 @@ class Context:
         a, b = C.c_uint64(), C.c_int()
         self.call("persistent_counts", C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def team_counts(self):
+        """Batch estimates run by the team-persistent kernel since the context was created (HIP library only)."""
+        a = C.c_uint64()
+        self.call("team_counts", C.byref(a))
+        return a.value
 
     def set_max_lanes(self, n):
         """Cap (n >= 1) or uncap (n <= 0) the estimation lanes of later batch calls (HIP library only)."""

@@ -100,6 +100,8 @@ struct Lane {
   hipEvent_t selected_ev = nullptr; // staggered batches: "the selection of this lane's templates has been queued" (FrameRun)
   unsigned* d_pk_ctl = nullptr;    // [kMaxLevels][kPkCtlWords] {arrivals, abort} of the persistent kernel, one slot per level
   unsigned* h_pk_ctl = nullptr;    // pinned copy
+  unsigned* d_team_ctl = nullptr;  // gn_team_ctl_words(kMaxTeams) words of the team-persistent kernel (lane 0 only)
+  unsigned* h_team_ctl = nullptr;  // pinned copy of its first line (abort word)
   GNState* h_states = nullptr;     // pinned [n_pairs]
   std::vector<EventPair> ev_pending;
   std::vector<hipEvent_t> ev_pool;
@@ -115,6 +117,7 @@ constexpr int kDefaultLanes = 2;
 constexpr int kDefaultLanesNarrow = 2;
 constexpr int kMinPairsPerLane = 8;
 constexpr int kPkCtlWords = 32;    // one 128-byte line per level
+constexpr int kMaxTeams = 1024;
 
 }  // namespace
 
@@ -168,6 +171,11 @@ struct bpvo_hip_ctx {
   // (workgroups not co-resident) — the context stays on the four-kernel chain from then on.
   int persistent = 1, persist_max_ws = 1, persist_grid = 64;
   long long persist_timeout = 50000000ll;   // ticks of the 100 MHz wall clock a grid barrier waits before it gives up (0.5 s)
+  // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
+  // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
+  // BPVO_HIP_TEAM=0 turns it off, BPVO_HIP_TEAM_MAX_PAIRS / BPVO_HIP_TEAM_SIZE (0 = CUs / pairs) size it.
+  int team_mode = 1, team_max_pairs = 256, team_size_env = 0, num_cus = 0;
+  std::atomic<uint64_t> team_launches{0};
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
   std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)
   // bpvo_hip_estimate_pose_trace: while trace_ws >= 0 the jobs of that workspace carry the device trace buffer
@@ -620,6 +628,15 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 
 // VisualOdometryPoseEstimator::estimatePose (reference: bpvo/vo_pose_estimator.cc:63-93) for a group of `n` workspaces on one
 // lane.  wss[i]: workspace, refs[i] / curs[i]: frame slots.  T_init host [n][16] or null (Identity).
+// Does a group of n pairs take the team-persistent kernel?  (kLinear, the f64 formulation, C = 8 or 1 like gn_persistent_kernel; not
+// while per-kernel timings are being collected: there are no kernels to time)
+bool team_serves(const bpvo_hip_ctx* c, int n)
+{
+  return c->team_mode && c->persistent && !c->persistent_failed.load() && n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs &&
+         (c->C == 8 || c->C == 1) && c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !c->profile_all && !c->profile_k6_all &&
+         c->num_cus >= 2 && g_live_ctx[c->device & 63].load() <= 1;
+}
+
 // allow_persistent: only a group that has the device to itself (a batch on ONE lane) may take the persistent kernel — two
 // hand-barrier grids of concurrent lanes must not be co-scheduled.
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init,
@@ -660,7 +677,32 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   // PoseEstimatorParameters(AlgorithmParameters) (bpvo/pose_estimator_params.cc:27-33): maxFuncEvals stays 6*200 (Q4);
   // the low-res parameter set equals the full-res one (Q3).
   const int max_fun_evals = 6 * 200;
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+  // Small batches: the whole level loop in ONE launch, a team of workgroups per pair (gn_team_kernel)
+  bool team_ran = false;
+  if(allow_persistent && ln == &c->lanes[0] && team_serves(c, n)) {
+    GNTeamLaunch t;
+    t.jobs_all = ln->d_pjobs; t.job_pitch = NP; t.n_pairs = n; t.level_hi = c->L - 1; t.level_lo = p.maxTestLevel;
+    t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
+    t.scale_is_moot = (p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen) ? 1 : 0;
+    // one workgroup per CU: teams of CUs / pairs workgroups (at most 64: the single-pair kernel's size), as many teams as fit
+    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(64, c->num_cus / n));
+    ts = std::max(1, std::min(ts, c->num_cus));
+    t.team_size = ts;
+    t.n_teams = std::max(1, std::min(std::min(n, c->num_cus / ts), kMaxTeams));
+    t.ctl = ln->d_team_ctl;
+    t.timeout_ticks = c->persist_timeout;
+    LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
+    const hipError_t te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+    if(te == hipSuccess) {
+      team_ran = true;
+      c->team_launches.fetch_add(1);
+      LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl, ln->d_team_ctl, sizeof(unsigned) * 8, hipMemcpyDeviceToHost, ln->stream));
+    } else {
+      (void) hipGetLastError();
+      c->persistent_failed.store(true);      // degrade to the chain, now and for later calls
+    }
+  }
+  for(int l = c->L - 1; l >= p.maxTestLevel && !team_ran; --l) {
     GNLaunch g;
     g.jobs = ln->d_pjobs + (size_t) l * NP;
     g.npairs = n;
@@ -786,6 +828,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       std::fprintf(stderr, " us per iteration\n");
     }
   }
+  if(team_ran && ln->h_team_ctl[1] != 0) {
+    // a team barrier timed out (teams not co-resident): rerun the group through the four-kernel chain and stay on it
+    c->persistent_failed.store(true);
+    return estimate_group(c, ln, n, wss, refs, curs, T_init, poses, stats, d_records_out, false);
+  }
   if(pk_group) {
     bool gave_up = false;
     for(int l = 0; l < c->L; ++l) gave_up = gave_up || ln->h_pk_ctl[(size_t) l * kPkCtlWords + 1] != 0;
@@ -818,7 +865,8 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   }
   const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
-  const int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
+  int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
+  if(team_serves(c, n)) nl = 1;      // the team-persistent kernel takes the whole chip
   // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
   if(nl > 1) HIP_CK(c, hipStreamSynchronize(c->stream));
@@ -1194,6 +1242,14 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_GRID")) cp->persist_grid = std::max(1, std::min(128, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS")) cp->persist_timeout = std::max(1ll, std::atoll(e));   // tests of the give-up path
+    if(const char* e = std::getenv("BPVO_HIP_TEAM")) cp->team_mode = std::atoi(e) != 0;
+    if(const char* e = std::getenv("BPVO_HIP_TEAM_MAX_PAIRS")) cp->team_max_pairs = std::max(0, std::atoi(e));
+    if(const char* e = std::getenv("BPVO_HIP_TEAM_SIZE")) cp->team_size_env = std::max(0, std::min(256, std::atoi(e)));
+    {
+      hipDeviceProp_t prop;
+      if(hipGetDeviceProperties(&prop, device) == hipSuccess) cp->num_cus = prop.multiProcessorCount;
+      if(const char* e = std::getenv("BPVO_HIP_TEAM_CUS")) cp->num_cus = std::max(1, std::atoi(e));      // (tests: fewer teams than pairs)
+    }
     cp->lanes.resize(std::max(1, std::min(max_lanes, n_pairs / kMinPairsPerLane)));
   }
   for(size_t k = 0; k < cp->lanes.size(); ++k) {
@@ -1212,6 +1268,11 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipHostMalloc((void**) &ln.h_active, 8 * sizeof(int)));
     CREATE_CK(hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
+    if(k == 0) {
+      CREATE_CK(hipMalloc((void**) &ln.d_team_ctl, sizeof(unsigned) * (size_t) gn_team_ctl_words(kMaxTeams)));
+      CREATE_CK(hipHostMalloc((void**) &ln.h_team_ctl, sizeof(unsigned) * 8));
+      std::memset(ln.h_team_ctl, 0, sizeof(unsigned) * 8);
+    }
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
@@ -1249,6 +1310,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     (void) hipFree(ln.d_pjobs); (void) hipFree(ln.d_Tinit); (void) hipFree(ln.d_active); (void) hipFree(ln.d_list);
     (void) hipHostFree(ln.h_pjobs); (void) hipHostFree(ln.h_T); (void) hipHostFree(ln.h_active); (void) hipHostFree(ln.h_states);
     (void) hipFree(ln.d_pk_ctl); (void) hipHostFree(ln.h_pk_ctl);
+    (void) hipFree(ln.d_team_ctl); (void) hipHostFree(ln.h_team_ctl);
     for(auto& ep : ln.ev_pending) { (void) hipEventDestroy(ep.a); (void) hipEventDestroy(ep.b); }
     for(auto e : ln.ev_pool) (void) hipEventDestroy(e);
     for(auto e : ln.round_ev) if(e) (void) hipEventDestroy(e);
@@ -1942,7 +2004,8 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   (void) hipSetDevice(c->device);
   if(n_pairs > 0 && (!images || !disparities)) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
   const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
-  const int nl = std::max(1, std::min(lanes_ok, n_pairs / kMinPairsPerLane));
+  int nl = std::max(1, std::min(lanes_ok, n_pairs / kMinPairsPerLane));
+  if(team_serves(c, n_pairs)) nl = 1;
   if(c->stagger && nl > 1 && !c->profile_all) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats);
   int rc = frames_set_data(c, 0, 1, 2 * n_pairs, images, disparities, on_device != 0);
   if(rc) return rc;
@@ -2026,6 +2089,13 @@ int bpvo_hip_persistent_counts(bpvo_hip_ctx* c, uint64_t* levels, int* gave_up)
   if(!c) return BPVO_ERR_INVALID_ARG;
   if(levels) *levels = c->persistent_levels.load();
   if(gave_up) *gave_up = c->persistent_failed.load() ? 1 : 0;
+  return BPVO_OK;
+}
+
+int bpvo_hip_team_counts(bpvo_hip_ctx* c, uint64_t* launches)
+{
+  if(!c || !launches) return BPVO_ERR_INVALID_ARG;
+  *launches = c->team_launches.load();
   return BPVO_OK;
 }
 

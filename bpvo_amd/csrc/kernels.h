@@ -109,6 +109,19 @@ bool gn_persistent_serves(const GNLaunch& g);
 int  gn_persistent_grid(const GNLaunch& g, int max_grid);
 hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol,
                                 unsigned* ctl, int grid, long long timeout_ticks);
+// Team-persistent kernel for small batches (kernels_gn.hip, gn_team_kernel): ONE launch runs every pair of the group through all its
+// pyramid levels; grid = team_size x n_teams workgroups, one per CU, all co-resident.  ctl: gn_team_ctl_words(n_teams) zeroed words;
+// after the launch ctl[1] != 0 says a team barrier gave up (rerun the group on the chain).
+struct GNTeamLaunch {
+  const PairJob* jobs_all;   // device [levels][job_pitch]
+  int job_pitch, n_pairs, level_hi, level_lo;
+  int C, loss, fuse_frozen, scale_is_moot;
+  int team_size, n_teams;
+  unsigned* ctl;
+  long long timeout_ticks;
+};
+int  gn_team_ctl_words(int n_teams);
+hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);
 int  gn_pts_per_block(int C);
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);

@@ -1195,10 +1195,16 @@ __device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPoint
   d.Pt = load_v4<false>(j.pts + i);
   const float4* qg = reinterpret_cast<const float4*>(j.grad.get());
   if constexpr(FUSED) {
-    d.key = j.tapkey[i];
-    const float4* tc = reinterpret_cast<const float4*>(j.tapcache.get());
+    if(j.tapcache_on) {      // (uniform over the workspace: the dense levels of a batch gather straight from the descriptor)
+      d.key = j.tapkey[i];
+      const float4* tc = reinterpret_cast<const float4*>(j.tapcache.get());
 #pragma unroll
-    for(int k = 0; k < 8; ++k) d.tc[k] = load_v4<false>(tc + tile_index<8>(i, k));
+      for(int k = 0; k < 8; ++k) d.tc[k] = load_v4<false>(tc + tile_index<8>(i, k));
+    } else {
+      d.key = 0xffffffffu;
+#pragma unroll
+      for(int k = 0; k < 8; ++k) d.tc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
     d.px[0] = load_v4<false>(p0 + tile_index<2>(i, 0)); d.px[1] = load_v4<false>(p0 + tile_index<2>(i, 1));
   } else {
@@ -1261,7 +1267,8 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
       if(valid) {
         const double wx = 1.0 - xf, wy = 1.0 - yf;
         const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
-        hit = d.key == key;
+        const bool cached = j.tapcache_on != 0;
+        hit = cached && d.key == key;
         float4 t[8];
 #pragma unroll
         for(int k = 0; k < 8; ++k) t[k] = d.tc[k];
@@ -1270,10 +1277,12 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
           const float4* q1 = q0 + (size_t) W * 2;
           t[0] = q0[0]; t[1] = q0[1]; t[2] = q0[2]; t[3] = q0[3];
           t[4] = q1[0]; t[5] = q1[1]; t[6] = q1[2]; t[7] = q1[3];
-          float4* tcw = reinterpret_cast<float4*>(j.tapcache.get());
+          if(cached) {
+            float4* tcw = reinterpret_cast<float4*>(j.tapcache.get());
 #pragma unroll
-          for(int k = 0; k < 8; ++k) store_v4<false>(tcw + tile_index<8>(i, k), t[k]);
-          j.tapkey[i] = key;
+            for(int k = 0; k < 8; ++k) store_v4<false>(tcw + tile_index<8>(i, k), t[k]);
+            j.tapkey[i] = key;
+          }
         }
         // pieces 0, 1: I00 of channels 0-3 / 4-7; 2, 3: I01; 4, 5: I10; 6, 7: I11 (warp_point)
         const float i00[8] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w};
@@ -1918,6 +1927,144 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// TEAM-persistent Gauss-Newton kernel for small BATCHES (2 .. ~256 pairs: the 128-pair shard of BASELINE config 5 on one of 8 GPUs).
+// The four-kernel chain pays a floor per launch (ramp, drain, the list -> job -> state chain of dependent loads: ~10 us) that a
+// 1024-pair batch amortises and a 128-pair batch does not: 4 launches x ~220 iterations x 10 us is a third of its Gauss-Newton time,
+// and every level lasts as long as its slowest pair (profiles/r02_pipe/, profiles/r03_persistent_grid_probe.txt).  Here the
+// workgroups of the grid form TEAMS, blockIdx.y = team, gridDim.x = workgroups per team (one per CU, all teams co-resident: the launcher
+// sizes the grid to the CUs).  A team runs ONE pair at a time through ALL its pyramid levels and all their iterations with the
+// phases of gn_persistent_kernel — the same device functions, chunk and tile indices as the chain, so every value is
+// bit-identical — synchronised by barriers of its own (a counter per team): no launch between iterations, no host round trip
+// between levels, no pair ever waits for another.  Pairs are handed out dynamically (one agent-scope counter), so a batch larger
+// than the number of teams balances itself.  Teams desynchronise, which is the point: the memory-bound phases of some overlap the
+// latency-bound ones (median, solve) of others.
+// Barrier that cannot complete (teams not co-resident): the poll gives up after `timeout`, raises the abort word and every workgroup
+// leaves; the host reruns the group on the chain, as for gn_persistent_kernel.
+constexpr int kTeamCtlWords = 32;       // one 128-byte line per team: [0] arrivals, [1] next pair broadcast slot; global line 0: [1] abort, [2] next pair
+__shared__ int pk_next_pair;
+
+__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout)
+{
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned target = epoch * gridDim.x;
+    __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while(__hip_atomic_load(team_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 63u) == 0u || timeout < 64) {
+        if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pk_ok = ok;
+  }
+  __syncthreads();
+  return pk_ok != 0;
+}
+
+// PoseEstimatorBase::reset + the head of run() on this workgroup's LDS copy (level_begin_kernel's body), and this workgroup's share
+// of the tap-cache keys of the level
+__device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int scale_is_moot)
+{
+  const int nthreads_team = (int) gridDim.x * PK_THREADS;
+  if(j.tapkey)
+    for(int i = (int) blockIdx.x * PK_THREADS + (int) threadIdx.x; i < j.n; i += nthreads_team) j.tapkey[i] = 0xffffffffu;
+  if(threadIdx.x < 4) pk_nrm[0][threadIdx.x] = j.nrm[threadIdx.x];
+  if(threadIdx.x == 4) pk_nrm[0][4] = j.dspace ? 1.0f : 0.0f;
+  if(threadIdx.x == 0) {
+    GNState* st = pk_st(0);
+    st->scale = 1.0f;
+    st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
+    st->f_norm_prev = 0.0f;
+    st->g_tol = 0.0f;
+    st->g_norm = 0.0f;
+    st->num_fun_evals = 0;
+    st->num_iterations = 0;
+    st->status = BPVO_STATUS_MAX_ITERATIONS;
+    st->phase = PHASE_FIRST;
+    st->has_converged = 0;
+    st->level = level;
+    st->median_valid = 0;
+    st->last_median = 0.0f;
+    for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
+    for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
+    st->active = (j.n > 0) ? 1 : 0;
+  }
+}
+
+template <int C, int LOSS>
+__global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
+                                                             int level_hi, int level_lo, int pts_per_block, GNParams prm, int fuse_frozen,
+                                                             int scale_is_moot, unsigned* ctl, long long timeout)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  const bool stats_wg = blockIdx.x == 0;
+  const bool fuse = kCanFuse && fuse_frozen;
+  unsigned* const global_ctl = ctl;                                           // [1] abort, [2] next pair to hand out
+  unsigned* const team_ctl = ctl + (size_t) (1 + blockIdx.y) * kTeamCtlWords; // [0] arrivals, [1] pair slot
+  unsigned epoch = 0, epoch_it = 0;
+
+  for(;;) {
+    // next pair of this team: its workgroup 0 draws, the barrier publishes the draw to the others
+    // (every workgroup reads the slot right after this barrier and before it arrives at the next one, which the drawing workgroup
+    // must pass before it can draw again: one slot is enough)
+    if(stats_wg && tid == 0) {
+      const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+    if(tid == 0) pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int pair = pk_next_pair;
+    if(pair >= n_pairs) return;
+
+    {   // the pair's state: HBM -> this workgroup's LDS copy (set_pose_kernel has run: T_out, statistics defaults)
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[0][i] = g[i];
+    }
+    __syncthreads();
+
+    for(int level = level_hi; level >= level_lo; --level) {
+      const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
+      pk_level_begin(jobs[0], level, scale_is_moot);
+      if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;         // keys reset before any phase reads them
+      for(;;) {
+        const GNState* st = pk_st(0);
+        if(!st->active) break;
+        const bool moving = st->delta_scale > 1e-6f;
+        if(!fuse || moving) {
+          pk_warp_phase<C>(jobs, 0, stats_wg);
+          if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+          if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
+        }
+        if constexpr(kCanFuse) {
+          if(fuse && !(pk_st(0)->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, 0, pts_per_block, epoch_it);   // (after the median: the chain's rule)
+          else pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+        } else {
+          pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+        }
+        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+        pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
+        ++epoch_it;
+      }
+    }
+    // the pair is done: its state back to HBM (one copy; the others are identical)
+    if(stats_wg) {
+      uint32_t* g = reinterpret_cast<uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[0][i];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 __global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2231,6 +2378,43 @@ hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterat
   prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
   if(g.C == 8) return launch_gn_persistent_c<8>(s, g, prm, ctl, grid, timeout_ticks);
   return launch_gn_persistent_c<1>(s, g, prm, ctl, grid, timeout_ticks);
+}
+// ---- team-persistent kernel for small batches
+int gn_team_ctl_words(int n_teams) { return (1 + n_teams) * kTeamCtlWords; }
+template <int C>
+static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const GNParams& prm)
+{
+  const int ppb = gn_pts_per_block(C);
+  const int fuse = (C == 8 && t.fuse_frozen) ? 1 : 0;
+  auto go = [&](auto kern) -> hipError_t {
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev &= 63;
+    std::call_once(once[dev], [&] {
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      int per_cu = 0;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, kMedianLds);
+      if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
+    });
+    if(status[dev] != hipSuccess) return status[dev];
+    hipLaunchKernelGGL(kern, dim3(t.team_size, t.n_teams), dim3(PK_THREADS), kMedianLds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.level_hi, t.level_lo, ppb,
+                       prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks);
+    return hipGetLastError();
+  };
+  switch(t.loss) {
+    case BPVO_LOSS_HUBER: return go(gn_team_kernel<C, BPVO_LOSS_HUBER>);
+    case BPVO_LOSS_TUKEY: return go(gn_team_kernel<C, BPVO_LOSS_TUKEY>);
+    default: return go(gn_team_kernel<C, BPVO_LOSS_L2>);
+  }
+}
+hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol)
+{
+  GNParams prm;
+  prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
+  if(t.C == 8) return launch_gn_team_c<8>(s, t, prm);
+  return launch_gn_team_c<1>(s, t, prm);
 }
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T, int reset_scale, int level, float given_scale)
 {

@@ -157,6 +157,20 @@ def make_sequence(rows: int, cols: int, n_frames: int, index: int = 0, step_rot:
     return dict(K=K, b=b, frames=frames, poses=poses)
 
 
+def make_stereo_sequence(rows: int, cols: int, n_frames: int, index: int = 0, step_rot: float = 0.004, step_trans: float = 0.03):
+    """make_sequence with the right image of every frame (the rig's right camera sits the baseline along +x of the left one):
+    list of (left, right) and the true left disparities — input of the stereo front-end + addFrame."""
+    seq = make_sequence(rows, cols, n_frames, index, step_rot, step_trans)
+    seed = 1000 + int(index)
+    shift = np.eye(4)
+    shift[0, 3] = -seq["b"]
+    frames = []
+    for (img, _disp), T in zip(seq["frames"], seq["poses"]):
+        right, _ = _render(seq["K"], seq["b"], rows, cols, shift @ T, seed, 10.0, (0.1, -0.15))
+        frames.append((img, right))
+    return dict(K=seq["K"], b=seq["b"], frames=frames, disps=[f[1] for f in seq["frames"]], poses=seq["poses"])
+
+
 def _pair_for_batch(args):
     rows, cols, idx = args
     d = make_pair(rows, cols, idx)

@@ -280,6 +280,10 @@ int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* ctx, const uint8_t* left, const uint
  * context then stays on the four-kernel chain; results are the same either way). */
 int bpvo_hip_persistent_counts(bpvo_hip_ctx* ctx, uint64_t* levels, int* gave_up);
 
+/* Batch estimates that ran their whole Gauss-Newton stage in one launch of the team-persistent kernel (batches of 2 ..
+ * BPVO_HIP_TEAM_MAX_PAIRS pairs) since the context was created. */
+int bpvo_hip_team_counts(bpvo_hip_ctx* ctx, uint64_t* launches);
+
 /* ---- measurement hooks (bench.py): per-kernel HIP-event timing on the ctx's own stream */
 typedef struct bpvo_hip_kernel_stat {
   char     name[48];

@@ -1,0 +1,61 @@
+"""A bounded run of the randomised stage-by-stage parity tool (tests/tools/fuzz_parity.py) inside the suite: fixed seeds, the
+configurations the reference can be configured to (withNormalization = 1, every descriptor on the device path, the four interpolation
+types, CD3 / CD5, three losses, NMS on / off, ragged sizes, 1-4 levels, the three warp formulations, the fused path), every stage up to
+the weights bit-identical with the oracle, every final pose inside the bar or explained by one of the tool's rules — each of which asks
+the ORACLE ITSELF (its other summation orders, a perturbed start, its f64 trace) whether the difference is the problem's, not the
+implementation's.  Plus the committed regression cases, replayed."""
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+
+pytestmark = pytest.mark.gpu
+
+ACCEPTED = {"ok", "template-error", "estimate-error", "non-finite", "unstable-problem", "iteration-limit", "stops-where-the-oracle-would",
+            "function-tol-at-the-noise-floor", "noise-floor-minimum"}
+
+
+@pytest.mark.parametrize("seed,n_cases", [(20261001, 160), (20261002, 160)])
+def test_bounded_fuzz_of_normalised_configurations(hip, orc, seed, n_cases):
+    import fuzz_parity as fz
+    rng = np.random.default_rng(seed)
+    outcomes = {}
+    n = 0
+    while n < n_cases:
+        rows, cols, kw, scene, s = fz.draw(rng)
+        if not kw["withNormalization"] or kw.get("_dspace"):     # no configuration of the reference switches the normalisation off
+            continue
+        n += 1
+        out = fz.check(hip, orc, rows, cols, kw, scene, s)        # raises AssertionError with the stage that differs
+        assert out in ACCEPTED, (rows, cols, scene, s, kw, out)
+        outcomes[out] = outcomes.get(out, 0) + 1
+        if n % 5 == 0 and out == "ok":
+            outb = fz.check_batch(hip, rows, cols, kw, s)
+            outcomes["batch-" + outb] = outcomes.get("batch-" + outb, 0) + 1
+    print(f"\nfuzz seed {seed}: {n} cases, outcomes {outcomes}")
+    assert outcomes.get("ok", 0) >= 0.85 * n_cases, outcomes
+
+
+def test_the_normalised_regression_cases_are_explained(hip, orc):
+    """The two normalised cases the randomised runs of round 2 left unexplained (tests/tools/fuzz_regressions.txt: 107x644 gradient / Tukey,
+    1.3e-2 rad from the oracle; 187x206 descriptor fields, 1.1 x the bar): both are stops of `|f - f_prev| < functionTolerance` on two
+    IDENTICAL consecutive f32 values of f_norm at an iterate where the exact f changes by less than the rounding error of the sum — the
+    oracle's f64 trace shows |f_k - f_(k-1)| <= 4e-6 f at that very iteration, and the GPU's pose is the oracle's iterate of that moment."""
+    import fuzz_parity as fz
+    seen = {}
+    for line in open(os.path.join(ROOT, "tests", "tools", "fuzz_regressions.txt")):
+        line = line.strip()
+        if not line or line.startswith("#") or "'withNormalization': 1" not in line:
+            continue
+        head, brace = line.split("{", 1)
+        rows, cols, scene, seed = (int(v) for v in head.split()[-4:])
+        kw = ast.literal_eval("{" + brace.split("}", 1)[0] + "}")
+        seen[(rows, cols)] = fz.check(hip, orc, rows, cols, kw, scene, seed)
+    print("\nnormalised regression cases:", seen)
+    assert seen and all(v in ACCEPTED for v in seen.values()), seen
+    assert seen.get((107, 644)) in ("function-tol-at-the-noise-floor", "ok"), seen

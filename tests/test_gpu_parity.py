@@ -295,13 +295,17 @@ def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
     rows, cols, levels, n = 120, 160, 3, 40
     batch = synth.make_batch(rows, cols, n, first_index=60, workers=1)
     out = {}
-    for lanes in (1, 2, 3):
-        monkeypatch.setenv("BPVO_HIP_LANES", str(lanes))
+    for lanes in (1, 2, 3, "team"):
+        # (a batch of this size would take the team-persistent kernel, which runs on one lane: switched off for the lane runs, and
+        # run last as a fourth variant — same bits again)
+        monkeypatch.setenv("BPVO_HIP_TEAM", "1" if lanes == "team" else "0")
+        monkeypatch.setenv("BPVO_HIP_LANES", "2" if lanes == "team" else str(lanes))
         ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels),
                          n_frames=2 * n, n_pairs=n)
         out[lanes] = ctx.batch_run(batch["images"], batch["disparities"])
+        assert ctx.team_counts() == (1 if lanes == "team" else 0)
         ctx.close()
-    for lanes in (2, 3):
+    for lanes in (2, 3, "team"):
         assert bits_equal(out[lanes][0], out[1][0]), lanes
         assert np.array_equal(out[lanes][1]["numIterations"], out[1][1]["numIterations"])
         assert np.array_equal(out[lanes][1]["status"], out[1][1]["status"])

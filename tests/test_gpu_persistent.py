@@ -97,3 +97,73 @@ def test_persistent_kernel_gives_up_cleanly(hip, monkeypatch):
     assert rec["pk"][1] == 1 and rec["pk"][0] <= levels          # gave up during the first estimate, never tried again
     assert bits_equal(ref["T"], rec["T"]) and bits_equal(ref["T2"], rec["T2"]) and ref["st"] == rec["st"] and ref["st2"] == rec["st2"]
     assert bits_equal(ref["r"], rec["r"]) and bits_equal(ref["w"], rec["w"]) and np.array_equal(ref["v"], rec["v"])
+
+
+# ---- the team-persistent kernel for small batches (gn_team_kernel): one launch for the whole Gauss-Newton stage of a batch -----------
+def run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=200, **kw):
+    b = synth.make_batch(rows, cols, n, first_index=first_index, workers=min(8, n))
+    ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels, **kw), n_frames=2 * n, n_pairs=n)
+    poses, stats = ctx.batch_run(b["images"], b["disparities"])
+    last = n - 1
+    rec = dict(poses=poses, stats=stats, r=ctx.get_residuals(last), v=ctx.get_valid(last), w=ctx.get_weights(last), frac=ctx.fraction_good(0, 0.85),
+               lin=ctx.total_linearizations(), med=ctx.median_path_counts(), fused=ctx.fused_point_counts(), taps=ctx.tap_cache_counts(),
+               team=ctx.team_counts(), pk=ctx.persistent_counts())
+    # a second batch on the same context (states, tap caches and counters of the first one are in place)
+    rec["poses2"], rec["stats2"] = ctx.batch_run(b["images"][::-1].copy(), b["disparities"][::-1].copy())
+    ctx.close()
+    return rec
+
+
+def assert_same_batch(a, b):
+    assert bits_equal(a["poses"], b["poses"]) and a["stats"].tobytes() == b["stats"].tobytes()
+    assert bits_equal(a["poses2"], b["poses2"]) and a["stats2"].tobytes() == b["stats2"].tobytes()
+    assert bits_equal(a["r"], b["r"]) and bits_equal(a["w"], b["w"]) and np.array_equal(a["v"], b["v"]) and a["frac"] == b["frac"]
+    assert a["lin"] == b["lin"] and a["med"] == b["med"] and a["fused"] == b["fused"] and a["taps"] == b["taps"]
+
+
+@pytest.mark.parametrize("rows,cols,levels,n", [pytest.param(120, 160, 3, 5, id="160x120-5pairs"), pytest.param(120, 160, 3, 37, id="160x120-37pairs"),
+                                                pytest.param(376, 1241, 4, 12, id="kitti-12pairs")])
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("bitplanes", "l2"), ("intensity", "huber")])
+def test_team_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, n, descriptor, loss, monkeypatch):
+    """Batches of 2 .. 256 pairs: every pair through all its levels in ONE launch, a team of workgroups per pair, against the
+    four-kernel chain with its host-driven level loop — poses, statistics, residuals, valid masks, weights, robust scale, and the
+    counters of the work done (linearisations, median selections by path, fused points, tap-cache lookups and hits)."""
+    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    ref = run_batch(hip, rows, cols, levels, n, descriptor, loss)
+    assert ref["team"] == 0
+    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
+    got = run_batch(hip, rows, cols, levels, n, descriptor, loss)
+    assert got["team"] == 2 and got["pk"][1] == 0, (got["team"], got["pk"])
+    assert_same_batch(ref, got)
+    assert len(np.unique(ref["stats"]["numIterations"][:, 0])) > 1            # the pairs really finish at different iterations
+
+
+@pytest.mark.parametrize("cus,team_size", [(6, 0), (7, 3), (4, 4), (300, 0)])
+def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
+    """Fewer teams than pairs (pairs are handed out dynamically: BPVO_HIP_TEAM_CUS caps the grid), teams of 1, 3 and 4 workgroups
+    (ragged chunk / tile splits), more CUs claimed than pairs need."""
+    rows, cols, levels, n = 120, 160, 3, 13
+    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
+    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
+    monkeypatch.setenv("BPVO_HIP_TEAM_CUS", str(cus))
+    if team_size:
+        monkeypatch.setenv("BPVO_HIP_TEAM_SIZE", str(team_size))
+    got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
+    assert got["team"] == 2 and got["pk"][1] == 0
+    assert_same_batch(ref, got)
+
+
+def test_team_kernel_gives_up_cleanly(hip, monkeypatch):
+    """A team barrier that cannot complete in its budget (10 ns): every workgroup leaves, the library reruns the batch through the chain
+    and stays on it.  Same results, no hang."""
+    rows, cols, levels, n = 120, 160, 3, 9
+    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
+    monkeypatch.setenv("BPVO_HIP_TEAM_SIZE", "4")
+    monkeypatch.setenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS", "1")
+    got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    assert got["pk"][1] == 1 and got["team"] == 1          # launched once, gave up, never tried again
+    assert bits_equal(ref["poses"], got["poses"]) and ref["stats"].tobytes() == got["stats"].tobytes()
+    assert bits_equal(ref["poses2"], got["poses2"]) and bits_equal(ref["r"], got["r"]) and bits_equal(ref["w"], got["w"])

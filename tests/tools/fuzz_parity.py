@@ -183,6 +183,26 @@ def check(hip, orc, rows, cols, kw, scene, seed):
         # happen to repeat) where the oracle's own sums did not trip it; handed the GPU's pose, the oracle's tests fire
         # there at once as well: both are stopping points of the reference's rule on a flat, slowly converging problem
         return "stops-where-the-oracle-would"
+    # A tolerance stop at the f32 noise floor of f_norm.  testConvergence's `|f - f_prev| < functionTolerance` (1e-6 by default) fires
+    # only when two consecutive f32 values of f_norm are IDENTICAL.  Where the true change of f between two iterates is smaller than
+    # the rounding error of the sum — at a turning point of a non-monotone f, or on a plateau — whether the two values coincide is
+    # decided by that rounding: the GPU (tree + f64 block combine, within 4e-6 of the exact sum: test_linearize_parity) and the
+    # oracle (serial f32, within 2e-4) draw differently.  Accepted when the oracle's own f64-accumulated trace shows, at the very
+    # iteration the GPU stopped on, a change of f below the GPU sum's error bound: nothing but rounding decided the test.
+    if sh[first]["status"] == capi.STATUS_FUNCTION_TOL and all(sh[l]["numIterations"] == so[l]["numIterations"] for l in range(first + 1, levels)):
+        co.call("set_reduction", 1)
+        _, _, tr64 = co.estimate_pose_trace(0, 0, 1)
+        co.call("set_reduction", 0)
+        t0 = tr64[tr64[:, 67] == first]
+        k = sh[first]["numIterations"]          # the level's linearisations 0 .. k: the stop compared f_k with f_(k-1)
+        if 1 <= k < len(t0) and abs(t0[k, 58] - t0[k - 1, 58]) <= 4e-6 * t0[k, 58]:
+            # ... and the GPU's pose is the oracle's iterate of that moment: T_k updated twice with dp_k (Q1: the update is repeated
+            # after convergence), i.e. the oracle's T_(k+2) up to the change of dp over one iteration
+            for kk in (k + 2, k + 1):
+                if kk < len(t0):
+                    rk, tk = pose_error(Th, t0[kk, :16].reshape(4, 4))
+                    if rk <= slack * ROT_TOL and tk <= slack * trans_tol(K):
+                        return "function-tol-at-the-noise-floor"
     assert near and abs(e_at - e_own) <= 2e-4 * abs(e_own), (
         "pose", rot, trans, "cpu-vs-cpu", rot8, trans8, "oracle restarted at the GPU pose", rot2, trans2, e_own, e_at,
         [s["status"] for s in sh], [s["status"] for s in so], [(s["status"], s["numIterations"]) for s in so2])
