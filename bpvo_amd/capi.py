@@ -21,6 +21,7 @@ STATUS_PARAMETER_TOL, STATUS_FUNCTION_TOL, STATUS_GRADIENT_TOL, STATUS_MAX_ITERA
 KF_LARGE_TRANSLATION, KF_LARGE_ROTATION, KF_SMALL_FRAC_GOOD, KF_NO_KEYFRAMING, KF_FIRST_FRAME = range(0x40, 0x45)
 MAX_LEVELS = 8
 TRACE_FLOATS = 68
+STEREO_BM, STEREO_SGM = 0, 1
 
 
 class Params(C.Structure):
@@ -56,7 +57,11 @@ class Result(C.Structure):
 class StereoParams(C.Structure):
     """bpvo_hip_stereo_params: the CvStereoBMState fields the reference sets (utils/stereo_algorithm.cc:63-82)."""
     _fields_ = [("preFilterCap", C.c_int), ("SADWindowSize", C.c_int), ("minDisparity", C.c_int), ("numberOfDisparities", C.c_int),
-                ("textureThreshold", C.c_int), ("uniquenessRatio", C.c_int)]
+                ("textureThreshold", C.c_int), ("uniquenessRatio", C.c_int),
+                # StereoAlgorithm: 0 block matching, 1 SgmStereo (utils/sgm.h:33-46) with the fields below
+                ("algorithm", C.c_int), ("sobelCapValue", C.c_int), ("censusRadius", C.c_int), ("windowRadius", C.c_int),
+                ("smoothnessPenaltySmall", C.c_int), ("smoothnessPenaltyLarge", C.c_int), ("consistencyThreshold", C.c_int), ("reserved_", C.c_int),
+                ("disparityFactor", C.c_double), ("censusWeightFactor", C.c_double)]
 
 
 class KernelStat(C.Structure):

@@ -174,7 +174,7 @@ struct bpvo_hip_ctx {
   // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
   // BPVO_HIP_TEAM=0 turns it off, BPVO_HIP_TEAM_MAX_PAIRS / BPVO_HIP_TEAM_SIZE (0 = CUs / pairs) size it.
-  int team_mode = 1, team_max_pairs = 256, team_size_env = 0, num_cus = 0;
+  int team_mode = 1, team_max_pairs = 64, team_size_env = 0, num_cus = 0;
   std::atomic<uint64_t> team_launches{0};
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
   std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)
@@ -186,6 +186,8 @@ struct bpvo_hip_ctx {
   uint8_t* st_left = nullptr; uint8_t* st_right = nullptr; uint8_t* st_left_pre = nullptr; uint8_t* st_right_pre = nullptr;
   float* st_disp = nullptr;
   int st_frames = 0;
+  void* st_sgm = nullptr;      // scratch of the semi-global matcher (cost volumes: sized for the largest disparity range seen)
+  size_t st_sgm_bytes = 0;
   bool counted_live = false;   // this context is in g_live_ctx
   // addFrame: the fraction of good points (should_keyframe's last criterion) is queued right behind the estimation, before the host
   // waits for the pose, instead of in a second round trip; frac_* hold it for fraction_good (same kernels, same count)
@@ -696,7 +698,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     if(te == hipSuccess) {
       team_ran = true;
       c->team_launches.fetch_add(1);
-      LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl, ln->d_team_ctl, sizeof(unsigned) * 8, hipMemcpyDeviceToHost, ln->stream));
+      LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl, ln->d_team_ctl, sizeof(unsigned) * 32, hipMemcpyDeviceToHost, ln->stream));
     } else {
       (void) hipGetLastError();
       c->persistent_failed.store(true);      // degrade to the chain, now and for later calls
@@ -825,6 +827,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       for(int k = 0; k < 6; ++k) std::fprintf(stderr, " %s %.2f", names[k], 0.01 * t[8 + k] / t[15]);
       std::fprintf(stderr, " | step: sum_partials %.2f unpack %.2f solve %.2f pose %.2f tests %.2f", 0.01 * t[20] / t[15], 0.01 * t[16] / t[15], 0.01 * t[17] / t[15],
                    0.01 * t[18] / t[15], 0.01 * t[19] / t[15]);
+      std::fprintf(stderr, " us per iteration\n");
+    }
+  }
+  if(team_ran && std::getenv("BPVO_HIP_PK_TIMING")) {       // library built with -DBPVO_PK_TIMING: phases of team 0's first workgroup
+    static const char* names[6] = {"warp", "barrier1", "median", "irls", "barrier2", "step"};
+    for(int l = c->L - 1; l >= 0 && l < 4; --l) {
+      const unsigned* t = ln->h_team_ctl + 4 + 7 * l;
+      if(!t[6]) continue;
+      std::fprintf(stderr, "team level %d: %u iterations;", l, t[6]);
+      for(int k = 0; k < 6; ++k) std::fprintf(stderr, " %s %.2f", names[k], 0.01 * t[k] / t[6]);
       std::fprintf(stderr, " us per iteration\n");
     }
   }
@@ -1270,8 +1282,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     if(k == 0) {
       CREATE_CK(hipMalloc((void**) &ln.d_team_ctl, sizeof(unsigned) * (size_t) gn_team_ctl_words(kMaxTeams)));
-      CREATE_CK(hipHostMalloc((void**) &ln.h_team_ctl, sizeof(unsigned) * 8));
-      std::memset(ln.h_team_ctl, 0, sizeof(unsigned) * 8);
+      CREATE_CK(hipHostMalloc((void**) &ln.h_team_ctl, sizeof(unsigned) * 32));
+      std::memset(ln.h_team_ctl, 0, sizeof(unsigned) * 32);
     }
     CREATE_CK(hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
   }
@@ -1304,6 +1316,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
+  (void) hipFree(c->st_sgm);
   (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
@@ -1732,6 +1745,22 @@ static int stereo_check(bpvo_hip_ctx* c, const bpvo_hip_stereo_params* sp)
 {
   // the argument checks of cvFindStereoCorrespondenceBM (stereobm.cpp) + what the kernel serves
   if(!sp) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr stereo parameters");
+  if(sp->algorithm == BPVO_STEREO_SGM) {
+    // the checks of SgmStereo::compute / the SGMStereo setters (utils/sgm.cc:168-171,208-254)
+    if(sp->numberOfDisparities <= 0 || sp->numberOfDisparities % 16) return fail(c, BPVO_ERR_INVALID_ARG, "numberOfDisparities must be a multiple of 16");
+    if(sp->censusRadius < 1 || sp->censusRadius > 2) return fail(c, BPVO_ERR_INVALID_ARG, "window radius of Census transform must be 1 or 2");
+    if(sp->censusWeightFactor < 0) return fail(c, BPVO_ERR_INVALID_ARG, "weight of Census transform must be positive");
+    if(sp->smoothnessPenaltySmall < 0 || sp->smoothnessPenaltyLarge < 0) return fail(c, BPVO_ERR_INVALID_ARG, "smoothness penalty value is less than zero");
+    if(sp->smoothnessPenaltySmall >= sp->smoothnessPenaltyLarge) return fail(c, BPVO_ERR_INVALID_ARG, "small value of smoothness penalty must be smaller than large penalty value");
+    if(sp->consistencyThreshold < 0) return fail(c, BPVO_ERR_INVALID_ARG, "threshold for LR consistency must be positive");
+    if(!(sp->disparityFactor > 0)) return fail(c, BPVO_ERR_INVALID_ARG, "disparity factor is less than zero");
+    if(sp->numberOfDisparities > 256) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: numberOfDisparities <= 256 are on the device path");
+    if(sp->windowRadius < 0 || sp->windowRadius > 7 || c->rows <= sp->windowRadius) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: windowRadius 0..7 (and fewer than image rows) are on the device path");
+    // int16 path costs: the sums of four paths stay clear of saturation for penalties below this (the original saturates silently)
+    if(sp->smoothnessPenaltyLarge > 4000) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: smoothnessPenaltyLarge <= 4000 on the device path");
+    return BPVO_OK;
+  }
+  if(sp->algorithm != BPVO_STEREO_BLOCK_MATCHING) return fail(c, BPVO_ERR_UNSUPPORTED, "StereoAlgorithm: BlockMatching and SGM are on the device path (SGBM is OpenCV's, RSGM is not built)");
   if(sp->preFilterCap < 1 || sp->preFilterCap > 63) return fail(c, BPVO_ERR_INVALID_ARG, "preFilterCap must be within 1..63");
   if(sp->SADWindowSize < 5 || sp->SADWindowSize > 255 || sp->SADWindowSize % 2 == 0 || sp->SADWindowSize >= std::min(c->cols, c->rows))
     return fail(c, BPVO_ERR_INVALID_ARG, "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height");
@@ -1772,6 +1801,26 @@ static int stereo_run(bpvo_hip_ctx* c, int count, const uint8_t* left, const uin
     HIP_CK(c, hipMemcpyAsync(c->st_right, right, npix, hipMemcpyHostToDevice, c->stream));
     dl = c->st_left; dr = c->st_right;
   }
+  if(sp->algorithm == BPVO_STEREO_SGM) {
+    const size_t need = sgm_scratch_bytes(c->rows, c->cols, sp->numberOfDisparities);
+    if(need > c->st_sgm_bytes) {
+      HIP_CK(c, hipStreamSynchronize(c->stream));
+      (void) hipFree(c->st_sgm);
+      c->st_sgm = nullptr; c->st_sgm_bytes = 0;
+      HIP_CK(c, hipMalloc(&c->st_sgm, need));
+      c->st_sgm_bytes = need;
+    }
+    SgmLaunch g;
+    g.left = dl; g.right = dr; g.disp = c->st_disp; g.scratch = c->st_sgm;
+    g.rows = c->rows; g.cols = c->cols; g.nframes = count;
+    g.ndisp = sp->numberOfDisparities; g.sobel_cap = sp->sobelCapValue; g.census_radius = sp->censusRadius; g.window_radius = sp->windowRadius;
+    g.P1 = sp->smoothnessPenaltySmall; g.P2 = sp->smoothnessPenaltyLarge; g.consistency_threshold = sp->consistencyThreshold;
+    g.disparity_factor = sp->disparityFactor; g.census_weight = sp->censusWeightFactor;
+    if(!launch_stereo_sgm(c->stream, g)) return fail(c, BPVO_ERR_UNSUPPORTED, "semi-global matching: disparity range not served by the kernels");
+    HIP_CK(c, hipGetLastError());
+    if(d_left) *d_left = dl;
+    return BPVO_OK;
+  }
   launch_stereo_prefilter(c->stream, dl, c->st_left_pre, c->rows, c->cols, sp->preFilterCap, count);
   launch_stereo_prefilter(c->stream, dr, c->st_right_pre, c->rows, c->cols, sp->preFilterCap, count);
   StereoLaunch g;
@@ -1787,7 +1836,12 @@ static int stereo_run(bpvo_hip_ctx* c, int count, const uint8_t* left, const uin
 
 void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p)   // utils/stereo_algorithm.cc:63-82 (numberOfDisparities has no default there)
 {
+  std::memset(p, 0, sizeof(*p));
   p->preFilterCap = 31; p->SADWindowSize = 15; p->minDisparity = 0; p->numberOfDisparities = 64; p->textureThreshold = 10; p->uniquenessRatio = 15;
+  // SgmStereo::Config() (utils/sgm.cc:47-56); algorithm: "BlockMatching" is the config file's default (utils/stereo_algorithm.cc:25)
+  p->algorithm = BPVO_STEREO_BLOCK_MATCHING;
+  p->sobelCapValue = 15; p->censusRadius = 2; p->windowRadius = 2; p->smoothnessPenaltySmall = 100; p->smoothnessPenaltyLarge = 1600;
+  p->consistencyThreshold = 1; p->disparityFactor = 256.0; p->censusWeightFactor = 1.0 / 6.0;
 }
 int bpvo_hip_stereo_bm(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, int on_device, const bpvo_hip_stereo_params* sp,
                        float* disparity, int disparity_on_device)

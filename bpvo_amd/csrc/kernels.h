@@ -65,6 +65,19 @@ struct StereoLaunch {
 void launch_stereo_prefilter(hipStream_t s, const uint8_t* src, uint8_t* dst, int rows, int cols, int cap, int nframes);
 bool launch_stereo_bm(hipStream_t s, const StereoLaunch& g);   // false: window size / disparity range outside what the kernel serves
 
+// semi-global matching (kernels_sgm.hip): the reference's in-tree SgmStereo (utils/sgm.cc)
+struct SgmLaunch {
+  const uint8_t* left;      // [nframes][rows*cols]
+  const uint8_t* right;
+  float* disp;              // [nframes][rows*cols]
+  void* scratch;            // sgm_scratch_bytes(rows, cols, ndisp) bytes, shared by the frames (processed one after the other)
+  int rows, cols, nframes;
+  int ndisp, sobel_cap, census_radius, window_radius, P1, P2, consistency_threshold;
+  double disparity_factor, census_weight;
+};
+size_t sgm_scratch_bytes(int rows, int cols, int ndisp);
+bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g);   // false: disparity range outside what the kernels serve (multiple of 16, <= 256)
+
 // Gauss-Newton stage (batched over workspaces / pairs)
 // Compacted list of the workspaces of a launch that are still iterating (estimate loops).  The host rebuilds it (on the
 // device) once per round of kItersPerSync iterations, together with the read-back of the count, and sizes the workspace

@@ -1744,6 +1744,138 @@ __device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restric
   }
 }
 
+// The same phase for the TEAM kernel (C = 8), where all CUs of the chip run teams at once and a memory round trip takes 2 - 3 us instead
+// of under one: with one point per thread the phase is a chain of dependent round trips (point -> projection -> key -> taps) at 8 waves
+// per CU, and it stretched from 28 to 80 - 110 us per iteration at the finest level of a 128-pair batch
+// (profiles/r03_team_phases_under_load_before.txt).  Here a thread carries U points — one from each of U chunks — through the phase in
+// stages: everything whose address depends on the point index only (point, tap-cache key, the eight cached tap vectors, template pixels) is
+// requested for all U points at once, then the U projections, then the gathers of the misses (at dense levels, which run without the
+// cache: of all points) for all U at once.  Same expressions as warp_point, operation for operation: same bits.  The cached taps are loaded
+// speculatively, as irls_tile_lat does (3 % of them are discarded at the sparse levels).
+struct WarpStage {
+  float4 X, t[8], px[2];
+  double xf, yf;
+  unsigned key;
+  int i, xi, yi, chunk;
+  bool has, in_block, valid, hit;
+};
+__shared__ BracketLds pk_br_u[PK_VB][4];
+template <int U, bool NT>
+__device__ __attribute__((noinline)) void pk_warp_phase_staged(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  static_assert(U >= 1 && U <= 4, "pk_br_u");
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const GNState* st = pk_st(ws);
+  const PairJob& j = jobs[ws];
+  const int n = j.n, W = j.cols, R = j.rows;
+  const int nchunks = (n + K6_BLOCK - 1) / K6_BLOCK;
+  float P[12];
+  projection_matrix(j, st->T, P);
+  const bool bracket = (st->delta_scale > 1e-6f) && st->median_valid;
+  const unsigned lo_key = st->lo_key, hi_key = st->hi_key;
+  const bool cached = j.tapcache_on != 0;
+  float4* const tc = reinterpret_cast<float4*>(j.tapcache.get());
+  const float4* const p0 = reinterpret_cast<const float4*>(j.pix.get());
+  if(stats_wg && tid == 0) j.cnt[4] += (unsigned long long) n;
+  for(int base = 0; base < nchunks; base += nwg * PK_VB * U) {
+    WarpStage s[U];
+    // stage A: everything addressed by the point index
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      s[u].chunk = base + (u * PK_VB + vsub) * nwg + (int) blockIdx.x;
+      s[u].has = s[u].chunk < nchunks;
+      const int i_raw = s[u].chunk * K6_BLOCK + vtid;
+      s[u].in_block = s[u].has && i_raw < n;
+      const int i = s[u].in_block ? i_raw : n - 1;
+      s[u].i = i;
+      s[u].X = load_v4<NT>(j.pts + i);
+      s[u].px[0] = load_v4<NT>(p0 + tile_index<2>(i, 0));
+      s[u].px[1] = load_v4<NT>(p0 + tile_index<2>(i, 1));
+      if(cached) {
+        s[u].key = j.tapkey[i];
+#pragma unroll
+        for(int k = 0; k < 8; ++k) s[u].t[k] = load_v4<NT>(tc + tile_index<8>(i, k));
+      } else {
+        s[u].key = 0xffffffffu;
+      }
+    }
+    // stage B: projection, validity (warp_point), and the gathers of the footprints the cache does not hold
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      const float4 X = s[u].X;
+      const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
+      double uu[3];
+#pragma unroll
+      for(int r = 0; r < 3; ++r) {
+        double a = (double) P[r * 4 + 0] * X0;
+        a += (double) P[r * 4 + 1] * X1;
+        a += (double) P[r * 4 + 2] * X2;
+        a += (double) P[r * 4 + 3] * X3;
+        uu[r] = a;
+      }
+      const double zi = 1.0 / uu[2];
+      const double x = zi * uu[0], y = zi * uu[1];
+      const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+      int xi = 0, yi = 0;
+      if(in_range) {
+        xi = (int) x; xi -= (xi > x);
+        yi = (int) y; yi -= (yi > y);
+      }
+      s[u].valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+      s[u].xi = xi; s[u].yi = yi;
+      s[u].xf = x - (double) xi; s[u].yf = y - (double) yi;
+      const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+      s[u].hit = s[u].valid && cached && s[u].key == key;
+      s[u].key = key;
+      if(s[u].valid && !s[u].hit) {
+        const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
+        const float4* q1 = q0 + (size_t) W * 2;
+        s[u].t[0] = q0[0]; s[u].t[1] = q0[1]; s[u].t[2] = q0[2]; s[u].t[3] = q0[3];
+        s[u].t[4] = q1[0]; s[u].t[5] = q1[1]; s[u].t[6] = q1[2]; s[u].t[7] = q1[3];
+      }
+    }
+    // stage C: residuals, stores, cache update, bracket step
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      const int i = s[u].i;
+      float res[8];
+      if(s[u].valid) {
+        const double xf = s[u].xf, yf = s[u].yf, wx = 1.0 - xf, wy = 1.0 - yf;
+        const float4* t = s[u].t;
+        // pieces 0, 1: I00 of channels 0-3 / 4-7; 2, 3: I01; 4, 5: I10; 6, 7: I11 (warp_point)
+        const float i00[8] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w};
+        const float i01[8] = {t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, t[3].z, t[3].w};
+        const float i10[8] = {t[4].x, t[4].y, t[4].z, t[4].w, t[5].x, t[5].y, t[5].z, t[5].w};
+        const float i11[8] = {t[6].x, t[6].y, t[6].z, t[6].w, t[7].x, t[7].y, t[7].z, t[7].w};
+        const float i0[8] = {s[u].px[0].x, s[u].px[0].y, s[u].px[0].z, s[u].px[0].w, s[u].px[1].x, s[u].px[1].y, s[u].px[1].z, s[u].px[1].w};
+#pragma unroll
+        for(int c = 0; c < 8; ++c) {
+          const double Iw = wy * ((double) i00[c] * wx + (double) i01[c] * xf) + yf * ((double) i10[c] * wx + (double) i11[c] * xf);
+          res[c] = (float) (Iw - (double) i0[c]);
+        }
+        if(!s[u].hit && s[u].in_block && cached) {
+#pragma unroll
+          for(int k = 0; k < 8; ++k) store_v4<NT>(tc + tile_index<8>(i, k), t[k]);
+          j.tapkey[i] = s[u].key;
+        }
+      } else {
+#pragma unroll
+        for(int c = 0; c < 8; ++c) res[c] = 0.0f;
+      }
+      if(s[u].in_block) {
+        j.valid[i] = s[u].valid ? 1 : 0;
+        float4* o = reinterpret_cast<float4*>(j.r.get());
+        store_v4<NT>(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
+        store_v4<NT>(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
+      }
+      if(bracket)
+        bracket_chunk<8>(j, lo_key, hi_key, s[u].valid && s[u].in_block, s[u].hit && s[u].valid && s[u].in_block, res, (unsigned) s[u].chunk, vtid >> 6,
+                         pk_br_u[vsub][u], s[u].has);
+    }
+  }
+}
+
 template <int C>
 __device__ __attribute__((noinline)) void pk_median_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
 {
@@ -1927,7 +2059,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// TEAM-persistent Gauss-Newton kernel for small BATCHES (2 .. ~256 pairs: the 128-pair shard of BASELINE config 5 on one of 8 GPUs).
+// TEAM-persistent Gauss-Newton kernel for small BATCHES (2 .. 64 pairs).
 // The four-kernel chain pays a floor per launch (ramp, drain, the list -> job -> state chain of dependent loads: ~10 us) that a
 // 1024-pair batch amortises and a 128-pair batch does not: 4 launches x ~220 iterations x 10 us is a third of its Gauss-Newton time,
 // and every level lasts as long as its slowest pair (profiles/r02_pipe/, profiles/r03_persistent_grid_probe.txt).  Here the
@@ -1940,6 +2072,14 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
 // latency-bound ones (median, solve) of others.
 // Barrier that cannot complete (teams not co-resident): the poll gives up after `timeout`, raises the abort word and every workgroup
 // leaves; the host reruns the group on the chain, as for gn_persistent_kernel.
+#ifndef TEAM_WARP_U_VALUE
+#define TEAM_WARP_U_VALUE 2
+#endif
+#ifndef TEAM_NT_VALUE
+#define TEAM_NT_VALUE 0
+#endif
+constexpr bool TEAM_NT = TEAM_NT_VALUE != 0;        // streaming (non-temporal) accesses in the team kernel's warp phase
+constexpr int TEAM_WARP_U = TEAM_WARP_U_VALUE;      // points a thread of the team kernel's warp phase carries at once
 constexpr int kTeamCtlWords = 32;       // one 128-byte line per team: [0] arrivals, [1] next pair broadcast slot; global line 0: [1] abort, [2] next pair
 __shared__ int pk_next_pair;
 
@@ -2010,6 +2150,16 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
   unsigned* const global_ctl = ctl;                                           // [1] abort, [2] next pair to hand out
   unsigned* const team_ctl = ctl + (size_t) (1 + blockIdx.y) * kTeamCtlWords; // [0] arrivals, [1] pair slot
   unsigned epoch = 0, epoch_it = 0;
+  // BPVO_PK_TIMING: workgroup 0 of team 0 accumulates the 100 MHz ticks of its phases, per pyramid level, in ctl[4 .. 31]: 7 words per level
+  // {warp, barrier1, median, irls, barrier2, step, iterations}
+#ifdef BPVO_PK_TIMING
+  long long tk = wall_clock64();
+  unsigned acc_t[kMaxLevels][7];
+  for(int l = 0; l < kMaxLevels; ++l) for(int k = 0; k < 7; ++k) acc_t[l][k] = 0;
+#define TEAM_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[level][k] += (unsigned) (t_ - tk); tk = t_; } while(0)
+#else
+#define TEAM_TICK(k) do { } while(0)
+#endif
 
   for(;;) {
     // next pair of this team: its workgroup 0 draws, the barrier publishes the draw to the others
@@ -2039,10 +2189,17 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
         const GNState* st = pk_st(0);
         if(!st->active) break;
         const bool moving = st->delta_scale > 1e-6f;
+#ifdef BPVO_PK_TIMING
+        tk = wall_clock64(); acc_t[level][6] += 1;
+#endif
         if(!fuse || moving) {
-          pk_warp_phase<C>(jobs, 0, stats_wg);
+          if constexpr(C == 8) pk_warp_phase_staged<TEAM_WARP_U, TEAM_NT>(jobs, 0, stats_wg);
+          else pk_warp_phase<C>(jobs, 0, stats_wg);
+          TEAM_TICK(0);
           if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+          TEAM_TICK(1);
           if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
+          TEAM_TICK(2);
         }
         if constexpr(kCanFuse) {
           if(fuse && !(pk_st(0)->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, 0, pts_per_block, epoch_it);   // (after the median: the chain's rule)
@@ -2050,11 +2207,18 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
         } else {
           pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
         }
+        TEAM_TICK(3);
         if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+        TEAM_TICK(4);
         pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
+        TEAM_TICK(5);
         ++epoch_it;
       }
     }
+#ifdef BPVO_PK_TIMING
+    if(blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+      for(int l = 0; l < 4; ++l) for(int k = 0; k < 7; ++k) global_ctl[4 + l * 7 + k] += acc_t[l][k];      // words 4 .. 31 of the global line, summed over the team's pairs
+#endif
     // the pair is done: its state back to HBM (one copy; the others are identical)
     if(stats_wg) {
       uint32_t* g = reinterpret_cast<uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());

@@ -1,0 +1,350 @@
+// Stereo front-end, second matcher: the reference's in-tree semi-global matcher SgmStereo (utils/sgm.{h,cc} — the
+// SPS-stereo SGM; selected by `StereoAlgorithm = SGM`, utils/stereo_algorithm.cc:42-59,127-133; conf/kitti_eval.cfg:27 and
+// conf/kitti_stereo.cfg:5 run the KITTI evaluation with it).  Integer arithmetic throughout (int16 saturating path costs; two double
+// expressions: the census weight and the sub-pixel step), so the bar is bit-equality with the oracle's restatement, which cites the
+// source line by line (parity unpinned: utils/sgm.cc includes OpenCV and cannot be built here).
+//
+// The CPU code is one sequential sweep per pass that carries two paths at once; on the device the same sums are computed from
+// their definitions, the sequential part reduced to what is sequential in the algorithm:
+//   sgm_census_sobel   capped x-Sobel (right image mirrored, as the original stores it) and the 5x5 / 3x3 census code       per pixel
+//   sgm_pixel_cost     Birchfield-Tomasi style sampling-insensitive |dSobel| + weighted census Hamming distance            per (y, x, d)
+//   sgm_box_cost       (2r+1)^2 box sum with clamped coordinates = the sliding row / column sums of the original, incl. the rows and
+//                      the column the original never writes (S1 in the oracle)                                                per (y, x, d)
+//   sgm_right_cost     the right image's cost volume: right(x, d) = left(x + d, d), clamped                                  per (y, x, d)
+//   sgm_path_kernel    one scanline (a row for the horizontal paths, a column for the vertical ones) per wavefront, lanes = disparities,
+//                      sequential along the line: L(p, d) = min(L'(d), L'(d +- 1) + P1, min L' + P2) - (min L' + P2) + C(p, d), int16
+//                      saturating, neighbours by wave shuffles, the minimum by a DPP tree; adds L into the sum volume         per line
+//   sgm_wta            winner takes all + the original's sub-pixel expression in double                                      per pixel
+//   speckle filter     connected components (|difference| <= 2 * factor between 4-neighbours) by lock-free union-find, sizes by
+//                      atomics, regions of <= 100 pixels zeroed — the flood fill of the original finds the same components
+//   sgm_lr_check       left-right consistency of the left map, conversion to float
+// Bounds: sgm_pixel_cost / sgm_box_cost are VALU / L1-bound (25 window terms per output), the path kernels latency-bound chains of
+// width x ~60 instructions with H (or W) wavefronts in flight, everything else streams the 2-byte volumes once.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace bpvo_hip {
+
+namespace {
+
+__device__ __forceinline__ int sat16(int v) { return min(32767, max(-32768, v)); }
+
+__global__ __launch_bounds__(256) void sgm_census_sobel_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ sobel, int* __restrict__ census,
+                                                              int rows, int cols, int pitch, int cap, int crad, int flip)
+{
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(y >= rows) return;
+  // the row pitch is wider than the image: the padding (and the image border) holds `cap` (memset in the original)
+  if(x >= cols) {
+    if(x < pitch) sobel[(size_t) pitch * y + x] = (uint8_t) cap;
+    return;
+  }
+  const int c = img[(size_t) cols * y + x];
+  int code = 0;
+  for(int oy = -crad; oy <= crad; ++oy)
+    for(int ox = -crad; ox <= crad; ++ox) {
+      code <<= 1;
+      const int yy = y + oy, xx = x + ox;
+      if(yy >= 0 && yy < rows && xx >= 0 && xx < cols && (int) img[(size_t) cols * yy + xx] >= c) code += 1;
+    }
+  census[(size_t) cols * y + x] = code;
+  int v = cap;
+  const bool interior = y >= 1 && y < rows - 1 && x >= 1 && x < cols - 1;
+  if(interior) {
+    const uint8_t* r0 = img + (size_t) cols * (y - 1);
+    const uint8_t* r1 = r0 + cols;
+    const uint8_t* r2 = r1 + cols;
+    v = ((int) r0[x + 1] + 2 * (int) r1[x + 1] + (int) r2[x + 1]) - ((int) r0[x - 1] + 2 * (int) r1[x - 1] + (int) r2[x - 1]);
+    v = v > cap ? 2 * cap : (v < -cap ? 0 : v + cap);
+  }
+  // interior pixels land mirrored for the right image; the border columns keep `cap` at their own (unmirrored) place — which the
+  // mirrored interior never touches (columns 0 and W - 1 map onto each other)
+  const int xo = (flip && interior) ? cols - x - 1 : x;
+  sobel[(size_t) pitch * y + xo] = (uint8_t) v;
+}
+
+__device__ __forceinline__ void half_minmax(const uint8_t* __restrict__ row, int x, int W, int& mn, int& mx)
+{
+  const int c = row[x];
+  const int l = x > 0 ? (c + (int) row[x - 1]) / 2 : c;
+  const int r = x < W - 1 ? (c + (int) row[x + 1]) / 2 : c;
+  mn = min(min(l, r), c);
+  mx = max(max(l, r), c);
+}
+
+// pixel-wise cost u8 [rows][cols][D]: threads = disparities of one pixel (blockDim.x = D rounded up to 64), blockIdx.x = x, blockIdx.y = y
+__global__ void sgm_pixel_cost_kernel(const uint8_t* __restrict__ sl, const uint8_t* __restrict__ sr, const int* __restrict__ cl, const int* __restrict__ cr,
+                                      uint8_t* __restrict__ pc, int rows, int cols, int pitch, int D, double cweight)
+{
+  const int x = blockIdx.x, y = blockIdx.y, d0 = threadIdx.x;
+  if(d0 >= D) return;
+  const int d = min(d0, x);                                   // costs beyond d = x repeat the one at d = x (S2)
+  const uint8_t* lrow = sl + (size_t) pitch * y;
+  const uint8_t* rrow = sr + (size_t) pitch * y;               // mirrored: original column x - d sits at cols - 1 - x + d
+  const int lc = lrow[x];
+  int lmin, lmax, rmin, rmax;
+  half_minmax(lrow, x, cols, lmin, lmax);
+  const int ri = cols - 1 - x + d;
+  half_minmax(rrow, ri, cols, rmin, rmax);
+  const int rc = rrow[ri];
+  int l2r = max(0, lc - rmax);
+  l2r = max(l2r, rmin - lc);
+  int r2l = max(0, rc - lmax);
+  r2l = max(r2l, lmin - rc);
+  const int sad = min(l2r, r2l);
+  const int ham = __popc((unsigned) (cl[(size_t) cols * y + x] ^ cr[(size_t) cols * y + x - d]));
+  pc[((size_t) cols * y + x) * D + d0] = (uint8_t) (sad + (int) (uint8_t) ((double) ham * cweight));
+}
+
+// (2r+1)^2 box sums with clamped coordinates; rows y + r >= rows and (for y >= 1) column 0 stay 0 (S1)
+__global__ void sgm_box_cost_kernel(const uint8_t* __restrict__ pc, uint16_t* __restrict__ cost, int rows, int cols, int D, int wrad)
+{
+  const int x = blockIdx.x, y = blockIdx.y, d = threadIdx.x;
+  if(d >= D) return;
+  int s = 0;
+  if(y + wrad < rows && (y == 0 || x >= 1)) {
+    for(int oy = -wrad; oy <= wrad; ++oy) {
+      const int yy = min(max(y + oy, 0), rows - 1);
+      for(int ox = -wrad; ox <= wrad; ++ox) {
+        const int xx = min(max(x + ox, 0), cols - 1);
+        s += pc[((size_t) cols * yy + xx) * D + d];
+      }
+    }
+  }
+  cost[((size_t) cols * y + x) * D + d] = (uint16_t) s;
+}
+
+__global__ void sgm_right_cost_kernel(const uint16_t* __restrict__ lcost, uint16_t* __restrict__ rcost, int rows, int cols, int D)
+{
+  const int x = blockIdx.x, y = blockIdx.y, d = threadIdx.x;
+  if(d >= D) return;
+  const int dd = min(d, cols - 1 - x);                         // past the image the last valid disparity's cost repeats
+  rcost[((size_t) cols * y + x) * D + d] = lcost[((size_t) cols * y + x + dd) * D + dd];
+}
+
+// One scanline per wavefront.  vertical = 0: line = row `line`, steps along x; 1: line = column `line`, steps along y.  dir = +1 / -1.
+// V disparities per lane (d = lane * V + k); sum += L (saturating).
+template <int V>
+__global__ __launch_bounds__(64) void sgm_path_kernel(const uint16_t* __restrict__ cost, int16_t* __restrict__ sum, int rows, int cols, int D, int P1, int P2,
+                                                      int vertical, int dir)
+{
+  const int line = blockIdx.x, lane = threadIdx.x;
+  const int nsteps = vertical ? rows : cols;
+  const size_t step_stride = (vertical ? (size_t) cols * D : (size_t) D);
+  const size_t base = vertical ? (size_t) line * D : (size_t) line * cols * D;
+  int prev[V];
+#pragma unroll
+  for(int k = 0; k < V; ++k) prev[k] = 0;                      // before the first pixel: all path costs and their minimum 0
+  int prev_min = 0;
+  const bool first_lane_group = lane == 0;
+  for(int s = 0; s < nsteps; ++s) {
+    const int pos = dir > 0 ? s : nsteps - 1 - s;
+    const size_t off = base + (size_t) pos * step_stride;
+    int c[V];
+#pragma unroll
+    for(int k = 0; k < V; ++k) {
+      const int d = lane * V + k;
+      c[k] = d < D ? (int) cost[off + d] : 0;
+    }
+    const int pm = (int) (int16_t) (prev_min + P2);
+    // neighbours across lanes: d - 1 of k = 0 is the previous lane's last, d + 1 of k = V - 1 the next lane's first
+    const int from_left = __shfl_up(prev[V - 1], 1), from_right = __shfl_down(prev[0], 1);
+    int cur[V];
+    int mn = 32767;
+#pragma unroll
+    for(int k = 0; k < V; ++k) {
+      const int d = lane * V + k;
+      int lm = k > 0 ? prev[k - 1] : (first_lane_group ? 32767 : from_left);
+      int lp = k < V - 1 ? prev[k + 1] : from_right;
+      if(d + 1 >= D) lp = 32767;                               // the sentinel behind the last disparity
+      if(d == 0) lm = 32767;
+      int a = min(prev[k], sat16(lm + P1));
+      a = min(a, sat16(lp + P1));
+      a = min(a, pm);
+      a = sat16(sat16(a - pm) + c[k]);
+      cur[k] = a;
+      if(d < D) mn = min(mn, a);
+    }
+#pragma unroll
+    for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+    prev_min = mn;
+#pragma unroll
+    for(int k = 0; k < V; ++k) {
+      const int d = lane * V + k;
+      prev[k] = cur[k];
+      if(d < D) sum[off + d] = (int16_t) sat16((int) sum[off + d] + cur[k]);
+    }
+  }
+}
+
+// winner takes all (first minimum) + the sub-pixel expression of the original in double; one wavefront per pixel would waste the chip:
+// a thread per pixel walks its D sums
+__global__ __launch_bounds__(256) void sgm_wta_kernel(const int16_t* __restrict__ sum, uint16_t* __restrict__ disp, size_t npix, int D, double factor)
+{
+  const size_t p = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if(p >= npix) return;
+  const int16_t* S = sum + p * D;
+  int best = S[0], bd = 0;
+  for(int d = 1; d < D; ++d) {
+    const int v = S[d];
+    if(v < best) { best = v; bd = d; }
+  }
+  int out;
+  if(bd > 0 && bd < D - 1) {
+    const int c = S[bd], l = S[bd - 1], r = S[bd + 1];
+    double v;
+    if(r < l) v = (double) bd * factor + (double) (r - l) / (double) (c - l) / 2.0 * factor + 0.5;
+    else v = (double) bd * factor + (double) (r - l) / (double) (c - r) / 2.0 * factor + 0.5;
+    // static_cast<int> on x86: truncation, INT_MIN for NaN / infinities / out of range (a zero denominator: S5)
+    const bool ok = (v == v) && v > -2147483649.0 && v < 2147483648.0;
+    out = ok ? (int) v : (int) 0x80000000;
+  } else {
+    out = (int) ((double) bd * factor);
+  }
+  disp[p] = (uint16_t) out;
+}
+
+// ---- speckle filter: connected components by lock-free union-find (roots = smallest pixel index of the component)
+__device__ __forceinline__ int uf_find(int* __restrict__ lab, int a)
+{
+  int p = lab[a];
+  while(p != a) { a = p; p = lab[a]; }
+  return a;
+}
+__device__ __forceinline__ void uf_union(int* __restrict__ lab, int a, int b)
+{
+  for(;;) {
+    a = uf_find(lab, a);
+    b = uf_find(lab, b);
+    if(a == b) return;
+    if(a < b) { const int t = a; a = b; b = t; }       // link the larger root under the smaller
+    const int old = atomicMin(&lab[a], b);
+    if(old == a) return;
+    a = old;
+  }
+}
+__global__ __launch_bounds__(256) void sgm_cc_init_kernel(const uint16_t* __restrict__ img, int* __restrict__ lab, int* __restrict__ size, int npix)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= npix) return;
+  lab[p] = img[p] != 0 ? p : -1;
+  size[p] = 0;
+}
+__global__ __launch_bounds__(256) void sgm_cc_merge_kernel(const uint16_t* __restrict__ img, int* __restrict__ lab, int rows, int cols, int max_diff)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= rows * cols) return;
+  const int v = img[p];
+  if(v == 0) return;
+  const int x = p % cols, y = p / cols;
+  if(x < cols - 1) { const int q = img[p + 1]; if(q != 0 && abs(v - q) <= max_diff) uf_union(lab, p, p + 1); }
+  if(y < rows - 1) { const int q = img[p + cols]; if(q != 0 && abs(v - q) <= max_diff) uf_union(lab, p, p + cols); }
+}
+__global__ __launch_bounds__(256) void sgm_cc_count_kernel(int* __restrict__ lab, int* __restrict__ size, int npix)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= npix || lab[p] < 0) return;
+  const int r = uf_find(lab, p);
+  lab[p] = r;                                              // (path compression; roots never change after the merge kernel)
+  atomicAdd(&size[r], 1);
+}
+__global__ __launch_bounds__(256) void sgm_cc_apply_kernel(uint16_t* __restrict__ img, const int* __restrict__ lab, const int* __restrict__ size, int npix,
+                                                          int max_size)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= npix || lab[p] < 0) return;
+  if(size[lab[p]] <= max_size) img[p] = 0;
+}
+
+// enforceLeftRightConsistency (left half) + disparity / factor -> float
+__global__ __launch_bounds__(256) void sgm_lr_check_kernel(const uint16_t* __restrict__ dl, const uint16_t* __restrict__ dr, float* __restrict__ out, int rows,
+                                                          int cols, double factor, int thresh)
+{
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if(p >= rows * cols) return;
+  const int x = p % cols;
+  int v = dl[p];
+  if(v != 0) {
+    const int ld = (int) ((double) v / factor + 0.5);
+    if(x - ld < 0) v = 0;
+    else {
+      const int rd = (int) ((double) dr[p - ld] / factor + 0.5);
+      if(rd == 0 || abs(ld - rd) > thresh) v = 0;
+    }
+  }
+  out[p] = (float) ((double) v / factor);
+}
+
+}  // namespace
+
+size_t sgm_scratch_bytes(int rows, int cols, int D)
+{
+  const size_t npix = (size_t) rows * cols, pitch = (size_t) cols + 15 - (cols - 1) % 16;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  return 2 * up(pitch * rows) + 2 * up(npix * 4) + up(npix * D) + 2 * up(npix * D * 2) + up(npix * D * 2) + 2 * up(npix * 2) + 2 * up(npix * 4);
+}
+
+// SGMStereo::compute (utils/sgm.cc:250-285) for `nframes` rectified pairs, one after the other on the stream (the cost volumes of a
+// 1241 x 376 x 128 frame are 120 MB each: the scratch is per context, not per frame)
+bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
+{
+  const int rows = g.rows, cols = g.cols, D = g.ndisp;
+  if(D <= 0 || D % 16 || D > 256) return false;
+  const size_t npix = (size_t) rows * cols;
+  const int pitch = cols + 15 - (cols - 1) % 16;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  unsigned char* w = (unsigned char*) g.scratch;
+  uint8_t* sob_l = w; w += up((size_t) pitch * rows);
+  uint8_t* sob_r = w; w += up((size_t) pitch * rows);
+  int* cen_l = (int*) w; w += up(npix * 4);
+  int* cen_r = (int*) w; w += up(npix * 4);
+  uint8_t* pc = w; w += up(npix * D);
+  uint16_t* cost_l = (uint16_t*) w; w += up(npix * D * 2);
+  uint16_t* cost_r = (uint16_t*) w; w += up(npix * D * 2);
+  int16_t* sum = (int16_t*) w; w += up(npix * D * 2);
+  uint16_t* disp_l = (uint16_t*) w; w += up(npix * 2);
+  uint16_t* disp_r = (uint16_t*) w; w += up(npix * 2);
+  int* lab = (int*) w; w += up(npix * 4);
+  int* size = (int*) w; w += up(npix * 4);
+  const int cap = (std::min(std::max(g.sobel_cap, 15), 127)) | 1;
+  const int dthreads = (D + 63) / 64 * 64;
+  const dim3 gpix((pitch + 63) / 64, (rows + 3) / 4), gxy(cols, rows);
+  const unsigned nb = (unsigned) ((npix + 255) / 256);
+  for(int f = 0; f < g.nframes; ++f) {
+    const uint8_t* L = g.left + npix * f;
+    const uint8_t* R = g.right + npix * f;
+    hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, L, sob_l, cen_l, rows, cols, pitch, cap, g.census_radius, 0);
+    hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, R, sob_r, cen_r, rows, cols, pitch, cap, g.census_radius, 1);
+    hipLaunchKernelGGL(sgm_pixel_cost_kernel, gxy, dim3(dthreads), 0, s, sob_l, sob_r, cen_l, cen_r, pc, rows, cols, pitch, D, g.census_weight);
+    hipLaunchKernelGGL(sgm_box_cost_kernel, gxy, dim3(dthreads), 0, s, pc, cost_l, rows, cols, D, g.window_radius);
+    hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
+    for(int side = 0; side < 2; ++side) {
+      const uint16_t* cost = side == 0 ? cost_l : cost_r;
+      uint16_t* disp = side == 0 ? disp_l : disp_r;
+      (void) hipMemsetAsync(sum, 0, npix * D * 2, s);
+      for(int pass = 0; pass < 2; ++pass) {
+        const int dir = pass == 0 ? 1 : -1;
+        auto paths = [&](auto v) {
+          constexpr int V = decltype(v)::value;
+          hipLaunchKernelGGL(sgm_path_kernel<V>, dim3(rows), dim3(64), 0, s, cost, sum, rows, cols, D, g.P1, g.P2, 0, dir);
+          hipLaunchKernelGGL(sgm_path_kernel<V>, dim3(cols), dim3(64), 0, s, cost, sum, rows, cols, D, g.P1, g.P2, 1, dir);
+        };
+        if(D <= 64) paths(std::integral_constant<int, 1>());
+        else if(D <= 128) paths(std::integral_constant<int, 2>());
+        else paths(std::integral_constant<int, 4>());
+      }
+      hipLaunchKernelGGL(sgm_wta_kernel, dim3(nb), dim3(256), 0, s, sum, disp, npix, D, g.disparity_factor);
+      // speckleFilter(100, 2 * factor) (utils/sgm.cc:898)
+      hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix);
+      hipLaunchKernelGGL(sgm_cc_merge_kernel, dim3(nb), dim3(256), 0, s, disp, lab, rows, cols, (int) (2 * g.disparity_factor));
+      hipLaunchKernelGGL(sgm_cc_count_kernel, dim3(nb), dim3(256), 0, s, lab, size, (int) npix);
+      hipLaunchKernelGGL(sgm_cc_apply_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix, 100);
+    }
+    hipLaunchKernelGGL(sgm_lr_check_kernel, dim3(nb), dim3(256), 0, s, disp_l, disp_r, g.disp + npix * f, rows, cols, g.disparity_factor, g.consistency_threshold);
+  }
+  return true;
+}
+
+}  // namespace bpvo_hip

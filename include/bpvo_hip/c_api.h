@@ -258,6 +258,7 @@ int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* ctx, float* d_dst, int n_pa
  * linear addressing, clamped at the end of the image; and for minDisparity > 0 the original's column loop runs past the end of the
  * row (its results there depend on the next row's bytes) — here and in the oracle that overrun is CUT at the last column, not
  * reproduced. */
+enum { BPVO_STEREO_BLOCK_MATCHING = 0, BPVO_STEREO_SGM = 1 };
 typedef struct bpvo_hip_stereo_params {
   int preFilterCap;          /* 31 */
   int SADWindowSize;         /* 15; odd, 5..21 on the device path */
@@ -265,10 +266,25 @@ typedef struct bpvo_hip_stereo_params {
   int numberOfDisparities;   /* no default in the reference ("must be provided"); multiple of 16, <= 256 */
   int textureThreshold;      /* 10 */
   int uniquenessRatio;       /* 15 */
+  /* `StereoAlgorithm` of the reference's config file (utils/stereo_algorithm.cc:25-27,42,62): BPVO_STEREO_BLOCK_MATCHING (the default,
+   * the fields above) or BPVO_STEREO_SGM — the in-tree semi-global matcher SgmStereo (utils/sgm.{h,cc}; conf/kitti_eval.cfg:27,
+   * conf/kitti_stereo.cfg:5) with SgmStereo::Config below (defaults utils/sgm.cc:47-56 = utils/stereo_algorithm.cc:46-56); it reads
+   * numberOfDisparities from the field above.  Invalid pixels carry 0.  Integer arithmetic restated line by line from the source,
+   * which includes OpenCV and cannot be built in this image: parity unpinned, HIP = oracle bit for bit. */
+  int    algorithm;
+  int    sobelCapValue;            /* 15 (clamped to 15..127, made odd: utils/sgm.cc:225-226) */
+  int    censusRadius;             /* 2; 1 or 2 */
+  int    windowRadius;             /* 2 */
+  int    smoothnessPenaltySmall;   /* 100 */
+  int    smoothnessPenaltyLarge;   /* 1600 */
+  int    consistencyThreshold;     /* 1 */
+  int    reserved_;
+  double disparityFactor;          /* 256.0 */
+  double censusWeightFactor;       /* 1.0 / 6.0 */
 } bpvo_hip_stereo_params;
 void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p);
 /* StereoAlgorithm::run for `count` rectified pairs of the ctx's image size ([count][rows*cols] u8 each, host or device) ->
- * f32 disparities [count][rows*cols] (host or device) */
+ * f32 disparities [count][rows*cols] (host or device); sp->algorithm selects the matcher (the entry point keeps its name) */
 int bpvo_hip_stereo_bm(bpvo_hip_ctx* ctx, int count, const uint8_t* left, const uint8_t* right, int on_device,
                        const bpvo_hip_stereo_params* sp, float* disparity, int disparity_on_device);
 /* VisualOdometry::addFrame(left, StereoAlgorithm::run(left, right)): the disparity map stays on the device */

@@ -442,6 +442,16 @@ int bpvo_orc_stereo_bm(const uint8_t* left, const uint8_t* right, int rows, int 
   return 0;
 }
 int bpvo_orc_stereo_prefilter(const uint8_t* src, int rows, int cols, int cap, uint8_t* dst) { stereoPrefilterXSobel(src, rows, cols, cap, dst); return 0; }
+// StereoAlgorithm::run (SemiGlobalMatching): iparams = {numberOfDisparities, sobelCapValue, censusRadius, windowRadius, smoothnessPenaltySmall,
+// smoothnessPenaltyLarge, consistencyThreshold}, dparams = {disparityFactor, censusWeightFactor}; 1 = arguments the original throws on
+int bpvo_orc_stereo_sgm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int iparams[7], const double dparams[2], float* dmap)
+{
+  SgmParams sp;
+  sp.numberOfDisparities = iparams[0]; sp.sobelCapValue = iparams[1]; sp.censusRadius = iparams[2]; sp.windowRadius = iparams[3];
+  sp.smoothnessPenaltySmall = iparams[4]; sp.smoothnessPenaltyLarge = iparams[5]; sp.consistencyThreshold = iparams[6];
+  sp.disparityFactor = dparams[0]; sp.censusWeightFactor = dparams[1];
+  return stereoSGM(left, right, rows, cols, sp, dmap) ? 0 : 1;
+}
 // MEstimator::ComputeWeights on raw arrays (r [n], valid [n] u16 -> w [n]); n a multiple of 16 runs the SIMD body only
 int bpvo_orc_compute_weights(int loss, const float* r, const uint16_t* valid, size_t n, float sigma, float* w)
 {

@@ -91,6 +91,13 @@ struct StereoParams {
 void stereoPrefilterXSobel(const uint8_t* src, int rows, int cols, int ftzero, uint8_t* dst);
 void stereoBlockMatching(const uint8_t* left, const uint8_t* right, int rows, int cols, const StereoParams& sp, int16_t* disp);
 void stereoBM(const uint8_t* left, const uint8_t* right, int rows, int cols, const StereoParams& sp, float* dmap);
+// SgmStereo::Config (utils/sgm.h:33-46; defaults utils/sgm.cc:47-56 = what utils/stereo_algorithm.cc:46-56 reads from the config)
+struct SgmParams {
+  int numberOfDisparities = 128, sobelCapValue = 15, censusRadius = 2, windowRadius = 2;
+  int smoothnessPenaltySmall = 100, smoothnessPenaltyLarge = 1600, consistencyThreshold = 1;
+  double disparityFactor = 256.0, censusWeightFactor = 1.0 / 6.0;
+};
+bool stereoSGM(const uint8_t* left, const uint8_t* right, int rows, int cols, const SgmParams& sp, float* dmap);
 
 // ---- descriptor (dense_descriptor.*, intensity_descriptor.cc, bitplanes_descriptor.cc)
 struct Descriptor {

@@ -24,7 +24,8 @@ def child(a):
     import bpvo_amd
     from bpvo_amd import capi
     d = np.load(a.child)
-    hip = bpvo_amd.load()
+    # BPVO_AB_LIB: an experimental build of the library (scripts/build_exp.sh) instead of the product's
+    hip = capi.Binding(os.path.join(ROOT, os.environ["BPVO_AB_LIB"]), "bpvo_hip_") if os.environ.get("BPVO_AB_LIB") else bpvo_amd.load()
     p = hip.default_params()
     p.numPyramidLevels = a.levels
     p.descriptor = capi.DESC_BITPLANES if a.descriptor == "bitplanes" else capi.DESC_INTENSITY

@@ -106,10 +106,10 @@ def run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=200, **k
     poses, stats = ctx.batch_run(b["images"], b["disparities"])
     last = n - 1
     rec = dict(poses=poses, stats=stats, r=ctx.get_residuals(last), v=ctx.get_valid(last), w=ctx.get_weights(last), frac=ctx.fraction_good(0, 0.85),
-               lin=ctx.total_linearizations(), med=ctx.median_path_counts(), fused=ctx.fused_point_counts(), taps=ctx.tap_cache_counts(),
-               team=ctx.team_counts(), pk=ctx.persistent_counts())
+               lin=ctx.total_linearizations(), med=ctx.median_path_counts(), fused=ctx.fused_point_counts(), taps=ctx.tap_cache_counts())
     # a second batch on the same context (states, tap caches and counters of the first one are in place)
     rec["poses2"], rec["stats2"] = ctx.batch_run(b["images"][::-1].copy(), b["disparities"][::-1].copy())
+    rec["team"], rec["pk"] = ctx.team_counts(), ctx.persistent_counts()
     ctx.close()
     return rec
 

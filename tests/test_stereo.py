@@ -187,3 +187,239 @@ def test_add_frame_stereo_equals_add_frame_with_the_same_disparity(hip, orc):
         assert np.array_equal(ra["pose"].view(np.uint32), rc["pose"].view(np.uint32))
         assert ra["isKeyFrame"] == rc["isKeyFrame"] and ra["stats"] == rc["stats"]
     assert np.array_equal(a.trajectory(), c.trajectory()) and a.vo_num_points_at_level() == c.vo_num_points_at_level() > 0
+
+
+# ---- semi-global matching: the reference's in-tree SgmStereo (utils/sgm.cc), BPVO_STEREO_SGM -----------------------------------------
+SGM_DEFAULT = dict(ndisp=64, cap=15, crad=2, wrad=2, p1=100, p2=1600, thr=1, factor=256.0, cw=1.0 / 6.0)
+
+
+def orc_sgm(orc, left, right, **kw):
+    q = dict(SGM_DEFAULT, **kw)
+    out = np.empty(left.shape, np.float32)
+    ip = (C.c_int * 7)(q["ndisp"], q["cap"], q["crad"], q["wrad"], q["p1"], q["p2"], q["thr"])
+    dp = (C.c_double * 2)(q["factor"], q["cw"])
+    rc = orc.lib.bpvo_orc_stereo_sgm(left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), left.shape[0], left.shape[1], ip, dp,
+                                     out.ctypes.data_as(C.c_void_p))
+    return out if rc == 0 else None
+
+
+def np_sgm(L, R, ndisp, cap, crad, wrad, p1, p2, thr, factor, cw):
+    """The algorithm of utils/sgm.cc from its definitions, written independently of the oracle: vectorised numpy over rows / disparities, the
+    scanline recursions as plain loops.  Returns the float disparity map."""
+    H, W = L.shape
+    D = ndisp
+    cap = min(max(cap, 15), 127) | 1
+    Li, Ri = L.astype(np.int64), R.astype(np.int64)
+
+    def sobel(I):
+        S = np.full((H, W), cap, np.int64)
+        v = (I[:-2, 2:] + 2 * I[1:-1, 2:] + I[2:, 2:]) - (I[:-2, :-2] + 2 * I[1:-1, :-2] + I[2:, :-2])
+        S[1:-1, 1:-1] = np.where(v > cap, 2 * cap, np.where(v < -cap, 0, v + cap))
+        return S
+
+    def census(I):
+        code = np.zeros((H, W), np.int64)
+        P = np.full((H + 2 * crad, W + 2 * crad), -1, np.int64)
+        P[crad:crad + H, crad:crad + W] = I
+        for oy in range(-crad, crad + 1):
+            for ox in range(-crad, crad + 1):
+                nb = P[crad + oy: crad + oy + H, crad + ox: crad + ox + W]
+                code = (code << 1) + (nb >= I).astype(np.int64) * (nb >= 0)
+        return code
+
+    def halfmm(S):
+        l = np.concatenate([S[:, :1], (S[:, 1:] + S[:, :-1]) // 2], axis=1)
+        r = np.concatenate([(S[:, :-1] + S[:, 1:]) // 2, S[:, -1:]], axis=1)
+        return np.minimum(np.minimum(l, r), S), np.maximum(np.maximum(l, r), S)
+
+    SL, SR = sobel(Li), sobel(Ri)
+    SRf = SR[:, ::-1].copy()
+    SRf[:, 0] = cap; SRf[:, -1] = cap                   # the mirrored interior leaves both border columns at `cap`
+    CL, CR = census(Li), census(Ri)
+    lmin, lmax = halfmm(SL)
+    rminf, rmaxf = halfmm(SRf)
+    pc = np.zeros((H, W, D), np.int64)
+    xs = np.arange(W)
+    pop = np.vectorize(lambda v: bin(int(v)).count("1"))
+    for d in range(D):
+        dd = np.minimum(d, xs)                           # costs past d = x repeat the cost at d = x
+        ri = W - 1 - xs + dd
+        rc, rmn, rmx = SRf[:, ri], rminf[:, ri], rmaxf[:, ri]
+        l2r = np.maximum(np.maximum(0, SL - rmx), rmn - SL)
+        r2l = np.maximum(np.maximum(0, rc - lmax), lmin - rc)
+        ham = pop(CL ^ CR[:, xs - dd])
+        pc[:, :, d] = (np.minimum(l2r, r2l) + (ham * cw).astype(np.int64).astype(np.uint8)) % 256
+    yy = np.clip(np.arange(-wrad, H + wrad), 0, H - 1)
+    xx = np.clip(np.arange(-wrad, W + wrad), 0, W - 1)
+    cost = np.zeros((H, W, D), np.int64)
+    for oy in range(2 * wrad + 1):
+        for ox in range(2 * wrad + 1):
+            cost += pc[yy[oy: oy + H]][:, xx[ox: ox + W]]
+    cost[H - wrad:] = 0                                  # rows the original never writes
+    cost[1:, 0] = 0                                      # ... and the first column of every row but the first
+    rcost = np.zeros_like(cost)
+    for x in range(W):
+        for d in range(D):
+            dd = min(d, W - 1 - x)
+            rcost[:, x, d] = cost[:, x + dd, dd]
+
+    def sat(v):
+        return np.clip(v, -32768, 32767)
+
+    def aggregate(Cv):
+        S = np.zeros((H, W, D), np.int64)
+        big = 32767
+
+        def step(prev, pmin, c):                         # prev [..., D], pmin [...], c [..., D]
+            pm = (pmin + p2)[..., None]
+            lm = np.concatenate([np.full(prev.shape[:-1] + (1,), big), prev[..., :-1]], axis=-1)
+            lp = np.concatenate([prev[..., 1:], np.full(prev.shape[:-1] + (1,), big)], axis=-1)
+            a = np.minimum(np.minimum(prev, sat(lm + p1)), np.minimum(sat(lp + p1), pm))
+            a = sat(sat(a - pm) + c)
+            return a, a.min(axis=-1)
+
+        for order in (1, -1):
+            xs_ = range(W) if order == 1 else range(W - 1, -1, -1)
+            ys_ = range(H) if order == 1 else range(H - 1, -1, -1)
+            prev, pmin = np.zeros((H, D), np.int64), np.zeros(H, np.int64)          # along the rows, all rows at once
+            for x in xs_:
+                prev, pmin = step(prev, pmin, Cv[:, x, :])
+                S[:, x, :] = sat(S[:, x, :] + prev)
+            prev, pmin = np.zeros((W, D), np.int64), np.zeros(W, np.int64)          # along the columns, all columns at once
+            for y in ys_:
+                prev, pmin = step(prev, pmin, Cv[y])
+                S[y] = sat(S[y] + prev)
+        bd = S.argmin(axis=2)                            # first minimum
+        out = np.zeros((H, W), np.int64)
+        for y in range(H):
+            for x in range(W):
+                b = int(bd[y, x])
+                if 0 < b < D - 1:
+                    c, l, r = float(S[y, x, b]), float(S[y, x, b - 1]), float(S[y, x, b + 1])
+                    den = (c - l) if r < l else (c - r)
+                    if den == 0.0:
+                        out[y, x] = 0                    # INT_MIN truncated to 16 bits
+                        continue
+                    out[y, x] = int(b * factor + (r - l) / den / 2.0 * factor + 0.5) & 0xffff
+                else:
+                    out[y, x] = int(b * factor)
+        # speckle filter: components of the "both non-zero and within 2 * factor" 4-neighbour relation, at most 100 pixels -> 0
+        lab = -np.ones((H, W), np.int64)
+        md = int(2 * factor)
+        for y0 in range(H):
+            for x0 in range(W):
+                if out[y0, x0] == 0 or lab[y0, x0] >= 0:
+                    continue
+                comp, stack = [], [(y0, x0)]
+                lab[y0, x0] = 1
+                while stack:
+                    y, x = stack.pop()
+                    comp.append((y, x))
+                    for y2, x2 in ((y, x + 1), (y, x - 1), (y + 1, x), (y - 1, x)):
+                        if 0 <= y2 < H and 0 <= x2 < W and lab[y2, x2] < 0 and out[y2, x2] != 0 and abs(out[y, x] - out[y2, x2]) <= md:
+                            lab[y2, x2] = 1
+                            stack.append((y2, x2))
+                if len(comp) <= 100:
+                    for y, x in comp:
+                        lab[y, x] = 2
+        out[lab == 2] = 0
+        return out
+
+    dl, dr = aggregate(cost), aggregate(rcost)
+    res = dl.copy()
+    for y in range(H):
+        for x in range(W):
+            if res[y, x] == 0:
+                continue
+            ld = int(res[y, x] / factor + 0.5)
+            if x - ld < 0:
+                res[y, x] = 0
+                continue
+            rd = int(dr[y, x - ld] / factor + 0.5)
+            if rd == 0 or abs(ld - rd) > thr:
+                res[y, x] = 0
+    return (res / factor).astype(np.float32)
+
+
+@pytest.mark.parametrize("rows,cols,kw", [(40, 72, dict(ndisp=16)), (33, 61, dict(ndisp=32, crad=1, wrad=1, p1=60, p2=900)),
+                                          (36, 50, dict(ndisp=16, cap=40, thr=2, cw=0.5, factor=16.0))])
+def test_sgm_oracle_against_a_numpy_evaluation_of_the_definition(orc, rows, cols, kw):
+    d = synth.make_stereo_pair(rows, cols, 6, z0=2.5)
+    rng = np.random.default_rng(rows)
+    left, right = d["left"].copy(), d["right"].copy()
+    right[: rows // 4] = rng.integers(0, 256, (rows // 4, cols), dtype=np.uint8)        # a band without a match: left-right check, speckles
+    left[rows // 2: rows // 2 + 5, 8:30] = 128                                           # a flat patch: ties, zero sub-pixel denominators
+    right[rows // 2: rows // 2 + 5, 8:30] = 128
+    got = orc_sgm(orc, left, right, **kw)
+    q = dict(SGM_DEFAULT, **kw)
+    want = np_sgm(left, right, q["ndisp"], q["cap"], q["crad"], q["wrad"], q["p1"], q["p2"], q["thr"], q["factor"], q["cw"])
+    assert np.array_equal(got, want), (np.argwhere(got != want)[:6], got[got != want][:6], want[got != want][:6])
+    assert (got == 0).any() and (got > 0).mean() > 0.3
+
+
+def test_sgm_recovers_the_disparity_of_a_plane_and_rejects_bad_arguments(orc):
+    rows, cols = 120, 320
+    d = synth.make_stereo_pair(rows, cols, 1, z0=6.0)
+    out = orc_sgm(orc, d["left"], d["right"], ndisp=32)
+    valid = out > 0
+    assert valid.mean() > 0.9
+    err = np.abs(out[valid] - d["disp"][valid])
+    assert np.median(err) < 0.15 and np.percentile(err, 95) < 0.5, (np.median(err), np.percentile(err, 95))
+    # (the last windowRadius rows have no data cost in the original — utils/sgm.cc:517-526 never writes them — and get their disparities
+    # from the smoothness terms alone: plausible values, not 0)
+    for bad in (dict(ndisp=24), dict(crad=3), dict(p1=200, p2=100), dict(thr=-1), dict(factor=0.0)):
+        assert orc_sgm(orc, d["left"], d["right"], **bad) is None, bad
+
+
+def _sgm_params(ctx, **kw):
+    q = dict(SGM_DEFAULT, **kw)
+    sp = ctx.default_stereo_params(q["ndisp"])
+    sp.algorithm = capi.STEREO_SGM
+    sp.sobelCapValue, sp.censusRadius, sp.windowRadius = q["cap"], q["crad"], q["wrad"]
+    sp.smoothnessPenaltySmall, sp.smoothnessPenaltyLarge, sp.consistencyThreshold = q["p1"], q["p2"], q["thr"]
+    sp.disparityFactor, sp.censusWeightFactor = q["factor"], q["cw"]
+    return sp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,kw", [(376, 1241, dict(ndisp=128)), (480, 640, dict(ndisp=64)), (121, 163, dict(ndisp=32, crad=1, wrad=1, p1=60, p2=900)),
+                                          (97, 203, dict(ndisp=48, cap=40, thr=2, cw=0.5)), (64, 300, dict(ndisp=256, factor=64.0)),
+                                          (50, 70, dict(ndisp=16, wrad=3))])
+def test_hip_sgm_bit_exact(hip, orc, rows, cols, kw):
+    d = synth.make_stereo_pair(rows, cols, 4, z0=8.0 if cols > 700 else 4.0)
+    rng = np.random.default_rng(cols)
+    left, right = d["left"].copy(), d["right"].copy()
+    right[: rows // 4] = rng.integers(0, 256, (rows // 4, cols), dtype=np.uint8)
+    left[rows // 2: rows // 2 + 20, 30: 30 + cols // 4] = 100
+    right[rows // 2: rows // 2 + 20, 30: 30 + cols // 4] = 100
+    p = hip.default_params(); p.numPyramidLevels = 2; p.verbosity = capi.VERB_SILENT
+    ctx = hip.create(d["K"], d["b"], rows, cols, p, n_frames=3, n_pairs=1)
+    got = ctx.stereo_bm(left, right, _sgm_params(ctx, **kw))
+    want = orc_sgm(orc, left, right, **kw)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (np.argwhere(got != want)[:8], got[got != want][:8], want[got != want][:8])
+    assert (got == 0).any() and (got > 0).mean() > 0.3
+
+
+@pytest.mark.gpu
+def test_hip_sgm_batch_errors_and_add_frame(hip, orc):
+    rows, cols, n = 120, 200, 3
+    pairs = [synth.make_stereo_pair(rows, cols, k, z0=4.0) for k in range(n)]
+    L = np.stack([q["left"] for q in pairs]); R = np.stack([q["right"] for q in pairs])
+    p = hip.default_params(); p.numPyramidLevels = 2; p.verbosity = capi.VERB_SILENT
+    ctx = hip.create(pairs[0]["K"], pairs[0]["b"], rows, cols, p, n_frames=3, n_pairs=1)
+    got = ctx.stereo_bm(L, R, _sgm_params(ctx, ndisp=32))
+    for k in range(n):
+        assert np.array_equal(got[k], orc_sgm(orc, L[k], R[k], ndisp=32)), k
+    for bad in (dict(ndisp=24), dict(crad=3), dict(p1=200, p2=100), dict(thr=-1), dict(factor=0.0), dict(ndisp=512), dict(p2=5000)):
+        with pytest.raises(capi.BpvoError):
+            ctx.stereo_bm(L[0], R[0], _sgm_params(ctx, **bad))
+    # addFrame fed by the matcher on the device = addFrame fed the oracle's map from the host
+    seq = synth.make_stereo_sequence(240, 320, 4, index=9)
+    pp = hip.default_params(); pp.numPyramidLevels = 3; pp.verbosity = capi.VERB_SILENT; pp.descriptor = capi.DESC_BITPLANES
+    a = hip.create(seq["K"], seq["b"], 240, 320, pp, n_frames=3, n_pairs=1)
+    c = hip.create(seq["K"], seq["b"], 240, 320, pp, n_frames=3, n_pairs=1)
+    sp = _sgm_params(a, ndisp=32)
+    for left, right in seq["frames"]:
+        ra = a.add_frame_stereo(left, right, sp)
+        rc = c.add_frame(left, orc_sgm(orc, left, right, ndisp=32))
+        assert np.array_equal(ra["pose"].view(np.uint32), rc["pose"].view(np.uint32)) and ra["isKeyFrame"] == rc["isKeyFrame"] and ra["stats"] == rc["stats"]
