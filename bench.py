@@ -186,12 +186,14 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
     SAD over a 15 x 15 window for every (pixel, disparity): VALU-bound (wave prefix sums + compares), not HBM-bound — two u8 images
     in, one f32 map out."""
     out = {}
-    for name, (rows, cols, ndisp, pairs) in stereo_in["batches"].items():
+    from bpvo_amd import capi
+    for name, (rows, cols, ndisp, pairs, algorithm) in stereo_in["batches"].items():
         left, right, K, b = pairs
         n = left.shape[0]
         p = hip.default_params(); p.numPyramidLevels = 1
         ctx = hip.create(K, b, rows, cols, p, device=dev_index, n_frames=1, n_pairs=1)
         sp = ctx.default_stereo_params(ndisp)
+        sp.algorithm = capi.STEREO_SGM if algorithm == "sgm" else capi.STEREO_BM
         dl, dr = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
         dd = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
         for _ in range(2):
@@ -203,11 +205,20 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
             ctx.stereo_bm_device(n, dl.data_ptr(), dr.data_ptr(), sp, dd.data_ptr())
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        valid = float((dd[0] >= 0).float().mean().item())
-        sums = float(n) * rows * (cols - ndisp + 1) * ndisp
-        out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "window_sums_per_s": sums / dt,
-                     "valid_fraction_frame0": valid, "disparities": ndisp, "SADWindowSize": sp.SADWindowSize,
-                     "bound": "VALU (integer SAD, wave prefix sums): 2 u8 images in + 1 f32 map out are " + "%.1f" % ((2 + 4) * rows * cols * n / dt / 1e9) + " GB/s of HBM traffic"}
+        if algorithm == "sgm":
+            valid = float((dd[0] > 0).float().mean().item())
+            # per frame: pixel cost (1 B) written + read 25 x by the box sum (L1 / L2), two 2-byte cost volumes written and read by 4 path
+            # passes each together with the 2-byte sum volume (read + write): ~ (1 + 2 + 2 + 2 * 4 * (2 + 2 + 2) + 2 * 2) B per (pixel, disparity)
+            vol = float(n) * rows * cols * ndisp
+            out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "pixel_disparities_per_s": vol / dt,
+                         "valid_fraction_frame0": valid, "disparities": ndisp,
+                         "bound": "the cost / sum volumes through HBM: ~57 B per (pixel, disparity) = %.0f GB/s achieved; the scanline kernels are latency-bound chains" % (57 * vol / dt / 1e9)}
+        else:
+            valid = float((dd[0] >= 0).float().mean().item())
+            sums = float(n) * rows * (cols - ndisp + 1) * ndisp
+            out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "window_sums_per_s": sums / dt,
+                         "valid_fraction_frame0": valid, "disparities": ndisp, "SADWindowSize": sp.SADWindowSize,
+                         "bound": "VALU (integer SAD, wave prefix sums): 2 u8 images in + 1 f32 map out are " + "%.1f" % ((2 + 4) * rows * cols * n / dt / 1e9) + " GB/s of HBM traffic"}
         ctx.close()
     seq = stereo_in.get("sequence")
     if seq is not None:
@@ -302,8 +313,11 @@ def main():
             ps = [synth.make_stereo_pair(rows_, cols_, i) for i in range(n_)]
             return (np.stack([q["left"] for q in ps]), np.stack([q["right"] for q in ps]), ps[0]["K"], ps[0]["b"])
         st_seq = synth.make_stereo_sequence(480, 640, 9, index=23, step_rot=0.004, step_trans=0.03)
-        seq640["stereo"] = {"batches": {"block matching 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, stereo_stack(376, 1241, 16)),
-                                        "block matching 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, stereo_stack(480, 640, 16))},
+        st_k, st_t = stereo_stack(376, 1241, 16), stereo_stack(480, 640, 16)
+        seq640["stereo"] = {"batches": {"block matching 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, st_k, "bm"),
+                                        "block matching 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "bm"),
+                                        "SGM (SgmStereo, conf/kitti_eval.cfg) 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, st_k, "sgm"),
+                                        "SGM 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "sgm")},
                             "sequence": (480, 640, 64, st_seq["frames"], st_seq["K"], st_seq["b"])}
 
     import torch

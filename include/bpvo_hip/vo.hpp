@@ -261,6 +261,14 @@ struct StereoParameters : bpvo_hip_stereo_params {
     bpvo_hip_default_stereo_params(this);
     numberOfDisparities = number_of_disparities;
   }
+  /* `StereoAlgorithm = SGM` (utils/stereo_algorithm.cc:42-59): the in-tree semi-global matcher with SgmStereo::Config() defaults
+   * (utils/sgm.cc:47-56; the KITTI evaluation of the reference runs it: conf/kitti_eval.cfg:27) */
+  static StereoParameters SemiGlobalMatching(int number_of_disparities = 128)
+  {
+    StereoParameters p(number_of_disparities);
+    p.algorithm = BPVO_STEREO_SGM;
+    return p;
+  }
 };
 
 /* bpvo::VisualOdometry (bpvo/vo.h:31-105).  The keyframe state machine of bpvo/vo.cc:125-224 runs inside the library
