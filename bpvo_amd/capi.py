@@ -443,6 +443,12 @@ class Context:
         self.call("persistent_counts", C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def upload_stats(self):
+        """(seconds, bytes) of the upload pipeline of the last host-buffer batch_run (HIP library only)."""
+        a, b = C.c_double(), C.c_uint64()
+        self.call("upload_stats", C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def team_counts(self):
         """Batch estimates run by the team-persistent kernel since the context was created (HIP library only)."""
         a = C.c_uint64()

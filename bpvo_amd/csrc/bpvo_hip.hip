@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +45,7 @@ struct LevelGeom {
 
 struct FrameSlot {
   bool has_data = false, has_template = false;
+  bool has_disp = false;     // the slot holds the disparity of its image (false for the current frames B of a pair batch: never uploaded)
   void* data_slab = nullptr;
   void* tmpl_slab = nullptr;
   uint8_t* img[kMaxLevels] = {};
@@ -188,6 +190,20 @@ struct bpvo_hip_ctx {
   int st_frames = 0;
   void* st_sgm = nullptr;      // scratch of the semi-global matcher (cost volumes: sized for the largest disparity range seen)
   size_t st_sgm_bytes = 0;
+  // Upload pipeline of pair batches handed over in HOST buffers (bpvo_hip_batch_run, on_device = 0): worker threads stage chunks of
+  // kUploadChunkPairs pairs in pinned memory and copy them on streams of their own into a device staging area, chunk after chunk in lane
+  // order, while the lanes already work on the chunks that have landed (upload_pipeline below).  BPVO_HIP_UPLOAD_WORKERS (0 = off).
+  int up_workers = 6;
+  std::vector<hipStream_t> up_streams;
+  std::vector<uint8_t*> up_pinned;       // [worker]: 2 slots of up_slot_bytes
+  std::vector<hipEvent_t> up_slot_free;  // [worker * 2 + slot]
+  std::vector<hipEvent_t> up_chunk_done; // pool, one per chunk of a call
+  size_t up_slot_bytes = 0;
+  uint8_t* up_d_img = nullptr;           // device staging: images [2 n][npix]
+  float* up_d_disp = nullptr;            //                 disparities of the A frames [n][npix]
+  int up_cap_pairs = 0;
+  double up_last_seconds = 0.0;          // wall time the workers of the last call needed for all chunks (measurement)
+  size_t up_last_bytes = 0;
   bool counted_live = false;   // this context is in g_live_ctx
   // addFrame: the fraction of good points (should_keyframe's last criterion) is queued right behind the estimation, before the host
   // waits for the pose, instead of in a second round trip; frac_* hold it for fraction_good (same kernels, same count)
@@ -476,8 +492,12 @@ int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const F
 }
 
 // VisualOdometryFrame::setData (reference: bpvo/vo_frame.cc:48-55) for `count` frames at once
+// skip_odd_disp: the frames are the (A, B) frames of pairs, in that order: B (odd i) only ever serves as the CURRENT frame of its pair,
+// whose disparity nothing reads (the reference copies what it is handed, bpvo/vo_frame.cc:50-51; estimatePose never looks at it) — it is
+// neither uploaded nor copied: 40 % of a pair's input bytes
+// (2: as 1, with the device-resident disparities packed for the even frames only — the staging area of the upload pipeline)
 int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device,
-                    const FrameRun& fr)
+                    const FrameRun& fr, int skip_odd_disp = 0)
 {
   if(count <= 0) return BPVO_OK;
   const size_t npix = c->geom[0].npix;
@@ -486,14 +506,15 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     for(int i = 0; i < count; ++i) {
       FrameSlot& f = c->frames[first + i * stride];
       FR_CK(c, fr, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, hipMemcpyHostToDevice, s));
-      FR_CK(c, fr, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, s));
+      if(!(skip_odd_disp && (i & 1)))
+        FR_CK(c, fr, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, s));
     }
   }
   const FrameJob* tab = nullptr;
   int rc = upload_frame_jobs(c, first, stride, count, fr, 0, &tab);
   if(rc) return rc;
   const int NF = c->n_frames;
-  if(on_device) launch_ingest(s, tab, images, disps, npix, count);   // one launch instead of 2 copies per frame
+  if(on_device) launch_ingest(s, tab, images, disps, npix, count, skip_odd_disp);   // one launch instead of 2 copies per frame
   {
     double px = 0;
     for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
@@ -527,15 +548,19 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     }
   }
   FR_CK(c, fr, hipGetLastError());
-  for(int i = 0; i < count; ++i) c->frames[first + i * stride].has_data = true;
+  for(int i = 0; i < count; ++i) {
+    FrameSlot& f = c->frames[first + i * stride];
+    f.has_data = true;
+    f.has_disp = !(skip_odd_disp && (i & 1));
+  }
   return BPVO_OK;
 }
-int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device)
+int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device, int skip_odd_disp = 0)
 {
   if(count <= 0) return BPVO_OK;
   if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
   if(!images || !disps) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
-  return frames_set_data(c, first, stride, count, images, disps, on_device, ctx_run(c));
+  return frames_set_data(c, first, stride, count, images, disps, on_device, ctx_run(c), skip_odd_disp);
 }
 
 // VisualOdometryFrame::setTemplate (reference: bpvo/vo_frame.cc:61-93 -> bpvo/template_data.cc:37-142) for `count` frames
@@ -611,8 +636,10 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 {
   if(count <= 0) return BPVO_OK;
   if(first < 0 || stride < 1 || first + (count - 1) * stride >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
-  for(int i = 0; i < count; ++i)
+  for(int i = 0; i < count; ++i) {
     if(!c->frames[first + i * stride].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");   // vo_frame.cc:63
+    if(!c->frames[first + i * stride].has_disp) return fail(c, BPVO_ERR_NO_DATA, "no disparity in frame (the current frame of a pair batch)");
+  }
   return frames_set_template(c, first, stride, count, ctx_run(c));
 }
 
@@ -1254,6 +1281,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_MAX_WS")) cp->persist_max_ws = std::max(1, std::min(kPersistMaxWs, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_GRID")) cp->persist_grid = std::max(1, std::min(128, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS")) cp->persist_timeout = std::max(1ll, std::atoll(e));   // tests of the give-up path
+    if(const char* e = std::getenv("BPVO_HIP_UPLOAD_WORKERS")) cp->up_workers = std::max(0, std::min(32, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_TEAM")) cp->team_mode = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_TEAM_MAX_PAIRS")) cp->team_max_pairs = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_TEAM_SIZE")) cp->team_size_env = std::max(0, std::min(256, std::atoi(e)));
@@ -1317,6 +1345,11 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
   (void) hipFree(c->st_sgm);
+  for(auto st : c->up_streams) if(st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }
+  for(auto p : c->up_pinned) (void) hipHostFree(p);
+  for(auto e : c->up_slot_free) if(e) (void) hipEventDestroy(e);
+  for(auto e : c->up_chunk_done) if(e) (void) hipEventDestroy(e);
+  (void) hipFree(c->up_d_img); (void) hipFree(c->up_d_disp);
   (void) hipHostFree(c->h_fjobs); (void) hipHostFree(c->h_ints); (void) hipFree(c->d_ints);
   for(auto& ln : c->lanes) {
     if(ln.stream) (void) hipStreamSynchronize(ln.stream);
@@ -1994,6 +2027,131 @@ int bpvo_hip_batch_estimate(bpvo_hip_ctx* c, int n_pairs, const float* T_init, f
   for(int p = 0; p < n_pairs; ++p) { wss[p] = p; refs[p] = 2 * p; curs[p] = 2 * p + 1; }
   return estimate_batch(c, n_pairs, wss.data(), refs.data(), curs.data(), T_init, poses, stats);
 }
+// ---- upload pipeline of host-buffer batches ---------------------------------------------------------------------------------
+// The caller's buffers are pageable: a hipMemcpyAsync from them is staged by the runtime through ONE thread's memcpy (a few GB/s) on the
+// stream that should be computing.  Here up_workers threads copy chunks of kUploadChunkPairs pairs (both images, the disparity of the
+// template frame A only) into pinned slots of their own and hand them to the copy engines on their own streams; a lane's frame stage
+// takes the chunks of its pairs as they land (one stream-wait per chunk) and ingests them from the device staging area.  The first chunk
+// is all the device ever waits for; the rest of the upload runs under the compute of the chunks before it.
+constexpr int kUploadChunkPairs = 16;
+struct UploadRun {
+  bpvo_hip_ctx* c = nullptr;
+  int n_pairs = 0;
+  std::vector<std::pair<int, int>> chunks;     // [first pair, count), lane after lane
+  std::vector<int> recorded;                   // 1: the chunk's event has been recorded (or the worker failed: error set)
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::thread> workers;
+  std::string err;
+  ~UploadRun() { for(auto& t : workers) if(t.joinable()) t.join(); }
+};
+
+int upload_prepare(bpvo_hip_ctx* c, int n_pairs)
+{
+  const size_t npix = c->geom[0].npix;
+  if((int) c->up_streams.size() < c->up_workers) {
+    for(int w = (int) c->up_streams.size(); w < c->up_workers; ++w) {
+      hipStream_t st = nullptr;
+      HIP_CK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      c->up_streams.push_back(st);
+      c->up_slot_bytes = (size_t) kUploadChunkPairs * npix * (2 + 4);
+      uint8_t* pin = nullptr;
+      HIP_CK(c, hipHostMalloc((void**) &pin, 2 * c->up_slot_bytes));
+      c->up_pinned.push_back(pin);
+      for(int sl = 0; sl < 2; ++sl) {
+        hipEvent_t e = nullptr;
+        HIP_CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->up_slot_free.push_back(e);
+      }
+    }
+  }
+  if(n_pairs > c->up_cap_pairs) {
+    HIP_CK(c, hipDeviceSynchronize());
+    (void) hipFree(c->up_d_img); (void) hipFree(c->up_d_disp);
+    c->up_d_img = nullptr; c->up_d_disp = nullptr; c->up_cap_pairs = 0;
+    HIP_CK(c, hipMalloc((void**) &c->up_d_img, (size_t) 2 * n_pairs * npix));
+    HIP_CK(c, hipMalloc((void**) &c->up_d_disp, (size_t) n_pairs * npix * sizeof(float)));
+    c->up_cap_pairs = n_pairs;
+  }
+  return BPVO_OK;
+}
+
+// starts the workers; chunks are cut inside the lanes' ranges [n k / nl, n (k + 1) / nl)
+int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, int nl, const uint8_t* images, const float* disparities)
+{
+  int rc = upload_prepare(c, n_pairs);
+  if(rc) return rc;
+  u.c = c; u.n_pairs = n_pairs;
+  for(int k = 0; k < nl; ++k) {
+    const int lo = (int) ((long long) n_pairs * k / nl), hi = (int) ((long long) n_pairs * (k + 1) / nl);
+    for(int p0 = lo; p0 < hi; p0 += kUploadChunkPairs) u.chunks.emplace_back(p0, std::min(kUploadChunkPairs, hi - p0));
+  }
+  const int nchunks = (int) u.chunks.size();
+  while((int) c->up_chunk_done.size() < nchunks) {
+    hipEvent_t e = nullptr;
+    HIP_CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->up_chunk_done.push_back(e);
+  }
+  u.recorded.assign(nchunks, 0);
+  const size_t npix = c->geom[0].npix;
+  const int T = std::min(c->up_workers, nchunks);
+  const auto t_start = std::chrono::steady_clock::now();
+  c->up_last_bytes = (size_t) n_pairs * npix * (2 + 4);
+  auto done_count = std::make_shared<std::atomic<int>>(0);
+  for(int w = 0; w < T; ++w) {
+    u.workers.emplace_back([c, &u, w, T, nchunks, npix, images, disparities, t_start, done_count] {
+      (void) hipSetDevice(c->device);
+      hipStream_t st = c->up_streams[w];
+      int turn = 0;
+      for(int k = w; k < nchunks; k += T, ++turn) {
+        const int p0 = u.chunks[k].first, np = u.chunks[k].second, sl = turn & 1;
+        hipError_t e = hipEventSynchronize(c->up_slot_free[2 * w + sl]);       // the copy that last read this slot has finished
+        uint8_t* pin_img = c->up_pinned[w] + (size_t) sl * c->up_slot_bytes;
+        float* pin_disp = reinterpret_cast<float*>(pin_img + (size_t) kUploadChunkPairs * npix * 2);
+        std::memcpy(pin_img, images + (size_t) 2 * p0 * npix, (size_t) 2 * np * npix);
+        for(int i = 0; i < np; ++i) std::memcpy(pin_disp + (size_t) i * npix, disparities + (size_t) 2 * (p0 + i) * npix, npix * sizeof(float));
+        if(e == hipSuccess) e = hipMemcpyAsync(c->up_d_img + (size_t) 2 * p0 * npix, pin_img, (size_t) 2 * np * npix, hipMemcpyHostToDevice, st);
+        if(e == hipSuccess) e = hipMemcpyAsync(c->up_d_disp + (size_t) p0 * npix, pin_disp, (size_t) np * npix * sizeof(float), hipMemcpyHostToDevice, st);
+        if(e == hipSuccess) e = hipEventRecord(c->up_slot_free[2 * w + sl], st);
+        if(e == hipSuccess) e = hipEventRecord(c->up_chunk_done[k], st);
+        {
+          std::lock_guard<std::mutex> lk(u.mu);
+          if(e != hipSuccess && u.err.empty()) u.err = std::string("upload pipeline: ") + hipGetErrorString(e);
+          u.recorded[k] = 1;
+        }
+        u.cv.notify_all();
+      }
+      (void) hipStreamSynchronize(st);
+      if(done_count->fetch_add(1) + 1 == T)
+        c->up_last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    });
+  }
+  return BPVO_OK;
+}
+
+// setData of the pairs [lo, hi) of a lane from the staging area, chunk by chunk as they land
+int upload_consume(bpvo_hip_ctx* c, UploadRun& u, int lo, int hi, const FrameRun& fr_lane)
+{
+  const size_t npix = c->geom[0].npix;
+  for(size_t k = 0; k < u.chunks.size(); ++k) {
+    const int p0 = u.chunks[k].first, np = u.chunks[k].second;
+    if(p0 < lo || p0 >= hi) continue;
+    {
+      std::unique_lock<std::mutex> lk(u.mu);
+      u.cv.wait(lk, [&] { return u.recorded[k] != 0; });
+      if(!u.err.empty()) { (fr_lane.own_thread ? fr_lane.ln->err : c->err) = u.err; return BPVO_ERR_DEVICE; }
+    }
+    FR_CK(c, fr_lane, hipStreamWaitEvent(fr_lane.stream, c->up_chunk_done[k], 0));
+    FrameRun fr = fr_lane;
+    fr.tab = 2 * p0;
+    fr.selected_ev = nullptr; fr.on_selected = nullptr;
+    // skip_odd_disp = 2: the staging area holds the A frames' disparities only, packed
+    int rc = frames_set_data(c, 2 * p0, 1, 2 * np, c->up_d_img + (size_t) 2 * p0 * npix, c->up_d_disp + (size_t) p0 * npix, true, fr, 2);
+    if(rc) return rc;
+  }
+  return BPVO_OK;
+}
+
 // Staggered lanes (round 2).  A batch whose frame stage ran as a whole before any estimation starts every lane at the coarsest
 // pyramid level at the same moment: for the first two levels (a few hundred points per pair) every launch is latency-bound and the
 // chip idles, whatever the number of lanes.  Here each lane runs ITS pairs end to end on its own stream — setData, setTemplate,
@@ -2001,7 +2159,7 @@ int bpvo_hip_batch_estimate(bpvo_hip_ctx* c, int n_pairs, const float* T_init, f
 // under the narrow coarse-level iterations of the previous one, and the coarse levels of lane k under the fine levels of lane k-1.
 // Same kernels on the same data per pair: results are bit-identical to the one-stage-at-a-time form (BPVO_HIP_STAGGER=0).
 int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* images, const float* disparities, bool on_device, float* poses,
-                        bpvo_hip_stats* stats)
+                        bpvo_hip_stats* stats, UploadRun* pipe)
 {
   HIP_CK(c, hipStreamSynchronize(c->stream));
   c->frac_valid = false;
@@ -2021,7 +2179,8 @@ int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* ima
       if(hipStreamWaitEvent(ln->stream, c->lanes[k - 1].selected_ev, 0) != hipSuccess) { ln->err = "hipStreamWaitEvent"; rcs[k] = BPVO_ERR_DEVICE; return; }
     }
     FrameRun fr{ln->stream, ln, 2 * lo, true, nullptr, nullptr};
-    int rc = frames_set_data(c, 2 * lo, 1, 2 * n, images + (size_t) 2 * lo * npix, disparities + (size_t) 2 * lo * npix, on_device, fr);
+    int rc = pipe ? upload_consume(c, *pipe, lo, hi, fr)
+                  : frames_set_data(c, 2 * lo, 1, 2 * n, images + (size_t) 2 * lo * npix, disparities + (size_t) 2 * lo * npix, on_device, fr, 1);
     if(rc) { rcs[k] = rc; return; }
     fr.selected_ev = ln->selected_ev;     // recorded, and the next lane released, before the template stage waits for its point counts
     fr.on_selected = release_next;
@@ -2060,8 +2219,24 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
   int nl = std::max(1, std::min(lanes_ok, n_pairs / kMinPairsPerLane));
   if(team_serves(c, n_pairs)) nl = 1;
-  if(c->stagger && nl > 1 && !c->profile_all) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats);
-  int rc = frames_set_data(c, 0, 1, 2 * n_pairs, images, disparities, on_device != 0);
+  // host buffers: batches of at least two chunks go through the upload pipeline
+  const bool use_pipe = !on_device && c->up_workers > 0 && n_pairs >= 2 * kUploadChunkPairs;
+  if(c->stagger && nl > 1 && !c->profile_all) {
+    if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr);
+    UploadRun pipe;
+    int rcp = upload_start(c, pipe, n_pairs, nl, images, disparities);
+    if(rcp) return rcp;
+    return batch_run_staggered(c, n_pairs, nl, images, disparities, false, poses, stats, &pipe);
+  }
+  int rc;
+  if(use_pipe) {
+    UploadRun pipe;
+    rc = upload_start(c, pipe, n_pairs, 1, images, disparities);
+    if(rc) return rc;
+    rc = upload_consume(c, pipe, 0, n_pairs, ctx_run(c));
+  } else {
+    rc = frames_set_data(c, 0, 1, 2 * n_pairs, images, disparities, on_device != 0, 1);
+  }
   if(rc) return rc;
   rc = frames_set_template(c, 0, 2, n_pairs);
   if(rc) return rc;
@@ -2146,6 +2321,13 @@ int bpvo_hip_persistent_counts(bpvo_hip_ctx* c, uint64_t* levels, int* gave_up)
   return BPVO_OK;
 }
 
+int bpvo_hip_upload_stats(bpvo_hip_ctx* c, double* seconds, uint64_t* bytes)
+{
+  if(!c) return BPVO_ERR_INVALID_ARG;
+  if(seconds) *seconds = c->up_last_seconds;
+  if(bytes) *bytes = (uint64_t) c->up_last_bytes;
+  return BPVO_OK;
+}
 int bpvo_hip_team_counts(bpvo_hip_ctx* c, uint64_t* launches)
 {
   if(!c || !launches) return BPVO_ERR_INVALID_ARG;

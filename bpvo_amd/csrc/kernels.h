@@ -32,7 +32,7 @@ constexpr int kMaxGaussTaps = 31;
 struct GaussTaps { int n = 0; float k[kMaxGaussTaps] = {}; int ki[kMaxGaussTaps] = {}; };
 
 // per-frame stage (batched over frames)
-void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes);
+void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes, int skip_odd_disp = 0);
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
 void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre);   // (I, Ix, Iy), C = 3

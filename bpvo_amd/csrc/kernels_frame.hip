@@ -31,11 +31,13 @@ __device__ __forceinline__ int reflect101_wide(int p, int len)
 // ---- input ingest: one launch copies the u8 image and f32 disparity of every frame of a batch from a packed device
 // buffer ([frame][rows*cols]) into the frame slots (VisualOdometryFrame::setData's image.copyTo / disparity.copyTo,
 // reference: bpvo/vo_frame.cc:50-51) instead of 2 memcpy calls per frame.
-__global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const uint8_t* images, const float* disps, size_t npix)
+// skip_odd_disp: pair batches (A0, B0, A1, B1, ...) — the current frame B of a pair never becomes a template, its disparity is not copied
+__global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const uint8_t* images, const float* disps, size_t npix, int skip_odd_disp)
 {
   const FrameJob& j = jobs[blockIdx.z];
   const uint8_t* __restrict__ si = images + (size_t) blockIdx.z * npix;
-  const float* __restrict__ sd = disps + (size_t) blockIdx.z * npix;
+  // skip_odd_disp 2: the disparities are packed for the even frames only ([frame / 2][npix]: the upload pipeline of host batches)
+  const float* __restrict__ sd = disps + (size_t) (skip_odd_disp == 2 ? blockIdx.z / 2 : blockIdx.z) * npix;
   uint8_t* __restrict__ di = const_cast<uint8_t*>(j.img.get());
   float* __restrict__ dd = const_cast<float*>(j.disp.get());
   const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x, stride = (size_t) gridDim.x * 256;
@@ -47,6 +49,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const
   } else {
     for(size_t k = t; k < npix; k += stride) di[k] = si[k];
   }
+  if(skip_odd_disp && (blockIdx.z & 1)) return;
   const bool f4 = (npix % 4 == 0) && (((uintptr_t) sd | (uintptr_t) dd) % 16 == 0);
   if(f4) {
     const float4* s4 = reinterpret_cast<const float4*>(sd);
@@ -1054,10 +1057,10 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 static inline dim3 grid2d(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 3) / 4, nz); }
 static inline dim3 grid2d_rows(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 4 * ROWS_PER_THREAD - 1) / (4 * ROWS_PER_THREAD), nz); }
 
-void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes)
+void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes, int skip_odd_disp)
 {
   const int blocks = (int) std::min<size_t>(256, (npix / 4 + 255) / 256);
-  hipLaunchKernelGGL(ingest_kernel, dim3(blocks, 1, nframes), dim3(256), 0, s, jobs_level0, d_images, d_disps, npix);
+  hipLaunchKernelGGL(ingest_kernel, dim3(blocks, 1, nframes), dim3(256), 0, s, jobs_level0, d_images, d_disps, npix, skip_odd_disp);
 }
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {

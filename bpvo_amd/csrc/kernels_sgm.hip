@@ -21,6 +21,7 @@
 // Bounds: sgm_pixel_cost / sgm_box_cost are VALU / L1-bound (25 window terms per output), the path kernels latency-bound chains of
 // width x ~60 instructions with H (or W) wavefronts in flight, everything else streams the 2-byte volumes once.
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -124,82 +125,131 @@ __global__ void sgm_right_cost_kernel(const uint16_t* __restrict__ lcost, uint16
   rcost[((size_t) cols * y + x) * D + d] = lcost[((size_t) cols * y + x + dd) * D + dd];
 }
 
-// One scanline per wavefront.  vertical = 0: line = row `line`, steps along x; 1: line = column `line`, steps along y.  dir = +1 / -1.
-// V disparities per lane (d = lane * V + k); sum += L (saturating).
+// One scanline per wavefront.  The four directions of a cost volume — along the rows left to right and back, along the columns down and
+// up — depend on the cost volume alone, and so do the two volumes (left, right image): ALL EIGHT sets of scanlines run in ONE launch,
+// 2 * (2 rows + 2 cols) wavefronts, every direction writing its path costs L into a volume of its own (the original adds them into one
+// sum volume as it goes; the winner-takes-all kernel adds the four in the original's order).  V disparities per lane (d = lane * V + k).
+// The loads of a step do not depend on the step before it: they are requested PF steps ahead, so the chain that is sequential is the
+// arithmetic alone.  (First version: one launch per direction, loads inside the chain, read-modify-write of the sum volume: 780 us per
+// launch, 8 launches per frame at 1241 x 376 x 128; with the prefetch 577 us; profiles/r03_stereo_first.txt.)
 template <int V>
-__global__ __launch_bounds__(64) void sgm_path_kernel(const uint16_t* __restrict__ cost, int16_t* __restrict__ sum, int rows, int cols, int D, int P1, int P2,
-                                                      int vertical, int dir)
+__global__ __launch_bounds__(64) void sgm_path_kernel(const uint16_t* __restrict__ cost_l, const uint16_t* __restrict__ cost_r, int16_t* __restrict__ Lvol,
+                                                      int rows, int cols, int D, int P1, int P2)
 {
-  const int line = blockIdx.x, lane = threadIdx.x;
+  constexpr int PF = 4;
+  // which scanline: per side [rows: along x, +1 | rows: along x, -1 | cols: along y, +1 | cols: along y, -1]
+  const int per_side = 2 * rows + 2 * cols;
+  const int side = blockIdx.x / per_side;
+  int q = blockIdx.x - side * per_side;
+  int path, line;
+  if(q < rows) { path = 0; line = q; }
+  else if(q < 2 * rows) { path = 2; line = q - rows; }
+  else if(q < 2 * rows + cols) { path = 1; line = q - 2 * rows; }
+  else { path = 3; line = q - 2 * rows - cols; }
+  // path: 0 = rows forward (pass 0, path 0 of the original), 1 = columns forward (pass 0, path 2), 2 = rows backward, 3 = columns backward
+  const int vertical = path & 1, dir = path < 2 ? 1 : -1;
+  const uint16_t* __restrict__ cost = side ? cost_r : cost_l;
+  const size_t vol = (size_t) rows * cols * D;
+  int16_t* __restrict__ L = Lvol + (size_t) (side * 4 + path) * vol;
+
+  const int lane = threadIdx.x;
   const int nsteps = vertical ? rows : cols;
   const size_t step_stride = (vertical ? (size_t) cols * D : (size_t) D);
   const size_t base = vertical ? (size_t) line * D : (size_t) line * cols * D;
+  const int d0 = lane * V;
+  const bool live = d0 < D;                                    // (D is a multiple of 16 and V divides it: a lane is all in or all out)
   int prev[V];
 #pragma unroll
   for(int k = 0; k < V; ++k) prev[k] = 0;                      // before the first pixel: all path costs and their minimum 0
   int prev_min = 0;
-  const bool first_lane_group = lane == 0;
-  for(int s = 0; s < nsteps; ++s) {
-    const int pos = dir > 0 ? s : nsteps - 1 - s;
-    const size_t off = base + (size_t) pos * step_stride;
-    int c[V];
+  auto offset = [&](int s) { return base + (size_t) (dir > 0 ? s : nsteps - 1 - s) * step_stride + d0; };
+  // V consecutive 16-bit values of this lane as one 16- / 32- / 64-bit word
+  using word_t = typename std::conditional<V == 1, uint16_t, typename std::conditional<V == 2, uint32_t, uint64_t>::type>::type;
+  word_t cw[PF];
 #pragma unroll
-    for(int k = 0; k < V; ++k) {
-      const int d = lane * V + k;
-      c[k] = d < D ? (int) cost[off + d] : 0;
-    }
-    const int pm = (int) (int16_t) (prev_min + P2);
-    // neighbours across lanes: d - 1 of k = 0 is the previous lane's last, d + 1 of k = V - 1 the next lane's first
-    const int from_left = __shfl_up(prev[V - 1], 1), from_right = __shfl_down(prev[0], 1);
-    int cur[V];
-    int mn = 32767;
+  for(int i = 0; i < PF; ++i) {
+    cw[i] = 0;
+    if(live && i < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(i));
+  }
+  for(int s0 = 0; s0 < nsteps; s0 += PF) {
 #pragma unroll
-    for(int k = 0; k < V; ++k) {
-      const int d = lane * V + k;
-      int lm = k > 0 ? prev[k - 1] : (first_lane_group ? 32767 : from_left);
-      int lp = k < V - 1 ? prev[k + 1] : from_right;
-      if(d + 1 >= D) lp = 32767;                               // the sentinel behind the last disparity
-      if(d == 0) lm = 32767;
-      int a = min(prev[k], sat16(lm + P1));
-      a = min(a, sat16(lp + P1));
-      a = min(a, pm);
-      a = sat16(sat16(a - pm) + c[k]);
-      cur[k] = a;
-      if(d < D) mn = min(mn, a);
-    }
+    for(int i = 0; i < PF; ++i) {
+      const int s = s0 + i;
+      if(s >= nsteps) break;
+      const word_t cword = cw[i];
+      const size_t off = offset(s);
+      if(live && s + PF < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(s + PF));      // refill the slot for step s + PF
+      const int pm = (int) (int16_t) (prev_min + P2);
+      // neighbours across lanes: d - 1 of k = 0 is the previous lane's last, d + 1 of k = V - 1 the next lane's first
+      const int from_left = __shfl_up(prev[V - 1], 1), from_right = __shfl_down(prev[0], 1);
+      int cur[V];
+      int mn = 32767;
+      word_t out = 0;
 #pragma unroll
-    for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
-    prev_min = mn;
+      for(int k = 0; k < V; ++k) {
+        const int d = d0 + k;
+        const int c = (int) (uint16_t) (cword >> (16 * k));
+        int lm = k > 0 ? prev[k - 1] : (lane == 0 ? 32767 : from_left);
+        int lp = k < V - 1 ? prev[k + 1] : from_right;
+        if(d + 1 >= D) lp = 32767;                             // the sentinel behind the last disparity
+        if(d == 0) lm = 32767;
+        int a = min(prev[k], sat16(lm + P1));
+        a = min(a, sat16(lp + P1));
+        a = min(a, pm);
+        a = sat16(sat16(a - pm) + c);
+        cur[k] = a;
+        if(live) mn = min(mn, a);
+        out |= (word_t) (uint16_t) (int16_t) a << (16 * k);
+      }
 #pragma unroll
-    for(int k = 0; k < V; ++k) {
-      const int d = lane * V + k;
-      prev[k] = cur[k];
-      if(d < D) sum[off + d] = (int16_t) sat16((int) sum[off + d] + cur[k]);
+      for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+      prev_min = mn;
+#pragma unroll
+      for(int k = 0; k < V; ++k) prev[k] = cur[k];
+      if(live) *reinterpret_cast<word_t*>(L + off) = out;
     }
   }
 }
 
-// winner takes all (first minimum) + the sub-pixel expression of the original in double; one wavefront per pixel would waste the chip:
-// a thread per pixel walks its D sums
-__global__ __launch_bounds__(256) void sgm_wta_kernel(const int16_t* __restrict__ sum, uint16_t* __restrict__ disp, size_t npix, int D, double factor)
+// winner takes all (first minimum) + the sub-pixel expression of the original in double.  A wavefront per pixel: the D sums are read
+// coalesced (V per lane), the first minimum is the wave minimum of (sum, d) packed into one integer.
+// The sum of the four path costs in the original's order and saturating arithmetic: ((((0 + rows forward) + columns forward) + rows
+// backward) + columns backward) (utils/sgm.cc:831-836, pass after pass).
+__device__ __forceinline__ int sgm_sum4(const int16_t* __restrict__ L, size_t vol, size_t i)
 {
-  const size_t p = (size_t) blockIdx.x * 256 + threadIdx.x;
+  int s = sat16(0 + (int) L[i]);
+  s = sat16(s + (int) L[vol + i]);
+  s = sat16(s + (int) L[2 * vol + i]);
+  return sat16(s + (int) L[3 * vol + i]);
+}
+template <int V>
+__global__ __launch_bounds__(256) void sgm_wta_kernel(const int16_t* __restrict__ L4, uint16_t* __restrict__ disp, size_t npix, int D, double factor)
+{
+  const size_t p = (size_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if(p >= npix) return;
-  const int16_t* S = sum + p * D;
-  int best = S[0], bd = 0;
-  for(int d = 1; d < D; ++d) {
-    const int v = S[d];
-    if(v < best) { best = v; bd = d; }
+  const size_t vol = npix * D;
+  int v[V];
+  int key = 0x7fffffff;
+#pragma unroll
+  for(int k = 0; k < V; ++k) {
+    const int d = lane * V + k;
+    v[k] = d < D ? sgm_sum4(L4, vol, p * D + d) : 32767;
+    if(d < D) key = min(key, ((v[k] + 32768) << 9) | d);      // (d < 512)
   }
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) key = min(key, __shfl_xor(key, o));
+  const int bd = key & 511;
+  if(lane != 0) return;
   int out;
   if(bd > 0 && bd < D - 1) {
-    const int c = S[bd], l = S[bd - 1], r = S[bd + 1];
-    double v;
-    if(r < l) v = (double) bd * factor + (double) (r - l) / (double) (c - l) / 2.0 * factor + 0.5;
-    else v = (double) bd * factor + (double) (r - l) / (double) (c - r) / 2.0 * factor + 0.5;
+    const int c = sgm_sum4(L4, vol, p * D + bd), l = sgm_sum4(L4, vol, p * D + bd - 1), r = sgm_sum4(L4, vol, p * D + bd + 1);
+    double w;
+    if(r < l) w = (double) bd * factor + (double) (r - l) / (double) (c - l) / 2.0 * factor + 0.5;
+    else w = (double) bd * factor + (double) (r - l) / (double) (c - r) / 2.0 * factor + 0.5;
     // static_cast<int> on x86: truncation, INT_MIN for NaN / infinities / out of range (a zero denominator: S5)
-    const bool ok = (v == v) && v > -2147483649.0 && v < 2147483648.0;
-    out = ok ? (int) v : (int) 0x80000000;
+    const bool ok = (w == w) && w > -2147483649.0 && w < 2147483648.0;
+    out = ok ? (int) w : (int) 0x80000000;
   } else {
     out = (int) ((double) bd * factor);
   }
@@ -245,10 +295,21 @@ __global__ __launch_bounds__(256) void sgm_cc_merge_kernel(const uint16_t* __res
 __global__ __launch_bounds__(256) void sgm_cc_count_kernel(int* __restrict__ lab, int* __restrict__ size, int npix)
 {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if(p >= npix || lab[p] < 0) return;
-  const int r = uf_find(lab, p);
-  lab[p] = r;                                              // (path compression; roots never change after the merge kernel)
-  atomicAdd(&size[r], 1);
+  int r = -1;
+  if(p < npix && lab[p] >= 0) {
+    r = uf_find(lab, p);
+    lab[p] = r;                                            // (path compression; roots never change after the merge kernel)
+  }
+  // the pixels of a wavefront mostly share one root (a plane is ONE component of 400 k pixels: one atomic per pixel on one address took
+  // 4.3 ms): the lanes with the leader's root are counted with one atomic, then the next root, ...
+  unsigned long long todo = __ballot(r >= 0);
+  while(todo) {
+    const int leader = __ffsll((long long) todo) - 1;
+    const int lr = __shfl(r, leader);
+    const unsigned long long same = __ballot(r == lr) & todo;
+    if((threadIdx.x & 63) == leader) atomicAdd(&size[lr], (int) __popcll(same));
+    todo &= ~same;
+  }
 }
 __global__ __launch_bounds__(256) void sgm_cc_apply_kernel(uint16_t* __restrict__ img, const int* __restrict__ lab, const int* __restrict__ size, int npix,
                                                           int max_size)
@@ -283,7 +344,7 @@ size_t sgm_scratch_bytes(int rows, int cols, int D)
 {
   const size_t npix = (size_t) rows * cols, pitch = (size_t) cols + 15 - (cols - 1) % 16;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  return 2 * up(pitch * rows) + 2 * up(npix * 4) + up(npix * D) + 2 * up(npix * D * 2) + up(npix * D * 2) + 2 * up(npix * 2) + 2 * up(npix * 4);
+  return 2 * up(pitch * rows) + 2 * up(npix * 4) + up(npix * D) + 2 * up(npix * D * 2) + up(8 * npix * D * 2) + 2 * up(npix * 2) + 2 * up(npix * 4);
 }
 
 // SGMStereo::compute (utils/sgm.cc:250-285) for `nframes` rectified pairs, one after the other on the stream (the cost volumes of a
@@ -303,7 +364,7 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
   uint8_t* pc = w; w += up(npix * D);
   uint16_t* cost_l = (uint16_t*) w; w += up(npix * D * 2);
   uint16_t* cost_r = (uint16_t*) w; w += up(npix * D * 2);
-  int16_t* sum = (int16_t*) w; w += up(npix * D * 2);
+  int16_t* Lvol = (int16_t*) w; w += up(8 * npix * D * 2);      // path costs: [side][direction][rows][cols][D]
   uint16_t* disp_l = (uint16_t*) w; w += up(npix * 2);
   uint16_t* disp_r = (uint16_t*) w; w += up(npix * 2);
   int* lab = (int*) w; w += up(npix * 4);
@@ -320,22 +381,21 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
     hipLaunchKernelGGL(sgm_pixel_cost_kernel, gxy, dim3(dthreads), 0, s, sob_l, sob_r, cen_l, cen_r, pc, rows, cols, pitch, D, g.census_weight);
     hipLaunchKernelGGL(sgm_box_cost_kernel, gxy, dim3(dthreads), 0, s, pc, cost_l, rows, cols, D, g.window_radius);
     hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
+    {
+      const dim3 gp((unsigned) (2 * (2 * rows + 2 * cols)));
+      if(D <= 64) hipLaunchKernelGGL(sgm_path_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+      else if(D <= 128) hipLaunchKernelGGL(sgm_path_kernel<2>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+      else hipLaunchKernelGGL(sgm_path_kernel<4>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+    }
     for(int side = 0; side < 2; ++side) {
-      const uint16_t* cost = side == 0 ? cost_l : cost_r;
       uint16_t* disp = side == 0 ? disp_l : disp_r;
-      (void) hipMemsetAsync(sum, 0, npix * D * 2, s);
-      for(int pass = 0; pass < 2; ++pass) {
-        const int dir = pass == 0 ? 1 : -1;
-        auto paths = [&](auto v) {
-          constexpr int V = decltype(v)::value;
-          hipLaunchKernelGGL(sgm_path_kernel<V>, dim3(rows), dim3(64), 0, s, cost, sum, rows, cols, D, g.P1, g.P2, 0, dir);
-          hipLaunchKernelGGL(sgm_path_kernel<V>, dim3(cols), dim3(64), 0, s, cost, sum, rows, cols, D, g.P1, g.P2, 1, dir);
-        };
-        if(D <= 64) paths(std::integral_constant<int, 1>());
-        else if(D <= 128) paths(std::integral_constant<int, 2>());
-        else paths(std::integral_constant<int, 4>());
+      const int16_t* L4 = Lvol + (size_t) side * 4 * npix * D;
+      {
+        const dim3 gw((unsigned) ((npix + 3) / 4));
+        if(D <= 64) hipLaunchKernelGGL(sgm_wta_kernel<1>, gw, dim3(256), 0, s, L4, disp, npix, D, g.disparity_factor);
+        else if(D <= 128) hipLaunchKernelGGL(sgm_wta_kernel<2>, gw, dim3(256), 0, s, L4, disp, npix, D, g.disparity_factor);
+        else hipLaunchKernelGGL(sgm_wta_kernel<4>, gw, dim3(256), 0, s, L4, disp, npix, D, g.disparity_factor);
       }
-      hipLaunchKernelGGL(sgm_wta_kernel, dim3(nb), dim3(256), 0, s, sum, disp, npix, D, g.disparity_factor);
       // speckleFilter(100, 2 * factor) (utils/sgm.cc:898)
       hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix);
       hipLaunchKernelGGL(sgm_cc_merge_kernel, dim3(nb), dim3(256), 0, s, disp, lab, rows, cols, (int) (2 * g.disparity_factor));

@@ -232,7 +232,9 @@ int bpvo_hip_get_trajectory(bpvo_hip_ctx* ctx, float* poses /*[n][16]*/);
 /* ---- batches of independent frame pairs (BASELINE.json config 5).
  * Pair p uses frame slots 2p (reference/template frame A) and 2p+1 (current frame B) and workspace p.
  * For each pair: A.setData, A.setTemplate, B.setData, estimatePose(A, B, Identity) -> poses[p].
- * images = [A0,B0,A1,B1,...] (2*n_pairs images), disparities likewise (B's disparity is stored but unused).
+ * images = [A0,B0,A1,B1,...] (2*n_pairs images), disparities likewise — B's disparity is never read: estimatePose uses the current
+ * frame's descriptor only (bpvo/vo_pose_estimator.cc:63-93), so it is neither uploaded nor stored (40 % of the input bytes); the B slots
+ * of a batch therefore cannot be turned into templates afterwards (bpvo_hip_frame_set_template: BPVO_ERR_NO_DATA).
  * stats = [n_pairs][numLevels].
  * A pyramid level of a pair whose template keeps no point does not fail the batch (the reference's computeResiduals throws there,
  * bpvo/template_data.cc:177, and so do the single-pair entry points: BPVO_ERR_NO_TEMPLATE): that level of that pair is skipped, its
@@ -295,6 +297,11 @@ int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* ctx, const uint8_t* left, const uint
  * pairs) since the context was created, and whether such a launch ever gave up at a grid barrier (the
  * context then stays on the four-kernel chain; results are the same either way). */
 int bpvo_hip_persistent_counts(bpvo_hip_ctx* ctx, uint64_t* levels, int* gave_up);
+
+/* Upload pipeline of the last bpvo_hip_batch_run that was handed HOST buffers (batches of at least 32 pairs): wall time from the start of
+ * the call until the last chunk had landed on the device, and the bytes that crossed the bus (both images, the template frame's
+ * disparity).  The uploads run under the compute of the chunks before them. */
+int bpvo_hip_upload_stats(bpvo_hip_ctx* ctx, double* seconds, uint64_t* bytes);
 
 /* Batch estimates that ran their whole Gauss-Newton stage in one launch of the team-persistent kernel (batches of 2 ..
  * BPVO_HIP_TEAM_MAX_PAIRS pairs) since the context was created. */

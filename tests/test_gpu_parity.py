@@ -1018,3 +1018,34 @@ def test_scale_sequence_every_channel_count(hip, orc, descriptor, kw):
     Th, sh = ch.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans, sh, so)
+
+
+@pytest.mark.parametrize("n,lanes,team", [(70, "2", "0"), (40, "2", "1"), (33, "1", "0")])
+def test_host_buffer_batches_go_through_the_upload_pipeline_unchanged(hip, n, lanes, team, monkeypatch):
+    """bpvo_hip_batch_run handed HOST buffers: batches of at least 32 pairs are staged in pinned chunks of 16 pairs by worker threads
+    and uploaded on streams of their own while the lanes work on the chunks that have landed (B's disparity never crosses the bus).
+    Same poses and statistics, bit for bit, as the batch with its inputs resident on the device and as the plain copies
+    (BPVO_HIP_UPLOAD_WORKERS=0) — with ragged chunk and lane boundaries, one lane, and the team kernel behind it."""
+    import torch
+    rows, cols, levels = 120, 160, 3
+    batch = synth.make_batch(rows, cols, n, first_index=400, workers=8)
+    monkeypatch.setenv("BPVO_HIP_LANES", lanes)
+    monkeypatch.setenv("BPVO_HIP_TEAM", team)
+    out = {}
+    for workers in ("6", "0", "dev"):
+        monkeypatch.setenv("BPVO_HIP_UPLOAD_WORKERS", "6" if workers == "dev" else workers)
+        ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels), n_frames=2 * n, n_pairs=n)
+        if workers == "dev":
+            di = torch.from_numpy(batch["images"]).cuda(); dd = torch.from_numpy(batch["disparities"]).cuda()
+            out[workers] = ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr())
+        else:
+            out[workers] = ctx.batch_run(batch["images"], batch["disparities"])
+            secs, nbytes = ctx.upload_stats()
+            assert (nbytes == n * rows * cols * 6 and secs > 0) if workers == "6" else nbytes == 0
+            # the B slots of a batch hold no disparity: they cannot become templates
+            with pytest.raises(capi.BpvoError):
+                ctx.frame_set_template(1)
+        ctx.close()
+    for k in ("0", "dev"):
+        assert bits_equal(out["6"][0], out[k][0]), k
+        assert out["6"][1].tobytes() == out[k][1].tobytes(), k
