@@ -151,6 +151,35 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
             "median_trans_err_vs_gt_m": float(np.median(dT))}
 
 
+def timed_batch_host(hip, torch, dev_index, batch, rows, cols, n, descriptor, levels, loss, resident_ms, steps=3, warmup=1):
+    """The same step with the inputs in HOST memory (what a drop-in caller hands over): bpvo_hip_batch_run(..., on_device = 0).  The library
+    stages chunks of 16 pairs in pinned memory with worker threads and uploads them on streams of their own while the lanes work on the
+    chunks that have landed; the current frames' disparities (40 % of the bytes) never cross the bus.  NEVER part of `value`."""
+    from types import SimpleNamespace
+    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0, tolerances="default"))
+    ctx = hip.create(batch["K"], batch["b"], rows, cols, p, device=dev_index, n_frames=2 * n, n_pairs=n)
+    imgs, disps = batch["images"][: 2 * n], batch["disparities"][: 2 * n]
+    for _ in range(warmup):
+        ctx.batch_run(imgs, disps)
+    ctx.profiling(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ups = []
+    for _ in range(steps):
+        ctx.batch_run(imgs, disps)
+        ups.append(ctx.upload_stats())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gn = ctx.total_linearizations()
+    ctx.close()
+    up_s = float(np.mean([u[0] for u in ups])); up_b = ups[-1][1]
+    return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "ms_per_step": 1e3 * dt / steps,
+            "vs_resident_inputs": (1e3 * dt / steps) / resident_ms if resident_ms else None,
+            "upload": {"bytes_per_step": up_b, "seconds": up_s, "GBps": up_b / up_s / 1e9 if up_s > 0 else None,
+                       "note": "host memcpy into pinned chunks + H2D copies on 6 streams, wall time until the last chunk has landed; it runs under the compute of the chunks before it"},
+            "note": "pageable numpy buffers handed to bpvo_hip_batch_run; PCIe-inclusive — reported beside `value`, never as `value`"}
+
+
 def add_frame_latency(hip, dev_index, seq, which):
     """Sequential VisualOdometry::addFrame on a 640x480 sequence with the parameters of the reference's own timing runs
     (conf/perf_intensity.cfg / conf/perf_bitplanes.cfg as AlgorithmParameters(filename) builds them, bpvo/types.cc:68-107):
@@ -255,6 +284,9 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
         # exactly this on every rank)
         out["config-5 shard: 128 of the 1024 pairs (1241x376 bitplanes, 4 levels, tukey) on one GPU"] = \
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 128, args.descriptor, args.levels, args.loss, steps=10, warmup=2)
+    if npairs >= 1024 and (args.rows, args.cols, args.descriptor, args.levels, args.loss) == (376, 1241, "bitplanes", 4, "tukey"):
+        out["1024 pairs handed over in HOST buffers (upload pipeline)"] = \
+            timed_batch_host(hip, torch, dev_index, batch, args.rows, args.cols, 1024, args.descriptor, args.levels, args.loss, args._resident_ms)
     if npairs >= 1024:
         # the reference's own timing tolerances (conf/perf_*.cfg: 1e-6 / 1e-4 / 1e-6, 3 levels): ~7x fewer iterations per level than the
         # AlgorithmParameters() defaults, so the per-frame stages are about half of the step
@@ -523,6 +555,7 @@ def main():
             ctx.close()
             del d_images, d_disps, d_records
             torch.cuda.empty_cache()
+            args._resident_ms = 1e3 * elapsed_max / args.steps
             others = other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640)
 
         iters = stats["numIterations"].astype(np.float64)

@@ -177,6 +177,7 @@ struct bpvo_hip_ctx {
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
   // BPVO_HIP_TEAM=0 turns it off, BPVO_HIP_TEAM_MAX_PAIRS / BPVO_HIP_TEAM_SIZE (0 = CUs / pairs) size it.
   int team_mode = 1, team_max_pairs = 64, team_size_env = 0, num_cus = 0;
+  int team_single = 0;         // BPVO_HIP_TEAM_SINGLE=1: single pairs through the team kernel too (all levels in one launch) instead of gn_persistent_kernel per level
   std::atomic<uint64_t> team_launches{0};
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
   std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)
@@ -194,6 +195,11 @@ struct bpvo_hip_ctx {
   // kUploadChunkPairs pairs in pinned memory and copy them on streams of their own into a device staging area, chunk after chunk in lane
   // order, while the lanes already work on the chunks that have landed (upload_pipeline below).  BPVO_HIP_UPLOAD_WORKERS (0 = off).
   int up_workers = 6;
+  int up_group = 4;                      // chunks a lane's frame stage takes at once (BPVO_HIP_UPLOAD_GROUP): 16-pair launches are too small to fill the chip
+  int up_subbatches = 1;                 // groups per lane of a host batch (BPVO_HIP_UPLOAD_SUBBATCHES; host_groups): 2 and more measured slower
+  int up_streams_n = 1;                  // copy streams the workers share (BPVO_HIP_UPLOAD_STREAMS).  A process has a handful of hardware queues
+                                         // and HIP streams are multiplexed onto them: with a stream per worker the lanes' kernels queued behind
+                                         // other workers' copies and nothing ran until the last chunk had landed (profiles/r03_host_timeline.txt)
   std::vector<hipStream_t> up_streams;
   std::vector<uint8_t*> up_pinned;       // [worker]: 2 slots of up_slot_bytes
   std::vector<hipEvent_t> up_slot_free;  // [worker * 2 + slot]
@@ -661,7 +667,8 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
 // while per-kernel timings are being collected: there are no kernels to time)
 bool team_serves(const bpvo_hip_ctx* c, int n)
 {
-  return c->team_mode && c->persistent && !c->persistent_failed.load() && n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs &&
+  const bool size_ok = (n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs) || (n == 1 && c->team_single);
+  return c->team_mode && c->persistent && !c->persistent_failed.load() && size_ok &&
          (c->C == 8 || c->C == 1) && c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !c->profile_all && !c->profile_k6_all &&
          c->num_cus >= 2 && g_live_ctx[c->device & 63].load() <= 1;
 }
@@ -1282,8 +1289,12 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_GRID")) cp->persist_grid = std::max(1, std::min(128, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS")) cp->persist_timeout = std::max(1ll, std::atoll(e));   // tests of the give-up path
     if(const char* e = std::getenv("BPVO_HIP_UPLOAD_WORKERS")) cp->up_workers = std::max(0, std::min(32, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_UPLOAD_GROUP")) cp->up_group = std::max(1, std::min(64, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_UPLOAD_SUBBATCHES")) cp->up_subbatches = std::max(1, std::min(8, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_UPLOAD_STREAMS")) cp->up_streams_n = std::max(1, std::min(32, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_TEAM")) cp->team_mode = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_TEAM_MAX_PAIRS")) cp->team_max_pairs = std::max(0, std::atoi(e));
+    if(const char* e = std::getenv("BPVO_HIP_TEAM_SINGLE")) cp->team_single = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_TEAM_SIZE")) cp->team_size_env = std::max(0, std::min(256, std::atoi(e)));
     {
       hipDeviceProp_t prop;
@@ -2076,16 +2087,28 @@ int upload_prepare(bpvo_hip_ctx* c, int n_pairs)
   return BPVO_OK;
 }
 
-// starts the workers; chunks are cut inside the lanes' ranges [n k / nl, n (k + 1) / nl)
-int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, int nl, const uint8_t* images, const float* disparities)
+// The pairs of a host batch are cut into nl * nsub groups of consecutive pairs, uploaded in that order; lane k runs the groups k, k + nl,
+// k + 2 nl, ... one after the other, each end to end (frame stage as its chunks land, template, estimate).  With nsub = 1 a lane's first
+// kernel of the Gauss-Newton stage waits for HALF the batch (2 lanes) to cross the bus and the second lane for all of it: 46 ms of a
+// 196 ms step were exposed upload (profiles/r03_host_buffers_first.txt).  With nsub = 2 the first group is a quarter of the batch and
+// every later group has landed long before its lane gets to it.
+void host_groups(int n_pairs, int nl, int nsub, std::vector<std::pair<int, int>>& groups)
+{
+  const int ng = nl * nsub;
+  groups.clear();
+  for(int g = 0; g < ng; ++g) {
+    const int lo = (int) ((long long) n_pairs * g / ng), hi = (int) ((long long) n_pairs * (g + 1) / ng);
+    groups.emplace_back(lo, hi);
+  }
+}
+// starts the workers; chunks are cut inside the groups, in group order
+int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, const std::vector<std::pair<int, int>>& groups, const uint8_t* images, const float* disparities)
 {
   int rc = upload_prepare(c, n_pairs);
   if(rc) return rc;
   u.c = c; u.n_pairs = n_pairs;
-  for(int k = 0; k < nl; ++k) {
-    const int lo = (int) ((long long) n_pairs * k / nl), hi = (int) ((long long) n_pairs * (k + 1) / nl);
-    for(int p0 = lo; p0 < hi; p0 += kUploadChunkPairs) u.chunks.emplace_back(p0, std::min(kUploadChunkPairs, hi - p0));
-  }
+  for(const auto& g : groups)
+    for(int p0 = g.first; p0 < g.second; p0 += kUploadChunkPairs) u.chunks.emplace_back(p0, std::min(kUploadChunkPairs, g.second - p0));
   const int nchunks = (int) u.chunks.size();
   while((int) c->up_chunk_done.size() < nchunks) {
     hipEvent_t e = nullptr;
@@ -2101,7 +2124,7 @@ int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, int nl, const uint8
   for(int w = 0; w < T; ++w) {
     u.workers.emplace_back([c, &u, w, T, nchunks, npix, images, disparities, t_start, done_count] {
       (void) hipSetDevice(c->device);
-      hipStream_t st = c->up_streams[w];
+      hipStream_t st = c->up_streams[w % std::max(1, std::min(c->up_streams_n, (int) c->up_streams.size()))];
       int turn = 0;
       for(int k = w; k < nchunks; k += T, ++turn) {
         const int p0 = u.chunks[k].first, np = u.chunks[k].second, sl = turn & 1;
@@ -2129,25 +2152,35 @@ int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, int nl, const uint8
   return BPVO_OK;
 }
 
-// setData of the pairs [lo, hi) of a lane from the staging area, chunk by chunk as they land
+// setData of the pairs [lo, hi) of a lane from the staging area as the chunks land, up_group chunks per frame-stage launch (the first
+// group of a lane is a single chunk: the device starts as soon as anything is there)
 int upload_consume(bpvo_hip_ctx* c, UploadRun& u, int lo, int hi, const FrameRun& fr_lane)
 {
   const size_t npix = c->geom[0].npix;
-  for(size_t k = 0; k < u.chunks.size(); ++k) {
-    const int p0 = u.chunks[k].first, np = u.chunks[k].second;
-    if(p0 < lo || p0 >= hi) continue;
-    {
-      std::unique_lock<std::mutex> lk(u.mu);
-      u.cv.wait(lk, [&] { return u.recorded[k] != 0; });
-      if(!u.err.empty()) { (fr_lane.own_thread ? fr_lane.ln->err : c->err) = u.err; return BPVO_ERR_DEVICE; }
+  std::vector<size_t> mine;
+  for(size_t k = 0; k < u.chunks.size(); ++k)
+    if(u.chunks[k].first >= lo && u.chunks[k].first < hi) mine.push_back(k);
+  for(size_t i = 0; i < mine.size();) {
+    const size_t take = std::min(mine.size() - i, (size_t) (i == 0 ? 1 : c->up_group));
+    for(size_t q = i; q < i + take; ++q) {
+      const size_t k = mine[q];
+      {
+        std::unique_lock<std::mutex> lk(u.mu);
+        u.cv.wait(lk, [&] { return u.recorded[k] != 0; });
+        if(!u.err.empty()) { (fr_lane.own_thread ? fr_lane.ln->err : c->err) = u.err; return BPVO_ERR_DEVICE; }
+      }
+      FR_CK(c, fr_lane, hipStreamWaitEvent(fr_lane.stream, c->up_chunk_done[k], 0));
     }
-    FR_CK(c, fr_lane, hipStreamWaitEvent(fr_lane.stream, c->up_chunk_done[k], 0));
+    const int p0 = u.chunks[mine[i]].first;
+    int np = 0;
+    for(size_t q = i; q < i + take; ++q) np += u.chunks[mine[q]].second;      // (the chunks of a lane are contiguous)
     FrameRun fr = fr_lane;
     fr.tab = 2 * p0;
     fr.selected_ev = nullptr; fr.on_selected = nullptr;
     // skip_odd_disp = 2: the staging area holds the A frames' disparities only, packed
     int rc = frames_set_data(c, 2 * p0, 1, 2 * np, c->up_d_img + (size_t) 2 * p0 * npix, c->up_d_disp + (size_t) p0 * npix, true, fr, 2);
     if(rc) return rc;
+    i += take;
   }
   return BPVO_OK;
 }
@@ -2159,7 +2192,7 @@ int upload_consume(bpvo_hip_ctx* c, UploadRun& u, int lo, int hi, const FrameRun
 // under the narrow coarse-level iterations of the previous one, and the coarse levels of lane k under the fine levels of lane k-1.
 // Same kernels on the same data per pair: results are bit-identical to the one-stage-at-a-time form (BPVO_HIP_STAGGER=0).
 int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* images, const float* disparities, bool on_device, float* poses,
-                        bpvo_hip_stats* stats, UploadRun* pipe)
+                        bpvo_hip_stats* stats, UploadRun* pipe, const std::vector<std::pair<int, int>>* host_group_list)
 {
   HIP_CK(c, hipStreamSynchronize(c->stream));
   c->frac_valid = false;
@@ -2168,28 +2201,40 @@ int batch_run_staggered(bpvo_hip_ctx* c, int n_pairs, int nl, const uint8_t* ima
   std::mutex mu;
   std::condition_variable cv;
   std::vector<int> selected(nl, 0);     // 1: the lane recorded its selected_ev (or failed before: nobody waits for ever)
+  // the groups of consecutive pairs a lane runs one after the other: one per lane, or (host buffers) nsub per lane in upload order
+  std::vector<std::pair<int, int>> groups;
+  if(host_group_list) groups = *host_group_list;
+  else host_groups(n_pairs, nl, 1, groups);
+  const int nsub = (int) groups.size() / nl;
   auto run = [&](int k) {
     Lane* ln = &c->lanes[k];
     (void) hipSetDevice(c->device);
-    const int lo = (int) ((long long) n_pairs * k / nl), hi = (int) ((long long) n_pairs * (k + 1) / nl), n = hi - lo;
     auto release_next = [&mu, &cv, &selected, k] { { std::lock_guard<std::mutex> lk(mu); selected[k] = 1; } cv.notify_all(); };
     struct Release { std::function<void()> f; ~Release() { f(); } } always{release_next};   // whatever happens, nobody waits for ever
-    if(k > 0) {
+    // device-resident inputs: lane k's frame stage starts behind lane k - 1's selection (stagger); host inputs arrive staggered anyway
+    if(k > 0 && !pipe) {
       { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return selected[k - 1] != 0; }); }
       if(hipStreamWaitEvent(ln->stream, c->lanes[k - 1].selected_ev, 0) != hipSuccess) { ln->err = "hipStreamWaitEvent"; rcs[k] = BPVO_ERR_DEVICE; return; }
     }
-    FrameRun fr{ln->stream, ln, 2 * lo, true, nullptr, nullptr};
-    int rc = pipe ? upload_consume(c, *pipe, lo, hi, fr)
-                  : frames_set_data(c, 2 * lo, 1, 2 * n, images + (size_t) 2 * lo * npix, disparities + (size_t) 2 * lo * npix, on_device, fr, 1);
-    if(rc) { rcs[k] = rc; return; }
-    fr.selected_ev = ln->selected_ev;     // recorded, and the next lane released, before the template stage waits for its point counts
-    fr.on_selected = release_next;
-    rc = frames_set_template(c, 2 * lo, 2, n, fr);
-    if(rc) { rcs[k] = rc; return; }
-    std::vector<int> wss(n), refs(n), curs(n);
-    for(int i = 0; i < n; ++i) { wss[i] = lo + i; refs[i] = 2 * (lo + i); curs[i] = 2 * (lo + i) + 1; }
-    rcs[k] = estimate_group(c, ln, n, wss.data(), refs.data(), curs.data(), nullptr, poses ? poses + 16 * (size_t) lo : nullptr,
-                            stats ? stats + (size_t) lo * c->L : nullptr, c->d_records + (size_t) kRecordFloats * lo, false);
+    for(int sub = 0; sub < nsub; ++sub) {
+      const int lo = groups[(size_t) sub * nl + k].first, hi = groups[(size_t) sub * nl + k].second, n = hi - lo;
+      if(n <= 0) continue;
+      FrameRun fr{ln->stream, ln, 2 * lo, true, nullptr, nullptr};
+      int rc = pipe ? upload_consume(c, *pipe, lo, hi, fr)
+                    : frames_set_data(c, 2 * lo, 1, 2 * n, images + (size_t) 2 * lo * npix, disparities + (size_t) 2 * lo * npix, on_device, fr, 1);
+      if(rc) { rcs[k] = rc; return; }
+      if(sub == 0) {
+        fr.selected_ev = ln->selected_ev;     // recorded, and the next lane released, before the template stage waits for its point counts
+        fr.on_selected = release_next;
+      }
+      rc = frames_set_template(c, 2 * lo, 2, n, fr);
+      if(rc) { rcs[k] = rc; return; }
+      std::vector<int> wss(n), refs(n), curs(n);
+      for(int i = 0; i < n; ++i) { wss[i] = lo + i; refs[i] = 2 * (lo + i); curs[i] = 2 * (lo + i) + 1; }
+      rc = estimate_group(c, ln, n, wss.data(), refs.data(), curs.data(), nullptr, poses ? poses + 16 * (size_t) lo : nullptr,
+                          stats ? stats + (size_t) lo * c->L : nullptr, c->d_records + (size_t) kRecordFloats * lo, false);
+      if(rc) { rcs[k] = rc; return; }
+    }
   };
   {
     std::vector<std::thread> th;
@@ -2222,16 +2267,21 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   // host buffers: batches of at least two chunks go through the upload pipeline
   const bool use_pipe = !on_device && c->up_workers > 0 && n_pairs >= 2 * kUploadChunkPairs;
   if(c->stagger && nl > 1 && !c->profile_all) {
-    if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr);
+    if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr, nullptr);
+    // (groups of at least 64 pairs: smaller ones cost more in launch floors than their earlier start is worth)
+    std::vector<std::pair<int, int>> groups;
+    host_groups(n_pairs, nl, std::max(1, std::min(c->up_subbatches, n_pairs / (64 * nl))), groups);
     UploadRun pipe;
-    int rcp = upload_start(c, pipe, n_pairs, nl, images, disparities);
+    int rcp = upload_start(c, pipe, n_pairs, groups, images, disparities);
     if(rcp) return rcp;
-    return batch_run_staggered(c, n_pairs, nl, images, disparities, false, poses, stats, &pipe);
+    return batch_run_staggered(c, n_pairs, nl, images, disparities, false, poses, stats, &pipe, &groups);
   }
   int rc;
   if(use_pipe) {
     UploadRun pipe;
-    rc = upload_start(c, pipe, n_pairs, 1, images, disparities);
+    std::vector<std::pair<int, int>> groups;
+    host_groups(n_pairs, 1, 1, groups);
+    rc = upload_start(c, pipe, n_pairs, groups, images, disparities);
     if(rc) return rc;
     rc = upload_consume(c, pipe, 0, n_pairs, ctx_run(c));
   } else {

@@ -39,13 +39,15 @@ def child(a):
     dev = torch.device("cuda", 0)
     di = torch.from_numpy(d["images"][: 2 * n]).to(dev)
     dd = torch.from_numpy(d["disparities"][: 2 * n]).to(dev)
+    hi, hd = d["images"][: 2 * n], d["disparities"][: 2 * n]
+    run = (lambda: ctx.batch_run(hi, hd)) if a.host else (lambda: ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr()))
     for _ in range(a.warmup):
-        ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr())
+        run()
     ctx.profiling(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        poses, stats = ctx.batch_run_device(n, di.data_ptr(), dd.data_ptr())
+        poses, stats = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gn = ctx.total_linearizations()
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--tolerances", default="default")
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--child", default="")
+    ap.add_argument("--host", action="store_true", help="hand the library HOST buffers (the upload pipeline) instead of device-resident inputs")
     ap.add_argument("variants", nargs="*")
     a = ap.parse_args()
     if a.child:
@@ -91,7 +94,7 @@ def main():
             for n in sizes:
                 steps = a.steps if n == a.pairs else max(2, a.steps // 4)
                 cmd = [sys.executable, os.path.abspath(__file__), "--child", path, "--pairs", str(n), "--steps", str(steps), "--warmup", str(a.warmup),
-                       "--levels", str(a.levels), "--descriptor", a.descriptor, "--loss", a.loss, "--tolerances", a.tolerances]
+                       "--levels", str(a.levels), "--descriptor", a.descriptor, "--loss", a.loss, "--tolerances", a.tolerances] + (["--host"] if a.host else [])
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 out.append(json.loads(line[-1]) if line else dict(error=(r.stdout + r.stderr)[-400:]))
