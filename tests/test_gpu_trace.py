@@ -9,16 +9,17 @@ dp added); the oracle has the same record (oracle/bpvo_oracle.h).  What is asser
     the persistent single-pair kernel, and the two write the SAME trace, bit for bit;
  2. the first linearisation (same pose on both sides by construction): valid count and robust scale EQUAL the oracle's, H, G,
     f_norm within the oracle's serial-f32 summation error;
- 3. every later iterate, for as long as both sides run a level: the GPU pose lies within 1e-6 rad / 1e-5 m of the oracle's, or within
-    the spread the REFERENCE ITSELF shows at that iteration under its own summation orders (LinearSystemBuilder runs
-    tbb::parallel_reduce when WITH_TBB is on, bpvo/linear_system_builder.cc:91-131,233-237; the oracle restates the decomposition
-    as n contiguous chunks, n = 1, 2, 4, 8, plus an f64 accumulation as an instrument).  That spread is not small: the scale
-    estimator's freeze rule (Q6) and the three tolerance tests turn 1e-7 differences of f_norm into different branches, and two
-    decompositions of the reference can be 1e-4 rad apart in the middle of a level before they meet again;
- 4. where the GPU run and the single-threaded oracle PART (first iterate further apart than 1e-6 rad / 1e-5 m, or one side stops a
-    level while the other goes on), nothing but rounding separates them: up to there the two f_norm sequences differ by no more
-    than the reference's own decompositions differ from each other (or the serial f32 sum's error bound, 2e-4 relative).  The
-    parting points are printed;
+ 3. every later iterate, for as long as the GPU run and the single-threaded oracle are TOGETHER (poses within 1e-6 rad / 1e-5 m, robust
+    scales within 5e-4 relative): valid counts within max(2, 1e-3 n) — the points a 1e-6 pose difference moves across the border —
+    and f_norm within the larger of 1e-3 relative and twice the spread the REFERENCE ITSELF shows at that iterate under its own
+    summation orders (LinearSystemBuilder runs tbb::parallel_reduce when WITH_TBB is on, bpvo/linear_system_builder.cc:91-131,233-237;
+    the oracle restates the decomposition as n contiguous chunks, n = 1, 2, 4, 8, plus an f64 accumulation as an instrument);
+ 4. once they have PARTED (the scale estimator's freeze rule, Q6, and the three tolerance tests turn 1e-7 differences of f_norm into
+    different branches; two decompositions of the reference can be 4e-4 rad apart in the middle of a level before they meet again
+    at the next): every iterate within 3 x the reference's own spread at that iterate, or within the bound of its branches
+    (BRANCH_ROT / BRANCH_TRANS below).  A level both sides run through the same iterates but leave at different iterations counts
+    as a parting too ("stop").  The coarsest level starts from the same pose and may not part at its first linearisation.  The
+    parting points are printed with the relative differences of f_norm and scale there;
  5. the final pose within the north-star bar of the oracle's.
 """
 import numpy as np

@@ -787,7 +787,7 @@ def test_unnormalised_fuzz_cases_sit_on_the_solver_fallback_edge(orc):
     the oracle's own trace there are linearisations where relative perturbations of 2e-7 of (H, G) — the size of the difference
     between two summation orders — flip the decision.  Whichever side a run lands on decides the basin it ends in; the GPU run
     (deterministic tree + f64 combine) and the serial f32 sum of the reference differ by exactly such perturbations
-    (profiles/r02_fuzz_replay.txt, tests/tools/debug_state.py on the GPU box)."""
+    (profiles/r02_fuzz_replay.txt: a linearisation-by-linearisation replay on the GPU box)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import fuzz_parity as fz

@@ -21,7 +21,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from bpvo_amd import capi, synth  # noqa: E402
-from util import ROT_TOL, bits_equal, make_params, pose_error, trans_tol  # noqa: E402
+from util import ROT_TOL, TRANS_TOL, bits_equal, make_params, pose_error  # noqa: E402
+
+
+def trans_tol(K):
+    """The bar of the randomised cases: 1e-3 m at the benchmark calibrations (fx >= 615 px); the same image-space disagreement between
+    two f32 summation orders is 615 / fx times more translation at the short focal lengths this tool draws (fx down to ~100 px)."""
+    return TRANS_TOL * max(1.0, 615.0 / float(K[0][0]))
 
 DESCRIPTORS = ["intensity", "bitplanes", "gradient", "laplacian", "fields1", "fields2", "centraldiff"]
 MAX_ROWS, MAX_COLS = 200, 300
@@ -82,12 +88,22 @@ def make_inputs(rows, cols, scene, seed):
 
 
 def check(hip, orc, rows, cols, kw, scene, seed):
+    """One case; the two contexts are closed whatever happens (a context left alive by a failed assertion keeps later batches of the
+    same process off the estimation lanes and the team kernel)."""
+    ctxs = []
+    try:
+        return check_case(hip, orc, rows, cols, kw, scene, seed, ctxs)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
+def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
     K, b, imgA, dispA, imgB, dispB, slack = make_inputs(rows, cols, scene, seed)
     kw = dict(kw)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
     formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
     os.environ["BPVO_HIP_FUSE_FROZEN"] = "1" if fuse else "0"
-    ctxs = []
     for bind in (hip, orc):
         ctx = bind.create(K, b, rows, cols, make_params(bind, **kw), n_frames=2, n_pairs=1)
         if formulation:
@@ -211,6 +227,15 @@ def check(hip, orc, rows, cols, kw, scene, seed):
 
 def check_batch(hip, rows, cols, kw, seed):
     """bpvo_hip_batch_run of 2-5 pairs against the same pairs estimated one at a time on a fresh context: bit for bit."""
+    ctxs = []
+    try:
+        return check_batch_case(hip, rows, cols, kw, seed, ctxs)
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
+def check_batch_case(hip, rows, cols, kw, seed, ctxs):
     kw = dict(kw)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
     formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
@@ -218,6 +243,7 @@ def check_batch(hip, rows, cols, kw, seed):
     n = 2 + seed % 4
     b = synth.make_batch(rows, cols, n, first_index=seed % 3000)
     bc = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)
+    ctxs.append(bc)
     if formulation:
         bc.set_warp_formulation(formulation)
     try:
@@ -225,6 +251,7 @@ def check_batch(hip, rows, cols, kw, seed):
     except capi.BpvoError:
         return "batch-error"
     sc = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2, n_pairs=1)
+    ctxs.append(sc)
     if formulation:
         sc.set_warp_formulation(formulation)
     for k in range(n):
