@@ -87,6 +87,33 @@ def make_inputs(rows, cols, scene, seed):
     return K, 0.2, img, disp, img2, disp, 20.0
 
 
+def at_stopped_pose(Th, trace, k, rot_tol, tr_tol):
+    """Is Th the pose the traced run would have returned had it stopped at its linearisation k?  A converged run applies the step of
+    that linearisation TWICE (Q1, bpvo/pose_estimator_base.h:373-393: the update after testConvergence and the one of the loop):
+    T_k P P with P = T_k^-1 T_(k+1), the pose of the next record being T_k P."""
+    if k + 1 >= len(trace):
+        return False
+    Tk, Tk1 = trace[k, :16].reshape(4, 4).astype(np.float64), trace[k + 1, :16].reshape(4, 4).astype(np.float64)
+    rot, tr = pose_error(Th, Tk1 @ np.linalg.inv(Tk) @ Tk1)
+    return rot <= rot_tol and tr <= tr_tol
+
+
+def exact_f_norm(orc, co, level, T, sigma, loss):
+    """f_norm of the linearisation at pose T with the GIVEN robust scale, its terms as LinearSystemBuilder forms them (f32) but summed
+    in f64 by numpy: residuals and valid flags from the oracle at T (bit-identical to the GPU's at the same pose: the stage checks of
+    check_case), weights from the oracle's ComputeWeights."""
+    import ctypes as C
+    co.linearize(0, 0, 1, level, T)
+    r, v = co.get_residuals(0), co.get_valid(0)
+    vv = np.ascontiguousarray(np.tile(v, r.size // v.size) if v.size != r.size else v).astype(np.uint16)
+    w = np.empty_like(r)
+    orc.fn("compute_weights")(int(loss), r.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p), C.c_size_t(r.size), C.c_float(sigma),
+                              w.ctypes.data_as(C.c_void_p))
+    wi = (w * vv.astype(np.float32)).astype(np.float32)
+    terms = ((wi * r).astype(np.float32) * r).astype(np.float32)
+    return float(np.sqrt(np.sum(terms.astype(np.float64))))
+
+
 def check(hip, orc, rows, cols, kw, scene, seed):
     """One case; the two contexts are closed whatever happens (a context left alive by a failed assertion keeps later batches of the
     same process off the estimation lanes and the team kernel)."""
@@ -212,13 +239,29 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
         t0 = tr64[tr64[:, 67] == first]
         k = sh[first]["numIterations"]          # the level's linearisations 0 .. k: the stop compared f_k with f_(k-1)
         if 1 <= k < len(t0) and abs(t0[k, 58] - t0[k - 1, 58]) <= 4e-6 * t0[k, 58]:
-            # ... and the GPU's pose is the oracle's iterate of that moment: T_k updated twice with dp_k (Q1: the update is repeated
-            # after convergence), i.e. the oracle's T_(k+2) up to the change of dp over one iteration
-            for kk in (k + 2, k + 1):
-                if kk < len(t0):
-                    rk, tk = pose_error(Th, t0[kk, :16].reshape(4, 4))
-                    if rk <= slack * ROT_TOL and tk <= slack * trans_tol(K):
-                        return "function-tol-at-the-noise-floor"
+            # ... and the GPU's pose is what the oracle's run gives when stopped at that iterate
+            if at_stopped_pose(Th, t0, k, slack * ROT_TOL, slack * trans_tol(K)):
+                return "function-tol-at-the-noise-floor"
+    # A GENUINE FunctionTol stop on the GPU's own sums, in an iteration that wanders: f_norm as a function of the pose has steps (a point
+    # crossing the image border, 1e-7 rad apart, changes it by ~1e-3 here) and the iteration walks around its minimum with changes of that
+    # size until maxIterations; two consecutive f32 values coincide once in a few hundred such steps, for the GPU's sums at one iterate,
+    # for the reference's at another (or never within 50).  Accepted when (a) up to the stop the GPU's iterates ARE the oracle's (1e-6 rad /
+    # 1e-5 m apart at most), (b) the stop is the reference's rule applied to correct values: at the GPU's own last two iterates, with its
+    # own robust scales, the exact (f64) sums over the oracle's residuals differ by less than the error bound of the GPU's sums, and
+    # (c) the GPU's pose is the oracle's iterate of that moment (Q1: T_k updated twice with dp_k).
+    if sh[first]["status"] == capi.STATUS_FUNCTION_TOL and all(sh[l]["numIterations"] == so[l]["numIterations"] for l in range(first + 1, levels)):
+        _, _, trh = ch.estimate_pose_trace(0, 0, 1)
+        _, _, tro = co.estimate_pose_trace(0, 0, 1)
+        h0, o0 = trh[trh[:, 67] == first], tro[tro[:, 67] == first]
+        k = len(h0) - 1
+        if k >= 1 and len(o0) > k and abs(h0[k, 58] - h0[k - 1, 58]) < kw.get("functionTolerance", 1e-6):
+            together = all(r_ <= 1e-6 and t_ <= 1e-2 * trans_tol(K) for r_, t_ in
+                           (pose_error(h0[i, :16].reshape(4, 4), o0[i, :16].reshape(4, 4)) for i in range(k + 1)))
+            fe = [exact_f_norm(orc, co, first, h0[i, :16].reshape(4, 4), float(h0[i, 59]), make_params(orc, **kw).lossFunction) for i in (k - 1, k)]
+            genuine = abs(fe[1] - fe[0]) <= 2.0 * 4e-6 * fe[1] and all(abs(fe[i] - h0[k - 1 + i, 58]) <= 4e-6 * fe[i] for i in (0, 1))
+            at_iterate = at_stopped_pose(Th, o0, k, slack * ROT_TOL, slack * trans_tol(K))
+            if together and genuine and at_iterate:
+                return "genuine-function-tol-stop"
     assert near and abs(e_at - e_own) <= 2e-4 * abs(e_own), (
         "pose", rot, trans, "cpu-vs-cpu", rot8, trans8, "oracle restarted at the GPU pose", rot2, trans2, e_own, e_at,
         [s["status"] for s in sh], [s["status"] for s in so], [(s["status"], s["numIterations"]) for s in so2])
