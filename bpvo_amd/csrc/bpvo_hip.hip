@@ -324,8 +324,9 @@ void carve_frame_tmpl(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
   for(int l = 0; l < c->L; ++l) {
     const LevelGeom& g = c->geom[l];
     f.sal[l] = cv.take<float>(g.npix);
-    f.flag[l] = cv.take<uint8_t>(g.npix);
-    f.blk_count[l] = cv.take<int>(g.nblk);
+    const size_t nwords = (size_t) g.rows * ((g.cols + 63) / 64);      // candidate bits of the tiled selection (kernels_frame.hip)
+    f.flag[l] = (uint8_t*) cv.take<unsigned long long>((std::max(g.npix, nwords * 8) + 7) / 8);
+    f.blk_count[l] = cv.take<int>(std::max((size_t) g.nblk, nwords));
     f.pts[l] = cv.take<float4>(g.cap);
     f.inds[l] = cv.take<int>(g.cap);
     f.pix[l] = cv.take<float>((size_t) g.cap * c->C);
@@ -360,6 +361,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   j.desc = f.desc[l];
   j.sal = f.sal[l];
   j.flag = f.flag[l];
+  j.words = reinterpret_cast<unsigned long long*>(f.flag[l]);
   j.blk_count = f.blk_count[l];
   j.n_out = f.n_dev ? f.n_dev + l : nullptr;
   j.disp = f.disp;
@@ -596,8 +598,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
     const FrameJob* jobs = tab + (size_t) l * NF;
     const LevelGeom& g = c->geom[l];
     ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count, fr.ln);
-    launch_saliency(s, jobs, c->C, g.cols, g.rows, count);
-    launch_select(s, jobs, g.cols, g.rows, count, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
+    launch_saliency_select(s, jobs, c->C, g.cols, g.rows, count, g.nms_radius, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
   }
   {
     // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch

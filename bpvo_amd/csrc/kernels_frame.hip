@@ -93,14 +93,15 @@ __global__ __launch_bounds__(256) void pyrdown_u8_kernel(const FrameJob* src_job
 }
 
 // The same through LDS (the form launch_pyrdown uses): a workgroup stages the (2*64+3) x (2*16+3) source pixels of a 64 x 16 output
-// tile with row-contiguous byte loads (a wavefront reads 64 consecutive bytes per request instead of 64 bytes strided by two, eleven
-// rows of five per thread), forms the horizontal [1 4 6 4 1] sums once per (source row, output column) and the vertical ones from
+// tile with row-contiguous loads (whole dwords where the tile allows: see below), forms the horizontal [1 4 6 4 1] sums once per (source row, output column) and the vertical ones from
 // those.  Integer arithmetic, same values.  1024 pairs of 1241x376: 2.5 -> see profiles/README.md ms per step for the three levels.
 constexpr int PDT_W = 64, PDT_H = 16;
-constexpr int PDS_W = 2 * PDT_W + 3, PDS_H = 2 * PDT_H + 3, PDS_PITCH = 2 * PDT_W + 4;
+constexpr int PDS_W = 2 * PDT_W + 3, PDS_H = 2 * PDT_H + 3;
+constexpr int PDS_DW = (PDS_W + 3 + 3) / 4;        // dwords that cover PDS_W bytes starting at any byte of a dword (34)
+constexpr int PDS_PITCH = 4 * (PDS_DW + 2);        // bytes per staged row (144)
 __global__ __launch_bounds__(256) void pyrdown_u8_lds_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
 {
-  __shared__ uint8_t s_src[PDS_H][PDS_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[PDS_H][PDS_PITCH];
   __shared__ uint16_t s_h[PDS_H][PDT_W];      // <= 16 * 255
   const FrameJob& sj = src_jobs[blockIdx.z];
   const FrameJob& dj = dst_jobs[blockIdx.z];
@@ -108,18 +109,35 @@ __global__ __launch_bounds__(256) void pyrdown_u8_lds_kernel(const FrameJob* src
   const int dx0 = blockIdx.x * PDT_W, dy0 = blockIdx.y * PDT_H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint8_t* __restrict__ s = sj.img;
-  for(int r = wave; r < PDS_H; r += 4) {
-    const uint8_t* row = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw;
+  const int c_first = 2 * dx0 - 2;
+  // Tiles whose source columns (and the up to three bytes either side that whole-dword loads add) lie inside one image row: the window
+  // is fetched as aligned dwords, 34 per row, and a row's bytes start `off` (0..3, its address modulo 4) into its LDS row.  The
+  // others (the first and last tile of a row of tiles, narrow images) go byte by byte through REFLECT_101.
+  const bool fast = c_first >= 3 && c_first + PDS_W + 3 <= sw;
+  if(fast) {
+    for(int i = threadIdx.x; i < PDS_H * PDS_DW; i += 256) {
+      const int r = i / PDS_DW, l = i - r * PDS_DW;
+      const uint8_t* p = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw + c_first;
+      const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+      if(4u * (unsigned) l < (unsigned) (a & 3u) + PDS_W)
+        reinterpret_cast<uint32_t*>(&s_src[r][0])[l] = *reinterpret_cast<const uint32_t*>(a - (a & 3u) + 4u * (unsigned) l);
+    }
+  } else {
+    for(int r = wave; r < PDS_H; r += 4) {
+      const uint8_t* row = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw;
 #pragma unroll
-    for(int c0 = 0; c0 < PDS_W; c0 += 64) {
-      const int c = c0 + lane;
-      if(c < PDS_W) s_src[r][c] = row[reflect101(min(2 * dx0 - 2 + c, sw + 1), sw)];
+      for(int c0 = 0; c0 < PDS_W; c0 += 64) {
+        const int c = c0 + lane;
+        if(c < PDS_W) s_src[r][c] = row[reflect101(min(c_first + c, sw + 1), sw)];
+      }
     }
   }
   __syncthreads();
   for(int idx = threadIdx.x; idx < PDS_H * PDT_W; idx += 256) {
     const int r = idx >> 6, x = idx & 63;
-    const uint8_t* q = &s_src[r][2 * x];
+    int off = 0;
+    if(fast) off = (int) (reinterpret_cast<uintptr_t>(s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw + c_first) & 3u);
+    const uint8_t* q = &s_src[r][2 * x + off];
     s_h[r][x] = (uint16_t) (q[2] * 6 + (q[1] + q[3]) * 4 + q[0] + q[4]);
   }
   __syncthreads();
@@ -835,6 +853,205 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
   }
 }
 
+// ---- K3 + K4 in tiles (the form launch_saliency_select uses when the NMS radius is <= 1): saliency, the 3 x 4 NMS test and the disparity gate
+// in ONE pass over 64 x 32 pixel tiles.  Channel 0 of the descriptor (its compact plane when C = 8) is staged in LDS with row-contiguous
+// loads, the saliency of the tile and its halo is formed from there (the closed form above; the few columns the reference's SIMD body
+// treats differently, x < 4 and x >= W & ~3, go through the per-pixel functions), written out once (bpvo_hip_get_saliency) and
+// kept in LDS for the NMS windows.  A candidate flag is one BIT: a wavefront ballots the 64 pixels of a row segment into one 64-bit
+// word, words[(y * WPR + x / 64)], WPR = ceil(W / 64) — words in (y, x / 64) order are pixels in row-major order, the order of the
+// reference's scan.  select_words_scan_kernel turns the words' popcounts into exclusive offsets, select_words_write_kernel lets a
+// wavefront walk words with one lane per pixel: rank = offset + popcount(lower bits), consecutive ranks from consecutive lanes.
+// Same values and order as the three-pass form above (which stays for radii > 1).
+constexpr int ST_W = 64, ST_H = 32, ST_ROWS_PER_WAVE = ST_H / 4;
+constexpr int ST_CH_ROWS = ST_H + 4, ST_CH_COLS = ST_W + 5, ST_CH_PITCH = 72;     // channel 0: rows y0-2 .. y0+H+1, columns x0-2 .. x0+W+2
+constexpr int ST_S_ROWS = ST_H + 2, ST_S_COLS = ST_W + 3, ST_S_PITCH = 68;        // saliency:  rows y0-1 .. y0+H,   columns x0-1 .. x0+W+1
+
+template <int C>
+__device__ __forceinline__ float saliency_generic(const FrameJob& j, int x, int y)
+{
+  // the per-pixel closed form (see saliency_kernel), for the columns the tile does not cover
+  const int W = j.cols, R = j.rows, n = W & ~3;
+  if(!(y >= 1 && y <= R - 2 && x != W - 1)) return 0.0f;
+  const float* __restrict__ I = j.desc;
+  const size_t row = (size_t) y * W;
+  if(x >= n) {
+    float S = grad_tail<C>(I, row + x, W, 0);
+    for(int c = 1; c < C; ++c) S += grad_tail<C>(I, row + x, W, c);
+    return S;
+  }
+  if(C == 1 || x >= 4) return grad_abs<C>(I, row + x, W, 0);
+  const int xs = n - 4 + x;
+  const float S0 = (xs == W - 1) ? 0.0f : grad_abs<C>(I, row + xs, W, 0);
+  return S0 + grad_abs<C>(I, row + xs, W, C - 1);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJob* jobs, float min_saliency, float min_disp, float max_disp, int border)
+{
+  __shared__ float s_ch[ST_CH_ROWS][ST_CH_PITCH];
+  __shared__ float s_sal[ST_S_ROWS][ST_S_PITCH];
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows, n = W & ~3;
+  const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // channel 0 with its halo (coordinates clamped into the image: such entries only feed saliencies that are defined as 0 or replaced)
+  const float* __restrict__ ch = (C == 8) ? j.ch0.get() : j.desc.get();
+  constexpr int CS = (C == 8) ? 1 : C;
+  // (flat index over rows x pitch: every pass of the 256 threads is 3.5 full rows instead of one row plus a 5-lane remainder)
+  for(int i = threadIdx.x; i < ST_CH_ROWS * ST_CH_PITCH; i += 256) {
+    const int r = i / ST_CH_PITCH, cc = i - r * ST_CH_PITCH;
+    if(cc < ST_CH_COLS) {
+      const int y = min(max(y0 - 2 + r, 0), R - 1), xx = min(max(x0 - 2 + cc, 0), W - 1);
+      s_ch[r][cc] = ch[((size_t) y * W + xx) * CS];
+    }
+  }
+  __syncthreads();
+  float* __restrict__ sal_out = j.sal;
+  for(int i = threadIdx.x; i < ST_S_ROWS * ST_S_PITCH; i += 256) {
+    const int r = i / ST_S_PITCH, cc = i - r * ST_S_PITCH;
+    if(cc >= ST_S_COLS) continue;
+    const int y = y0 - 1 + r, xx = x0 - 1 + cc;
+    // the SIMD body's form from the tile, unconditionally; the exceptions (image border, the columns the reference treats apart) after it
+    float S = fabsf(s_ch[r + 1][cc] - s_ch[r + 1][cc + 2]) + fabsf(s_ch[r][cc + 1] - s_ch[r + 2][cc + 1]);
+    const bool inside = xx >= 0 && xx < W && y >= 0 && y < R;
+    if(!(xx >= 4 && xx < n && xx != W - 1 && y >= 1 && y <= R - 2)) S = (inside && (xx < 4 || xx >= n)) ? saliency_generic<C>(j, xx, y) : 0.0f;
+    if(inside && r >= 1 && r <= ST_H && cc >= 1 && cc <= ST_W) sal_out[(size_t) y * W + xx] = S;
+    s_sal[r][cc] = S;
+  }
+  __syncthreads();
+  // candidates: one column per lane, ST_ROWS_PER_WAVE rows per wave, the 3 x 4 window slides down the column
+  const int x = x0 + lane, c = lane + 1;
+  const int radius = j.nms_radius;
+  const bool col_ok = x >= border && x < W - border - 1;
+  const int ry0 = wave * ST_ROWS_PER_WAVE;        // first row of this wave inside the tile
+  // strict > against the 11 neighbours (Q8: 3 rows, columns x-1 .. x+2) = v > their maximum (saliencies are finite sums of |.|);
+  // per row: side = max of columns x-1, x+1, x+2, full = max(side, column x)
+  float vrow[ST_ROWS_PER_WAVE + 2], side[ST_ROWS_PER_WAVE + 2], full[ST_ROWS_PER_WAVE + 2];
+#pragma unroll
+  for(int q = 0; q < ST_ROWS_PER_WAVE + 2; ++q) {
+    const float* t = &s_sal[ry0 + q][c - 1];
+    vrow[q] = t[1];
+    side[q] = fmaxf(fmaxf(t[0], t[2]), t[3]);
+    full[q] = fmaxf(side[q], t[1]);
+  }
+  bool ok[ST_ROWS_PER_WAVE];
+#pragma unroll
+  for(int q = 0; q < ST_ROWS_PER_WAVE; ++q) {
+    const int y = y0 + ry0 + q;
+    const float v = vrow[q + 1];
+    bool t = col_ok && y >= border && y < R - border - 1 && v >= min_saliency;
+    if(radius == 1) t = t & (v > fmaxf(fmaxf(full[q], side[q + 1]), full[q + 2]));
+    ok[q] = t;
+  }
+  // disparity gate for the survivors (full-resolution map, template_data.cc:73-83): all rows' loads in flight together
+  float dv[ST_ROWS_PER_WAVE];
+#pragma unroll
+  for(int q = 0; q < ST_ROWS_PER_WAVE; ++q)
+    dv[q] = ok[q] ? j.disp[(size_t) (1 << j.level) * ((size_t) (y0 + ry0 + q) * j.disp_cols + x)] : 0.0f;
+  unsigned long long words = 0;      // lane q keeps the word of row q
+#pragma unroll
+  for(int q = 0; q < ST_ROWS_PER_WAVE; ++q) {
+    const unsigned long long m = __ballot(ok[q] && dv[q] >= min_disp && dv[q] <= max_disp);
+    if(lane == q) words = m;
+  }
+  const int y = y0 + ry0 + lane;
+  if(lane < ST_ROWS_PER_WAVE && y < R) j.words[(size_t) y * gridDim.x + blockIdx.x] = words;
+}
+
+// exclusive scan of the words' popcounts in (y, x / 64) order; N = total & ~15 (the reference drops the LAST N mod 16 points)
+__global__ __launch_bounds__(1024) void select_words_scan_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.x];
+  const int nw = j.rows * ((j.cols + 63) / 64);
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  if(threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for(int base = 0; base < nw; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < nw) ? __popcll(j.words[i]) : 0;
+    int incl = v;
+#pragma unroll
+    for(int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if(lane >= o) incl += t;
+    }
+    if(lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for(int w = 0; w < wave; ++w) woff += s_wave[w];
+    const int carry = s_carry;
+    if(i < nw) j.blk_count[i] = carry + woff + incl - v;
+    __syncthreads();
+    if(threadIdx.x == 1023) s_carry = carry + woff + incl;
+    __syncthreads();
+  }
+  if(threadIdx.x == 0) {
+    int total = s_carry;
+    if(total > j.cap) total = j.cap;
+    *j.n_out = total & ~15;
+  }
+}
+
+// order-preserving compaction: a wavefront takes SW_WORDS consecutive words and hands their set bits to its lanes 64 at a time (the t-th
+// set bit of the group has rank offset + t: the arithmetic below runs on full wavefronts at the sparse levels too); writes (y*W+x)
+// and makePoint (rigid_body_warp.h:47-60) of the bits whose rank is below N
+constexpr int SW_WORDS = 8;
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n)      // position of the n-th (0-based) set bit of m
+{
+  int pos = 0;
+#pragma unroll
+  for(int w = 32; w >= 1; w >>= 1) {
+    const int cnt = __popcll(m & ((1ull << w) - 1ull));
+    if(n >= cnt) { n -= cnt; m >>= w; pos += w; }
+  }
+  return pos;
+}
+__global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob* jobs)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, WPR = (W + 63) / 64;
+  const int nw = j.rows * WPR;
+  const int lane = threadIdx.x & 63;
+  const int w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SW_WORDS;
+  if(w0 >= nw) return;
+  unsigned long long m[SW_WORDS];
+  int before[SW_WORDS + 1];        // set bits of the group in front of word k
+  before[0] = 0;
+#pragma unroll
+  for(int k = 0; k < SW_WORDS; ++k) {
+    m[k] = (w0 + k < nw) ? j.words[w0 + k] : 0ull;
+    before[k + 1] = before[k] + __popcll(m[k]);
+  }
+  const int total = before[SW_WORDS];
+  if(total == 0) return;
+  const int off = j.blk_count[w0];
+  const int N = *j.n_out;
+  const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
+  const float Bf = j.b * fx;
+  for(int t = lane; t < total; t += 64) {
+    const int r = off + t;
+    if(r >= N) break;
+    int k = 0;
+    unsigned long long mk = m[0];
+    int first = 0;
+#pragma unroll
+    for(int q = 1; q < SW_WORDS; ++q)
+      if(t >= before[q]) { k = q; mk = m[q]; first = before[q]; }
+    const int bit = nth_set_bit(mk, t - first);
+    const int w = w0 + k;
+    const int y = w / WPR, x = (w - y * WPR) * 64 + bit;
+    const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+    const float Z = (float) ((double) Bf * (1.0 / (double) d));
+    const float X = ((float) x - cx) * Z * (1.0f / fx);
+    const float Y = ((float) y - cy) * Z * (1.0f / fy);
+    // DisparitySpaceWarp::makePoint (bpvo/disparity_space_warp.h:31-34): (x - cx, y - cy, d, 1)
+    j.pts[r] = j.dspace ? make_float4((float) x - cx, (float) y - cy, d, 1.0f) : make_float4(X, Y, Z, 1.0f);
+    j.inds[r] = y * W + x;
+  }
+}
+
 // ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
 // The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too (LDS-staged
 // chunks, one wave adding in point order).  It runs once per keyframe and level, all levels and frames side by side.
@@ -1201,13 +1418,22 @@ void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nfr
   else
     hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
 }
-void launch_saliency(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes)
+void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes, int nms_radius, float min_saliency,
+                            float min_disp, float max_disp, int border)
 {
+  if(nms_radius <= 1) {
+    // tiles: saliency + NMS + gate in one pass, candidate bits, word scan, lane-per-pixel compaction
+    const int WPR = (W + 63) / 64, nw = R * WPR;
+    dispatch_channels(C, [&](auto c) {
+      hipLaunchKernelGGL(saliency_select_tile_kernel<decltype(c)::value>, dim3(WPR, (R + ST_H - 1) / ST_H, nframes), dim3(256), 0, s, jobs,
+                         min_saliency, min_disp, max_disp, border);
+    });
+    hipLaunchKernelGGL(select_words_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
+    hipLaunchKernelGGL(select_words_write_kernel, dim3((nw + 4 * SW_WORDS - 1) / (4 * SW_WORDS), 1, nframes), dim3(256), 0, s, jobs);
+    return;
+  }
+  // larger NMS windows: the saliency map first, then flag bytes / chunk scan / compaction straight from it
   dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(saliency_kernel<decltype(c)::value>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs); });
-}
-void launch_select(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float min_saliency, float min_disp,
-                   float max_disp, int border)
-{
   const int nblk = (W * R + SEL_BLOCK_PX - 1) / SEL_BLOCK_PX;
   hipLaunchKernelGGL(select_flag_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs, min_saliency, min_disp, max_disp, border);
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);

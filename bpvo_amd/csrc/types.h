@@ -203,8 +203,9 @@ struct FrameJob {
                             // compact plane spares it a strided pass over the 32-byte records
   GPtr<float> scratch;   // descriptor fields: kDfPlanes work planes of the level-0 size
   GPtr<float> sal;       // [rows*cols]
-  GPtr<uint8_t> flag;      // [rows*cols] candidate flags
-  GPtr<int> blk_count; // [nblk] then exclusive offsets
+  GPtr<uint8_t> flag;      // [rows*cols] candidate flags (NMS radius > 1)
+  GPtr<unsigned long long> words;   // [rows * ceil(cols / 64)] candidate bits, the same storage (NMS radius <= 1)
+  GPtr<int> blk_count; // per 256-pixel chunk / per word: count, then exclusive offset
   GPtr<int> n_out;     // device: number of points kept (multiple of 16)
   GPtr<const float> disp;      // full-resolution disparity
   GPtr<float4> pts;
