@@ -197,6 +197,8 @@ struct bpvo_hip_ctx {
   int up_workers = 6;
   int up_group = 4;                      // chunks a lane's frame stage takes at once (BPVO_HIP_UPLOAD_GROUP): 16-pair launches are too small to fill the chip
   int up_subbatches = 1;                 // groups per lane of a host batch (BPVO_HIP_UPLOAD_SUBBATCHES; host_groups): 2 and more measured slower
+  int ctl_kernel_mode = 1;               // BPVO_HIP_CTL_KERNEL_COPY: control tables by copy_rows_kernel never (0) / while an upload pipeline runs (1) / always (2)
+  std::atomic<bool> ctl_by_kernel{false};
   int up_streams_n = 1;                  // copy streams the workers share (BPVO_HIP_UPLOAD_STREAMS).  A process has a handful of hardware queues
                                          // and HIP streams are multiplexed onto them: with a stream per worker the lanes' kernels queued behind
                                          // other workers' copies and nothing ran until the last chunk had landed (profiles/r03_host_timeline.txt)
@@ -208,6 +210,9 @@ struct bpvo_hip_ctx {
   uint8_t* up_d_img = nullptr;           // device staging: images [2 n][npix]
   float* up_d_disp = nullptr;            //                 disparities of the A frames [n][npix]
   int up_cap_pairs = 0;
+  // host batches on two lanes: the pairs are cut into a SMALL first group (lane 0 starts its Gauss-Newton stage while most of the batch
+  // is still crossing the bus), a large second one for lane 1, and the rest for lane 0 again (host_groups_plan); fractions of the batch
+  double up_plan[2] = {0.19, 0.50};      // BPVO_HIP_UPLOAD_PLAN="f0:f1"; f0 = 0: two equal groups.  Measured: profiles/r03_host_buffers_plan.txt
   double up_last_seconds = 0.0;          // wall time the workers of the last call needed for all chunks (measurement)
   size_t up_last_bytes = 0;
   bool counted_live = false;   // this context is in g_live_ctx
@@ -492,8 +497,12 @@ int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const F
   }
   // rows [tab, tab + count) of every level in one copy
   const size_t pitch = sizeof(FrameJob) * (size_t) c->n_frames;
-  FR_CK(c, fr, hipMemcpy2DAsync(c->d_fjobs + table + fr.tab, pitch, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, (size_t) c->L,
-                                hipMemcpyHostToDevice, fr.stream));
+  static_assert(sizeof(FrameJob) % 8 == 0 && sizeof(PairJob) % 8 == 0, "copy_rows_kernel moves 8-byte words");
+  if(c->ctl_by_kernel.load())
+    launch_copy_rows(fr.stream, c->d_fjobs + table + fr.tab, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, c->L);
+  else
+    FR_CK(c, fr, hipMemcpy2DAsync(c->d_fjobs + table + fr.tab, pitch, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, (size_t) c->L,
+                                  hipMemcpyHostToDevice, fr.stream));
   FR_CK(c, fr, hipEventRecord(fr.ln->staging_ev[which], fr.stream));
   *tab = c->d_fjobs + table + fr.tab;
   return BPVO_OK;
@@ -699,11 +708,13 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       }
       max_pts[l] = std::max(max_pts[l], pj.n);
     }
-  LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
+  if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, sizeof(PairJob) * (size_t) c->L * NP, 1);
+  else LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
   const float* dT = nullptr;
   if(T_init) {
     std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
-    LANE_CK(ln, hipMemcpyAsync(ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, ln->stream));
+    if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, sizeof(float) * 16 * n, 1);
+    else LANE_CK(ln, hipMemcpyAsync(ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, ln->stream));
     dT = ln->d_Tinit;
   }
   launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
@@ -1293,6 +1304,12 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(const char* e = std::getenv("BPVO_HIP_UPLOAD_GROUP")) cp->up_group = std::max(1, std::min(64, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_UPLOAD_SUBBATCHES")) cp->up_subbatches = std::max(1, std::min(8, std::atoi(e)));
     if(const char* e = std::getenv("BPVO_HIP_UPLOAD_STREAMS")) cp->up_streams_n = std::max(1, std::min(32, std::atoi(e)));
+    if(const char* e = std::getenv("BPVO_HIP_UPLOAD_PLAN")) {
+      double f0 = 0, f1 = 0;
+      if(std::sscanf(e, "%lf%*[,:]%lf", &f0, &f1) == 2 && f0 >= 0.0 && f1 > 0.0 && f0 + f1 < 1.0) { cp->up_plan[0] = f0; cp->up_plan[1] = f1; }
+    }
+    if(const char* e = std::getenv("BPVO_HIP_CTL_KERNEL_COPY")) cp->ctl_kernel_mode = std::max(0, std::min(2, std::atoi(e)));
+    cp->ctl_by_kernel = cp->ctl_kernel_mode == 2;
     if(const char* e = std::getenv("BPVO_HIP_TEAM")) cp->team_mode = std::atoi(e) != 0;
     if(const char* e = std::getenv("BPVO_HIP_TEAM_MAX_PAIRS")) cp->team_max_pairs = std::max(0, std::atoi(e));
     if(const char* e = std::getenv("BPVO_HIP_TEAM_SINGLE")) cp->team_single = std::atoi(e) != 0;
@@ -2102,6 +2119,21 @@ void host_groups(int n_pairs, int nl, int nsub, std::vector<std::pair<int, int>>
     groups.emplace_back(lo, hi);
   }
 }
+// Two lanes, three groups in upload order: [0, a) -> lane 0, [a, a + b) -> lane 1, the rest -> lane 0 again (group 3, lane 1's second, is
+// empty).  With two equal groups nothing but frame kernels runs for the first 30 ms of a 1024-pair step (lane 0's half has to land
+// first: profiles/r03_host_timeline.txt); a first group of a fifth of the batch has landed after 10 ms, and what it loses as a small
+// batch is less than the 17 ms it gains.
+void host_groups_plan(const bpvo_hip_ctx* c, int n_pairs, std::vector<std::pair<int, int>>& groups)
+{
+  auto chunks = [](double pairs) { return (int) std::lround(pairs / kUploadChunkPairs) * kUploadChunkPairs; };
+  const int a = std::max(4 * kUploadChunkPairs, chunks(c->up_plan[0] * n_pairs));
+  const int b = std::max(4 * kUploadChunkPairs, std::min(n_pairs - a - 4 * kUploadChunkPairs, chunks(c->up_plan[1] * n_pairs)));
+  groups.clear();
+  groups.emplace_back(0, a);
+  groups.emplace_back(a, a + b);
+  groups.emplace_back(a + b, n_pairs);
+  groups.emplace_back(n_pairs, n_pairs);
+}
 // starts the workers; chunks are cut inside the groups, in group order
 int upload_start(bpvo_hip_ctx* c, UploadRun& u, int n_pairs, const std::vector<std::pair<int, int>>& groups, const uint8_t* images, const float* disparities)
 {
@@ -2271,11 +2303,17 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
     if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr, nullptr);
     // (groups of at least 64 pairs: smaller ones cost more in launch floors than their earlier start is worth)
     std::vector<std::pair<int, int>> groups;
-    host_groups(n_pairs, nl, std::max(1, std::min(c->up_subbatches, n_pairs / (64 * nl))), groups);
+    const int nsub = std::max(1, std::min(c->up_subbatches, n_pairs / (64 * nl)));
+    const bool plan = nl == 2 && nsub == 1 && c->up_plan[0] > 0.0 && n_pairs >= 32 * kUploadChunkPairs;
+    if(plan) host_groups_plan(c, n_pairs, groups);
+    else host_groups(n_pairs, nl, nsub, groups);
     UploadRun pipe;
     int rcp = upload_start(c, pipe, n_pairs, groups, images, disparities);
     if(rcp) return rcp;
-    return batch_run_staggered(c, n_pairs, nl, images, disparities, false, poses, stats, &pipe, &groups);
+    if(c->ctl_kernel_mode == 1) c->ctl_by_kernel = true;
+    rcp = batch_run_staggered(c, n_pairs, nl, images, disparities, false, poses, stats, &pipe, &groups);
+    if(c->ctl_kernel_mode == 1) c->ctl_by_kernel = false;
+    return rcp;
   }
   int rc;
   if(use_pipe) {

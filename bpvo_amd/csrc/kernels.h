@@ -46,6 +46,7 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image);
 void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes, int nms_radius, float min_saliency,
                             float min_disp, float max_disp, int border);
+void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, size_t pitch_bytes, size_t width_bytes, int rows);   // multiples of 8 bytes
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level, int num_levels,
                           int* out /*[nframes][kMaxLevels]*/);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,

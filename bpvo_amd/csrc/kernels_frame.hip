@@ -1439,6 +1439,24 @@ void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, i
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
   hipLaunchKernelGGL(select_write_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs);
 }
+// Small control tables (job rows, initial poses) copied by a KERNEL that reads the pinned host rows directly: while the upload pipeline
+// keeps the DMA engines busy with 45 MB chunks a hipMemcpyAsync of a few KB on a lane's stream waits its turn behind them
+__global__ __launch_bounds__(256) void copy_rows_kernel(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, size_t pitch8,
+                                                        size_t width8, int rows)
+{
+  const size_t n = width8 * (size_t) rows;
+  for(size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) {
+    const size_t r = i / width8, k = i - r * width8;
+    dst[r * pitch8 + k] = src[r * pitch8 + k];
+  }
+}
+void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, size_t pitch_bytes, size_t width_bytes, int rows)
+{
+  const size_t n = width_bytes / 8 * (size_t) rows;
+  if(n == 0) return;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned) std::min<size_t>(64, (n + 255) / 256)), dim3(256), 0, s, (unsigned long long*) dst,
+                     (const unsigned long long*) src_host_pinned, pitch_bytes / 8, width_bytes / 8, rows);
+}
 void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels,
                           int with_normalization)
 {

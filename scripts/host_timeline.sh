@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 python3 $R/scripts/shard_ab.py --host --pairs ${1:-1024} --steps 1 --warmup 1 --repeat 1 -- "" > /dev/null 2>&1     # renders the inputs
-rm -rf /tmp/htl; timeout 400 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/htl -- python3 $R/scripts/shard_ab.py --child /tmp/shard_ab_376x1241_${1:-1024}.npz --host --pairs ${1:-1024} --steps 1 --warmup 1 > /tmp/htl.json 2>/tmp/htl.err
+rm -rf /tmp/htl; timeout 400 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/htl -- python3 $R/scripts/shard_ab.py --child /tmp/shard_ab_376x1241_${1:-1024}.npz --host --pairs ${1:-1024} --steps 1 --warmup 2 > /tmp/htl.json 2>/tmp/htl.err
 tail -2 /tmp/htl.err; cat /tmp/htl.json
 python3 - <<PY
 import glob, sqlite3, os, collections
@@ -19,10 +19,11 @@ print("copy columns:", mc)
 M = list(db.execute("select start, end, size from %s order by start" % mt[0])) if mt else []
 # the last step = after the last big gap in copies: take the last 1/2 of the run by locating the last ingest burst
 ing = [r for r in K if "ingest" in r[0]]
-# two steps (warmup + timed): split at the largest gap between consecutive H2D copies > 5 ms
+# warm-up steps + the timed one: the timed step starts at the first big H2D copy after the last pause of more than 20 ms between such copies
 big = [m for m in M if m[2] > 1000000]
-cut = big[len(big) // 2][0] if big else K[len(K) // 2][1]
-t0 = min([m[0] for m in big if m[0] >= cut] + [r[1] for r in K if r[1] >= cut])
+t0 = big[0][0]
+for a, b in zip(big, big[1:]):
+    if b[0] - a[1] > 20e6: t0 = b[0]
 tend = max(r[2] for r in K)
 print("timed step: %.1f ms" % ((tend - t0) / 1e6))
 B = 10e6
