@@ -51,6 +51,7 @@ struct FrameSlot {
   uint8_t* img[kMaxLevels] = {};
   uint8_t* cen[kMaxLevels] = {};
   float* ch0[kMaxLevels] = {};
+  bool ch0_valid = true;          // false: the descriptor of the slot's current data was computed without the compact channel-0 plane
   float* desc[kMaxLevels] = {};
   float* disp = nullptr;
   float* scratch = nullptr;   // descriptor fields: kDfPlanes work planes
@@ -361,7 +362,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   std::memset(&j, 0, sizeof(j));
   j.img = f.img[l];
   j.cen = f.cen[l];
-  j.ch0 = f.ch0[l];
+  j.ch0 = f.ch0_valid ? f.ch0[l] : nullptr;
   j.scratch = f.scratch;
   j.desc = f.desc[l];
   j.sal = f.sal[l];
@@ -527,6 +528,9 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
         FR_CK(c, fr, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, s));
     }
   }
+  // pair batches: the compact channel-0 plane serves the saliency map of TEMPLATE frames only; the current frames' descriptor kernel
+  // skips its store (the selection reads channel 0 from the records should such a frame be made a template later)
+  for(int i = 0; i < count; ++i) c->frames[first + i * stride].ch0_valid = !(skip_odd_disp && (i & 1));
   const FrameJob* tab = nullptr;
   int rc = upload_frame_jobs(c, first, stride, count, fr, 0, &tab);
   if(rc) return rc;

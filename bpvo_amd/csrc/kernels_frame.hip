@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
       break;
     }
     case DF_TO_CH0:
-      j.ch0[q] = at(y, x);
+      if(j.ch0) j.ch0[q] = at(y, x);
       return;
     default: {           // DF_SPLIT
       const float s = at(y, x);
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       float4* d = reinterpret_cast<float4*>(desc + ((size_t) gy * W + gx) * 8);
       store_stream(d, out[0]);
       store_stream(d + 1, out[1]);
-      ch0[(size_t) gy * W + gx] = out[0].x;
+      if(ch0) ch0[(size_t) gy * W + gx] = out[0].x;      // (not for frames that only ever serve as the current frame of a pair batch)
     }
     __syncthreads();   // s_cen / s_row are rewritten by the next tile
   }
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void bitplanes_noblur_kernel(const FrameJob* j
   if(i >= n) return;
   const unsigned c = j.cen[i];
   float4* d = reinterpret_cast<float4*>(j.desc + (size_t) i * 8);
-  j.ch0[i] = (float) (c & 1u);
+  if(j.ch0) j.ch0[i] = (float) (c & 1u);
   d[0] = make_float4((float) (c & 1u), (float) ((c >> 1) & 1u), (float) ((c >> 2) & 1u), (float) ((c >> 3) & 1u));
   d[1] = make_float4((float) ((c >> 4) & 1u), (float) ((c >> 5) & 1u), (float) ((c >> 6) & 1u), (float) ((c >> 7) & 1u));
 }
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void saliency_kernel(const FrameJob* jobs)
       } else if(C == 1) {
         S = grad_abs<C>(I, row + x, W, 0);
       } else if(x >= 4) {
-        if constexpr(C == 8) S = grad_abs<1>(j.ch0, row + x, W, 0);     // channel 0 from its compact plane
+        if(C == 8 && j.ch0) S = grad_abs<1>(j.ch0, row + x, W, 0);     // channel 0 from its compact plane
         else S = grad_abs<C>(I, row + x, W, 0);
       } else {
         const int xs = n - 4 + x;
@@ -895,8 +895,11 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
   const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // channel 0 with its halo (coordinates clamped into the image: such entries only feed saliencies that are defined as 0 or replaced)
-  const float* __restrict__ ch = (C == 8) ? j.ch0.get() : j.desc.get();
-  constexpr int CS = (C == 8) ? 1 : C;
+  // (a frame whose descriptor was computed without the compact plane — the current frame of a pair batch made a template after all — reads
+  // channel 0 out of the records)
+  const bool compact = C == 8 && j.ch0;
+  const float* __restrict__ ch = compact ? j.ch0.get() : j.desc.get();
+  const int CS = compact ? 1 : C;
   // (flat index over rows x pitch: every pass of the 256 threads is 3.5 full rows instead of one row plus a 5-lane remainder)
   for(int i = threadIdx.x; i < ST_CH_ROWS * ST_CH_PITCH; i += 256) {
     const int r = i / ST_CH_PITCH, cc = i - r * ST_CH_PITCH;

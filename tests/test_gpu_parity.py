@@ -1049,3 +1049,28 @@ def test_host_buffer_batches_go_through_the_upload_pipeline_unchanged(hip, n, la
     for k in ("0", "dev"):
         assert bits_equal(out["6"][0], out[k][0]), k
         assert out["6"][1].tobytes() == out[k][1].tobytes(), k
+
+
+def test_current_frames_of_a_batch_keep_a_complete_descriptor(hip, orc):
+    """The current frames of a pair batch get neither their disparity (never read) nor the compact channel-0 plane of their descriptor
+    (it serves the saliency map of template frames only).  The descriptor records themselves are complete, and set_template on such a
+    frame is refused — there is no disparity to select by — until setData hands the frame over again."""
+    rows, cols, n = 120, 160, 3
+    batch = synth.make_batch(rows, cols, n, first_index=90)
+    p = make_params(hip, levels=3)
+    ctx = hip.create(batch["K"], batch["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
+    ctx.batch_run(batch["images"], batch["disparities"])
+    oc = orc.create(batch["K"], batch["b"], rows, cols, make_params(orc, levels=3), n_frames=2, n_pairs=1)
+    oc.frame_set_data(0, batch["images"][1], batch["disparities"][1])
+    oc.frame_set_template(0)
+    for l in range(3):
+        for ch in range(ctx.Cn):
+            assert bits_equal(ctx.get_descriptor_channel(1, l, ch), oc.get_descriptor_channel(0, l, ch))
+    with pytest.raises(capi.BpvoError):
+        ctx.frame_set_template(1)
+    ctx.frame_set_data(1, batch["images"][1], batch["disparities"][1])
+    ctx.frame_set_template(1)
+    for l in range(3):
+        assert np.array_equal(ctx.get_point_indices(1, l), oc.get_point_indices(0, l))
+        assert bits_equal(ctx.get_pixels(1, l), oc.get_pixels(0, l)) and bits_equal(ctx.get_saliency(1, l), oc.get_saliency(0, l))
+    ctx.close(); oc.close()
