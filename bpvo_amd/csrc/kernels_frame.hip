@@ -433,6 +433,9 @@ __global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, 
 #endif
 constexpr int BP_TW = BP_TW_VALUE, BP_TH = BP_TH_VALUE, BP_HALO = 2;
 constexpr int BP_STACK = 32 / BP_TH;   // vertically adjacent tiles per workgroup (32 rows)
+// row-pass results in LDS: one float4 plane per half (channels 0-3, 4-7) of (BP_TH + 4) rows x BP_TW columns; the second plane starts
+// 128 bytes out of phase with the first, so that the two lanes of a pixel (same position, different plane) hit different banks
+constexpr int BP_PLANE = (BP_TH + 2 * BP_HALO) * BP_TW + 8;
 // The workgroup walks BP_STACK vertically adjacent tiles; the census bytes of the next tile are fetched into registers
 // before the current tile's passes run, so the global-load latency is hidden behind the LDS/VALU work instead of being
 // exposed once per (short-lived) workgroup.
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   constexpr int NPRE = (NSRC + 255) / 256;                               // ... per thread
   __shared__ uint2 s_cen[CR * CW];          // census bytes spread to one byte per plane (spread_planes)
   __shared__ uint8_t s_img[FROM_IMAGE ? IR * IW : 4];
-  __shared__ float s_row[CR * BP_TW * 8];
+  __shared__ float s_row[(BP_PLANE + CR * BP_TW) * 4];
   __shared__ float s_lut[18];
   const FrameJob& j = jobs[blockIdx.z];
   const int W = j.cols, R = j.rows;
@@ -551,34 +554,28 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       // both passes are bank-conflict free (one [8]-float record per pixel would put lanes 32 bytes apart: 2-way conflicts)
       float4* o = reinterpret_cast<float4*>(s_row);
       o[i] = make_float4(tt[0], tt[1], tt[2], tt[3]);
-      o[CR * BP_TW + i] = make_float4(tt[4], tt[5], tt[6], tt[7]);
+      o[BP_PLANE + i] = make_float4(tt[4], tt[5], tt[6], tt[7]);
     }
     __syncthreads();
 
-    // vertical pass: consecutive threads -> consecutive pixels (2 KB contiguous per wave store)
-    for(int i = tid; i < BP_TH * BP_TW; i += 256) {
+    // vertical pass.  A LANE PAIR per pixel: the even lane forms channels 0-3, the odd lane channels 4-7, so that every store instruction
+    // of a wavefront covers 1 KB of contiguous records (32 pixels) instead of every other 16 bytes of 2 KB: the kernel runs at the rate of
+    // its stores plus what of its arithmetic they do not cover (profiles/r03_bitplanes_stores.txt): 8.86 -> 8.68 ms per level-0 launch of 2048 frames
+    for(int u = tid; u < 2 * BP_TH * BP_TW; u += 256) {
+      const int i = u >> 1, h = u & 1;
       const int ly = i / BP_TW, lx = i - ly * BP_TW;
       const int gx = x0 + lx, gy = y0 + ly;
       if(gx >= W || gy >= R) continue;
-      const float4* T = reinterpret_cast<const float4*>(s_row);
-      const int base = ly * BP_TW + lx;               // row ly of s_row is image row gy-2
-      const int pitch = BP_TW, plane = CR * BP_TW;
-      float4 out[2];
-#pragma unroll
-      for(int h = 0; h < 2; ++h) {
-        const float4* Th = T + h * plane + base;
-        const float4 Tm2 = Th[0], Tm1 = Th[pitch], T0 = Th[2 * pitch], Tp1 = Th[3 * pitch], Tp2 = Th[4 * pitch];
-        float4 s;
-        s.x = k0 * T0.x; s.x += k1 * (Tp1.x + Tm1.x); s.x += k2 * (Tp2.x + Tm2.x);
-        s.y = k0 * T0.y; s.y += k1 * (Tp1.y + Tm1.y); s.y += k2 * (Tp2.y + Tm2.y);
-        s.z = k0 * T0.z; s.z += k1 * (Tp1.z + Tm1.z); s.z += k2 * (Tp2.z + Tm2.z);
-        s.w = k0 * T0.w; s.w += k1 * (Tp1.w + Tm1.w); s.w += k2 * (Tp2.w + Tm2.w);
-        out[h] = s;
-      }
-      float4* d = reinterpret_cast<float4*>(desc + ((size_t) gy * W + gx) * 8);
-      store_stream(d, out[0]);
-      store_stream(d + 1, out[1]);
-      if(ch0) ch0[(size_t) gy * W + gx] = out[0].x;      // (not for frames that only ever serve as the current frame of a pair batch)
+      const float4* Th = reinterpret_cast<const float4*>(s_row) + h * BP_PLANE + ly * BP_TW + lx;     // row ly of s_row is image row gy-2
+      constexpr int pitch = BP_TW;
+      const float4 Tm2 = Th[0], Tm1 = Th[pitch], T0 = Th[2 * pitch], Tp1 = Th[3 * pitch], Tp2 = Th[4 * pitch];
+      float4 o4;
+      o4.x = k0 * T0.x; o4.x += k1 * (Tp1.x + Tm1.x); o4.x += k2 * (Tp2.x + Tm2.x);
+      o4.y = k0 * T0.y; o4.y += k1 * (Tp1.y + Tm1.y); o4.y += k2 * (Tp2.y + Tm2.y);
+      o4.z = k0 * T0.z; o4.z += k1 * (Tp1.z + Tm1.z); o4.z += k2 * (Tp2.z + Tm2.z);
+      o4.w = k0 * T0.w; o4.w += k1 * (Tp1.w + Tm1.w); o4.w += k2 * (Tp2.w + Tm2.w);
+      store_stream(reinterpret_cast<float4*>(desc + ((size_t) gy * W + gx) * 8) + h, o4);
+      if(h == 0 && ch0) ch0[(size_t) gy * W + gx] = o4.x;      // (not for frames that only ever serve as the current frame of a pair batch)
     }
     __syncthreads();   // s_cen / s_row are rewritten by the next tile
   }
