@@ -432,7 +432,10 @@ __global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, 
 #define BP_TH_VALUE 8
 #endif
 constexpr int BP_TW = BP_TW_VALUE, BP_TH = BP_TH_VALUE, BP_HALO = 2;
-constexpr int BP_STACK = 32 / BP_TH;   // vertically adjacent tiles per workgroup (32 rows)
+#ifndef BP_ROWS_PER_WG
+#define BP_ROWS_PER_WG 32
+#endif
+constexpr int BP_STACK = BP_ROWS_PER_WG / BP_TH;   // vertically adjacent tiles per workgroup
 // row-pass results in LDS: one float4 plane per half (channels 0-3, 4-7) of (BP_TH + 4) rows x BP_TW columns; the second plane starts
 // 128 bytes out of phase with the first, so that the two lanes of a pixel (same position, different plane) hit different banks
 constexpr int BP_PLANE = (BP_TH + 2 * BP_HALO) * BP_TW + 8;
@@ -484,35 +487,49 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   }
 
   uint8_t pre[NPRE];
+  // (every lane loads, the lanes past the end of the window a byte they do not stage: no branch and no zero-initialisation around the
+  // loads — with them the compiler waits for the whole memory queue, the previous tile's stores included, before it reuses `pre`)
   auto prefetch = [&](int y0) {
 #pragma unroll
     for(int k = 0; k < NPRE; ++k) {
-      const int i = tid + k * 256;
+      const int i = min(tid + k * 256, NSRC - 1);
       if constexpr(FROM_IMAGE) {
         // image window rows y0-3 .. y0+BP_TH+2, columns x0-3 .. x0+BP_TW+2, clamped (clamped positions are never used: a census
         // position on the image border is 0 without looking at its neighbours)
         const int ly = i / IC, lx = i - ly * IC;
         const int gy = min(max(y0 + ly - BP_HALO - 1, 0), R - 1), gx = min(max(x0 + lx - BP_HALO - 1, 0), W - 1);
-        pre[k] = (i < IR * IC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
+        pre[k] = cen[(size_t) gy * W + gx];
       } else {
         const int ly = i / CC, lx = i - ly * CC;
         const int gy = reflect101(min(y0 + ly - BP_HALO, R + 1), R), gx = reflect101(min(x0 + lx - BP_HALO, W + 1), W);
-        pre[k] = (i < CR * CC) ? cen[(size_t) gy * W + gx] : (uint8_t) 0;
+        pre[k] = cen[(size_t) gy * W + gx];
       }
     }
   };
+  // registers -> LDS: the image window (FROM_IMAGE) or the spread census bytes of the tile
+  auto stage = [&]() {
+#pragma unroll
+    for(int k = 0; k < NPRE; ++k) {
+      const int i = tid + k * 256;
+      if constexpr(FROM_IMAGE) {
+        if(i < IR * IC) { const int ly = i / IC, lx = i - ly * IC; s_img[ly * IW + lx] = pre[k]; }
+      } else {
+        if(i < CR * CC) { const int ly = i / CC, lx = i - ly * CC; s_cen[ly * CW + lx] = spread_planes(pre[k]); }
+      }
+    }
+  };
+  // Order of a tile: census (from s_img) | barrier | next tile's loads issued, row pass | barrier | next tile staged, column pass with
+  // its stores | barrier.  The staging sits BEFORE the stores on purpose: its wait for the loads is a wait for everything older in the
+  // memory queue (one in-order counter for loads and stores on gfx9) — placed at the top of the next tile it waited for the stores the
+  // column pass had just issued, a full memory round trip per tile; here the youngest stores in the queue are a census and a row pass old.
   const int ybase = blockIdx.y * BP_TH * BP_STACK;
   prefetch(ybase);
+  stage();
+  __syncthreads();
   for(int t = 0; t < BP_STACK; ++t) {
     const int y0 = ybase + t * BP_TH;
     if(y0 >= R) break;
     if constexpr(FROM_IMAGE) {
-#pragma unroll
-      for(int k = 0; k < NPRE; ++k) {
-        const int i = tid + k * 256;
-        if(i < IR * IC) { const int ly = i / IC, lx = i - ly * IC; s_img[ly * IW + lx] = pre[k]; }
-      }
-      __syncthreads();
       // census of the staged positions: (gy, gx) = REFLECT_101 of the census coordinate, read from the image window
       for(int i = tid; i < CR * CC; i += 256) {
         const int ly = i / CC, lx = i - ly * CC;
@@ -527,15 +544,10 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
         }
         s_cen[ly * CW + lx] = spread_planes(out);
       }
-    } else {
-#pragma unroll
-      for(int k = 0; k < NPRE; ++k) {
-        const int i = tid + k * 256;
-        if(i < CR * CC) { const int ly = i / CC, lx = i - ly * CC; s_cen[ly * CW + lx] = spread_planes(pre[k]); }
-      }
+      __syncthreads();
     }
-    __syncthreads();
-    if(t + 1 < BP_STACK && y0 + BP_TH < R) prefetch(y0 + BP_TH);
+    const bool more = t + 1 < BP_STACK && y0 + BP_TH < R;
+    if(more) prefetch(y0 + BP_TH);
 
     // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
     for(int i = tid; i < CR * BP_TW; i += 256) {
@@ -557,6 +569,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       o[BP_PLANE + i] = make_float4(tt[4], tt[5], tt[6], tt[7]);
     }
     __syncthreads();
+    if(more) stage();
 
     // vertical pass.  A LANE PAIR per pixel: the even lane forms channels 0-3, the odd lane channels 4-7, so that every store instruction
     // of a wavefront covers 1 KB of contiguous records (32 pixels) instead of every other 16 bytes of 2 KB: the kernel runs at the rate of
