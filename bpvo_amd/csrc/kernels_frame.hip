@@ -432,14 +432,13 @@ __global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, 
 #define BP_TH_VALUE 8
 #endif
 constexpr int BP_TW = BP_TW_VALUE, BP_TH = BP_TH_VALUE, BP_HALO = 2;
-#ifndef BP_ROWS_PER_WG
-#define BP_ROWS_PER_WG 32
-#endif
-constexpr int BP_STACK = BP_ROWS_PER_WG / BP_TH;   // vertically adjacent tiles per workgroup
+// vertically adjacent tiles a workgroup walks (kernel argument `stack`): 8 (64 rows) for batches — the prologue of a workgroup, a memory
+// round trip nothing covers, is paid half as often: 11.35 -> 11.03 ms for the four levels of 2048 frames — and 4 for single frames, whose
+// 640x480 level 0 would otherwise be 80 workgroups on 256 CUs
 // row-pass results in LDS: one float4 plane per half (channels 0-3, 4-7) of (BP_TH + 4) rows x BP_TW columns; the second plane starts
 // 128 bytes out of phase with the first, so that the two lanes of a pixel (same position, different plane) hit different banks
 constexpr int BP_PLANE = (BP_TH + 2 * BP_HALO) * BP_TW + 8;
-// The workgroup walks BP_STACK vertically adjacent tiles; the census bytes of the next tile are fetched into registers
+// The workgroup walks `stack` vertically adjacent tiles; the census bytes of the next tile are fetched into registers
 // before the current tile's passes run, so the global-load latency is hidden behind the LDS/VALU work instead of being
 // exposed once per (short-lived) workgroup.
 // FROM_IMAGE (sigma_ct <= 0, the default): the census transform is fused in — the workgroup stages the u8 IMAGE tile with a
@@ -461,7 +460,7 @@ __device__ __forceinline__ uint2 spread_planes(unsigned c)
 }
 
 template <bool FROM_IMAGE>
-__global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2)
+__global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2, int stack)
 {
   constexpr int CR = BP_TH + 2 * BP_HALO, CC = BP_TW + 2 * BP_HALO;   // staged census rows / columns
   constexpr int CW = CC + 4;                                             // padded LDS row pitch of the census tile
@@ -522,11 +521,11 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   // its stores | barrier.  The staging sits BEFORE the stores on purpose: its wait for the loads is a wait for everything older in the
   // memory queue (one in-order counter for loads and stores on gfx9) — placed at the top of the next tile it waited for the stores the
   // column pass had just issued, a full memory round trip per tile; here the youngest stores in the queue are a census and a row pass old.
-  const int ybase = blockIdx.y * BP_TH * BP_STACK;
+  const int ybase = blockIdx.y * BP_TH * stack;
   prefetch(ybase);
   stage();
   __syncthreads();
-  for(int t = 0; t < BP_STACK; ++t) {
+  for(int t = 0; t < stack; ++t) {
     const int y0 = ybase + t * BP_TH;
     if(y0 >= R) break;
     if constexpr(FROM_IMAGE) {
@@ -546,7 +545,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
       }
       __syncthreads();
     }
-    const bool more = t + 1 < BP_STACK && y0 + BP_TH < R;
+    const bool more = t + 1 < stack && y0 + BP_TH < R;
     if(more) prefetch(y0 + BP_TH);
 
     // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
@@ -1423,11 +1422,12 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
 }
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image)
 {
-  const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * BP_STACK - 1) / (BP_TH * BP_STACK), nframes);
+  const int stack = nframes >= 16 ? 8 : 4;
+  const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * stack - 1) / (BP_TH * stack), nframes);
   if(sigma > 0.0f && from_image)
-    hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2]);
+    hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack);
   else if(sigma > 0.0f)
-    hipLaunchKernelGGL(bitplanes_blur_kernel<false>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2]);
+    hipLaunchKernelGGL(bitplanes_blur_kernel<false>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack);
   else
     hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
 }
