@@ -1020,12 +1020,13 @@ def test_scale_sequence_every_channel_count(hip, orc, descriptor, kw):
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans, sh, so)
 
 
-@pytest.mark.parametrize("n,lanes,team", [(70, "2", "0"), (40, "2", "1"), (33, "1", "0")])
+@pytest.mark.parametrize("n,lanes,team", [(70, "2", "0"), (40, "2", "1"), (33, "1", "0"), (530, "2", "0")])
 def test_host_buffer_batches_go_through_the_upload_pipeline_unchanged(hip, n, lanes, team, monkeypatch):
     """bpvo_hip_batch_run handed HOST buffers: batches of at least 32 pairs are staged in pinned chunks of 16 pairs by worker threads
     and uploaded on streams of their own while the lanes work on the chunks that have landed (B's disparity never crosses the bus).
     Same poses and statistics, bit for bit, as the batch with its inputs resident on the device and as the plain copies
-    (BPVO_HIP_UPLOAD_WORKERS=0) — with ragged chunk and lane boundaries, one lane, and the team kernel behind it."""
+    (BPVO_HIP_UPLOAD_WORKERS=0) — with ragged chunk and lane boundaries, one lane, the team kernel behind it, and (530 pairs) the
+    three-group upload plan of large batches with the lanes' job tables copied by a kernel."""
     import torch
     rows, cols, levels = 120, 160, 3
     batch = synth.make_batch(rows, cols, n, first_index=400, workers=8)
@@ -1074,3 +1075,24 @@ def test_current_frames_of_a_batch_keep_a_complete_descriptor(hip, orc):
         assert np.array_equal(ctx.get_point_indices(1, l), oc.get_point_indices(0, l))
         assert bits_equal(ctx.get_pixels(1, l), oc.get_pixels(0, l)) and bits_equal(ctx.get_saliency(1, l), oc.get_saliency(0, l))
     ctx.close(); oc.close()
+
+
+@pytest.mark.parametrize("rows,cols", [(33, 70), (64, 64), (65, 129), (200, 37), (97, 301)])
+@pytest.mark.parametrize("radius,nms_from", [(1, 1), (1, 10 ** 9), (2, 1)])
+def test_selection_on_odd_shapes(hip, orc, rows, cols, radius, nms_from):
+    """The tiled saliency + selection pass (NMS radius <= 1: 64 x 32 tiles, candidate bit words, word scan, full-wave compaction) and the
+    three-pass form it leaves to larger radii, on images narrower than a tile, one pixel wider than one, taller than wide: saliency,
+    point order, points and template pixels equal the oracle's at every level."""
+    d = synth.make_pair(rows, cols, 5)
+    kw = dict(levels=2, nonMaxSuppRadius=radius, minNumPixelsForNonMaximaSuppression=nms_from, minSaliency=0.05)
+    ch = hip.create(d["K"], d["b"], rows, cols, make_params(hip, **kw), n_frames=2, n_pairs=1)
+    co = orc.create(d["K"], d["b"], rows, cols, make_params(orc, **kw), n_frames=2, n_pairs=1)
+    for c in (ch, co):
+        c.frame_set_data(0, d["imgA"], d["dispA"])
+        c.frame_set_template(0)
+    for l in range(2):
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l)), l
+        assert ch.num_points(0, l) == co.num_points(0, l), (l, ch.num_points(0, l), co.num_points(0, l))
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l)), l
+        assert bits_equal(ch.get_points(0, l), co.get_points(0, l)) and bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)), l
+    ch.close(); co.close()
