@@ -1077,7 +1077,7 @@ def test_current_frames_of_a_batch_keep_a_complete_descriptor(hip, orc):
     ctx.close(); oc.close()
 
 
-@pytest.mark.parametrize("rows,cols", [(33, 70), (64, 64), (65, 129), (200, 37), (97, 301)])
+@pytest.mark.parametrize("rows,cols", [(33, 70), (64, 64), (65, 129), (200, 37), (97, 301), (16, 64), (24, 40)])
 @pytest.mark.parametrize("radius,nms_from", [(1, 1), (1, 10 ** 9), (2, 1)])
 def test_selection_on_odd_shapes(hip, orc, rows, cols, radius, nms_from):
     """The tiled saliency + selection pass (NMS radius <= 1: 64 x 32 tiles, candidate bit words, word scan, full-wave compaction) and the
