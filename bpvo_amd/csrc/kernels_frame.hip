@@ -918,7 +918,6 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
     }
   }
   __syncthreads();
-  float* __restrict__ sal_out = j.sal;
   for(int i = threadIdx.x; i < ST_S_ROWS * ST_S_PITCH; i += 256) {
     const int r = i / ST_S_PITCH, cc = i - r * ST_S_PITCH;
     if(cc >= ST_S_COLS) continue;
@@ -927,7 +926,6 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
     float S = fabsf(s_ch[r + 1][cc] - s_ch[r + 1][cc + 2]) + fabsf(s_ch[r][cc + 1] - s_ch[r + 2][cc + 1]);
     const bool inside = xx >= 0 && xx < W && y >= 0 && y < R;
     if(!(xx >= 4 && xx < n && xx != W - 1 && y >= 1 && y <= R - 2)) S = (inside && (xx < 4 || xx >= n)) ? saliency_generic<C>(j, xx, y) : 0.0f;
-    if(inside && r >= 1 && r <= ST_H && cc >= 1 && cc <= ST_W) sal_out[(size_t) y * W + xx] = S;
     s_sal[r][cc] = S;
   }
   __syncthreads();
@@ -968,6 +966,16 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
   }
   const int y = y0 + ry0 + lane;
   if(lane < ST_ROWS_PER_WAVE && y < R) j.words[(size_t) y * gridDim.x + blockIdx.x] = words;
+  // the saliency map itself (bpvo_hip_get_saliency), LAST: stores issued before the gate's loads would be waited for with them (one in-order
+  // counter for loads and stores), a memory round trip per tile
+  if(x < W) {
+    float* __restrict__ sal_out = j.sal;
+#pragma unroll
+    for(int q = 0; q < ST_ROWS_PER_WAVE; ++q) {
+      const int yy = y0 + ry0 + q;
+      if(yy < R) sal_out[(size_t) yy * W + x] = vrow[q + 1];
+    }
+  }
 }
 
 // exclusive scan of the words' popcounts in (y, x / 64) order; N = total & ~15 (the reference drops the LAST N mod 16 points)
@@ -1042,19 +1050,32 @@ __global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob*
   const int N = *j.n_out;
   const float fx = j.K[0], fy = j.K[4], cx = j.K[2], cy = j.K[5];
   const float Bf = j.b * fx;
-  for(int t = lane; t < total; t += 64) {
-    const int r = off + t;
-    if(r >= N) break;
-    int k = 0;
-    unsigned long long mk = m[0];
-    int first = 0;
+  // all disparities of the group first (at most SW_WORDS rounds of 64 set bits), then the arithmetic and the stores: a store issued
+  // before the next round's load would be waited for together with it
+  int px[SW_WORDS], py[SW_WORDS];
+  float dd[SW_WORDS];
 #pragma unroll
-    for(int q = 1; q < SW_WORDS; ++q)
-      if(t >= before[q]) { k = q; mk = m[q]; first = before[q]; }
-    const int bit = nth_set_bit(mk, t - first);
-    const int w = w0 + k;
-    const int y = w / WPR, x = (w - y * WPR) * 64 + bit;
-    const float d = j.disp[(size_t) (1 << j.level) * ((size_t) y * j.disp_cols + x)];
+  for(int it = 0; it < SW_WORDS; ++it) {
+    const int t = lane + 64 * it;
+    px[it] = -1; py[it] = 0; dd[it] = 1.0f;
+    if(t < total && off + t < N) {
+      int k = 0;
+      unsigned long long mk = m[0];
+      int first = 0;
+#pragma unroll
+      for(int q = 1; q < SW_WORDS; ++q)
+        if(t >= before[q]) { k = q; mk = m[q]; first = before[q]; }
+      const int bit = nth_set_bit(mk, t - first);
+      const int w = w0 + k;
+      py[it] = w / WPR; px[it] = (w - py[it] * WPR) * 64 + bit;
+      dd[it] = j.disp[(size_t) (1 << j.level) * ((size_t) py[it] * j.disp_cols + px[it])];
+    }
+  }
+#pragma unroll
+  for(int it = 0; it < SW_WORDS; ++it) {
+    if(px[it] < 0) continue;
+    const int r = off + lane + 64 * it, x = px[it], y = py[it];
+    const float d = dd[it];
     const float Z = (float) ((double) Bf * (1.0 / (double) d));
     const float X = ((float) x - cx) * Z * (1.0f / fx);
     const float Y = ((float) y - cy) * Z * (1.0f / fy);

@@ -262,6 +262,35 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
             at_iterate = at_stopped_pose(Th, o0, k, slack * ROT_TOL, slack * trans_tol(K))
             if together and genuine and at_iterate:
                 return "genuine-function-tol-stop"
+    # A GENUINE freeze of the robust scale on one side only (Q6: AutoScaleEstimator stops re-estimating for the rest of the level once
+    # |sigma - sigma_prev| <= 1e-6, bpvo/mestimator.cc:467-490).  In a slowly converging iteration sigma moves by ~1e-5 per step and two
+    # consecutive estimates come that close once in a while — for the GPU's iterates at one step, for the reference's (1e-7 rad away, the
+    # medians 1e-6 apart) at another or never; from there on the two sides minimise different objectives.  Accepted when (a) up to that step
+    # the GPU's iterates ARE the oracle's, (b) the decision is the reference's rule on exact values: the robust scales of the GPU's last two
+    # estimates equal, bit for bit, the oracle's fresh estimates at the GPU's own poses (an exact median of bit-identical residuals), and
+    # the rule fires on them exactly as the side that froze says.
+    if True:
+        _, _, trh = ch.estimate_pose_trace(0, 0, 1)
+        _, _, tro = co.estimate_pose_trace(0, 0, 1)
+        h0, o0 = trh[trh[:, 67] == first], tro[tro[:, 67] == first]
+
+        def freeze_step(t):      # first k with |sigma_k - sigma_(k-1)| <= 1e-6: sigma_k stays for the rest of the level
+            for k in range(1, len(t)):
+                if abs(np.float32(t[k, 59]) - np.float32(t[k - 1, 59])) <= np.float32(1e-6):
+                    return k
+            return None
+
+        kh, ko = freeze_step(h0), freeze_step(o0)
+        if kw.get("loss") != "l2" and kh != ko and (kh is not None or ko is not None):
+            k = min(v for v in (kh, ko) if v is not None)
+            if k < min(len(h0), len(o0)):
+                together = all(r_ <= 1e-6 and t_ <= 1e-2 * trans_tol(K) for r_, t_ in
+                               (pose_error(h0[i, :16].reshape(4, 4), o0[i, :16].reshape(4, 4)) for i in range(k + 1)))
+                fresh = [np.float32(co.linearize(0, 0, 1, first, h0[i, :16].reshape(4, 4), reset_scale=True)["sigma"]) for i in (k - 1, k)]
+                exact = all(fresh[i] == np.float32(h0[k - 1 + i, 59]) for i in (0, 1))
+                fires = abs(fresh[1] - fresh[0]) <= np.float32(1e-6)
+                if together and exact and fires == (kh == k):
+                    return "genuine-scale-freeze"
     assert near and abs(e_at - e_own) <= 2e-4 * abs(e_own), (
         "pose", rot, trans, "cpu-vs-cpu", rot8, trans8, "oracle restarted at the GPU pose", rot2, trans2, e_own, e_at,
         [s["status"] for s in sh], [s["status"] for s in so], [(s["status"], s["numIterations"]) for s in so2])
