@@ -176,7 +176,7 @@ def timed_batch_host(hip, torch, dev_index, batch, rows, cols, n, descriptor, le
     return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "ms_per_step": 1e3 * dt / steps,
             "vs_resident_inputs": (1e3 * dt / steps) / resident_ms if resident_ms else None,
             "upload": {"bytes_per_step": up_b, "seconds": up_s, "GBps": up_b / up_s / 1e9 if up_s > 0 else None,
-                       "note": "host memcpy into pinned chunks + H2D copies on 6 streams, wall time until the last chunk has landed; it runs under the compute of the chunks before it"},
+                       "note": "6 worker threads copy chunks of 16 pairs into pinned slots, H2D copies on one copy stream, wall time until the last chunk has landed; it runs under the compute of the chunks before it (three groups: 19 %, 50 %, 31 % of the pairs)"},
             "note": "pageable numpy buffers handed to bpvo_hip_batch_run; PCIe-inclusive — reported beside `value`, never as `value`"}
 
 
