@@ -868,8 +868,8 @@ __global__ __launch_bounds__(256) void select_write_kernel(const FrameJob* jobs)
 // treats differently, x < 4 and x >= W & ~3, go through the per-pixel functions), written out once (bpvo_hip_get_saliency) and
 // kept in LDS for the NMS windows.  A candidate flag is one BIT: a wavefront ballots the 64 pixels of a row segment into one 64-bit
 // word, words[(y * WPR + x / 64)], WPR = ceil(W / 64) — words in (y, x / 64) order are pixels in row-major order, the order of the
-// reference's scan.  select_words_scan_kernel turns the words' popcounts into exclusive offsets, select_words_write_kernel lets a
-// wavefront walk words with one lane per pixel: rank = offset + popcount(lower bits), consecutive ranks from consecutive lanes.
+// reference's scan.  select_words_scan_kernel turns the words' popcounts into exclusive offsets, select_words_write_kernel hands the
+// set bits of a group of words to the lanes of a wavefront 64 at a time: rank = offset of the group + index of the bit in the group.
 // Same values and order as the three-pass form above (which stays for radii > 1).
 constexpr int ST_W = 64, ST_H = 32, ST_ROWS_PER_WAVE = ST_H / 4;
 constexpr int ST_CH_ROWS = ST_H + 4, ST_CH_COLS = ST_W + 5, ST_CH_PITCH = 72;     // channel 0: rows y0-2 .. y0+H+1, columns x0-2 .. x0+W+2
