@@ -1284,7 +1284,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
       CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
     }
-    CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * nblk_max * kPartialStride));
+    // two buffers of tile partials (the persistent kernels double-buffer them by iteration parity, kernels_gn.hip pk_partials)
+    CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * (size_t) gn_partials_entries(cp->cap_max, cp->C) * kPartialStride));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));

@@ -137,6 +137,7 @@ int  gn_team_ctl_words(int n_teams);
 hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);
 int  gn_pts_per_block(int C);
+int  gn_partials_entries(int cap, int C);   // kPartialStride-float entries of a workspace's (double-buffered) tile partials
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records);

@@ -1,0 +1,667 @@
+// Persistent Gauss-Newton kernels (gfx950): a whole pyramid level of ONE pair (gn_persistent_kernel) or the whole Gauss-Newton stage
+// of a small BATCH (gn_team_kernel: a team of workgroups per pair) in one launch.  The phases call the device functions of the
+// four-kernel chain (gn_warp.h, gn_median.h, gn_irls.h, gn_step.h) with the chain's chunk and tile indices: bit-identical results.
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
+#include "gn_common.h"
+#include "gn_warp.h"
+#include "gn_median.h"
+#include "gn_irls.h"
+#include "gn_step.h"
+
+namespace bpvo_hip {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent Gauss-Newton kernel for SMALL groups (a single pair: sequential addFrame; up to kPersistMaxWs pairs): a whole
+// pyramid level — every linearisation, median, reduction, solve and pose update until the last workspace of the group has
+// finished — in ONE launch.  The four-kernel chain spends a single pair's iteration on four dependent launches of 5 - 9 us
+// each, every one of which re-reads the job and the state from HBM; here
+//   * the state of every workspace lives in LDS for the whole level, one copy per workgroup, all copies identical: the serial
+//     steps (robust scale, 6x6 solve, pose update, convergence tests) are executed REDUNDANTLY by every workgroup on its own
+//     copy — deterministic arithmetic on identical inputs — so nothing has to be broadcast and two of the four
+//     synchronisation points of an iteration disappear;
+//   * the two that remain (all residual chunks before the median, all tile partials before the solve) are grid barriers: one
+//     agent-scope release + arrive + poll + acquire per workgroup (guide: "barrier-counter"), a frozen robust scale needs only
+//     the second;
+//   * a 512-thread workgroup works as two 256-thread chunks of warp_residual / tiles of irls_reduce side by side, calling the
+//     very device functions of the four kernels (warp_point, bracket_chunk, median_block, irls_tile, gn_sum_partials,
+//     gn_serial_step) with the same chunk / tile indices, so every value — residuals, median, partials, their f64 sum — is
+//     bit-identical to the chain's.
+// Residency: the grid (at most kPersistMaxGrid workgroups, one per CU: 123 KB of LDS) is far below the chip's 256 CUs and the
+// launcher checks the occupancy query; should the workgroups still not become co-resident (another process holding the CUs), the
+// poll of a barrier gives up after `timeout` ticks of the 100 MHz wall clock, raises ctl[1] and every workgroup leaves WITHOUT
+// writing the states back — the host then reruns the group through the four-kernel chain (bpvo_hip.hip).  The GPU cannot hang.
+// 512 threads: two waves per SIMD, i.e. 256 VGPRs — a 1024-thread workgroup leaves 128, and the fused irls_tile (136 as a kernel)
+// then spills inside its point loop (measured: 23 us per iteration for that phase instead of 8)
+constexpr int PK_THREADS = 512;
+constexpr int PK_VB = PK_THREADS / 256;      // 256-thread chunks / tiles per workgroup
+static_assert(K6_BLOCK == 256 && GN_BLOCK == 256, "the persistent kernel's virtual blocks are 256 threads");
+static_assert(PK_THREADS / 64 >= kPersistMaxWs, "pk_step_phase: one wave per workspace");
+
+
+struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
+
+// The phases are separate NON-inlined functions: inlined into one body the compiler hoists every workspace's addresses and job
+// fields across all of them and spills hundreds of bytes per lane; as functions each gets its own register allocation.  Their
+// LDS is declared at namespace scope for that reason.
+constexpr int kStateWords = (int) (sizeof(GNState) / sizeof(uint32_t));
+__shared__ uint32_t pk_state[kPersistMaxWs][kStateWords];
+__shared__ float pk_sum[kPersistMaxWs][kPartialStride];
+__shared__ float pk_nrm[kPersistMaxWs][8];
+__shared__ SolveScratch pk_scratch[kPersistMaxWs];
+__shared__ BracketLds pk_br[PK_VB];
+__shared__ IrlsPartLds pk_part[PK_VB];
+__shared__ int pk_ok;
+__device__ __forceinline__ GNState* pk_st(int ws) { return reinterpret_cast<GNState*>(pk_state[ws]); }
+
+// warp_residual (+ bracket step) of workspace ws: chunk c goes to workgroup c % nwg, virtual block (c / nwg) % PK_VB
+template <int C>
+__device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const GNState* st = pk_st(ws);
+  const PairJob& j = jobs[ws];
+  const int n = j.n;
+  const int nchunks = (n + K6_BLOCK - 1) / K6_BLOCK;
+  float P[12];
+  projection_matrix(j, st->T, P);
+  const bool bracket = (st->delta_scale > 1e-6f) && st->median_valid;
+  const unsigned lo_key = st->lo_key, hi_key = st->hi_key;
+  if(stats_wg && tid == 0) j.cnt[4] += (unsigned long long) n;
+  for(int base = 0; base < nchunks; base += nwg * PK_VB) {
+    const int chunk = base + vsub * nwg + (int) blockIdx.x;
+    const bool has = chunk < nchunks;
+    const int i_raw = chunk * K6_BLOCK + vtid;
+    const bool in_block = has && i_raw < n;
+    const int i = in_block ? i_raw : n - 1;
+    float res[C];
+    bool hit;
+    const bool valid = warp_point<C, false, false, false>(j, P, i, in_block, res, hit);      // cached (not streaming) accesses
+    if(in_block) {
+      j.valid[i] = valid ? 1 : 0;
+      if constexpr(C == 8) {
+        float4* o = reinterpret_cast<float4*>(j.r.get());
+        o[tile_index<2>(i, 0)] = make_float4(res[0], res[1], res[2], res[3]);
+        o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
+      } else {
+#pragma unroll
+        for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
+      }
+    }
+    if(bracket) bracket_chunk<C>(j, lo_key, hi_key, valid && in_block, hit && valid && in_block, res, (unsigned) chunk, vtid >> 6, pk_br[vsub], has);
+  }
+}
+
+// The same phase for the TEAM kernel (C = 8), where all CUs of the chip run teams at once and a memory round trip takes 2 - 3 us instead
+// of under one: with one point per thread the phase is a chain of dependent round trips (point -> projection -> key -> taps) at 8 waves
+// per CU, and it stretched from 28 to 80 - 110 us per iteration at the finest level of a 128-pair batch
+// (profiles/r03_team_phases_under_load_before.txt).  Here a thread carries U points — one from each of U chunks — through the phase in
+// stages: everything whose address depends on the point index only (point, tap-cache key, the eight cached tap vectors, template pixels) is
+// requested for all U points at once, then the U projections, then the gathers of the misses (at dense levels, which run without the
+// cache: of all points) for all U at once.  Same expressions as warp_point, operation for operation: same bits.  The cached taps are loaded
+// speculatively, as irls_tile_lat does (3 % of them are discarded at the sparse levels).
+struct WarpStage {
+  float4 X, t[8], px[2];
+  double xf, yf;
+  unsigned key;
+  int i, xi, yi, chunk;
+  bool has, in_block, valid, hit;
+};
+__shared__ BracketLds pk_br_u[PK_VB][4];
+template <int U, bool NT>
+__device__ __attribute__((noinline)) void pk_warp_phase_staged(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  static_assert(U >= 1 && U <= 4, "pk_br_u");
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const GNState* st = pk_st(ws);
+  const PairJob& j = jobs[ws];
+  const int n = j.n, W = j.cols, R = j.rows;
+  const int nchunks = (n + K6_BLOCK - 1) / K6_BLOCK;
+  float P[12];
+  projection_matrix(j, st->T, P);
+  const bool bracket = (st->delta_scale > 1e-6f) && st->median_valid;
+  const unsigned lo_key = st->lo_key, hi_key = st->hi_key;
+  const bool cached = j.tapcache_on != 0;
+  float4* const tc = reinterpret_cast<float4*>(j.tapcache.get());
+  const float4* const p0 = reinterpret_cast<const float4*>(j.pix.get());
+  if(stats_wg && tid == 0) j.cnt[4] += (unsigned long long) n;
+  for(int base = 0; base < nchunks; base += nwg * PK_VB * U) {
+    WarpStage s[U];
+    // stage A: everything addressed by the point index
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      s[u].chunk = base + (u * PK_VB + vsub) * nwg + (int) blockIdx.x;
+      s[u].has = s[u].chunk < nchunks;
+      const int i_raw = s[u].chunk * K6_BLOCK + vtid;
+      s[u].in_block = s[u].has && i_raw < n;
+      const int i = s[u].in_block ? i_raw : n - 1;
+      s[u].i = i;
+      s[u].X = load_v4<NT>(j.pts + i);
+      s[u].px[0] = load_v4<NT>(p0 + tile_index<2>(i, 0));
+      s[u].px[1] = load_v4<NT>(p0 + tile_index<2>(i, 1));
+      if(cached) {
+        s[u].key = j.tapkey[i];
+#pragma unroll
+        for(int k = 0; k < 8; ++k) s[u].t[k] = load_v4<NT>(tc + tile_index<8>(i, k));
+      } else {
+        s[u].key = 0xffffffffu;
+      }
+    }
+    // stage B: projection, validity (warp_point), and the gathers of the footprints the cache does not hold
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      const float4 X = s[u].X;
+      const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
+      double uu[3];
+#pragma unroll
+      for(int r = 0; r < 3; ++r) {
+        double a = (double) P[r * 4 + 0] * X0;
+        a += (double) P[r * 4 + 1] * X1;
+        a += (double) P[r * 4 + 2] * X2;
+        a += (double) P[r * 4 + 3] * X3;
+        uu[r] = a;
+      }
+      const double zi = 1.0 / uu[2];
+      const double x = zi * uu[0], y = zi * uu[1];
+      const bool in_range = (x > -2147483648.0) && (x < 2147483648.0) && (y > -2147483648.0) && (y < 2147483648.0);
+      int xi = 0, yi = 0;
+      if(in_range) {
+        xi = (int) x; xi -= (xi > x);
+        yi = (int) y; yi -= (yi > y);
+      }
+      s[u].valid = in_range && xi >= 0 && xi < W - 1 && yi >= 0 && yi < R - 1;
+      s[u].xi = xi; s[u].yi = yi;
+      s[u].xf = x - (double) xi; s[u].yf = y - (double) yi;
+      const unsigned key = ((unsigned) yi << 16) | (unsigned) xi;
+      s[u].hit = s[u].valid && cached && s[u].key == key;
+      s[u].key = key;
+      if(s[u].valid && !s[u].hit) {
+        const float4* q0 = reinterpret_cast<const float4*>(j.desc + ((size_t) yi * W + xi) * 8);
+        const float4* q1 = q0 + (size_t) W * 2;
+        s[u].t[0] = q0[0]; s[u].t[1] = q0[1]; s[u].t[2] = q0[2]; s[u].t[3] = q0[3];
+        s[u].t[4] = q1[0]; s[u].t[5] = q1[1]; s[u].t[6] = q1[2]; s[u].t[7] = q1[3];
+      }
+    }
+    // stage C: residuals, stores, cache update, bracket step
+#pragma unroll
+    for(int u = 0; u < U; ++u) {
+      const int i = s[u].i;
+      float res[8];
+      if(s[u].valid) {
+        const double xf = s[u].xf, yf = s[u].yf, wx = 1.0 - xf, wy = 1.0 - yf;
+        const float4* t = s[u].t;
+        // pieces 0, 1: I00 of channels 0-3 / 4-7; 2, 3: I01; 4, 5: I10; 6, 7: I11 (warp_point)
+        const float i00[8] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w};
+        const float i01[8] = {t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, t[3].z, t[3].w};
+        const float i10[8] = {t[4].x, t[4].y, t[4].z, t[4].w, t[5].x, t[5].y, t[5].z, t[5].w};
+        const float i11[8] = {t[6].x, t[6].y, t[6].z, t[6].w, t[7].x, t[7].y, t[7].z, t[7].w};
+        const float i0[8] = {s[u].px[0].x, s[u].px[0].y, s[u].px[0].z, s[u].px[0].w, s[u].px[1].x, s[u].px[1].y, s[u].px[1].z, s[u].px[1].w};
+#pragma unroll
+        for(int c = 0; c < 8; ++c) {
+          const double Iw = wy * ((double) i00[c] * wx + (double) i01[c] * xf) + yf * ((double) i10[c] * wx + (double) i11[c] * xf);
+          res[c] = (float) (Iw - (double) i0[c]);
+        }
+        if(!s[u].hit && s[u].in_block && cached) {
+#pragma unroll
+          for(int k = 0; k < 8; ++k) store_v4<NT>(tc + tile_index<8>(i, k), t[k]);
+          j.tapkey[i] = s[u].key;
+        }
+      } else {
+#pragma unroll
+        for(int c = 0; c < 8; ++c) res[c] = 0.0f;
+      }
+      if(s[u].in_block) {
+        j.valid[i] = s[u].valid ? 1 : 0;
+        float4* o = reinterpret_cast<float4*>(j.r.get());
+        store_v4<NT>(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
+        store_v4<NT>(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
+      }
+      if(bracket)
+        bracket_chunk<8>(j, lo_key, hi_key, s[u].valid && s[u].in_block, s[u].hit && s[u].valid && s[u].in_block, res, (unsigned) s[u].chunk, vtid >> 6,
+                         pk_br_u[vsub][u], s[u].has);
+    }
+  }
+}
+
+template <int C>
+__device__ __attribute__((noinline)) void pk_median_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];     // median_block's histograms and key cache
+  median_block<C, PK_THREADS>(jobs[ws], pk_st(ws), smem_raw, stats_wg);
+  __syncthreads();
+}
+
+// irls_reduce of workspace ws: tile t goes to workgroup t % nwg, virtual block (t / nwg) % PK_VB
+// (inlined into the kernel, unlike the other phases: as a function it uses all 256 VGPRs and would save and restore ~110
+// callee-saved registers per call through scratch — 250 KB per workgroup each way: measured 12.6 instead of 9.2 us per iteration.
+// Splitting a tile's points over the workgroup's two virtual blocks, contributions exchanged through LDS and added in point
+// order, was measured as well: 10.2 us — the exchange costs more than the halved arithmetic saves.)
+// The tile partials are DOUBLE-BUFFERED by iteration parity.  An iteration whose active workspaces all have a frozen scale (fused
+// path) or a moot one (kL2) has no warp / median phase and hence no grid barrier between the step of iteration k and the reduction
+// of iteration k + 1: a workgroup that finishes its step early would overwrite partials a slower workgroup is still summing (every
+// workgroup sums all tiles for its own copy of the state).  With two buffers the writes of iteration k + 1 go to the other one; the
+// buffer of iteration k is written again in iteration k + 2 at the earliest, i.e. after the barrier of iteration k + 1, which every
+// workgroup only reaches after its step of iteration k.  The second buffer starts right behind the ntiles entries of the first (the
+// allocation holds gn_partials_entries() = 2 * ceil(cap / pts_per_block) entries).
+__device__ __forceinline__ float* pk_partials(const PairJob& j, int pts_per_block, unsigned parity)
+{
+  const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
+  return j.partials + (size_t) (parity & 1u) * (size_t) ntiles * kPartialStride;
+}
+template <int C, int LOSS, bool FUSED>
+__device__ __forceinline__ void pk_irls_phase(const PairJob* __restrict__ jobs, int ws, int pts_per_block, unsigned parity)
+{
+  const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
+  const int nwg = (int) gridDim.x;
+  const PairJob& j = jobs[ws];
+  const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
+  float* const partials = pk_partials(j, pts_per_block, parity);
+  for(int base = 0; base < ntiles; base += nwg * PK_VB) {
+    const int tile = base + vsub * nwg + (int) blockIdx.x;
+    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
+    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
+    __syncthreads();
+  }
+}
+
+// gn_step: wave w sums the partials of workspace w, its lane 0 runs the serial step on this workgroup's copy of the state
+__device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm, int fuse, bool stats_wg,
+                                                        unsigned parity)
+{
+  const int ws = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool mine = ws < nws && pk_st(ws < nws ? ws : 0)->active;
+#ifdef BPVO_PK_TIMING
+  long long sub_t = wall_clock64();
+#endif
+  if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws], pk_partials(jobs[ws], pts_per_block, parity));
+  __syncthreads();
+#ifdef BPVO_PK_TIMING
+  if(threadIdx.x == 0) GN_SUBTICK(4);
+#endif
+  if(mine && lane == 0)
+    gn_serial_step(jobs[ws], pk_st(ws), pk_nrm[ws], pk_sum[ws], &pk_scratch[ws], 0, prm.max_iterations, prm.max_fun_evals, prm.p_tol, prm.f_tol,
+                   prm.g_tol, fuse, stats_wg);
+  __syncthreads();
+}
+
+// returns false when the barrier gave up (timeout, or another workgroup's abort)
+__device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigned epoch, long long timeout)
+{
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned target = epoch * gridDim.x;
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while(__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 63u) == 0u || timeout < 64) {     // (tiny budgets: the tests of this path)
+        if(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pk_ok = ok;
+  }
+  __syncthreads();
+  return pk_ok != 0;
+}
+
+template <int C, int LOSS>
+__global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm,
+                                                                   int fuse_frozen, unsigned* ctl, long long timeout)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  const bool stats_wg = blockIdx.x == 0;
+  const bool fuse = kCanFuse && fuse_frozen;
+
+  for(int ws = 0; ws < nws; ++ws) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs[ws].st.get());
+    for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[ws][i] = g[i];
+    if(tid < 4) pk_nrm[ws][tid] = jobs[ws].nrm[tid];
+    if(tid == 4) pk_nrm[ws][4] = jobs[ws].dspace ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+
+  unsigned epoch = 0, epoch_it = 0;     // grid barriers passed; iterations done (parity of the partials buffer)
+  bool ok = true;
+  // BPVO_PK_TIMING: workgroup 0 accumulates the 100 MHz wall-clock ticks of every phase in ctl[8..13] and the iterations in ctl[15]
+#ifdef BPVO_PK_TIMING
+  long long tk = wall_clock64();
+  unsigned acc_t[6] = {0, 0, 0, 0, 0, 0}, iters = 0;
+  if(tid < 8) pk_sub[tid] = 0;
+  __syncthreads();
+#define PK_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[k] += (unsigned) (t_ - tk); tk = t_; } while(0)
+#else
+#define PK_TICK(k) do { } while(0)
+#endif
+  for(;;) {
+    // who does what in this iteration: the same answer in every workgroup (identical state copies)
+    bool any_active = false, any_warp = false;
+    for(int ws = 0; ws < nws; ++ws) {
+      const GNState* st = pk_st(ws);
+      if(!st->active) continue;
+      any_active = true;
+      if(!fuse || st->delta_scale > 1e-6f) any_warp = true;
+    }
+    if(!any_active) break;
+#ifdef BPVO_PK_TIMING
+    tk = wall_clock64(); ++iters;
+#endif
+
+    if(any_warp) {
+      // warp_residual of the workspaces whose robust scale still moves (all of them without the fused path) ...
+      for(int ws = 0; ws < nws; ++ws) {
+        const GNState* st = pk_st(ws);
+        if(st->active && (!fuse || st->delta_scale > 1e-6f)) pk_warp_phase<C>(jobs, ws, stats_wg);
+      }
+      PK_TICK(0);
+      ok = pk_grid_barrier(ctl, ++epoch, timeout);
+      PK_TICK(1);
+      if(!ok) break;
+      // ... and their exact median + robust scale, every workgroup on its own copy of the state
+      for(int ws = 0; ws < nws; ++ws) {
+        const GNState* st = pk_st(ws);
+        if(st->active && st->delta_scale > 1e-6f) pk_median_phase<C>(jobs, ws, stats_wg);
+      }
+      PK_TICK(2);
+    }
+    // weights + normal equations per tile (frozen scale with the fused path: residuals recomputed there)
+    for(int ws = 0; ws < nws; ++ws) {
+      const GNState* st = pk_st(ws);
+      if(!st->active) continue;
+      if constexpr(kCanFuse) {
+        if(fuse && !(st->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, ws, pts_per_block, epoch_it);
+        else pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block, epoch_it);
+      } else {
+        pk_irls_phase<C, LOSS, false>(jobs, ws, pts_per_block, epoch_it);
+      }
+    }
+    PK_TICK(3);
+    ok = pk_grid_barrier(ctl, ++epoch, timeout);
+    PK_TICK(4);
+    if(!ok) break;
+    pk_step_phase(jobs, nws, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
+    PK_TICK(5);
+    ++epoch_it;
+  }
+#ifdef BPVO_PK_TIMING
+  if(blockIdx.x == 0 && tid == 0) {
+    for(int k = 0; k < 6; ++k) ctl[8 + k] = acc_t[k];
+    ctl[15] = iters;
+    for(int k = 0; k < 5; ++k) ctl[16 + k] = pk_sub[k];
+  }
+#endif
+
+  if(ok && blockIdx.x == 0) {
+    for(int ws = 0; ws < nws; ++ws) {
+      uint32_t* g = reinterpret_cast<uint32_t*>(jobs[ws].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[ws][i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// TEAM-persistent Gauss-Newton kernel for small BATCHES (2 .. 64 pairs).
+// The four-kernel chain pays a floor per launch (ramp, drain, the list -> job -> state chain of dependent loads: ~10 us) that a
+// 1024-pair batch amortises and a 128-pair batch does not: 4 launches x ~220 iterations x 10 us is a third of its Gauss-Newton time,
+// and every level lasts as long as its slowest pair (profiles/r02_pipe/, profiles/r03_persistent_grid_probe.txt).  Here the
+// workgroups of the grid form TEAMS, blockIdx.y = team, gridDim.x = workgroups per team (one per CU, all teams co-resident: the launcher
+// sizes the grid to the CUs).  A team runs ONE pair at a time through ALL its pyramid levels and all their iterations with the
+// phases of gn_persistent_kernel — the same device functions, chunk and tile indices as the chain, so every value is
+// bit-identical — synchronised by barriers of its own (a counter per team): no launch between iterations, no host round trip
+// between levels, no pair ever waits for another.  Pairs are handed out dynamically (one agent-scope counter), so a batch larger
+// than the number of teams balances itself.  Teams desynchronise, which is the point: the memory-bound phases of some overlap the
+// latency-bound ones (median, solve) of others.
+// Barrier that cannot complete (teams not co-resident): the poll gives up after `timeout`, raises the abort word and every workgroup
+// leaves; the host reruns the group on the chain, as for gn_persistent_kernel.
+#ifndef TEAM_WARP_U_VALUE
+#define TEAM_WARP_U_VALUE 2
+#endif
+#ifndef TEAM_NT_VALUE
+#define TEAM_NT_VALUE 0
+#endif
+constexpr bool TEAM_NT = TEAM_NT_VALUE != 0;        // streaming (non-temporal) accesses in the team kernel's warp phase
+constexpr int TEAM_WARP_U = TEAM_WARP_U_VALUE;      // points a thread of the team kernel's warp phase carries at once
+constexpr int kTeamCtlWords = 32;       // one 128-byte line per team: [0] arrivals, [1] next pair broadcast slot; global line 0: [1] abort, [2] next pair
+__shared__ int pk_next_pair;
+
+__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout)
+{
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned target = epoch * gridDim.x;
+    __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while(__hip_atomic_load(team_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 63u) == 0u || timeout < 64) {
+        if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pk_ok = ok;
+  }
+  __syncthreads();
+  return pk_ok != 0;
+}
+
+// PoseEstimatorBase::reset + the head of run() on this workgroup's LDS copy (level_begin_kernel's body), and this workgroup's share
+// of the tap-cache keys of the level
+__device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int scale_is_moot)
+{
+  const int nthreads_team = (int) gridDim.x * PK_THREADS;
+  if(j.tapkey)
+    for(int i = (int) blockIdx.x * PK_THREADS + (int) threadIdx.x; i < j.n; i += nthreads_team) j.tapkey[i] = 0xffffffffu;
+  if(threadIdx.x < 4) pk_nrm[0][threadIdx.x] = j.nrm[threadIdx.x];
+  if(threadIdx.x == 4) pk_nrm[0][4] = j.dspace ? 1.0f : 0.0f;
+  if(threadIdx.x == 0) {
+    GNState* st = pk_st(0);
+    st->scale = 1.0f;
+    st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
+    st->f_norm_prev = 0.0f;
+    st->g_tol = 0.0f;
+    st->g_norm = 0.0f;
+    st->num_fun_evals = 0;
+    st->num_iterations = 0;
+    st->status = BPVO_STATUS_MAX_ITERATIONS;
+    st->phase = PHASE_FIRST;
+    st->has_converged = 0;
+    st->level = level;
+    st->median_valid = 0;
+    st->last_median = 0.0f;
+    for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
+    for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
+    st->active = (j.n > 0) ? 1 : 0;
+  }
+}
+
+template <int C, int LOSS>
+__global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
+                                                             int level_hi, int level_lo, int pts_per_block, GNParams prm, int fuse_frozen,
+                                                             int scale_is_moot, unsigned* ctl, long long timeout)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  const bool stats_wg = blockIdx.x == 0;
+  const bool fuse = kCanFuse && fuse_frozen;
+  unsigned* const global_ctl = ctl;                                           // [1] abort, [2] next pair to hand out
+  unsigned* const team_ctl = ctl + (size_t) (1 + blockIdx.y) * kTeamCtlWords; // [0] arrivals, [1] pair slot
+  unsigned epoch = 0, epoch_it = 0;
+  // BPVO_PK_TIMING: workgroup 0 of team 0 accumulates the 100 MHz ticks of its phases, per pyramid level, in ctl[4 .. 31]: 7 words per level
+  // {warp, barrier1, median, irls, barrier2, step, iterations}
+#ifdef BPVO_PK_TIMING
+  long long tk = wall_clock64();
+  unsigned acc_t[kMaxLevels][7];
+  for(int l = 0; l < kMaxLevels; ++l) for(int k = 0; k < 7; ++k) acc_t[l][k] = 0;
+#define TEAM_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[level][k] += (unsigned) (t_ - tk); tk = t_; } while(0)
+#else
+#define TEAM_TICK(k) do { } while(0)
+#endif
+
+  for(;;) {
+    // next pair of this team: its workgroup 0 draws, the barrier publishes the draw to the others
+    // (every workgroup reads the slot right after this barrier and before it arrives at the next one, which the drawing workgroup
+    // must pass before it can draw again: one slot is enough)
+    if(stats_wg && tid == 0) {
+      const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+    if(tid == 0) pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int pair = pk_next_pair;
+    if(pair >= n_pairs) return;
+
+    {   // the pair's state: HBM -> this workgroup's LDS copy (set_pose_kernel has run: T_out, statistics defaults)
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[0][i] = g[i];
+    }
+    __syncthreads();
+
+    for(int level = level_hi; level >= level_lo; --level) {
+      const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
+      pk_level_begin(jobs[0], level, scale_is_moot);
+      if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;         // keys reset before any phase reads them
+      for(;;) {
+        const GNState* st = pk_st(0);
+        if(!st->active) break;
+        const bool moving = st->delta_scale > 1e-6f;
+#ifdef BPVO_PK_TIMING
+        tk = wall_clock64(); acc_t[level][6] += 1;
+#endif
+        if(!fuse || moving) {
+          if constexpr(C == 8) pk_warp_phase_staged<TEAM_WARP_U, TEAM_NT>(jobs, 0, stats_wg);
+          else pk_warp_phase<C>(jobs, 0, stats_wg);
+          TEAM_TICK(0);
+          if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+          TEAM_TICK(1);
+          if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
+          TEAM_TICK(2);
+        }
+        if constexpr(kCanFuse) {
+          if(fuse && !(pk_st(0)->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, 0, pts_per_block, epoch_it);   // (after the median: the chain's rule)
+          else pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+        } else {
+          pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+        }
+        TEAM_TICK(3);
+        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+        TEAM_TICK(4);
+        pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
+        TEAM_TICK(5);
+        ++epoch_it;
+      }
+    }
+#ifdef BPVO_PK_TIMING
+    if(blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+      for(int l = 0; l < 4; ++l) for(int k = 0; k < 7; ++k) global_ctl[4 + l * 7 + k] += acc_t[l][k];      // words 4 .. 31 of the global line, summed over the team's pairs
+#endif
+    // the pair is done: its state back to HBM (one copy; the others are identical)
+    if(stats_wg) {
+      uint32_t* g = reinterpret_cast<uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[0][i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- persistent kernel for small groups
+bool gn_persistent_serves(const GNLaunch& g)
+{
+  return (g.C == 8 || g.C == 1) && g.interp == BPVO_INTERP_LINEAR && !g.fast_warp && g.npairs >= 1 && g.npairs <= kPersistMaxWs && !g.active.list;
+}
+int gn_persistent_grid(const GNLaunch& g, int max_grid)
+{
+  const int chunks = (g.max_points + K6_BLOCK - 1) / K6_BLOCK;
+  return std::max(1, std::min(max_grid, (chunks + PK_VB - 1) / PK_VB));
+}
+template <int C>
+static hipError_t launch_gn_persistent_c(hipStream_t s, const GNLaunch& g, const GNParams& prm, unsigned* ctl, int grid, long long timeout)
+{
+  const int ppb = gn_pts_per_block(C);
+  const int fuse = (C == 8 && g.fuse_frozen) ? 1 : 0;
+  auto go = [&](auto kern) -> hipError_t {
+    // once per kernel and device (the lanes' host threads may race here): the opt-in for the 123 KB of median_block's LDS and the
+    // residency check — one workgroup per CU must fit, the grid itself (<= 128) is far below the number of CUs
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev &= 63;
+    std::call_once(once[dev], [&] {
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      int per_cu = 0;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, kMedianLds);
+      if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
+    });
+    if(status[dev] != hipSuccess) return status[dev];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PK_THREADS), kMedianLds, s, g.jobs, g.npairs, ppb, prm, fuse, ctl, timeout);
+    return hipGetLastError();
+  };
+  switch(g.loss) {
+    case BPVO_LOSS_HUBER: return go(gn_persistent_kernel<C, BPVO_LOSS_HUBER>);
+    case BPVO_LOSS_TUKEY: return go(gn_persistent_kernel<C, BPVO_LOSS_TUKEY>);
+    default: return go(gn_persistent_kernel<C, BPVO_LOSS_L2>);
+  }
+}
+hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol,
+                                unsigned* ctl, int grid, long long timeout_ticks)
+{
+  if(g.max_points <= 0) return hipSuccess;
+  GNParams prm;
+  prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
+  if(g.C == 8) return launch_gn_persistent_c<8>(s, g, prm, ctl, grid, timeout_ticks);
+  return launch_gn_persistent_c<1>(s, g, prm, ctl, grid, timeout_ticks);
+}
+// ---- team-persistent kernel for small batches
+int gn_team_ctl_words(int n_teams) { return (1 + n_teams) * kTeamCtlWords; }
+template <int C>
+static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const GNParams& prm)
+{
+  const int ppb = gn_pts_per_block(C);
+  const int fuse = (C == 8 && t.fuse_frozen) ? 1 : 0;
+  auto go = [&](auto kern) -> hipError_t {
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev &= 63;
+    std::call_once(once[dev], [&] {
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      int per_cu = 0;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, kMedianLds);
+      if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
+    });
+    if(status[dev] != hipSuccess) return status[dev];
+    hipLaunchKernelGGL(kern, dim3(t.team_size, t.n_teams), dim3(PK_THREADS), kMedianLds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.level_hi, t.level_lo, ppb,
+                       prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks);
+    return hipGetLastError();
+  };
+  switch(t.loss) {
+    case BPVO_LOSS_HUBER: return go(gn_team_kernel<C, BPVO_LOSS_HUBER>);
+    case BPVO_LOSS_TUKEY: return go(gn_team_kernel<C, BPVO_LOSS_TUKEY>);
+    default: return go(gn_team_kernel<C, BPVO_LOSS_L2>);
+  }
+}
+hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol)
+{
+  GNParams prm;
+  prm.max_iterations = max_iterations; prm.max_fun_evals = max_fun_evals; prm.p_tol = p_tol; prm.f_tol = f_tol; prm.g_tol = g_tol;
+  if(t.C == 8) return launch_gn_team_c<8>(s, t, prm);
+  return launch_gn_team_c<1>(s, t, prm);
+}
+}  // namespace bpvo_hip
