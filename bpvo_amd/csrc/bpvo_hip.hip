@@ -737,10 +737,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
     t.scale_is_moot = (p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen) ? 1 : 0;
     // one workgroup per CU: teams of CUs / pairs workgroups (at most 64: the single-pair kernel's size), as many teams as fit
-    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(64, c->num_cus / n));
-    ts = std::max(1, std::min(ts, c->num_cus));
+    const int slots = c->num_cus;
+    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(64, slots / n));
+    ts = std::max(1, std::min(ts, slots));
     t.team_size = ts;
-    t.n_teams = std::max(1, std::min(std::min(n, c->num_cus / ts), kMaxTeams));
+    t.n_teams = std::max(1, std::min(std::min(n, slots / ts), kMaxTeams));
     t.ctl = ln->d_team_ctl;
     t.timeout_ticks = c->persist_timeout;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));

@@ -54,6 +54,9 @@ __shared__ SolveScratch pk_scratch[kPersistMaxWs];
 __shared__ BracketLds pk_br[PK_VB];
 __shared__ IrlsPartLds pk_part[PK_VB];
 __shared__ int pk_ok;
+// this workgroup's place in its group: member index and number of workgroups that share a pair's chunks / tiles and meet at its
+// barriers (gn_persistent_kernel: blockIdx.x of gridDim.x; gn_team_kernel: see team_geometry)
+__shared__ int pk_member, pk_nwg;
 __device__ __forceinline__ GNState* pk_st(int ws) { return reinterpret_cast<GNState*>(pk_state[ws]); }
 
 // warp_residual (+ bracket step) of workspace ws: chunk c goes to workgroup c % nwg, virtual block (c / nwg) % PK_VB
@@ -61,7 +64,7 @@ template <int C>
 __device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restrict__ jobs, int ws, bool stats_wg)
 {
   const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
-  const int nwg = (int) gridDim.x;
+  const int nwg = pk_nwg;
   const GNState* st = pk_st(ws);
   const PairJob& j = jobs[ws];
   const int n = j.n;
@@ -72,7 +75,7 @@ __device__ __attribute__((noinline)) void pk_warp_phase(const PairJob* __restric
   const unsigned lo_key = st->lo_key, hi_key = st->hi_key;
   if(stats_wg && tid == 0) j.cnt[4] += (unsigned long long) n;
   for(int base = 0; base < nchunks; base += nwg * PK_VB) {
-    const int chunk = base + vsub * nwg + (int) blockIdx.x;
+    const int chunk = base + vsub * nwg + pk_member;
     const bool has = chunk < nchunks;
     const int i_raw = chunk * K6_BLOCK + vtid;
     const bool in_block = has && i_raw < n;
@@ -116,7 +119,7 @@ __device__ __attribute__((noinline)) void pk_warp_phase_staged(const PairJob* __
 {
   static_assert(U >= 1 && U <= 4, "pk_br_u");
   const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
-  const int nwg = (int) gridDim.x;
+  const int nwg = pk_nwg;
   const GNState* st = pk_st(ws);
   const PairJob& j = jobs[ws];
   const int n = j.n, W = j.cols, R = j.rows;
@@ -134,7 +137,7 @@ __device__ __attribute__((noinline)) void pk_warp_phase_staged(const PairJob* __
     // stage A: everything addressed by the point index
 #pragma unroll
     for(int u = 0; u < U; ++u) {
-      s[u].chunk = base + (u * PK_VB + vsub) * nwg + (int) blockIdx.x;
+      s[u].chunk = base + (u * PK_VB + vsub) * nwg + pk_member;
       s[u].has = s[u].chunk < nchunks;
       const int i_raw = s[u].chunk * K6_BLOCK + vtid;
       s[u].in_block = s[u].has && i_raw < n;
@@ -256,12 +259,12 @@ template <int C, int LOSS, bool FUSED>
 __device__ __forceinline__ void pk_irls_phase(const PairJob* __restrict__ jobs, int ws, int pts_per_block, unsigned parity)
 {
   const int tid = threadIdx.x, vsub = tid >> 8, vtid = tid & 255;
-  const int nwg = (int) gridDim.x;
+  const int nwg = pk_nwg;
   const PairJob& j = jobs[ws];
   const int ntiles = (j.n + pts_per_block - 1) / pts_per_block;
   float* const partials = pk_partials(j, pts_per_block, parity);
   for(int base = 0; base < ntiles; base += nwg * PK_VB) {
-    const int tile = base + vsub * nwg + (int) blockIdx.x;
+    const int tile = base + vsub * nwg + pk_member;
     if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
     else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
     __syncthreads();
@@ -295,7 +298,7 @@ __device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigne
   if(threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned target = epoch * gridDim.x;
+    const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     int ok = 1;
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
   const int tid = threadIdx.x;
   const bool stats_wg = blockIdx.x == 0;
   const bool fuse = kCanFuse && fuse_frozen;
+  if(tid == 0) { pk_member = (int) blockIdx.x; pk_nwg = (int) gridDim.x; }
 
   for(int ws = 0; ws < nws; ++ws) {
     const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs[ws].st.get());
@@ -440,7 +444,7 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
   if(threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned target = epoch * gridDim.x;
+    const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long t0 = wall_clock64();
     int ok = 1;
@@ -463,9 +467,9 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
 // of the tap-cache keys of the level
 __device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int scale_is_moot)
 {
-  const int nthreads_team = (int) gridDim.x * PK_THREADS;
+  const int nthreads_team = pk_nwg * PK_THREADS;
   if(j.tapkey)
-    for(int i = (int) blockIdx.x * PK_THREADS + (int) threadIdx.x; i < j.n; i += nthreads_team) j.tapkey[i] = 0xffffffffu;
+    for(int i = pk_member * PK_THREADS + (int) threadIdx.x; i < j.n; i += nthreads_team) j.tapkey[i] = 0xffffffffu;
   if(threadIdx.x < 4) pk_nrm[0][threadIdx.x] = j.nrm[threadIdx.x];
   if(threadIdx.x == 4) pk_nrm[0][4] = j.dspace ? 1.0f : 0.0f;
   if(threadIdx.x == 0) {
@@ -489,17 +493,35 @@ __device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int 
   }
 }
 
+// Grid: 1-D, n_teams * team_size workgroups.  Workgroups are dealt to the XCDs round robin by their linear index (guide: block b runs on
+// XCD b % 8 — observed, for speed only); when the teams divide evenly over the 8 XCDs a team's workgroups are taken from ONE XCD so that
+// the pair's taps, residuals and partials stay in that XCD's L2 between phases.  Any mapping is correct (the barriers are agent-scope).
+// (A WIDE form of this kernel — every phase under 128 VGPRs and 68 KB of LDS, two workgroups per CU — was built and measured in round 4:
+// slower at every batch size, profiles/r04_team_wide_rejected.txt.)
 template <int C, int LOSS>
 __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
-                                                             int level_hi, int level_lo, int pts_per_block, GNParams prm, int fuse_frozen,
-                                                             int scale_is_moot, unsigned* ctl, long long timeout)
+                                                             int team_size, int n_teams, int level_hi, int level_lo, int pts_per_block,
+                                                             GNParams prm, int fuse_frozen, int scale_is_moot, unsigned* ctl, long long timeout)
 {
   constexpr bool kCanFuse = (C == 8);
   const int tid = threadIdx.x;
-  const bool stats_wg = blockIdx.x == 0;
+  int team, member;
+  {
+    const int b = (int) blockIdx.x;
+    if((n_teams & 7) == 0) {
+      const int xcd = b & 7, slot = b >> 3;            // slot-th workgroup of its XCD
+      team = xcd * (n_teams >> 3) + slot / team_size;
+      member = slot % team_size;
+    } else {
+      team = b / team_size;
+      member = b % team_size;
+    }
+  }
+  if(tid == 0) { pk_member = member; pk_nwg = team_size; }
+  const bool stats_wg = member == 0;
   const bool fuse = kCanFuse && fuse_frozen;
   unsigned* const global_ctl = ctl;                                           // [1] abort, [2] next pair to hand out
-  unsigned* const team_ctl = ctl + (size_t) (1 + blockIdx.y) * kTeamCtlWords; // [0] arrivals, [1] pair slot
+  unsigned* const team_ctl = ctl + (size_t) (1 + team) * kTeamCtlWords;       // [0] arrivals, [1] pair slot
   unsigned epoch = 0, epoch_it = 0;
   // BPVO_PK_TIMING: workgroup 0 of team 0 accumulates the 100 MHz ticks of its phases, per pyramid level, in ctl[4 .. 31]: 7 words per level
   // {warp, barrier1, median, irls, barrier2, step, iterations}
@@ -567,7 +589,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       }
     }
 #ifdef BPVO_PK_TIMING
-    if(blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    if(team == 0 && member == 0 && tid == 0)
       for(int l = 0; l < 4; ++l) for(int k = 0; k < 7; ++k) global_ctl[4 + l * 7 + k] += acc_t[l][k];      // words 4 .. 31 of the global line, summed over the team's pairs
 #endif
     // the pair is done: its state back to HBM (one copy; the others are identical)
@@ -634,6 +656,8 @@ static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const G
 {
   const int ppb = gn_pts_per_block(C);
   const int fuse = (C == 8 && t.fuse_frozen) ? 1 : 0;
+  constexpr size_t lds = kMedianLds;
+  constexpr int need_per_cu = 1;
   auto go = [&](auto kern) -> hipError_t {
     static std::once_flag once[64];
     static hipError_t status[64];
@@ -641,14 +665,14 @@ static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const G
     (void) hipGetDevice(&dev);
     dev &= 63;
     std::call_once(once[dev], [&] {
-      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
       int per_cu = 0;
-      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, kMedianLds);
-      if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, lds);
+      if(status[dev] == hipSuccess && per_cu < need_per_cu) status[dev] = hipErrorLaunchOutOfResources;
     });
     if(status[dev] != hipSuccess) return status[dev];
-    hipLaunchKernelGGL(kern, dim3(t.team_size, t.n_teams), dim3(PK_THREADS), kMedianLds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.level_hi, t.level_lo, ppb,
-                       prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks);
+    hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
+                       t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks);
     return hipGetLastError();
   };
   switch(t.loss) {
