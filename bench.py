@@ -284,6 +284,12 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
         # exactly this on every rank)
         out["config-5 shard: 128 of the 1024 pairs (1241x376 bitplanes, 4 levels, tukey) on one GPU"] = \
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 128, args.descriptor, args.levels, args.loss, steps=10, warmup=2)
+    if npairs >= 1024:
+        # ... and what a rank of the 4- and 2-GPU jobs holds, so that the whole strong-scaling curve of config 5 is on this record
+        out["config-5 shard: 256 of the 1024 pairs on one GPU (a rank of the 4-GPU job)"] = \
+            timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 256, args.descriptor, args.levels, args.loss, steps=6, warmup=2)
+        out["config-5 shard: 512 of the 1024 pairs on one GPU (a rank of the 2-GPU job)"] = \
+            timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 512, args.descriptor, args.levels, args.loss, steps=4, warmup=1)
     if npairs >= 1024 and (args.rows, args.cols, args.descriptor, args.levels, args.loss) == (376, 1241, "bitplanes", 4, "tukey"):
         out["1024 pairs handed over in HOST buffers (upload pipeline)"] = \
             timed_batch_host(hip, torch, dev_index, batch, args.rows, args.cols, 1024, args.descriptor, args.levels, args.loss, args._resident_ms)
@@ -558,6 +564,20 @@ def main():
             args._resident_ms = 1e3 * elapsed_max / args.steps
             others = other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640)
 
+        # Strong scaling of config 5 (ONE 1024-pair batch over G GPUs), PROJECTED from this one GPU: rank r of a G-GPU job runs the
+        # 1024 / G-pair shard timed above, the ranks do not talk to each other until the single gather of 32-float records (128 KB in all),
+        # so the job's rate is G x the shard's rate minus that gather.  No xGMI, no RCCL in these numbers.
+        projected = None
+        if others is not None and world == 1 and P == 1024:
+            shard_rate = {1: gn_total / elapsed_max}
+            for k, v in others.items():
+                if k.startswith("config-5 shard:"):
+                    shard_rate[1024 // v["pairs"]] = v["value"]
+            projected = {"note": "one-GPU projection of `--gpus G` (strong scaling: the 1024-pair batch split over G ranks): G x the rate of a "
+                                 "1024 / G-pair shard measured on THIS GPU; no xGMI, no RCCL gather (128 KB per job) in it",
+                         "points": [{"gpus": g, "pairs_per_rank": 1024 // g, "gn_it_per_s_per_rank": shard_rate[g], "gn_it_per_s_job": g * shard_rate[g],
+                                     "efficiency_vs_1_gpu": shard_rate[g] / shard_rate[1]} for g in sorted(shard_rate)]}
+
         iters = stats["numIterations"].astype(np.float64)
         out = {
             "metric": "GN iterations/s (dense photometric alignment, 1241x376 bit-planes 8ch, 4 levels, Tukey IRLS; one iteration = one "
@@ -599,6 +619,7 @@ def main():
             "kernels_timed_region": kernels,
             "cpu_baseline": cpu,
             "other_configs": others,
+            "projected_strong_scaling": projected,
             "setup": {"synth_seconds": t_gen, "gen_workers": workers},
         }
         print(json.dumps(out))

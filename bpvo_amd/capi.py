@@ -14,7 +14,7 @@ import numpy as np
 LOSS_HUBER, LOSS_TUKEY, LOSS_L2 = 0x10, 0x11, 0x12
 VERB_ITERATION, VERB_FINAL, VERB_SILENT, VERB_DEBUG = 0x20, 0x21, 0x22, 0x23
 DESC_INTENSITY, DESC_GRADIENT, DESC_LAPLACIAN, DESC_BITPLANES = 0x30, 0x31, 0x36, 0x37
-DESC_FIELDS1, DESC_FIELDS2, DESC_CENTRAL_DIFFERENCE = 0x32, 0x33, 0x35
+DESC_FIELDS1, DESC_FIELDS2, DESC_LATCH, DESC_CENTRAL_DIFFERENCE = 0x32, 0x33, 0x34, 0x35
 GRAD_CD3, GRAD_CD5 = 0, 1
 INTERP_LINEAR, INTERP_COSINE, INTERP_CUBIC, INTERP_CUBIC_HERMITE = 0, 1, 2, 3
 STATUS_PARAMETER_TOL, STATUS_FUNCTION_TOL, STATUS_GRADIENT_TOL, STATUS_MAX_ITERATIONS, STATUS_SOLVER_ERROR = range(0x30, 0x35)

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "latch_table.h"
 
 using namespace bpvo_hip;
 
@@ -135,6 +136,9 @@ struct bpvo_hip_ctx {
   GaussTaps df_g1, df_g2;       // imsmooth kernels of dfSigma1 / dfSigma2 (descriptor fields); n = 0: sigma <= 0
   GaussTaps cd_before, cd_after; // imsmooth kernels of centralDifferenceSigmaBefore (u8 fixed point) / After (f32)
   GaussTaps grad_pre;           // cv::GaussianBlur(Size(), sigma) of GradientDescriptor (sigmaPriorToCensusTransform > 0)
+  GaussTaps latch_after;        // imsmooth(1.75) of every LATCH channel (bpvo/latch_descriptor.cc:1082)
+  int latch_taps[2] = {0, 0};   // fixed-point {centre, side} taps of LATCH's cv::GaussianBlur(Size(3,3), 2, 2) (:147)
+  signed char* d_latch_off = nullptr;   // [48 * latchNumBytes] triplet coordinates as CalcuateSums uses them (:170-236)
   bool plane_scratch = false; // descriptor built from plane operations (descriptor fields, central difference, smoothed gradient)
   hipStream_t stream = nullptr;
   std::vector<FrameSlot> frames;
@@ -552,6 +556,9 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
       const LevelGeom& g = c->geom[l];
       if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
         launch_central_difference(s, jobs, g.cols, g.rows, count, c->params.centralDifferenceRadius, c->cd_before, c->cd_after);
+      } else if(c->params.descriptor == BPVO_DESC_LATCH) {
+        launch_latch(s, jobs, g.cols, g.rows, count, c->params.latchNumBytes, c->params.latchHalfSsdSize, c->d_latch_off, c->latch_taps[0], c->latch_taps[1],
+                     c->latch_after);
       } else if(c->C == 5 || c->C == 10) {
         launch_descriptor_fields(s, jobs, g.cols, g.rows, count, c->C == 10, c->df_g1, c->df_g2);
       } else if(c->C == 3) {
@@ -1168,8 +1175,20 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   if(c->params.maxTestLevel < 0 || c->params.maxTestLevel >= c->L) { g_create_error = "invalid maxTestLevel"; return BPVO_ERR_INVALID_ARG; }
   const bool desc_fields = c->params.descriptor == BPVO_DESC_FIELDS_FIRST_ORDER || c->params.descriptor == BPVO_DESC_FIELDS_SECOND_ORDER;
   if(c->params.descriptor != BPVO_DESC_INTENSITY && c->params.descriptor != BPVO_DESC_BITPLANES && c->params.descriptor != BPVO_DESC_LAPLACIAN &&
-     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.descriptor != BPVO_DESC_CENTRAL_DIFFERENCE && !desc_fields)
-    return unsupported("descriptor: every DenseDescriptor of the reference but LATCH is on the device path");
+     c->params.descriptor != BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.descriptor != BPVO_DESC_CENTRAL_DIFFERENCE && c->params.descriptor != BPVO_DESC_LATCH &&
+     !desc_fields) {
+    g_create_error = "unknown DescriptorType";      // DenseDescriptor::Create's default branch (bpvo/dense_descriptor.cc:86-87)
+    return BPVO_ERR_INVALID_ARG;
+  }
+  if(c->params.descriptor == BPVO_DESC_LATCH) {
+    const int nb = c->params.latchNumBytes;
+    if(nb != 1 && nb != 2 && nb != 4 && nb != 8 && nb != 16 && nb != 32 && nb != 64) {       // bpvo/latch_descriptor.cc:104
+      g_create_error = "descriptorSize must be 1, 2, 4, 8, 16, 32, or 64";
+      return BPVO_ERR_INVALID_ARG;
+    }
+    if(nb > 4) return unsupported("latchNumBytes: 1, 2 and 4 (8, 16 and 32 channels) are on the device path");
+    if(c->params.latchHalfSsdSize < 0 || c->params.latchHalfSsdSize > 8) return unsupported("latchHalfSsdSize: 0 .. 8 are on the device path");
+  }
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
     if(c->params.centralDifferenceRadius <= 0) { g_create_error = "invalid radius"; return BPVO_ERR_INVALID_ARG; }   // central_difference_descriptor.cc:19
     if(c->params.centralDifferenceRadius > 3) return unsupported("centralDifferenceRadius: 1, 2 and 3 (8, 24 and 48 channels) are on the device path");
@@ -1200,10 +1219,11 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     case BPVO_DESC_FIELDS_FIRST_ORDER: c->C = 5; break;
     case BPVO_DESC_FIELDS_SECOND_ORDER: c->C = 10; break;
     case BPVO_DESC_CENTRAL_DIFFERENCE: c->C = (2 * c->params.centralDifferenceRadius + 1) * (2 * c->params.centralDifferenceRadius + 1) - 1; break;
+    case BPVO_DESC_LATCH: c->C = 8 * c->params.latchNumBytes; break;
     default: c->C = 1; break;
   }
   const bool grad_smoothed = c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f;
-  c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE || grad_smoothed;
+  c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE || c->params.descriptor == BPVO_DESC_LATCH || grad_smoothed;
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
     gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaBefore), c->params.centralDifferenceSigmaBefore, &c->cd_before);
     gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaAfter), c->params.centralDifferenceSigmaAfter, &c->cd_after);
@@ -1214,15 +1234,20 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   }
   if(grad_smoothed) gaussian_taps(auto_gauss_taps_f32(c->params.sigmaPriorToCensusTransform), c->params.sigmaPriorToCensusTransform, &c->grad_pre);
   gaussian_kernel5(c->params.sigmaBitPlanes, c->gauss_k);
-  if(c->params.sigmaPriorToCensusTransform > 0.0f) {   // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
-    const double sg = c->params.sigmaPriorToCensusTransform, scale2X = -0.5 / (sg * sg);
+  auto gauss3_fixed = [](double sg, int taps[2]) {      // cv::getGaussianKernel(3, sigma) in f32, then cvRound(k * 256)
+    const double scale2X = -0.5 / (sg * sg);
     float kk[3];
     double sum = 0;
     for(int i = 0; i < 3; ++i) { const double x = i - 1.0; kk[i] = (float) std::exp(scale2X * x * x); sum += kk[i]; }
     sum = 1. / sum;
     for(int i = 0; i < 3; ++i) kk[i] = (float) (kk[i] * sum);
-    c->census_taps[0] = (int) std::nearbyint((double) kk[1] * 256.0);
-    c->census_taps[1] = (int) std::nearbyint((double) kk[2] * 256.0);
+    taps[0] = (int) std::nearbyint((double) kk[1] * 256.0);
+    taps[1] = (int) std::nearbyint((double) kk[2] * 256.0);
+  };
+  if(c->params.sigmaPriorToCensusTransform > 0.0f) gauss3_fixed(c->params.sigmaPriorToCensusTransform, c->census_taps);
+  if(c->params.descriptor == BPVO_DESC_LATCH) {
+    gauss3_fixed(2.0, c->latch_taps);
+    gaussian_taps(imsmooth_taps(1.75f), 1.75f, &c->latch_after);
   }
 
   // level geometry (bpvo/vo_frame.cc:21-28: K *= 0.5, K(2,2) = 1, b *= 2; pyrDown sizes)
@@ -1292,6 +1317,27 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_fjobs, 2 * sizeof(FrameJob) * (size_t) cp->L * n_frames));
   CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
+  if(cp->params.descriptor == BPVO_DESC_LATCH) {
+    // The triplet coordinates as CalcuateSums uses them (bpvo/latch_descriptor.cc:170-236): the table's, or — latchRotationInvariance —
+    // rotated by the key point's angle and clamped to the patch.  The dense evaluation builds its key points with cv::KeyPoint() (:135-141),
+    // angle -1, so the rotation is one and the same for every pixel: angle = -1 * (float)(CV_PI / 180.f), cos / sin of that float
+    // (:259-262), (int)((float) ax * cos - (float) ay * sin) (:193-200).
+    const int n_ints = 48 * cp->params.latchNumBytes;
+    std::vector<signed char> off(n_ints);
+    const float angle = -1.0f * (float) (3.1415926535897932384626433832795 / 180.f);
+    const float cos_theta = std::cos(angle), sin_theta = std::sin(angle);
+    for(int t = 0; t < n_ints; t += 2) {
+      int x = kLatchTable[t], y = kLatchTable[t + 1];
+      if(cp->params.latchRotationInvariance) {
+        const int xr = (int) (((float) x) * cos_theta - ((float) y) * sin_theta), yr = (int) (((float) x) * sin_theta + ((float) y) * cos_theta);
+        x = std::max(-24, std::min(24, xr));
+        y = std::max(-24, std::min(24, yr));
+      }
+      off[t] = (signed char) x; off[t + 1] = (signed char) y;
+    }
+    CREATE_CK(hipMalloc((void**) &cp->d_latch_off, (size_t) n_ints));
+    CREATE_CK(hipMemcpy(cp->d_latch_off, off.data(), (size_t) n_ints, hipMemcpyHostToDevice));
+  }
   {
     int max_lanes = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
     if(const char* e = std::getenv("BPVO_HIP_LANES")) max_lanes = std::max(1, std::min(8, std::atoi(e)));
@@ -1375,7 +1421,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
   for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
-  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1);
+  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1); (void) hipFree(c->d_latch_off);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);

@@ -8,7 +8,7 @@
 #include <type_traits>
 
 // The channel counts the kernels are instantiated for: Intensity / Laplacian 1, IntensityAndGradient 3, DescriptorFields 5,
-// BitPlanes 8, DescriptorFields2ndOrder 10.  f receives std::integral_constant<int, C>.
+// BitPlanes 8, DescriptorFields2ndOrder 10, CentralDifference 8 / 24 / 48, Latch 8 / 16 / 32.  f receives std::integral_constant<int, C>.
 template <class F>
 static inline void dispatch_channels(int C, F&& f)
 {
@@ -17,6 +17,8 @@ static inline void dispatch_channels(int C, F&& f)
     case 3: f(std::integral_constant<int, 3>()); break;
     case 5: f(std::integral_constant<int, 5>()); break;
     case 10: f(std::integral_constant<int, 10>()); break;
+    case 16: f(std::integral_constant<int, 16>()); break;
+    case 32: f(std::integral_constant<int, 32>()); break;
     case 24: f(std::integral_constant<int, 24>()); break;
     case 48: f(std::integral_constant<int, 48>()); break;
     default: f(std::integral_constant<int, 8>()); break;
@@ -40,6 +42,8 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
                               const GaussTaps& g2);   // C = 5 / 10
 void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const GaussTaps& before,
                                const GaussTaps& after);   // C = 8 / 24 / 48
+void launch_latch(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int bytes, int half_ssd, const signed char* d_offsets, int kc, int ks,
+                  const GaussTaps& after);   // C = 8 * bytes, bytes = 1 / 2 / 4
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 // from_image: the census transform is computed inside the bit-planes kernel (no launch_census, sigma_bp > 0 and sigma_ct <= 0)

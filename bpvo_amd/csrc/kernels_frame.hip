@@ -7,26 +7,9 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "kernels.h"
+#include "frame_common.h"
 
 namespace bpvo_hip {
-
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-  // cv::borderInterpolate(BORDER_REFLECT_101); one reflection suffices for the <= 3 pixel halos used here
-  if(p < 0) p = -p;
-  if(p >= len) p = 2 * len - 2 - p;
-  if(p < 0) p = 0;   // degenerate len == 1
-  return p;
-}
-
-// the same for halos that may exceed the image (wide smoothing kernels on the coarsest levels): reflect until inside
-__device__ __forceinline__ int reflect101_wide(int p, int len)
-{
-  if(len == 1) return 0;
-  while(p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
-  return p;
-}
 
 // ---- input ingest: one launch copies the u8 image and f32 disparity of every frame of a batch from a packed device
 // buffer ([frame][rows*cols]) into the frame slots (VisualOdometryFrame::setData's image.copyTo / disparity.copyTo,
@@ -165,170 +148,6 @@ __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
   } else {
     for(int k = i; k < n && k < i + 4; ++k) j.desc[k] = (float) j.img[k];
   }
-}
-
-// ---- LaplacianDescriptor::compute (reference: bpvo/gradient_descriptor.cc:64-67): cv::Laplacian(u8 -> f32), kernel size 1
-// ({0,1,0,1,-4,1,0,1,0}), 3 ({2,0,2,0,-8,0,2,0,2}), 5 or 7 (Sobel second derivatives), BORDER_REFLECT_101; integer-valued,
-// hence exact in f32.
-__global__ __launch_bounds__(256) void laplacian_kernel(const FrameJob* jobs, int ksize)
-{
-  const FrameJob& j = jobs[blockIdx.z];
-  const int W = j.cols, R = j.rows;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if(x >= W || y >= R) return;
-  const uint8_t* __restrict__ I = j.img;
-  if(ksize > 3) {
-    // ksize 5 / 7: d2/dx2 + d2/dy2 with the separable Sobel kernels of cv::getSobelKernels (second derivative x binomial
-    // smoothing): [1 0 -2 0 1] x [1 4 6 4 1] and [1 2 -1 -4 -1 2 1] x [1 6 15 20 15 6 1].  Integer sums far below 2^24
-    // (and below the 16-bit work type OpenCV uses for ksize 5): exact in any order.
-    const int d5[5] = {1, 0, -2, 0, 1}, s5[5] = {1, 4, 6, 4, 1};
-    const int d7[7] = {1, 2, -1, -4, -1, 2, 1}, s7[7] = {1, 6, 15, 20, 15, 6, 1};
-    const int r = ksize >> 1;
-    int acc = 0;
-    for(int dy = 0; dy < ksize; ++dy) {
-      const uint8_t* row = I + (size_t) reflect101_wide(y - r + dy, R) * W;
-      const int dyk = ksize == 5 ? d5[dy] : d7[dy], syk = ksize == 5 ? s5[dy] : s7[dy];
-      for(int dx = 0; dx < ksize; ++dx) {
-        const int dxk = ksize == 5 ? d5[dx] : d7[dx], sxk = ksize == 5 ? s5[dx] : s7[dx];
-        acc += (dxk * syk + sxk * dyk) * (int) row[reflect101_wide(x - r + dx, W)];
-      }
-    }
-    j.desc[(size_t) y * W + x] = (float) acc;
-    return;
-  }
-  const int xm = reflect101(x - 1, W), xp = reflect101(x + 1, W), ym = reflect101(y - 1, R), yp = reflect101(y + 1, R);
-  const float k_edge = ksize == 3 ? 0.0f : 1.0f, k_diag = ksize == 3 ? 2.0f : 0.0f, k_ctr = ksize == 3 ? -8.0f : -4.0f;
-  const uint8_t *rm = I + (size_t) ym * W, *r0 = I + (size_t) y * W, *rp = I + (size_t) yp * W;
-  float v = k_diag * (float) rm[xm] + k_edge * (float) rm[x] + k_diag * (float) rm[xp];
-  v += k_edge * (float) r0[xm] + k_ctr * (float) r0[x] + k_edge * (float) r0[xp];
-  v += k_diag * (float) rp[xm] + k_edge * (float) rp[x] + k_diag * (float) rp[xp];
-  j.desc[(size_t) y * W + x] = v;
-}
-
-// ---- GradientDescriptor::compute (reference: bpvo/gradient_descriptor.cc:42-63) with sigma <= 0: channels (I, Ix, Iy),
-// Ix / Iy = xgradient / ygradient (bpvo/imgproc.h:214-265): 0.5 * central difference, one-sided 0.5 * (I1 - I0) at the borders.
-__global__ __launch_bounds__(256) void gradient_descriptor_kernel(const FrameJob* jobs)
-{
-  const FrameJob& j = jobs[blockIdx.z];
-  const int W = j.cols, R = j.rows;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if(x >= W || y >= R) return;
-  const uint8_t* __restrict__ I = j.img;
-  auto at = [&](int yy, int xx) { return (float) I[(size_t) yy * W + xx]; };
-  const int xa = x == 0 ? 0 : (x == W - 1 ? W - 2 : x - 1), xb = x == 0 ? 1 : (x == W - 1 ? W - 1 : x + 1);
-  const int ya = y == 0 ? 0 : (y == R - 1 ? R - 2 : y - 1), yb = y == 0 ? 1 : (y == R - 1 ? R - 1 : y + 1);
-  float* d = j.desc + ((size_t) y * W + x) * 3;
-  d[0] = at(y, x);
-  d[1] = 0.5f * (at(y, xb) - at(y, xa));
-  d[2] = 0.5f * (at(yb, x) - at(ya, x));
-}
-
-// ---- DescriptorFields / DescriptorFields2ndOrder (reference: bpvo/gradient_descriptor.cc:100-160): chains of plane operations
-// -- convertTo, imsmooth (5 x 5 f32 Gaussian, bpvo/imgproc.cc:166-171), xgradient / ygradient (bpvo/imgproc.h:214-265),
-// splitPosNeg (gradient_descriptor.cc:80-98) -- each one launch of this kernel.  A plane code >= 0 is a work plane of
-// FrameJob::scratch, a code < 0 is descriptor channel -1-code of the interleaved [npix][C] records.
-enum { DF_CONVERT = 0, DF_GAUSS_ROW, DF_GAUSS_COL, DF_GRAD_X, DF_GRAD_Y, DF_SPLIT, DF_U8_ROW, DF_U8_COL, DF_SHIFT_DIFF, DF_TO_CH0,
-       DF_GAUSS_ROW_N, DF_GAUSS_COL_N, DF_U8_ROW_N, DF_U8_COL_N };
-struct PlaneRef { float* p; int stride; };
-__device__ __forceinline__ PlaneRef df_plane(const FrameJob& j, int code, int C)
-{
-  if(code >= 0) return PlaneRef{j.scratch + (size_t) code * j.rows * j.cols, 1};
-  return PlaneRef{j.desc + (-1 - code), C};
-}
-// CentralDifferenceDescriptor (bpvo/central_difference_descriptor.cc:36-131) adds: the u8 5 x 5 fixed-point Gaussian of the
-// image (DF_U8_ROW keeps the int row sums as bit patterns in a work plane, DF_U8_COL rounds them to the u8 value, held as
-// float), the image minus its clamped shift by (i0, i1) (DF_SHIFT_DIFF), and the copy of channel 0 into the compact
-// FrameJob::ch0 plane that the C = 8 kernels expect (DF_TO_CH0).
-// Kernels wider than 5 taps (imsmooth with sigma >= 2.5, the automatic size of GradientDescriptor's pre-smoothing) take
-// the generic forms of OpenCV 2.4's filter engine: DF_GAUSS_ROW_N s = k[0]*S[x-r]; s += k[j]*S[x-r+j] (RowFilter, left to
-// right), DF_GAUSS_COL_N s = k[r]*S0; s += k[r+j]*(S[+j] + S[-j]) (SymmColumnFilter); DF_U8_*_N the 8-bit fixed-point pair.
-__global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int op, int src_code, int dst_code, int dst2_code, int C,
-                                                       float k0, float k1, float k2, int i0, int i1, int i2, GaussTaps gt)
-{
-  const FrameJob& j = jobs[blockIdx.z];
-  const int W = j.cols, R = j.rows;
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if(x >= W || y >= R) return;
-  const PlaneRef S = df_plane(j, src_code, C), D = df_plane(j, dst_code, C);
-  auto at = [&](int yy, int xx) { return S.p[((size_t) yy * W + xx) * S.stride]; };
-  const size_t q = (size_t) y * W + x;
-  float v;
-  switch(op) {
-    case DF_CONVERT: v = (float) j.img[q]; break;
-    case DF_GAUSS_ROW:   // s = S[0]*k0 + (S[-1]+S[1])*k1 + (S[-2]+S[2])*k2
-      v = at(y, x) * k0 + (at(y, reflect101(x - 1, W)) + at(y, reflect101(x + 1, W))) * k1 +
-          (at(y, reflect101(x - 2, W)) + at(y, reflect101(x + 2, W))) * k2;
-      break;
-    case DF_GAUSS_COL:   // s = k0*S0; s += k1*(S+1 + S-1); s += k2*(S+2 + S-2)
-      v = k0 * at(y, x);
-      v += k1 * (at(reflect101(y + 1, R), x) + at(reflect101(y - 1, R), x));
-      v += k2 * (at(reflect101(y + 2, R), x) + at(reflect101(y - 2, R), x));
-      break;
-    case DF_GRAD_X:
-      v = x == 0 ? 0.5f * (at(y, 1) - at(y, 0)) : (x == W - 1 ? 0.5f * (at(y, x) - at(y, x - 1)) : 0.5f * (at(y, x + 1) - at(y, x - 1)));
-      break;
-    case DF_GRAD_Y:
-      v = y == 0 ? 0.5f * (at(1, x) - at(0, x)) : (y == R - 1 ? 0.5f * (at(y, x) - at(y - 1, x)) : 0.5f * (at(y + 1, x) - at(y - 1, x)));
-      break;
-    case DF_U8_ROW: {
-      const uint8_t* row = j.img + (size_t) y * W;
-      const int t = row[x] * i0 + (row[reflect101(x - 1, W)] + row[reflect101(x + 1, W)]) * i1 +
-                    (row[reflect101(x - 2, W)] + row[reflect101(x + 2, W)]) * i2;
-      v = __int_as_float(t);
-      break;
-    }
-    case DF_U8_COL: {
-      auto it = [&](int yy) { return __float_as_int(at(yy, x)); };
-      const int t = (it(y) * i0 + (it(reflect101(y - 1, R)) + it(reflect101(y + 1, R))) * i1 +
-                     (it(reflect101(y - 2, R)) + it(reflect101(y + 2, R))) * i2 + (1 << 15)) >> 16;
-      v = (float) min(255, max(0, t));
-      break;
-    }
-    case DF_SHIFT_DIFF:
-      v = at(y, x) - at(min(max(y + i1, 0), R - 1), min(max(x + i0, 0), W - 1));
-      break;
-    case DF_GAUSS_ROW_N: {
-      const int r = gt.n >> 1;
-      v = gt.k[0] * at(y, reflect101_wide(x - r, W));
-      for(int t = 1; t < gt.n; ++t) v += gt.k[t] * at(y, reflect101_wide(x - r + t, W));
-      break;
-    }
-    case DF_GAUSS_COL_N: {
-      const int r = gt.n >> 1;
-      v = gt.k[r] * at(y, x);
-      for(int t = 1; t <= r; ++t) v += gt.k[r + t] * (at(reflect101_wide(y + t, R), x) + at(reflect101_wide(y - t, R), x));
-      break;
-    }
-    case DF_U8_ROW_N: {
-      const uint8_t* row = j.img + (size_t) y * W;
-      const int r = gt.n >> 1;
-      int t = 0;
-      for(int q = 0; q < gt.n; ++q) t += gt.ki[q] * row[reflect101_wide(x - r + q, W)];
-      v = __int_as_float(t);
-      break;
-    }
-    case DF_U8_COL_N: {
-      const int r = gt.n >> 1;
-      int t = 0;
-      for(int q = 0; q < gt.n; ++q) t += gt.ki[q] * __float_as_int(at(reflect101_wide(y - r + q, R), x));
-      t = (t + (1 << 15)) >> 16;
-      v = (float) min(255, max(0, t));
-      break;
-    }
-    case DF_TO_CH0:
-      if(j.ch0) j.ch0[q] = at(y, x);
-      return;
-    default: {           // DF_SPLIT
-      const float s = at(y, x);
-      const PlaneRef N = df_plane(j, dst2_code, C);
-      N.p[q * N.stride] = s < 0 ? s : 0.0f;
-      v = s >= 0 ? s : 0.0f;
-    }
-  }
-  D.p[q * D.stride] = v;
 }
 
 // ---- K1a: census transform (reference: bpvo/census.cc:42-91, bpvo/v128.h:102-105).
@@ -1304,7 +1123,6 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 }
 
 // ---- host-callable launchers ------------------------------------------------------------------------------------
-static inline dim3 grid2d(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 3) / 4, nz); }
 static inline dim3 grid2d_rows(int W, int R, int nz) { return dim3((W + 63) / 64, (R + 4 * ROWS_PER_THREAD - 1) / (4 * ROWS_PER_THREAD), nz); }
 
 void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes, int skip_odd_disp)
@@ -1321,117 +1139,6 @@ void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {
   hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes), dim3(256), 0, s, jobs);
-}
-void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize)
-{
-  hipLaunchKernelGGL(laplacian_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs, ksize);
-}
-// smoothing of a work plane / channel with either form of the kernel (5 taps: the small-kernel ops, wider: the generic ones)
-template <class Op>
-static void df_smooth(Op&& op, int src, int tmp, int dst, const GaussTaps& g)
-{
-  if(g.n == 5) {
-    const float k[3] = {g.k[2], g.k[3], g.k[4]};
-    op(DF_GAUSS_ROW, src, tmp, k, nullptr);
-    op(DF_GAUSS_COL, tmp, dst, k, nullptr);
-  } else {
-    op(DF_GAUSS_ROW_N, src, tmp, nullptr, &g);
-    op(DF_GAUSS_COL_N, tmp, dst, nullptr, &g);
-  }
-}
-void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre)
-{
-  if(pre.n == 0) {
-    hipLaunchKernelGGL(gradient_descriptor_kernel, grid2d(W, R, nframes), dim3(256), 0, s, jobs);
-    return;
-  }
-  // GradientDescriptor::compute with sigma > 0 (bpvo/gradient_descriptor.cc:42-63): channel 0 keeps the unsmoothed
-  // intensities, the gradients are taken of cv::GaussianBlur(I, Size(), sigma)
-  const dim3 grid = grid2d(W, R, nframes);
-  auto op = [&](int o, int src, int dst, const float* k, const GaussTaps* g) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, 3, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0,
-                       g ? *g : GaussTaps());
-  };
-  enum { P_S = 0, P_TMP = 1 };
-  op(DF_CONVERT, 0, -1, nullptr, nullptr);
-  df_smooth(op, -1, P_TMP, P_S, pre);
-  op(DF_GRAD_X, P_S, -2, nullptr, nullptr);
-  op(DF_GRAD_Y, P_S, -3, nullptr, nullptr);
-}
-// one level of DescriptorFields (second_order = 0: 5 channels) or DescriptorFields2ndOrder (10 channels); g1 / g2 are the
-// imsmooth kernels of sigma1 / sigma2 (n = 0: sigma <= 0, no smoothing)
-void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, const GaussTaps& g1,
-                              const GaussTaps& g2)
-{
-  const int C = second_order ? 10 : 5;
-  const dim3 grid = grid2d(W, R, nframes);
-  auto op5 = [&](int o, int src, int dst, const float* k, const GaussTaps* g, int dst2 = 0) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, dst2, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0,
-                       g ? *g : GaussTaps());
-  };
-  auto op = [&](int o, int src, int dst, int dst2 = 0) { op5(o, src, dst, nullptr, nullptr, dst2); };
-  auto ch = [](int c) { return -1 - c; };
-  enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6 };
-  auto smooth = [&](int src, int dst, const GaussTaps& g) { df_smooth(op5, src, P_TMP, dst, g); };
-  auto split = [&](int src, int cpos, int cneg) {
-    if(g2.n > 0) {
-      op(DF_SPLIT, src, P_POS, P_NEG);
-      smooth(P_POS, ch(cpos), g2);
-      smooth(P_NEG, ch(cneg), g2);
-    } else {
-      op(DF_SPLIT, src, ch(cpos), ch(cneg));
-    }
-  };
-  const int I0 = second_order ? P_I0 : ch(0);     // first order keeps the unsmoothed intensities as channel 0
-  op(DF_CONVERT, 0, I0);
-  int I = I0;
-  if(g1.n > 0) { smooth(I0, P_I, g1); I = P_I; }
-  if(!second_order) {
-    op(DF_GRAD_X, I, P_B1); split(P_B1, 1, 2);
-    op(DF_GRAD_Y, I, P_B1); split(P_B1, 3, 4);
-  } else {
-    op(DF_GRAD_X, I, P_B1);    split(P_B1, 0, 1);   // Ix
-    op(DF_GRAD_X, P_B1, P_B2); split(P_B2, 2, 3);   // Ixx
-    split(P_B2, 4, 5);                              // "Ixy": the reference splits Ixx again (gradient_descriptor.cc:149-150)
-    op(DF_GRAD_Y, I, P_B1);    split(P_B1, 6, 7);   // Iy
-    op(DF_GRAD_Y, P_B1, P_B2); split(P_B2, 8, 9);   // Iyy
-  }
-}
-// one level of CentralDifferenceDescriptor: C = (2r+1)^2 - 1 channels; before = the u8 blur of sigma_before (fixed-point taps),
-// after = the f32 kernel of sigma_after (n = 0: not applied)
-void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int radius, const GaussTaps& before,
-                               const GaussTaps& after)
-{
-  const int C = (2 * radius + 1) * (2 * radius + 1) - 1;
-  const dim3 grid = grid2d(W, R, nframes);
-  auto opi = [&](int o, int src, int dst, const float* k, const GaussTaps* g, int i0 = 0, int i1 = 0, int i2 = 0) {
-    hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, i0, i1, i2,
-                       g ? *g : GaussTaps());
-  };
-  auto op5 = [&](int o, int src, int dst, const float* k, const GaussTaps* g) { opi(o, src, dst, k, g); };
-  enum { P_IMG = 0, P_DIFF = 1, P_TMP = 2 };
-  if(before.n == 5) {
-    opi(DF_U8_ROW, 0, P_TMP, nullptr, nullptr, before.ki[2], before.ki[3], before.ki[4]);
-    opi(DF_U8_COL, P_TMP, P_IMG, nullptr, nullptr, before.ki[2], before.ki[3], before.ki[4]);
-  } else if(before.n > 5) {
-    opi(DF_U8_ROW_N, 0, P_TMP, nullptr, &before);
-    opi(DF_U8_COL_N, P_TMP, P_IMG, nullptr, &before);
-  } else {
-    opi(DF_CONVERT, 0, P_IMG, nullptr, nullptr);
-  }
-  int c = 0;
-  for(int oy = -radius; oy <= radius; ++oy)
-    for(int ox = -radius; ox <= radius; ++ox) {
-      if(ox == 0 && oy == 0) continue;
-      if(after.n > 0) {
-        opi(DF_SHIFT_DIFF, P_IMG, P_DIFF, nullptr, nullptr, ox, oy);
-        df_smooth(op5, P_DIFF, P_TMP, -1 - c, after);
-      } else {
-        opi(DF_SHIFT_DIFF, P_IMG, -1 - c, nullptr, nullptr, ox, oy);
-      }
-      ++c;
-    }
-  if(C == 8) opi(DF_TO_CH0, -1, 0, nullptr, nullptr);
 }
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
 {

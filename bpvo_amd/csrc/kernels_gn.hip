@@ -506,7 +506,7 @@ void launch_median(hipStream_t s, const GNLaunch& g)
   int dev = 0;
   (void) hipGetDevice(&dev);
   std::call_once(attr_once[dev & 63], [] {
-    for(int C : {1, 3, 5, 8, 10, 24, 48})
+    for(int C : {1, 3, 5, 8, 10, 16, 24, 32, 48})
       dispatch_channels(C, [&](auto c) {
         constexpr int CC = decltype(c)::value;
         (void) hipFuncSetAttribute((const void*) median_finish_kernel<CC, MED_THREADS, MED_COPIES, MED_CACHE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLds);

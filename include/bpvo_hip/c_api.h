@@ -35,7 +35,7 @@ extern "C" {
 enum { BPVO_LOSS_HUBER = 0x10, BPVO_LOSS_TUKEY = 0x11, BPVO_LOSS_L2 = 0x12 };
 enum { BPVO_VERB_ITERATION = 0x20, BPVO_VERB_FINAL = 0x21, BPVO_VERB_SILENT = 0x22, BPVO_VERB_DEBUG = 0x23 };
 enum { BPVO_DESC_INTENSITY = 0x30, BPVO_DESC_INTENSITY_AND_GRADIENT = 0x31, BPVO_DESC_FIELDS_FIRST_ORDER = 0x32,
-       BPVO_DESC_FIELDS_SECOND_ORDER = 0x33, BPVO_DESC_CENTRAL_DIFFERENCE = 0x35, BPVO_DESC_LAPLACIAN = 0x36, BPVO_DESC_BITPLANES = 0x37 };
+       BPVO_DESC_FIELDS_SECOND_ORDER = 0x33, BPVO_DESC_LATCH = 0x34, BPVO_DESC_CENTRAL_DIFFERENCE = 0x35, BPVO_DESC_LAPLACIAN = 0x36, BPVO_DESC_BITPLANES = 0x37 };
 enum { BPVO_GRAD_CD3 = 0, BPVO_GRAD_CD5 = 1 };
 enum { BPVO_INTERP_LINEAR = 0, BPVO_INTERP_COSINE = 1, BPVO_INTERP_CUBIC = 2, BPVO_INTERP_CUBIC_HERMITE = 3 };
 enum { BPVO_STATUS_PARAMETER_TOL = 0x30, BPVO_STATUS_FUNCTION_TOL = 0x31, BPVO_STATUS_GRADIENT_TOL = 0x32,

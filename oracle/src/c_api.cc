@@ -124,6 +124,7 @@ int bpvo_orc_num_channels(const bpvo_orc_ctx* c)
     case kDescriptorFieldsFirstOrder: return 5;
     case kDescriptorFieldsSecondOrder: return 10;
     case kCentralDifference: return (2 * c->params.centralDifferenceRadius + 1) * (2 * c->params.centralDifferenceRadius + 1) - 1;
+    case kLatch: return 8 * c->params.latchNumBytes;
     default: return 1;
   }
 }

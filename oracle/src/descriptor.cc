@@ -54,14 +54,117 @@ void defaultParams(Params& p)
 //   kIntensityAndGradient -> GradientDescriptor::compute (bpvo/gradient_descriptor.cc:42-63): (I, Ix, Iy).
 //   kDescriptorFieldsFirstOrder / SecondOrder -> DescriptorFields[2ndOrder]::compute (bpvo/gradient_descriptor.cc:100-160): 5 / 10 channels.
 //   kCentralDifference -> CentralDifferenceDescriptor::compute (bpvo/central_difference_descriptor.cc:113-131): (2r+1)^2 - 1 channels.
+//   kLatch -> LatchDescriptor::compute (bpvo/latch_descriptor.cc:1041-1086): 8 * latchNumBytes channels, see latchDescriptor below.
 //   kBitPlanes -> BitPlanesDescriptor::compute (bpvo/bitplanes_descriptor.cc:84-91): census(I, sigma_ct) then for each
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
+// ---- LATCH, evaluated densely (bpvo/latch_descriptor.cc).
+// The sampling table: 512 triplets of patch-centre offsets, `sampling_points_arr` (:507-1019), numbers only (scripts/make_latch_table.py).
+static const int kLatchPoints[3072] = {
+#include "latch_table.inc"
+};
+
+// The triplet offsets as CalcuateSums uses them (:180-236): as they stand, or — rotationInvariance — rotated by the key point's angle and
+// clamped to [-24, 24].  The dense evaluation creates its key points with cv::KeyPoint() (:135-141), whose angle is -1, so the rotation
+// is the same for every pixel: angle = -1 * (float)(CV_PI / 180.f), cos / sin of the float (:259-262; the float overloads of <cmath> —
+// with ::cos(double) instead the cosine could differ in its last bit; every one of the 3072 products is further than 1e-4 from an integer,
+// so the truncated offsets are the same either way: tests/test_oracle_cpu.py::test_latch_rotated_offsets_are_insensitive_to_the_last_bit_of_the_cosine).
+void latchOffsets(bool rotationInvariance, int n_ints, int* out)
+{
+  const float angle = -1.0f * (float) (3.1415926535897932384626433832795 / 180.f);
+  const float cos_theta = std::cos(angle), sin_theta = std::sin(angle);
+  for(int t = 0; t < n_ints; t += 2) {
+    const int ax = kLatchPoints[t], ay = kLatchPoints[t + 1];
+    int ax2 = ax, ay2 = ay;
+    if(rotationInvariance) {
+      ax2 = (int) (((float) ax) * cos_theta - ((float) ay) * sin_theta);
+      ay2 = (int) (((float) ax) * sin_theta + ((float) ay) * cos_theta);
+      ax2 = std::min(24, std::max(-24, ax2));
+      ay2 = std::min(24, std::max(-24, ay2));
+    }
+    out[t] = ax2; out[t + 1] = ay2;
+  }
+}
+
+// LatchDescriptor::compute (:1041-1086) over LATCHDescriptorExtractorImpl::compute (:124-167) and pixelTests<bytes> (:264-493):
+//  1. key points: every pixel with border <= y < rows - border - 1, border <= x < cols - border - 1, row-major; border = 24 + half_ssd_size;
+//  2. the image smoothed with cv::GaussianBlur(Size(3,3), 2, 2) (8-bit fixed point, gaussianBlurU8_3x3);
+//  3. per key point and descriptor byte ix: bit j = 7 .. 0 is [suma < sumc] of triplet 8 * ix + (7 - j), suma / sumc the sums of squared
+//     differences of the (2K+1)^2 mini-patches around a and b / around c and b (integers: (int)(double(difference)^2));
+//  4. channel 8 c + i of the dense descriptor = 255 * bit i of a byte - 128 inside the key-point region, 0 outside, then imsmooth(1.75).
+//     WHICH byte: the reference walks `_buffer.col(c).ptr()` with ++ (:1066-1078) — the pointer of a column view advanced by one BYTE per
+//     key point, i.e. through the row-major [key points][bytes] buffer from offset c — so key point k of channel byte c reads byte
+//     (c + k) % bytes of key point (c + k) / bytes.  For latchNumBytes = 1 (the default and the only value in conf/) that IS byte c of
+//     key point k; for more bytes it is what the reference computes, restated as it is.
+static void latchDescriptor(const Params& p, const uint8_t* img, int rows, int cols, Descriptor& d, int nthreads)
+{
+  const int bytes = p.latchNumBytes, K = p.latchHalfSsdSize;
+  if(bytes != 1 && bytes != 2 && bytes != 4 && bytes != 8 && bytes != 16 && bytes != 32 && bytes != 64)
+    throw std::runtime_error("descriptorSize must be 1, 2, 4, 8, 16, 32, or 64");      // :104
+  const size_t n = (size_t) rows * cols;
+  const int border = 24 + K;                                       // getBorder(): PATCH_SIZE / 2 + half_ssd_size
+  const int y0 = border, y1 = rows - border - 1, x0 = border, x1 = cols - border - 1;
+  const int ny = std::max(0, y1 - y0), nx = std::max(0, x1 - x0);
+  const size_t nkp = (size_t) ny * nx;
+  std::vector<uint8_t> gray(n);
+  gaussianBlurU8_3x3(img, rows, cols, 2.0f, gray.data());
+  std::vector<int> off(6 * 8 * bytes);
+  latchOffsets(p.latchRotationInvariance != 0, (int) off.size(), off.data());
+  std::vector<uint8_t> buffer(nkp * bytes + 1, 0);
+  (void) nthreads;
+#pragma omp parallel for num_threads(nthreads) if(nthreads > 1)
+  for(int ky = 0; ky < ny; ++ky)
+    for(int kx = 0; kx < nx; ++kx) {
+      const int px = (int) ((float) (x0 + kx) + 0.5), py = (int) ((float) (y0 + ky) + 0.5);      // (int)(pt.pt.x + 0.5), pt a Point2f
+      uint8_t* desc = buffer.data() + ((size_t) ky * nx + kx) * bytes;
+      int count = 0;
+      for(int ix = 0; ix < bytes; ++ix) {
+        desc[ix] = 0;
+        for(int j = 7; j >= 0; --j) {
+          int suma = 0, sumc = 0;
+          const int ax2 = off[count] + px, ay2 = off[count + 1] + py, bx2 = off[count + 2] + px, by2 = off[count + 3] + py,
+                    cx2 = off[count + 4] + px, cy2 = off[count + 5] + py;
+          for(int iy = -K; iy <= K; ++iy) {
+            const uint8_t* Mi_a = gray.data() + (size_t) (ay2 + iy) * cols;
+            const uint8_t* Mi_b = gray.data() + (size_t) (by2 + iy) * cols;
+            const uint8_t* Mi_c = gray.data() + (size_t) (cy2 + iy) * cols;
+            for(int ixx = -K; ixx <= K; ++ixx) {
+              const double difa = Mi_a[ax2 + ixx] - Mi_b[bx2 + ixx];
+              suma += (int) (difa * difa);
+              const double difc = Mi_c[cx2 + ixx] - Mi_b[bx2 + ixx];
+              sumc += (int) (difc * difc);
+            }
+          }
+          desc[ix] += (uint8_t) ((suma < sumc) << j);
+          count += 6;
+        }
+      }
+    }
+  d.ch.assign(8 * bytes, std::vector<float>());
+#pragma omp parallel for num_threads(nthreads) if(nthreads > 1)
+  for(int j = 0; j < 8 * bytes; ++j) {
+    const int c = j / 8, bit = j % 8;
+    std::vector<float> tmp(n, 0.0f);
+    const uint8_t* src_ptr = buffer.data() + c;                    // _buffer.col(c).ptr<const uint8_t>(), then *src_ptr++
+    for(int y = y0; y < y1; ++y)
+      for(int x = x0; x < x1; ++x) {
+        const uint8_t val = *src_ptr++;
+        tmp[(size_t) y * cols + x] = 255.0f * (float) ((val & (1 << bit)) >> bit) + -128.0f;
+      }
+    d.ch[j].resize(n);
+    gaussianBlurF32_5x5(tmp.data(), rows, cols, 1.75f, d.ch[j].data());       // imsmooth(ch, ch, 1.75): 5 x 5 (bpvo/imgproc.cc:166-171)
+  }
+}
+
 void computeDescriptor(const Params& p, const uint8_t* img, int rows, int cols, Descriptor& d, int nthreads)
 {
   d.rows = rows;
   d.cols = cols;
   const size_t n = (size_t) rows * cols;
+  if(p.descriptor == kLatch) {
+    latchDescriptor(p, img, rows, cols, d, nthreads);
+    return;
+  }
   if(p.descriptor == kIntensity) {
     d.ch.resize(1);
     d.ch[0].resize(n);

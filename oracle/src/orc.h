@@ -37,7 +37,7 @@ namespace orc {
 // ---- enums (bpvo/types.h:127-169, 418-441): same numeric values
 enum { kHuber = 0x10, kTukey = 0x11, kL2 = 0x12 };
 enum { kIntensity = 0x30, kIntensityAndGradient = 0x31, kDescriptorFieldsFirstOrder = 0x32, kDescriptorFieldsSecondOrder = 0x33,
-       kCentralDifference = 0x35, kLaplacian = 0x36, kBitPlanes = 0x37 };
+       kLatch = 0x34, kCentralDifference = 0x35, kLaplacian = 0x36, kBitPlanes = 0x37 };
 enum { kCD3 = 0, kCD5 = 1 };
 enum { kLinear = 0, kCosine = 1, kCubic = 2, kCubicHermite = 3 };
 enum { kParameterTolReached = 0x30, kFunctionTolReached, kGradientTolReached, kMaxIterations, kSolverError };

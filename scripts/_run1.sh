@@ -1,3 +1,5 @@
-mkdir -p gpurun_out/r04c
-for n in 128 1024; do python scripts/shard_phases.py --pairs $n; BPVO_HIP_LANES=1 python scripts/shard_phases.py --pairs $n --steps 4; done > gpurun_out/r04c/phases.txt 2>&1
-cat gpurun_out/r04c/phases.txt
+mkdir -p gpurun_out/r04d
+rm -f gpurun_out/fuzz_outcomes.txt
+python -m pytest tests -m gpu -x -q -s > gpurun_out/r04d/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r04d/pytest_gpu.txt
+tail -5 gpurun_out/r04d/pytest_gpu.txt
+python bench.py > gpurun_out/r04d/bench.json 2> gpurun_out/r04d/bench.err; tail -c 600 gpurun_out/r04d/bench.json

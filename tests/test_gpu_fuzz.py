@@ -16,8 +16,16 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 
 pytestmark = pytest.mark.gpu
 
-ACCEPTED = {"ok", "template-error", "estimate-error", "non-finite", "unstable-problem", "iteration-limit", "stops-where-the-oracle-would",
-            "function-tol-at-the-noise-floor", "genuine-function-tol-stop", "genuine-scale-freeze", "noise-floor-minimum"}
+# Outcomes of fuzz_parity.check.  AGREED: both sides behave identically and there is no pose to compare (the same error raised by the
+# product and by the oracle — an empty template, a solver failure — or the same non-finite pose): parity of the error path.  EXPLAINED: every
+# stage up to the weights is bit-identical, the final pose is outside the bar, and one of the tool's rules shows — by asking the oracle
+# itself — that the difference is the problem's.  Each explained rule is capped, and so is their sum: a rule that starts to fire often is a
+# finding, not an explanation.
+AGREED = {"template-error", "estimate-error", "non-finite"}
+EXPLAINED = {"unstable-problem", "iteration-limit", "stops-where-the-oracle-would", "function-tol-at-the-noise-floor", "genuine-function-tol-stop",
+             "genuine-scale-freeze", "noise-floor-minimum"}
+ACCEPTED = {"ok"} | AGREED | EXPLAINED
+RULE_CAP, EXPLAINED_CAP, AGREED_CAP = 0.03, 0.08, 0.10      # fractions of the normalised cases of a run
 
 
 @pytest.mark.parametrize("seed,n_cases", [(20261001, 160), (20261002, 160)])
@@ -37,8 +45,18 @@ def test_bounded_fuzz_of_normalised_configurations(hip, orc, seed, n_cases):
         if n % 5 == 0 and out == "ok":
             outb = fz.check_batch(hip, rows, cols, kw, s)
             outcomes["batch-" + outb] = outcomes.get("batch-" + outb, 0) + 1
-    print(f"\nfuzz seed {seed}: {n} cases, outcomes {outcomes}")
-    assert outcomes.get("ok", 0) >= 0.85 * n_cases, outcomes
+    table = f"fuzz seed {seed}: {n} cases, outcomes {dict(sorted(outcomes.items()))}"
+    print("\n" + table)
+    out_dir = os.path.join(ROOT, "gpurun_out")       # (scratch that travels back from the GPU box; the committed copy: profiles/r04_fuzz_outcomes.txt)
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "fuzz_outcomes.txt"), "a") as f:
+        f.write(table + "\n")
+    explained = {k: v for k, v in outcomes.items() if k in EXPLAINED}
+    assert all(v <= RULE_CAP * n_cases for v in explained.values()), ("a rule explains more than %g of the cases" % RULE_CAP, outcomes)
+    assert sum(explained.values()) <= EXPLAINED_CAP * n_cases, outcomes
+    assert sum(v for k, v in outcomes.items() if k in AGREED) <= AGREED_CAP * n_cases, outcomes
+    assert outcomes.get("ok", 0) >= (1.0 - EXPLAINED_CAP - AGREED_CAP) * n_cases, outcomes
+    assert not [k for k in outcomes if k.startswith("batch-") and k != "batch-ok"], outcomes
 
 
 def test_the_normalised_regression_cases_are_explained(hip, orc):

@@ -275,9 +275,13 @@ def test_unsupported_and_invalid_create(hip):
     with pytest.raises(capi.BpvoError):
         hip.create(K, b, 120, 160, p)
     p = make_params(hip, levels=3)
-    p.descriptor = 0x34      # kLatch (bpvo/types.h:148), a research descriptor: not on the device path
+    p.descriptor = 0x38      # past the last DescriptorType (bpvo/types.h:142-152): DenseDescriptor::Create throws
     with pytest.raises(capi.BpvoError):
         hip.create(K, b, 120, 160, p)
+    for nbytes in (3, 8):    # kLatch: a size LATCHDescriptorExtractorImpl rejects (bpvo/latch_descriptor.cc:104); one the device path does not serve
+        p = make_params(hip, levels=3, descriptor="latch", latchNumBytes=nbytes)
+        with pytest.raises(capi.BpvoError):
+            hip.create(K, b, 120, 160, p)
     p = make_params(hip, levels=3)
     p.maxTestLevel = 7
     with pytest.raises(capi.BpvoError):

@@ -16,8 +16,8 @@ dp added); the oracle has the same record (oracle/bpvo_oracle.h).  What is asser
     the oracle restates the decomposition as n contiguous chunks, n = 1, 2, 4, 8, plus an f64 accumulation as an instrument);
  4. once they have PARTED (the scale estimator's freeze rule, Q6, and the three tolerance tests turn 1e-7 differences of f_norm into
     different branches; two decompositions of the reference can be 4e-4 rad apart in the middle of a level before they meet again
-    at the next): every iterate within 3 x the reference's own spread at that iterate, or within the bound of its branches
-    (BRANCH_ROT / BRANCH_TRANS below).  A level both sides run through the same iterates but leave at different iterations counts
+    at the next): every iterate within 3 x the reference's own spread at that iterate, or within 3 x the largest spread the
+    reference's decompositions show anywhere in that level (floor BRANCH_FLOOR_ROT / BRANCH_FLOOR_TRANS below).  A level both sides run through the same iterates but leave at different iterations counts
     as a parting too ("stop").  The coarsest level starts from the same pose and may not part at its first linearisation.  The
     parting points are printed with the relative differences of f_norm and scale there;
  5. the final pose within the north-star bar of the oracle's.
@@ -34,8 +34,10 @@ IT_ROT, IT_TRANS = 1e-6, 1e-5            # per-iterate agreement asked for while
 # Once two runs have taken different branches of the scale-freeze rule inside a level they head for different minima of that level
 # (different robust scale, different weights) and meet again at the next level.  Two decompositions of the REFERENCE do that: seed
 # 1000 at 1241x376, 4 chunks against 1: 4.1e-4 rad / 4.2e-3 m apart at level 1, 7e-7 rad / 8e-6 m at the end
-# (tests/tools/oracle_envelope.py).  Bound for iterates after such a parting:
-BRANCH_ROT, BRANCH_TRANS = 2e-3, 2e-2
+# (tests/tools/oracle_envelope.py).  Bound for iterates after such a parting: 3 x the largest spread the reference's own
+# decompositions show ANYWHERE IN THAT LEVEL of that configuration (computed below from the same traces), with this floor for levels at
+# which the five decompositions happen to stay together:
+BRANCH_FLOOR_ROT, BRANCH_FLOOR_TRANS = 5e-4, 5e-3
 VARIANTS = [("t1", 1, 0), ("t2", 2, 0), ("t4", 4, 0), ("t8", 8, 0), ("f64", 1, 1)]   # (name, chunks of the reduction, f64 accumulation)
 
 CONFIGS = [
@@ -113,6 +115,14 @@ def test_gpu_iterates_follow_the_reference_iteration_by_iteration(hip, orc, rows
         gl, ol = by_level(g["rec"], l), by_level(o1["rec"], l)
         others = [by_level(ref[name]["rec"], l) for name, _, _ in VARIANTS[1:]]
         K = min(len(gl), len(ol))
+        # the reference's own envelope over the whole level: the largest distance of any decomposition from the serial one at any iterate
+        lvl_rot = lvl_tr = 0.0
+        for v in others:
+            for k in range(min(len(v), len(ol))):
+                r_, t_ = dist(v[k], ol[k])
+                lvl_rot, lvl_tr = max(lvl_rot, r_), max(lvl_tr, t_)
+        branch_rot = max(BRANCH_FLOOR_ROT, 3.0 * lvl_rot)
+        branch_tr = max(BRANCH_FLOOR_TRANS * it_trans / IT_TRANS, 3.0 * lvl_tr)
         parted = None
         for k in range(K):
             rot, tr = dist(gl[k], ol[k])
@@ -135,8 +145,8 @@ def test_gpu_iterates_follow_the_reference_iteration_by_iteration(hip, orc, rows
                 assert abs(gl[k, 58] - ol[k, 58]) <= max(2.0 * env_f, 1e-3 * ol[k, 58]), (l, k, gl[k, 58], ol[k, 58], env_f)
             else:
                 # apart: inside what the reference's own decompositions show at this iterate, or inside the bound of its branches
-                assert (rot <= max(IT_ROT, 3.0 * env_rot) and tr <= max(it_trans, 3.0 * env_tr)) or (rot <= BRANCH_ROT and tr <= BRANCH_TRANS * it_trans / IT_TRANS), \
-                    (l, k, rot, tr, env_rot, env_tr)
+                assert (rot <= max(IT_ROT, 3.0 * env_rot) and tr <= max(it_trans, 3.0 * env_tr)) or (rot <= branch_rot and tr <= branch_tr), \
+                    (l, k, rot, tr, env_rot, env_tr, branch_rot, branch_tr)
         if parted is None and len(gl) != len(ol):
             parted = (K, "stop")       # same iterates, one side stops the level earlier: a tolerance test decided by rounding
         if parted is not None:

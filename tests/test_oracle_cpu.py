@@ -831,3 +831,112 @@ def test_unnormalised_fuzz_cases_sit_on_the_solver_fallback_edge(orc):
     # (the GPU run of the other two leaves the oracle's path elsewhere: one of them follows the f64-accumulating oracle to 5e-8 rad,
     #  profiles/r02_fuzz_replay.txt)
     assert sum(1 for e in edges if e[4] > 0) >= len(edges) - 2, edges
+
+
+# ---- LATCH (bpvo/latch_descriptor.cc), the last DenseDescriptor of the factory ---------------------------------------------------------
+def _latch_table():
+    import re
+    txt = open(os.path.join(ROOT, "oracle", "src", "latch_table.inc")).read()
+    body = txt.split("numbers only.")[1]
+    return np.array([int(v) for v in re.findall(r"-?\d+", body)], dtype=np.int64)
+
+
+def _latch_offsets(table, n_ints, rotation):
+    """CalcuateSums' coordinates (:170-236): the table's, or rotated by the constant key-point angle of cv::KeyPoint() (-1 degree) in f32,
+    truncated and clamped to the patch."""
+    t = table[:n_ints].reshape(-1, 2)
+    if not rotation:
+        return t.copy()
+    ang = np.float32(-1.0) * np.float32(3.1415926535897932384626433832795 / np.float32(180.0))
+    c, s = np.cos(ang, dtype=np.float32), np.sin(ang, dtype=np.float32)
+    x, y = t[:, 0].astype(np.float32), t[:, 1].astype(np.float32)
+    xr = np.trunc(x * c - y * s).astype(np.int64)
+    yr = np.trunc(x * s + y * c).astype(np.int64)
+    return np.stack([np.clip(xr, -24, 24), np.clip(yr, -24, 24)], axis=1)
+
+
+def _latch_numpy(img, nbytes, K, rotation):
+    """The definition, evaluated with whole-array operations: smoothed image, per triplet the two box sums of squared differences over
+    the key-point grid, bits -> bytes -> the channel planes as the reference fills them -> 5 x 5 Gaussian of sigma 1.75."""
+    R, W = img.shape
+    # cv::GaussianBlur(u8, 3 x 3, sigma 2): fixed-point taps round(k * 256), (sum + 2^15) >> 16
+    x = np.arange(3) - 1.0
+    k = np.exp(-0.5 * x * x / 4.0).astype(np.float32)
+    k = (k * np.float32(1.0 / np.float64(k.astype(np.float64).sum()))).astype(np.float32)
+    ki = np.rint(k.astype(np.float64) * 256.0).astype(np.int64)
+    rows = scipy.ndimage.correlate1d(img.astype(np.int64), ki, axis=1, mode="mirror")
+    gray = np.clip((scipy.ndimage.correlate1d(rows, ki, axis=0, mode="mirror") + (1 << 15)) >> 16, 0, 255)
+    H = 24 + K
+    ny, nx = R - 2 * H - 1, W - 2 * H - 1
+    C = 8 * nbytes
+    planes = np.zeros((C, R, W), np.float32)
+    if ny > 0 and nx > 0:
+        off = _latch_offsets(_latch_table(), 6 * C, rotation).reshape(C, 3, 2)        # [triplet][a, b, c][x, y]
+
+        def patch_sum(p, q):
+            acc = np.zeros((ny, nx), np.int64)
+            for iy in range(-K, K + 1):
+                for ix in range(-K, K + 1):
+                    A = gray[H + p[1] + iy: H + p[1] + iy + ny, H + p[0] + ix: H + p[0] + ix + nx]
+                    B = gray[H + q[1] + iy: H + q[1] + iy + ny, H + q[0] + ix: H + q[0] + ix + nx]
+                    acc += (A - B) ** 2
+            return acc
+        bits = np.stack([patch_sum(off[t, 0], off[t, 1]) < patch_sum(off[t, 2], off[t, 1]) for t in range(C)])     # [triplet][ky][kx]
+        buf = np.zeros((ny * nx, nbytes), np.uint8)
+        for ix in range(nbytes):
+            for j in range(7, -1, -1):
+                buf[:, ix] |= (bits[8 * ix + (7 - j)].reshape(-1).astype(np.uint8) << j)
+        flat = buf.reshape(-1)
+        for c in range(nbytes):
+            vals = flat[c: c + ny * nx].reshape(ny, nx)          # `_buffer.col(c).ptr()` advanced by ONE byte per key point (:1066-1078)
+            for i in range(8):
+                planes[8 * c + i, H: H + ny, H: H + nx] = 255.0 * ((vals >> i) & 1) - 128.0
+    xx = np.arange(5) - 2.0
+    g = np.exp(-0.5 * xx * xx / 1.75 ** 2)
+    g /= g.sum()
+    return np.stack([scipy.ndimage.correlate1d(scipy.ndimage.correlate1d(pl.astype(np.float64), g, axis=1, mode="mirror"), g, axis=0, mode="mirror")
+                     for pl in planes])
+
+
+def test_latch_tables_agree():
+    """The two data copies of the sampling table (product, oracle) hold the same 3072 integers — and, where the reference checkout
+    exists, they are `sampling_points_arr` of bpvo/latch_descriptor.cc."""
+    import re
+    t = _latch_table()
+    assert t.shape == (3072,) and t.min() == -24 and t.max() == 24
+    prod = open(os.path.join(ROOT, "bpvo_amd", "csrc", "latch_table.h")).read().split("kLatchTable[kLatchTableInts] = {")[1].split("};")[0]
+    assert np.array_equal(t, np.array([int(v) for v in re.findall(r"-?\d+", prod)]))
+    ref = "/root/reference/bpvo/latch_descriptor.cc"
+    if os.path.exists(ref):
+        txt = open(ref).read()
+        a = txt.index("{", txt.index("sampling_points_arr[]"))
+        assert np.array_equal(t, np.array([int(v) for v in re.findall(r"-?\d+", txt[a: txt.index("};", a)])]))
+
+
+def test_latch_rotated_offsets_are_insensitive_to_the_last_bit_of_the_cosine():
+    """latchRotationInvariance: the offsets are (int)(x cos - y sin) with the cosine / sine of -1 degree.  Whether the reference's `cos(angle)`
+    resolves to the float or to the double overload is a property of its toolchain; every product is at least 1e-4 from an integer, three
+    orders of magnitude more than the last bit of either cosine can move it."""
+    t = _latch_table().reshape(-1, 2).astype(np.float64)
+    ang = float(np.float32(-1.0) * np.float32(3.1415926535897932384626433832795 / np.float32(180.0)))
+    for c, s in ((np.cos(ang), np.sin(ang)), (float(np.cos(np.float32(ang), dtype=np.float32)), float(np.sin(np.float32(ang), dtype=np.float32)))):
+        for v in (t[:, 0] * c - t[:, 1] * s, t[:, 0] * s + t[:, 1] * c):
+            assert np.abs(v - np.rint(v)).min() > 1e-4
+
+
+@pytest.mark.parametrize("nbytes,K,rotation", [(1, 1, 0), (1, 3, 0), (4, 1, 0), (2, 0, 1), (4, 2, 1)])
+def test_latch_descriptor_against_a_numpy_evaluation_of_the_definition(orc, nbytes, K, rotation):
+    rows, cols = 97, 131
+    d = synth.make_pair(rows, cols, 3)
+    p = make_params(orc, descriptor="latch", levels=2, latchNumBytes=nbytes, latchHalfSsdSize=K, latchRotationInvariance=rotation)
+    ctx = orc.create(d["K"], d["b"], rows, cols, p, n_frames=2, n_pairs=1)
+    ctx.frame_set_data(0, d["imgA"], d["dispA"])
+    assert ctx.Cn == 8 * nbytes
+    want = _latch_numpy(d["imgA"], nbytes, K, rotation)
+    got = np.stack([ctx.get_descriptor_channel(0, 0, c) for c in range(8 * nbytes)])
+    assert np.abs(got - want).max() < 1e-3, np.abs(got - want).max()
+    assert got.min() < -100 and got.max() > 50                    # both bit values occur: the planes are not trivially zero
+    # level 1 (66 x 49): narrower than two borders — no key point, a zero descriptor (the loops of :136-141 never run)
+    if 49 - 2 * (24 + K) - 1 <= 0:
+        assert all(np.all(ctx.get_descriptor_channel(0, 1, c) == 0.0) for c in range(8 * nbytes))
+    ctx.close()

@@ -20,7 +20,7 @@ def make_params(b, descriptor="bitplanes", loss="tukey", levels=4, **kw):
     p.numPyramidLevels = levels
     p.descriptor = {"bitplanes": capi.DESC_BITPLANES, "intensity": capi.DESC_INTENSITY, "laplacian": capi.DESC_LAPLACIAN,
                     "gradient": capi.DESC_GRADIENT, "fields1": capi.DESC_FIELDS1, "fields2": capi.DESC_FIELDS2,
-                    "centraldiff": capi.DESC_CENTRAL_DIFFERENCE}[descriptor]
+                    "centraldiff": capi.DESC_CENTRAL_DIFFERENCE, "latch": capi.DESC_LATCH}[descriptor]
     p.lossFunction = {"tukey": capi.LOSS_TUKEY, "huber": capi.LOSS_HUBER, "l2": capi.LOSS_L2}[loss]
     p.verbosity = capi.VERB_SILENT
     for k, v in kw.items():
