@@ -1100,3 +1100,51 @@ def test_selection_on_odd_shapes(hip, orc, rows, cols, radius, nms_from):
         assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l)), l
         assert bits_equal(ch.get_points(0, l), co.get_points(0, l)) and bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)), l
     ch.close(); co.close()
+
+
+@pytest.mark.parametrize("rows,cols,levels,nbytes,K,rotation", [
+    pytest.param(120, 160, 3, 1, 1, 0, id="160x120-1byte"), pytest.param(120, 160, 3, 4, 1, 0, id="160x120-4bytes"),
+    pytest.param(480, 640, 4, 1, 1, 0, id="640x480-1byte"), pytest.param(480, 640, 4, 4, 1, 0, id="640x480-4bytes"),
+    pytest.param(121, 163, 2, 2, 3, 1, id="163x121-2bytes-K3-rotation"), pytest.param(120, 160, 2, 1, 0, 1, id="160x120-1byte-K0-rotation")])
+def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotation):
+    """kLatch (LatchDescriptor, bpvo/latch_descriptor.cc:83-165,1041-1086; factory bpvo/dense_descriptor.cc:69-72; parameters of
+    conf/tsukuba_eval.cfg:49-52 in the first cases): 8 * latchNumBytes channels of +-128-valued bit planes of the densely evaluated LATCH
+    bytes, each smoothed with imsmooth(1.75) — integer sums of squared differences over u8 patches, so the planes must equal the oracle's
+    BIT FOR BIT, as must everything built from them; poses within the bar.  Levels too small for a key point (border 24 + K on every side)
+    give a zero descriptor and an empty template on both sides."""
+    ch, co, d = both(hip, orc, rows, cols, levels, descriptor="latch", loss="tukey", latchNumBytes=nbytes, latchHalfSsdSize=K,
+                     latchRotationInvariance=rotation)
+    C = 8 * nbytes
+    assert ch.Cn == co.Cn == C
+    some_points = False
+    for l in range(levels):
+        for c in range(C):
+            a = ch.get_descriptor_channel(1, l, c)
+            assert bits_equal(a, co.get_descriptor_channel(1, l, c)), (l, c)
+        assert bits_equal(ch.get_saliency(0, l), co.get_saliency(0, l)), l
+        assert np.array_equal(ch.get_point_indices(0, l), co.get_point_indices(0, l))
+        if ch.num_points(0, l) == 0:
+            continue
+        some_points = True
+        assert bits_equal(ch.get_pixels(0, l), co.get_pixels(0, l)) and bits_equal(ch.get_jacobians(0, l), co.get_jacobians(0, l))
+        for T in (np.eye(4, dtype=np.float32), _perturbed_pose(1.0)):
+            a, b = ch.linearize(0, 0, 1, l, T), co.linearize(0, 0, 1, l, T)
+            vo = co.get_valid(0)
+            assert np.array_equal(ch.get_valid(0), vo) and bits_equal(ch.get_residuals(0), co.get_residuals(0))
+            assert a["sigma"] == b["sigma"] and bits_equal(ch.get_weights(0), co.get_weights(0))
+            H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, C)
+            assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
+    assert some_points
+    hip_err = orc_err = None
+    try:
+        Th, _ = ch.estimate_pose(0, 0, 1)
+    except capi.BpvoError as e:
+        hip_err = str(e)
+    try:
+        To, _ = co.estimate_pose(0, 0, 1)
+    except capi.BpvoError as e:
+        orc_err = str(e)
+    assert (hip_err is None) == (orc_err is None), (hip_err, orc_err)
+    if hip_err is None:
+        rot, trans = pose_error(Th, To)
+        assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
