@@ -455,6 +455,17 @@ class Context:
         self.call("team_counts", C.byref(a))
         return a.value
 
+    def set_option(self, key, value):
+        """bpvo_hip_set_option: per-context scheduling options (include/bpvo_hip/c_api.h)."""
+        self.b.fn("set_option").argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        self._ck(self.b.fn("set_option")(self.h, key.encode(), C.c_double(float(value))))
+
+    def get_option(self, key):
+        v = C.c_double(0.0)
+        self.b.fn("get_option").argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        self._ck(self.b.fn("get_option")(self.h, key.encode(), C.byref(v)))
+        return v.value
+
     def set_max_lanes(self, n):
         """Cap (n >= 1) or uncap (n <= 0) the estimation lanes of later batch calls (HIP library only)."""
         self.call("set_max_lanes", int(n))

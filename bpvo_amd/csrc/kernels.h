@@ -103,7 +103,6 @@ struct GNLaunch {
   int fuse_frozen = 0;   // estimate loops, C = 8, kLinear, f64 formulation: once a workspace's scale is frozen, irls_reduce
                          // recomputes the residuals itself and warp_residual skips the workspace
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
-  int merge_irls = 0;    // fuse_frozen: one irls_reduce launch with a per-workspace branch instead of two instantiations sharing the slot
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);

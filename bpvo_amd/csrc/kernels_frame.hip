@@ -45,37 +45,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const
 
 // ---- K0: cv::pyrDown u8 (reference call site: bpvo/image_pyramid.cc:49).  [1 4 6 4 1]^2 / 256 with (s + 128) >> 8,
 // BORDER_REFLECT_101, dst = ((W+1)/2, (R+1)/2).  Integer arithmetic: evaluation order is irrelevant.
-// Every thread produces PD_ROWS vertically adjacent outputs of one column: the horizontal [1 4 6 4 1] sums of the
-// 2*PD_ROWS + 3 source rows involved are formed once and shared between the outputs.
-constexpr int PD_ROWS = 4;
-__global__ __launch_bounds__(256) void pyrdown_u8_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
-{
-  const FrameJob& sj = src_jobs[blockIdx.z];
-  const FrameJob& dj = dst_jobs[blockIdx.z];
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
-  if(x >= dj.cols || y0 >= dj.rows) return;
-  const int sw = sj.cols, sh = sj.rows;
-  const uint8_t* __restrict__ s = sj.img;
-  int xs[5];
-#pragma unroll
-  for(int k = 0; k < 5; ++k) xs[k] = reflect101(2 * x - 2 + k, sw);
-  int h[2 * PD_ROWS + 3];
-#pragma unroll
-  for(int k = 0; k < 2 * PD_ROWS + 3; ++k) {
-    const uint8_t* row = s + (size_t) reflect101(min(2 * y0 - 2 + k, sh + 1), sh) * sw;
-    h[k] = row[xs[2]] * 6 + (row[xs[1]] + row[xs[3]]) * 4 + row[xs[0]] + row[xs[4]];
-  }
-#pragma unroll
-  for(int r = 0; r < PD_ROWS; ++r) {
-    const int y = y0 + r;
-    if(y >= dj.rows) break;
-    const int acc = h[2 * r] + 4 * h[2 * r + 1] + 6 * h[2 * r + 2] + 4 * h[2 * r + 3] + h[2 * r + 4];
-    const_cast<uint8_t*>(dj.img.get())[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
-  }
-}
-
-// The same through LDS (the form launch_pyrdown uses): a workgroup stages the (2*64+3) x (2*16+3) source pixels of a 64 x 16 output
+// Through LDS: a workgroup stages the (2*64+3) x (2*16+3) source pixels of a 64 x 16 output
 // tile with row-contiguous loads (whole dwords where the tile allows: see below), forms the horizontal [1 4 6 4 1] sums once per (source row, output column) and the vertical ones from
 // those.  Integer arithmetic, same values.  1024 pairs of 1241x376: 2.5 -> see profiles/README.md ms per step for the three levels.
 constexpr int PDT_W = 64, PDT_H = 16;
@@ -1132,9 +1102,7 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 }
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {
-  static const bool direct = std::getenv("BPVO_HIP_PYRDOWN_DIRECT") != nullptr;     // A/B switch: the register-only form
-  if(direct) hipLaunchKernelGGL(pyrdown_u8_kernel, dim3((dW + 63) / 64, (dR + 4 * PD_ROWS - 1) / (4 * PD_ROWS), nframes), dim3(256), 0, s, src, dst);
-  else hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H - 1) / PDT_H, nframes), dim3(256), 0, s, src, dst);
+  hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H - 1) / PDT_H, nframes), dim3(256), 0, s, src, dst);
 }
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {

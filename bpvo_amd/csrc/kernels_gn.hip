@@ -513,7 +513,7 @@ void launch_median(hipStream_t s, const GNLaunch& g)
         (void) hipFuncSetAttribute((const void*) median_finish_kernel<CC, MED_THREADS_B, MED_COPIES_B, MED_CACHE_B>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) kMedianLdsB);
       });
   });
-  static const int wide_from = std::getenv("BPVO_HIP_MEDIAN_WIDE_FROM") ? std::atoi(std::getenv("BPVO_HIP_MEDIAN_WIDE_FROM")) : 257;   // A/B
+  constexpr int wide_from = 257;      // launches of more workgroups than CUs take the 512-thread shape (profiles/r02_median_shapes.txt, r03_shard_ab_lanes_median.txt)
   dispatch_channels(g.C, [&](auto c) {
     constexpr int CC = decltype(c)::value;
     if(g.npairs >= wide_from)
@@ -529,7 +529,7 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
   const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
   if constexpr(C == 8) {
-    if(fuse && g.merge_irls) {
+    if(fuse) {      // one launch serves the workspaces with a moving scale and the frozen ones (per-workspace branch)
       switch(g.loss) {
         case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
         case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
@@ -542,14 +542,6 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
     case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
     case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
     default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-  }
-  if constexpr(C == 8) {
-    if(!fuse) return;
-    switch(g.loss) {
-      case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_HUBER, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-      case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_TUKEY, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-      default: hipLaunchKernelGGL((irls_reduce_kernel<8, BPVO_LOSS_L2, true>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-    }
   }
 }
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)

@@ -1,0 +1,314 @@
+// libbpvo_hip, host side: VisualOdometry::addFrame (reference: bpvo/vo.cc:125-224) on device-resident frame slots, point cloud, trajectory, and the stereo
+// front-end (block matching, SGM) that feeds it.
+#include "host_ctx.h"
+
+using namespace bpvo_hip;
+using namespace bpvo_hip_host;
+
+extern "C" {
+
+// ---- VisualOdometry -------------------------------------------------------------------------------------------------
+static int should_keyframe(bpvo_hip_ctx* c, const M44& pose, int* reason)   // reference: bpvo/vo.cc:199-224
+{
+  const bpvo_hip_params& p = c->params;
+  const float t_norm = pose.m[3] * pose.m[3] + pose.m[7] * pose.m[7] + pose.m[11] * pose.m[11];
+  if(t_norm > p.minTranslationMagToKeyFrame * p.minTranslationMagToKeyFrame) { *reason = BPVO_KF_LARGE_TRANSLATION; return BPVO_OK; }
+  // math::RotationMatrixToEulerAngles (bpvo/math_utils.h:203-216); compared in radians (Q17)
+  const float R00 = pose.m[0], R10 = pose.m[4], R20 = pose.m[8], R21 = pose.m[9];
+  const float eta = (float) (1.0 / (std::sqrt(R00 * R00 + R10 * R10)));
+  const float rz = std::asin(eta * R10), ry = std::asin(-R20), rx = std::asin(eta * R21);
+  const float r_norm = rx * rx + ry * ry + rz * rz;
+  if(r_norm > p.minRotationMagToKeyFrame * p.minRotationMagToKeyFrame) { *reason = BPVO_KF_LARGE_ROTATION; return BPVO_OK; }
+  float frac = 0.0f;
+  int rc = fraction_good(c, 0, p.goodPointThreshold, &frac);
+  if(rc) return rc;
+  *reason = (frac < p.maxFractionOfGoodPointsToKeyFrame) ? BPVO_KF_SMALL_FRAC_GOOD : BPVO_KF_NO_KEYFRAMING;
+  return BPVO_OK;
+}
+
+// getPointCloudFromRefFrame + GetColor (reference: bpvo/vo.cc:250-281)
+static int build_point_cloud(bpvo_hip_ctx* c)
+{
+  const int lvl = c->params.maxTestLevel;
+  FrameSlot& ref = c->frames[c->vo_ref];
+  const int n = ref.n_host[lvl];
+  std::vector<float> w_cm;
+  int nw = 0;
+  int rc = get_weights_host(c, 0, w_cm, &nw);
+  if(rc) return rc;
+  if((size_t) n > w_cm.size()) return fail(c, BPVO_ERR_INVALID_ARG, "size mismatch");
+  std::vector<float> pts((size_t) n * 4);
+  std::vector<uint8_t> img(c->geom[0].npix);
+  if(n) HIP_CK(c, hipMemcpyAsync(pts.data(), ref.pts[lvl], pts.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipMemcpyAsync(img.data(), ref.img[0], img.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  c->cloud.resize(n);
+  const float* Kl = c->geom[lvl].K;
+  for(int i = 0; i < n; ++i) {
+    const float* X = pts.data() + 4 * (size_t) i;
+    float x[3];
+    for(int r = 0; r < 3; ++r) {   // getImagePoint (bpvo/rigid_body_warp.h:123-128)
+      float s = Kl[r * 3 + 0] * X[0];
+      s += Kl[r * 3 + 1] * X[1];
+      s += Kl[r * 3 + 2] * X[2];
+      x[r] = s;
+    }
+    const float z_i = 1.0f / x[2];
+    float u = z_i * x[0], v = z_i * x[1];
+    if(c->dspace) { u = X[0] + Kl[2]; v = X[1] + Kl[5]; }   // DisparitySpaceWarp::getImagePoint (disparity_space_warp.h:73-76)
+    uint8_t col = 0;
+    if(v >= 0 && v < c->rows && u >= 0 && u < c->cols) col = img[(size_t) ((int) v) * c->cols + (int) u];
+    bpvo_hip_point_with_info& pw = c->cloud[i];
+    std::memset(&pw, 0, sizeof(pw));
+    std::memcpy(pw.xyzw, X, 4 * sizeof(float));
+    pw.rgba[0] = col; pw.rgba[1] = col; pw.rgba[2] = col; pw.rgba[3] = 255;
+    pw.weight = w_cm[i];
+  }
+  return BPVO_OK;
+}
+
+// ---- stereo front-end (reference: utils/stereo_algorithm.cc:63-82,98-111 -> OpenCV 2.4 cvFindStereoCorrespondenceBM) ----
+static int stereo_check(bpvo_hip_ctx* c, const bpvo_hip_stereo_params* sp)
+{
+  // the argument checks of cvFindStereoCorrespondenceBM (stereobm.cpp) + what the kernel serves
+  if(!sp) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr stereo parameters");
+  if(sp->algorithm == BPVO_STEREO_SGM) {
+    // the checks of SgmStereo::compute / the SGMStereo setters (utils/sgm.cc:168-171,208-254)
+    if(sp->numberOfDisparities <= 0 || sp->numberOfDisparities % 16) return fail(c, BPVO_ERR_INVALID_ARG, "numberOfDisparities must be a multiple of 16");
+    if(sp->censusRadius < 1 || sp->censusRadius > 2) return fail(c, BPVO_ERR_INVALID_ARG, "window radius of Census transform must be 1 or 2");
+    if(sp->censusWeightFactor < 0) return fail(c, BPVO_ERR_INVALID_ARG, "weight of Census transform must be positive");
+    if(sp->smoothnessPenaltySmall < 0 || sp->smoothnessPenaltyLarge < 0) return fail(c, BPVO_ERR_INVALID_ARG, "smoothness penalty value is less than zero");
+    if(sp->smoothnessPenaltySmall >= sp->smoothnessPenaltyLarge) return fail(c, BPVO_ERR_INVALID_ARG, "small value of smoothness penalty must be smaller than large penalty value");
+    if(sp->consistencyThreshold < 0) return fail(c, BPVO_ERR_INVALID_ARG, "threshold for LR consistency must be positive");
+    if(!(sp->disparityFactor > 0)) return fail(c, BPVO_ERR_INVALID_ARG, "disparity factor is less than zero");
+    if(sp->numberOfDisparities > 256) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: numberOfDisparities <= 256 are on the device path");
+    if(sp->windowRadius < 0 || sp->windowRadius > 7 || c->rows <= sp->windowRadius) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: windowRadius 0..7 (and fewer than image rows) are on the device path");
+    // int16 path costs: the sums of four paths stay clear of saturation for penalties below this (the original saturates silently)
+    if(sp->smoothnessPenaltyLarge > 4000) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: smoothnessPenaltyLarge <= 4000 on the device path");
+    return BPVO_OK;
+  }
+  if(sp->algorithm != BPVO_STEREO_BLOCK_MATCHING) return fail(c, BPVO_ERR_UNSUPPORTED, "StereoAlgorithm: BlockMatching and SGM are on the device path (SGBM is OpenCV's, RSGM is not built)");
+  if(sp->preFilterCap < 1 || sp->preFilterCap > 63) return fail(c, BPVO_ERR_INVALID_ARG, "preFilterCap must be within 1..63");
+  if(sp->SADWindowSize < 5 || sp->SADWindowSize > 255 || sp->SADWindowSize % 2 == 0 || sp->SADWindowSize >= std::min(c->cols, c->rows))
+    return fail(c, BPVO_ERR_INVALID_ARG, "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height");
+  if(sp->numberOfDisparities <= 0 || sp->numberOfDisparities % 16 != 0) return fail(c, BPVO_ERR_INVALID_ARG, "numberOfDisparities must be positive and divisble by 16");
+  if(sp->textureThreshold < 0) return fail(c, BPVO_ERR_INVALID_ARG, "texture threshold must be non-negative");
+  if(sp->uniquenessRatio < 0) return fail(c, BPVO_ERR_INVALID_ARG, "uniqueness ratio must be non-negative");
+  if(sp->SADWindowSize > 21) return fail(c, BPVO_ERR_UNSUPPORTED, "SADWindowSize: 5..21 are on the device path");
+  if(sp->minDisparity < 0 || sp->numberOfDisparities > 256) return fail(c, BPVO_ERR_UNSUPPORTED, "minDisparity >= 0 and numberOfDisparities <= 256 are on the device path");
+  return BPVO_OK;
+}
+static int stereo_reserve(bpvo_hip_ctx* c, int count)
+{
+  if(count <= c->st_frames) return BPVO_OK;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
+  c->st_left = c->st_right = c->st_left_pre = c->st_right_pre = nullptr; c->st_disp = nullptr; c->st_frames = 0;
+  const size_t npix = c->geom[0].npix * (size_t) count;
+  HIP_CK(c, hipMalloc((void**) &c->st_left, npix)); HIP_CK(c, hipMalloc((void**) &c->st_right, npix));
+  HIP_CK(c, hipMalloc((void**) &c->st_left_pre, npix)); HIP_CK(c, hipMalloc((void**) &c->st_right_pre, npix));
+  HIP_CK(c, hipMalloc((void**) &c->st_disp, npix * sizeof(float)));
+  c->st_frames = count;
+  return BPVO_OK;
+}
+// disparities of `count` rectified pairs into c->st_disp (device); d_left: where the left images are on the device afterwards
+static int stereo_run(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, bool on_device, const bpvo_hip_stereo_params* sp,
+                      const uint8_t** d_left)
+{
+  int rc = stereo_check(c, sp);
+  if(rc) return rc;
+  if(count <= 0 || !left || !right) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image");
+  rc = stereo_reserve(c, count);
+  if(rc) return rc;
+  const size_t npix = c->geom[0].npix * (size_t) count;
+  const uint8_t* dl = left;
+  const uint8_t* dr = right;
+  if(!on_device) {
+    HIP_CK(c, hipMemcpyAsync(c->st_left, left, npix, hipMemcpyHostToDevice, c->stream));
+    HIP_CK(c, hipMemcpyAsync(c->st_right, right, npix, hipMemcpyHostToDevice, c->stream));
+    dl = c->st_left; dr = c->st_right;
+  }
+  if(sp->algorithm == BPVO_STEREO_SGM) {
+    const size_t need = sgm_scratch_bytes(c->rows, c->cols, sp->numberOfDisparities);
+    if(need > c->st_sgm_bytes) {
+      HIP_CK(c, hipStreamSynchronize(c->stream));
+      (void) hipFree(c->st_sgm);
+      c->st_sgm = nullptr; c->st_sgm_bytes = 0;
+      HIP_CK(c, hipMalloc(&c->st_sgm, need));
+      c->st_sgm_bytes = need;
+    }
+    SgmLaunch g;
+    g.left = dl; g.right = dr; g.disp = c->st_disp; g.scratch = c->st_sgm;
+    g.rows = c->rows; g.cols = c->cols; g.nframes = count;
+    g.ndisp = sp->numberOfDisparities; g.sobel_cap = sp->sobelCapValue; g.census_radius = sp->censusRadius; g.window_radius = sp->windowRadius;
+    g.P1 = sp->smoothnessPenaltySmall; g.P2 = sp->smoothnessPenaltyLarge; g.consistency_threshold = sp->consistencyThreshold;
+    g.disparity_factor = sp->disparityFactor; g.census_weight = sp->censusWeightFactor;
+    if(!launch_stereo_sgm(c->stream, g)) return fail(c, BPVO_ERR_UNSUPPORTED, "semi-global matching: disparity range not served by the kernels");
+    HIP_CK(c, hipGetLastError());
+    if(d_left) *d_left = dl;
+    return BPVO_OK;
+  }
+  launch_stereo_prefilter(c->stream, dl, c->st_left_pre, c->rows, c->cols, sp->preFilterCap, count);
+  launch_stereo_prefilter(c->stream, dr, c->st_right_pre, c->rows, c->cols, sp->preFilterCap, count);
+  StereoLaunch g;
+  g.left_pre = c->st_left_pre; g.right_pre = c->st_right_pre; g.disp = c->st_disp;
+  g.rows = c->rows; g.cols = c->cols; g.nframes = count;
+  g.wsz = sp->SADWindowSize; g.ndisp = sp->numberOfDisparities; g.mindisp = sp->minDisparity; g.cap = sp->preFilterCap;
+  g.texture_threshold = sp->textureThreshold; g.uniqueness_ratio = sp->uniquenessRatio;
+  if(!launch_stereo_bm(c->stream, g)) return fail(c, BPVO_ERR_UNSUPPORTED, "stereo block matching: window / disparity range not served by the kernel");
+  HIP_CK(c, hipGetLastError());
+  if(d_left) *d_left = dl;
+  return BPVO_OK;
+}
+
+void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p)   // utils/stereo_algorithm.cc:63-82 (numberOfDisparities has no default there)
+{
+  std::memset(p, 0, sizeof(*p));
+  p->preFilterCap = 31; p->SADWindowSize = 15; p->minDisparity = 0; p->numberOfDisparities = 64; p->textureThreshold = 10; p->uniquenessRatio = 15;
+  // SgmStereo::Config() (utils/sgm.cc:47-56); algorithm: "BlockMatching" is the config file's default (utils/stereo_algorithm.cc:25)
+  p->algorithm = BPVO_STEREO_BLOCK_MATCHING;
+  p->sobelCapValue = 15; p->censusRadius = 2; p->windowRadius = 2; p->smoothnessPenaltySmall = 100; p->smoothnessPenaltyLarge = 1600;
+  p->consistencyThreshold = 1; p->disparityFactor = 256.0; p->censusWeightFactor = 1.0 / 6.0;
+}
+int bpvo_hip_stereo_bm(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, int on_device, const bpvo_hip_stereo_params* sp,
+                       float* disparity, int disparity_on_device)
+{
+  CHECK_CTX(c);
+  if(!disparity) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr disparity");
+  (void) hipSetDevice(c->device);
+  int rc = stereo_run(c, count, left, right, on_device != 0, sp, nullptr);
+  if(rc) return rc;
+  HIP_CK(c, hipMemcpyAsync(disparity, c->st_disp, c->geom[0].npix * (size_t) count * sizeof(float),
+                           disparity_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
+}
+
+static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bool on_device, bpvo_hip_result* ret);
+int bpvo_hip_add_frame(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bpvo_hip_result* ret)
+{
+  CHECK_CTX(c);
+  if(!image || !disparity) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");   // bpvo/vo.cc:68-69
+  return add_frame_impl(c, image, disparity, false, ret);
+}
+// addFrame fed by the stereo front-end: the reference's apps run StereoAlgorithm::run on the rectified pair and hand the f32
+// disparity to VisualOdometry::addFrame (apps/vo_app.cc, utils/dataset.h); here the disparity never leaves the device
+int bpvo_hip_add_frame_stereo(bpvo_hip_ctx* c, const uint8_t* left, const uint8_t* right, const bpvo_hip_stereo_params* sp, bpvo_hip_result* ret)
+{
+  CHECK_CTX(c);
+  if(!left || !right) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image");
+  (void) hipSetDevice(c->device);
+  const uint8_t* d_left = nullptr;
+  int rc = stereo_run(c, 1, left, right, false, sp, &d_left);
+  if(rc) return rc;
+  return add_frame_impl(c, d_left, c->st_disp, true, ret);
+}
+static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* disparity, bool on_device, bpvo_hip_result* ret)
+{
+  if(!ret) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr result");
+  if(c->n_frames < 3) return fail(c, BPVO_ERR_INVALID_ARG, "add_frame needs a ctx with n_frames >= 3");
+  (void) hipSetDevice(c->device);
+  const M44 I = m44_identity();
+  std::memset(ret, 0, sizeof(*ret));
+  std::memcpy(ret->pose, I.m, 64);
+  for(int i = 0; i < 36; ++i) ret->covariance[i] = (i % 7 == 0) ? 1.0f : 0.0f;   // Q16
+  ret->numLevels = c->L;
+  for(int l = 0; l < kMaxLevels; ++l) ret->optimizerStatistics[l] = bpvo_hip_stats{0, -1.0f, -1.0f, BPVO_STATUS_SOLVER_ERROR};
+  ret->isKeyFrame = 0;
+  ret->keyFramingReason = BPVO_KF_NO_KEYFRAMING;
+  ret->hasPointCloud = 0;
+  c->cloud.clear();                 // the point cloud belongs to one Result (bpvo/types.h:549-563)
+  c->cloud_pose = I;
+
+  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, on_device);   // _cur_frame->setData (vo.cc:131)
+  if(rc) return rc;
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+
+  if(!c->frames[c->vo_ref].has_template) {            // first frame (vo.cc:133-139)
+    std::swap(c->vo_ref, c->vo_cur);
+    rc = frames_set_template(c, c->vo_ref, 1, 1);
+    if(rc) return rc;
+    trajectory_push(c, c->T_kf);
+    ret->isKeyFrame = 1;
+    ret->keyFramingReason = BPVO_KF_FIRST_FRAME;
+    return BPVO_OK;
+  }
+
+  M44 T_est;
+  const int ws0 = 0;
+  rc = check_template_not_empty(c, c->vo_ref);
+  if(rc) return rc;
+  c->prefetch_frac_thr = c->params.goodPointThreshold;      // should_keyframe's fraction of good points rides behind the estimate
+  rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, c->T_kf.m, T_est.m, ret->optimizerStatistics);
+  c->prefetch_frac_thr = -1.0f;
+  if(rc) return rc;
+  int reason = BPVO_KF_NO_KEYFRAMING;
+  rc = should_keyframe(c, T_est, &reason);
+  if(rc) return rc;
+  ret->keyFramingReason = reason;
+  ret->isKeyFrame = reason != BPVO_KF_NO_KEYFRAMING;
+
+  M44 pose;
+  if(!ret->isKeyFrame) {
+    std::swap(c->vo_prev, c->vo_cur);
+    pose = m44_mul(T_est, m44_inverse(c->T_kf));
+    c->T_kf = T_est;
+  } else {
+    rc = build_point_cloud(c);
+    if(rc) return rc;
+    ret->hasPointCloud = 1;
+    if(!c->frames[c->vo_prev].has_data) {               // vo.cc:161-173
+      std::swap(c->vo_cur, c->vo_ref);
+      rc = frames_set_template(c, c->vo_ref, 1, 1);
+      if(rc) return rc;
+      pose = m44_mul(T_est, m44_inverse(c->T_kf));
+      c->T_kf = m44_identity();
+    } else {                                            // vo.cc:174-188
+      std::swap(c->vo_prev, c->vo_ref);
+      c->frames[c->vo_prev].has_data = false;
+      c->frames[c->vo_prev].has_template = false;
+      rc = frames_set_template(c, c->vo_ref, 1, 1);
+      if(rc) return rc;
+      rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, I.m, T_est.m, ret->optimizerStatistics);
+      if(rc) return rc;
+      pose = T_est;
+      c->T_kf = T_est;
+    }
+  }
+  std::memcpy(ret->pose, pose.m, 64);
+  trajectory_push(c, pose);
+  if(ret->hasPointCloud) c->cloud_pose = c->trajectory.back();
+  return BPVO_OK;
+}
+
+int bpvo_hip_vo_num_points_at_level(bpvo_hip_ctx* c, int level, int* n)
+{
+  CHECK_CTX(c);
+  if(level < 0) level = c->params.maxTestLevel;
+  if(level >= c->L) return fail(c, BPVO_ERR_INVALID_ARG, "bad level");
+  *n = c->frames[c->vo_ref].has_template ? c->frames[c->vo_ref].n_host[level] : 0;
+  return BPVO_OK;
+}
+int bpvo_hip_vo_points_at_level(bpvo_hip_ctx* c, int level, float* xyzw)
+{
+  CHECK_CTX(c);
+  if(level < 0) level = c->params.maxTestLevel;
+  return bpvo_hip_get_points(c, c->vo_ref, level, xyzw);
+}
+int bpvo_hip_get_point_cloud(bpvo_hip_ctx* c, bpvo_hip_point_with_info* pts, size_t* n, float pose[16])
+{
+  CHECK_CTX(c);
+  if(n) *n = c->cloud.size();
+  if(pts) std::memcpy(pts, c->cloud.data(), c->cloud.size() * sizeof(bpvo_hip_point_with_info));
+  if(pose) std::memcpy(pose, c->cloud_pose.m, 64);
+  return BPVO_OK;
+}
+int bpvo_hip_trajectory_size(bpvo_hip_ctx* c, int* n) { CHECK_CTX(c); *n = (int) c->trajectory.size(); return BPVO_OK; }
+int bpvo_hip_get_trajectory(bpvo_hip_ctx* c, float* poses)
+{
+  CHECK_CTX(c);
+  for(size_t i = 0; i < c->trajectory.size(); ++i) std::memcpy(poses + 16 * i, c->trajectory[i].m, 64);
+  return BPVO_OK;
+}
+
+}  // extern "C"

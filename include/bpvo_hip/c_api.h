@@ -330,9 +330,39 @@ int bpvo_hip_fused_point_counts(bpvo_hip_ctx* ctx, uint64_t* fused, uint64_t* to
 /* tap cache of warp_residual since the last counter reset: out[0] hits, out[1] lookups (= valid points), out[2] / out[3] the same over
  * the first 8 linearisations of every level (the moving-pose regime) */
 int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
-/* estimation lanes (streams) later batch calls may use: n >= 1 caps them, n <= 0 lifts the cap.  Batches are split over up to two
- * lanes by default so that the narrow per-pair kernels of one overlap the wide kernels of the other; per-launch timings are only
- * clean with one lane.  Results never depend on it. */
+/* ---- per-context options: how the library schedules its work.  None of them changes a result (every setting is covered by a
+ * bit-identity test); they exist so that a caller — not the process environment — decides, per context.  Call between API calls, from the
+ * thread that drives the context.  Unknown key or value out of range: BPVO_ERR_INVALID_ARG (bpvo_hip_last_error names the key).
+ *
+ *   key                      default   meaning
+ *   "lanes"                  2         estimation lanes (HIP streams driven by host threads) a pair batch fans out over, 1 .. 8 (at least 8
+ *                                      pairs per lane).  The narrow per-pair kernels of one lane overlap the chip-filling kernels of another;
+ *                                      per-launch timings are only clean with 1.  Lanes beyond those the context holds are allocated here.
+ *   "persistent"             1         single pairs (estimatePose, addFrame) run every pyramid level in ONE persistent launch; 0: the
+ *                                      four-kernel chain.  Also the master switch of "team".
+ *   "persist_max_ws"         1         groups of up to this many pairs take the persistent kernel (1 .. 8; more than 1 measured slower)
+ *   "persist_grid"           64        workgroups of the persistent kernel (one per CU)
+ *   "persist_timeout_ticks"  5e7       100 MHz ticks a device-side barrier waits before the launch gives up and the call falls back to
+ *                                      the chain (0.5 s; the tests of that path set 1)
+ *   "team"                   1         batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in one team-persistent launch
+ *   "team_max_pairs"         64        (the chain is faster from ~96 pairs on: DESIGN.md §4)
+ *   "team_size"              0         workgroups per team; 0 = CUs / pairs
+ *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
+ *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
+ *   "stagger"                1         lanes run their pairs end to end (frame stage of one lane under the estimation of another)
+ *   "tapcache_max_density"   0.5       pyramid levels with more template points per pixel than this gather straight from the descriptor
+ *   "upload_workers"         6         host threads that stage a HOST-buffer batch in pinned chunks (0: plain copies)
+ *   "upload_plan_first"      0.19      fractions of a host batch in the first (lane 0) and second (lane 1) group of the upload plan;
+ *   "upload_plan_second"     0.50      first = 0: two equal groups
+ *   "keep_current_disparity" 0         bpvo_hip_batch_run stores the disparity of the CURRENT frame (B) of every pair too.  By default it is
+ *                                      neither uploaded nor stored — nothing on the path reads it — and bpvo_hip_frame(s)_set_template on
+ *                                      such a slot returns BPVO_ERR_NO_DATA; set 1 before batches whose B frames become templates later.
+ *
+ * The environment variable BPVO_HIP_OPTIONS="key=value,key=value" applies the same settings to every context a process creates
+ * (measurement scripts and tests; the library reads no other variable). */
+int bpvo_hip_set_option(bpvo_hip_ctx* ctx, const char* key, double value);
+int bpvo_hip_get_option(bpvo_hip_ctx* ctx, const char* key, double* value);
+/* = bpvo_hip_set_option(ctx, "lanes", n); n <= 0 restores the default */
 int bpvo_hip_set_max_lanes(bpvo_hip_ctx* ctx, int n);
 /* diagnostics: Gauss-Newton state of a workspace after its last call: T (16), H (36), G (6), dp (6), f_norm, scale, delta_scale,
  * g_norm, pose of the last linearisation (16) */

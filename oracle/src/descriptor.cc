@@ -59,7 +59,7 @@ void defaultParams(Params& p)
 //                 bit b: ExtractChannel (:37-57) dst = 1.0f * ((c & (1<<b)) >> b) - 0.0f, GaussianBlur 5x5 sigma_bp if > 0.
 //                 The 8 channels are the reference's parallel_for range (:89-90) -> OpenMP here.
 // ---- LATCH, evaluated densely (bpvo/latch_descriptor.cc).
-// The sampling table: 512 triplets of patch-centre offsets, `sampling_points_arr` (:507-1019), numbers only (scripts/make_latch_table.py).
+// The sampling table: 512 triplets of patch-centre offsets, `sampling_points_arr` (:507-1019), numbers only (tests/tools/make_latch_table.py).
 static const int kLatchPoints[3072] = {
 #include "latch_table.inc"
 };

@@ -3,7 +3,7 @@
 P=${1:-1024}
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
-export BPVO_HIP_LANES=1
+export BPVO_HIP_OPTIONS=lanes=1
 timeout 300 python3 $R/bench.py --pairs $P --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache /tmp/bpvo_bench_inputs > /dev/null 2>&1
 rm -rf /tmp/trf; timeout 400 rocprofv3 --kernel-trace -d /tmp/trf -- python3 $R/bench.py --pairs $P --steps 1 --warmup 1 --cpu-pairs 0 --other-configs 0 --no-profile --gen-workers 1 --input-cache /tmp/bpvo_bench_inputs > /tmp/trf.json 2>/tmp/trf.err
 tail -2 /tmp/trf.err

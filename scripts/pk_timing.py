@@ -1,8 +1,7 @@
 """Per-phase timing of the persistent GN kernel (library built with -DBPVO_PK_TIMING as bpvo_amd/csrc/libbpvo_hip_pktiming.so):
-one 1241x376 bit-planes pair, estimate_pose; the library prints the per-level averages on stderr (BPVO_HIP_PK_TIMING=1)."""
+one 1241x376 bit-planes pair, estimate_pose; the library prints the per-level averages on stderr (a build with -DBPVO_PK_TIMING: scripts/build_exp.sh pkt "-DBPVO_PK_TIMING", BPVO_AB_LIB)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["BPVO_HIP_PK_TIMING"] = "1"
 import numpy as np
 import bpvo_amd
 from bpvo_amd import capi, synth

@@ -5,11 +5,11 @@ cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 CACHE=/tmp/bpvo_bench_inputs_128
 ARGS="--pairs-per-gpu 128 --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --fixed-iters 2"
-BPVO_HIP_LANES=1 timeout 300 python3 $R/bench.py $ARGS --input-cache $CACHE > /dev/null 2>&1
+BPVO_HIP_OPTIONS=lanes=1 timeout 300 python3 $R/bench.py $ARGS --input-cache $CACHE > /dev/null 2>&1
 i=0
 for CNT in "$@"; do
   i=$((i+1)); rm -rf /tmp/pk$i
-  BPVO_HIP_LANES=1 timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/pk$i -- python3 $R/bench.py $ARGS --gen-workers 1 --input-cache $CACHE > /tmp/pk$i.json 2> /tmp/pk$i.err
+  BPVO_HIP_OPTIONS=lanes=1 timeout 300 rocprofv3 --pmc $CNT --kernel-trace -d /tmp/pk$i -- python3 $R/bench.py $ARGS --gen-workers 1 --input-cache $CACHE > /tmp/pk$i.json 2> /tmp/pk$i.err
   python3 - <<PY
 import glob, sqlite3, os
 fs = sorted(glob.glob("/tmp/pk$i/*/*_results.db"), key=os.path.getmtime)

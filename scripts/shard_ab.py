@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """A/B of run-time settings on one batch size, every variant in a process of its own (several settings are read once per process).
 
-  python scripts/shard_ab.py --pairs 128 --steps 10 -- "" "BPVO_HIP_MEDIAN_WIDE_FROM=1" "BPVO_HIP_LANES=1,BPVO_HIP_STAGGER=0"
+  python scripts/shard_ab.py --pairs 128 --steps 10 -- "" "lanes=1,stagger=0" "team_max_pairs=128" "BPVO_AB_LIB=bpvo_amd/csrc/exp/libbpvo_hip_x.so,lanes=3"
+
+A variant is a comma-separated list of settings: lower-case keys are library options (bpvo_hip_set_option, handed over through
+BPVO_HIP_OPTIONS), upper-case keys are environment variables of the child process (BPVO_AB_LIB, GPU_MAX_HW_QUEUES, ...).
 
 The parent renders the synthetic inputs once (no GPU in the parent: children are plain child processes), every child loads them, runs
 `warmup` + `steps` steps of bpvo_hip_batch_run on device-resident inputs and prints GN iterations/s — bench.py's step, nothing else
@@ -87,9 +90,15 @@ def main():
     for rep in range(a.repeat):
         for v in variants:
             env = dict(os.environ)
+            opts = []
             for kv in filter(None, v.split(",")):
                 k, val = kv.split("=", 1)
-                env[k] = val
+                if k.islower():
+                    opts.append(kv)
+                else:
+                    env[k] = val
+            if opts:
+                env["BPVO_HIP_OPTIONS"] = ",".join(opts)
             out = []
             for n in sizes:
                 steps = a.steps if n == a.pairs else max(2, a.steps // 4)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a batch's step goes when its stages are run ONE AFTER THE OTHER on one lane, each followed by a synchronisation:
 setData (pyramid + descriptors), setTemplate (saliency, selection, normalisation, template build), estimate (the Gauss-Newton stage),
-next to bpvo_hip_batch_run (staggered lanes).  python scripts/shard_phases.py --pairs 128 [--lanes 1]"""
+next to bpvo_hip_batch_run (staggered lanes).  BPVO_HIP_OPTIONS=lanes=1 python scripts/shard_phases.py --pairs 128"""
 import argparse
 import os
 import sys
@@ -61,7 +61,7 @@ def main():
         v = np.sort(its[:, l])
         print(f"level {l}: iterations min {v[0]} p25 {v[len(v) // 4]} median {v[len(v) // 2]} p75 {v[3 * len(v) // 4]} p90 {v[9 * len(v) // 10]} max {v[-1]} mean {v.mean():.1f}")
     ms = {k: 1e3 * v / a.steps for k, v in acc.items()}
-    print(f"{n} pairs, lanes env {os.environ.get('BPVO_HIP_LANES', 'default')}: set_data {ms['set_data']:.2f} ms, set_template {ms['set_template']:.2f} ms, "
+    print(f"{n} pairs, options {os.environ.get('BPVO_HIP_OPTIONS', 'default')}: set_data {ms['set_data']:.2f} ms, set_template {ms['set_template']:.2f} ms, "
           f"estimate {ms['estimate']:.2f} ms, sum {ms['set_data'] + ms['set_template'] + ms['estimate']:.2f} ms | batch_run {ms['batch_run']:.2f} ms")
 
 

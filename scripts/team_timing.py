@@ -2,7 +2,6 @@
 a batch of n 1241x376 bit-planes pairs, the phases of team 0's first workgroup per pyramid level (stderr of the library)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["BPVO_HIP_PK_TIMING"] = "1"
 import numpy as np
 import bpvo_amd
 from bpvo_amd import capi, synth

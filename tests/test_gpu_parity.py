@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from bpvo_amd import capi, synth
-from util import ROT_TOL, bits_equal, make_params, pose_error, setup_pair, trans_tol
+from util import ROT_TOL, bits_equal, make_params, pose_error, setup_pair, trans_tol, set_options
 
 pytestmark = pytest.mark.gpu
 
@@ -293,7 +293,7 @@ def test_unsupported_and_invalid_create(hip):
 
 @pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
 def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
-    """BPVO_HIP_LANES (read by bpvo_hip_create): a batch split over 2 or 3 estimation streams driven by host threads gives,
+    """Option "lanes" (bpvo_hip_set_option; here through BPVO_HIP_OPTIONS): a batch split over 2 or 3 estimation streams driven by host threads gives,
     pair for pair, the bits of the single-lane run — the lanes only change what overlaps in time."""
     import os
     rows, cols, levels, n = 120, 160, 3, 40
@@ -302,8 +302,8 @@ def test_estimation_lanes_are_bit_identical(hip, descriptor, loss, monkeypatch):
     for lanes in (1, 2, 3, "team"):
         # (a batch of this size would take the team-persistent kernel, which runs on one lane: switched off for the lane runs, and
         # run last as a fourth variant — same bits again)
-        monkeypatch.setenv("BPVO_HIP_TEAM", "1" if lanes == "team" else "0")
-        monkeypatch.setenv("BPVO_HIP_LANES", "2" if lanes == "team" else str(lanes))
+        set_options(monkeypatch, team="1" if lanes == "team" else "0")
+        set_options(monkeypatch, lanes="2" if lanes == "team" else str(lanes))
         ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor=descriptor, loss=loss, levels=levels),
                          n_frames=2 * n, n_pairs=n)
         out[lanes] = ctx.batch_run(batch["images"], batch["disparities"])
@@ -354,7 +354,7 @@ def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch,
     poses, stats = ctx.batch_run(b1["images"], b1["disparities"])
     r, w, v = ctx.get_residuals(2), ctx.get_weights(2), ctx.get_valid(2)
     ctx.close()
-    monkeypatch.setenv("BPVO_HIP_TAPCACHE_MAX_DENSITY", "2.0")        # the cache at every level, as before
+    set_options(monkeypatch, tapcache_max_density="2.0")        # the cache at every level, as before
     ref = hip.create(b1["K"], b1["b"], rows, cols, p, n_frames=2 * n, n_pairs=n)
     poses_ref, stats_ref = ref.batch_run(b1["images"], b1["disparities"])
     assert bits_equal(poses, poses_ref) and stats.tobytes() == stats_ref.tobytes()
@@ -660,10 +660,8 @@ def test_fused_frozen_scale_path_is_bit_identical(hip, rows, cols, levels, loss,
     itself and warp_residual skips the workspace; the residual / valid buffers are refreshed on demand from the pose of the
     last linearisation.  Everything observable must equal the two-kernel form bit for bit."""
     out = []
-    for fuse, merge in (("0", "0"), ("1", "0"), ("1", "100000")):
-        # merge: the two irls_reduce instantiations (plain / fused) as one launch with a per-workspace branch (small batches) or two
-        monkeypatch.setenv("BPVO_HIP_FUSE_FROZEN", fuse)
-        monkeypatch.setenv("BPVO_HIP_IRLS_MERGE_BELOW", merge)
+    for fuse in ("0", "1"):
+        set_options(monkeypatch, fuse_frozen=fuse)
         ctx, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss=loss)
         T, st = ctx.estimate_pose(0, 0, 1)
         rec = dict(T=T, st=st, frac=ctx.fraction_good(0, 0.85), r=ctx.get_residuals(0), v=ctx.get_valid(0), w=ctx.get_weights(0),
@@ -1029,16 +1027,16 @@ def test_host_buffer_batches_go_through_the_upload_pipeline_unchanged(hip, n, la
     """bpvo_hip_batch_run handed HOST buffers: batches of at least 32 pairs are staged in pinned chunks of 16 pairs by worker threads
     and uploaded on streams of their own while the lanes work on the chunks that have landed (B's disparity never crosses the bus).
     Same poses and statistics, bit for bit, as the batch with its inputs resident on the device and as the plain copies
-    (BPVO_HIP_UPLOAD_WORKERS=0) — with ragged chunk and lane boundaries, one lane, the team kernel behind it, and (530 pairs) the
+    (option upload_workers = 0) — with ragged chunk and lane boundaries, one lane, the team kernel behind it, and (530 pairs) the
     three-group upload plan of large batches with the lanes' job tables copied by a kernel."""
     import torch
     rows, cols, levels = 120, 160, 3
     batch = synth.make_batch(rows, cols, n, first_index=400, workers=8)
-    monkeypatch.setenv("BPVO_HIP_LANES", lanes)
-    monkeypatch.setenv("BPVO_HIP_TEAM", team)
+    set_options(monkeypatch, lanes=lanes)
+    set_options(monkeypatch, team=team)
     out = {}
     for workers in ("6", "0", "dev"):
-        monkeypatch.setenv("BPVO_HIP_UPLOAD_WORKERS", "6" if workers == "dev" else workers)
+        set_options(monkeypatch, upload_workers="6" if workers == "dev" else workers)
         ctx = hip.create(batch["K"], batch["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels), n_frames=2 * n, n_pairs=n)
         if workers == "dev":
             di = torch.from_numpy(batch["images"]).cuda(); dd = torch.from_numpy(batch["disparities"]).cuda()

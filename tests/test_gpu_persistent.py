@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from bpvo_amd import synth
-from util import bits_equal, make_params, setup_pair
+from util import bits_equal, make_params, setup_pair, set_options
 
 pytestmark = pytest.mark.gpu
 
@@ -28,7 +28,7 @@ def run_single(hip, rows, cols, levels, descriptor, loss, **kw):
 def test_persistent_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, descriptor, loss, monkeypatch):
     out = []
     for on in ("0", "1"):
-        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
+        set_options(monkeypatch, persistent=on)
         out.append(run_single(hip, rows, cols, levels, descriptor, loss))
     a, b = out
     assert a["pk"] == (0, 0)
@@ -43,14 +43,14 @@ def test_persistent_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels
 
 @pytest.mark.parametrize("n_pairs", [2, 5, 8])
 def test_persistent_kernel_groups_of_pairs(hip, n_pairs, monkeypatch):
-    """Groups of up to 8 pairs in one persistent launch (BPVO_HIP_PERSIST_MAX_WS): pairs converge after different numbers of
+    """Groups of up to 8 pairs in one persistent launch (option persist_max_ws): pairs converge after different numbers of
     iterations, so workspaces drop out of the loop one by one while the others go on."""
     rows, cols, levels = 120, 160, 3
     b = synth.make_batch(rows, cols, n_pairs, first_index=11)
     out = []
     for on in ("0", "1"):
-        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
-        monkeypatch.setenv("BPVO_HIP_PERSIST_MAX_WS", "8")
+        set_options(monkeypatch, persistent=on)
+        set_options(monkeypatch, persist_max_ws="8")
         ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels),
                          n_frames=2 * n_pairs, n_pairs=n_pairs)
         poses, stats = ctx.batch_run(b["images"], b["disparities"])
@@ -71,8 +71,8 @@ def test_persistent_kernel_small_grid_and_sequence(hip, monkeypatch):
     rows, cols, levels = 120, 160, 3
     ref = None
     for on, grid in (("0", "64"), ("1", "1"), ("1", "3"), ("1", "64")):
-        monkeypatch.setenv("BPVO_HIP_PERSISTENT", on)
-        monkeypatch.setenv("BPVO_HIP_PERSIST_GRID", grid)
+        set_options(monkeypatch, persistent=on)
+        set_options(monkeypatch, persist_grid=grid)
         rec = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
         seq = synth.make_sequence(rows, cols, 6)
         vo = hip.create(seq["K"], seq["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels), n_frames=3, n_pairs=1)
@@ -89,10 +89,10 @@ def test_persistent_kernel_gives_up_cleanly(hip, monkeypatch):
     """A grid barrier that cannot complete in time (here: a 10 ns budget) makes every workgroup leave without writing the states
     back; the library reruns the group through the four-kernel chain and stays on it.  Same results, no hang."""
     rows, cols, levels = 376, 1241, 4
-    monkeypatch.setenv("BPVO_HIP_PERSISTENT", "0")
+    set_options(monkeypatch, persistent="0")
     ref = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
-    monkeypatch.setenv("BPVO_HIP_PERSISTENT", "1")
-    monkeypatch.setenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS", "1")
+    set_options(monkeypatch, persistent="1")
+    set_options(monkeypatch, persist_timeout_ticks="1")
     rec = run_single(hip, rows, cols, levels, "bitplanes", "tukey")
     assert rec["pk"][1] == 1 and rec["pk"][0] <= levels          # gave up during the first estimate, never tried again
     assert bits_equal(ref["T"], rec["T"]) and bits_equal(ref["T2"], rec["T2"]) and ref["st"] == rec["st"] and ref["st2"] == rec["st2"]
@@ -128,10 +128,10 @@ def test_team_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, n, d
     """Batches of 2 .. 256 pairs: every pair through all its levels in ONE launch, a team of workgroups per pair, against the
     four-kernel chain with its host-driven level loop — poses, statistics, residuals, valid masks, weights, robust scale, and the
     counters of the work done (linearisations, median selections by path, fused points, tap-cache lookups and hits)."""
-    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    set_options(monkeypatch, team="0")
     ref = run_batch(hip, rows, cols, levels, n, descriptor, loss)
     assert ref["team"] == 0
-    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
+    set_options(monkeypatch, team="1")
     got = run_batch(hip, rows, cols, levels, n, descriptor, loss)
     assert got["team"] == 2 and got["pk"][1] == 0, (got["team"], got["pk"])
     assert_same_batch(ref, got)
@@ -140,15 +140,15 @@ def test_team_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, n, d
 
 @pytest.mark.parametrize("cus,team_size", [(6, 0), (7, 3), (4, 4), (300, 0)])
 def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
-    """Fewer teams than pairs (pairs are handed out dynamically: BPVO_HIP_TEAM_CUS caps the grid), teams of 1, 3 and 4 workgroups
+    """Fewer teams than pairs (pairs are handed out dynamically: option team_cus caps the grid), teams of 1, 3 and 4 workgroups
     (ragged chunk / tile splits), more CUs claimed than pairs need."""
     rows, cols, levels, n = 120, 160, 3, 13
-    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    set_options(monkeypatch, team="0")
     ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
-    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
-    monkeypatch.setenv("BPVO_HIP_TEAM_CUS", str(cus))
+    set_options(monkeypatch, team="1")
+    set_options(monkeypatch, team_cus=str(cus))
     if team_size:
-        monkeypatch.setenv("BPVO_HIP_TEAM_SIZE", str(team_size))
+        set_options(monkeypatch, team_size=str(team_size))
     got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
     assert got["team"] == 2 and got["pk"][1] == 0
     assert_same_batch(ref, got)
@@ -158,11 +158,11 @@ def test_team_kernel_gives_up_cleanly(hip, monkeypatch):
     """A team barrier that cannot complete in its budget (10 ns): every workgroup leaves, the library reruns the batch through the chain
     and stays on it.  Same results, no hang."""
     rows, cols, levels, n = 120, 160, 3, 9
-    monkeypatch.setenv("BPVO_HIP_TEAM", "0")
+    set_options(monkeypatch, team="0")
     ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
-    monkeypatch.setenv("BPVO_HIP_TEAM", "1")
-    monkeypatch.setenv("BPVO_HIP_TEAM_SIZE", "4")
-    monkeypatch.setenv("BPVO_HIP_PERSIST_TIMEOUT_TICKS", "1")
+    set_options(monkeypatch, team="1")
+    set_options(monkeypatch, team_size="4")
+    set_options(monkeypatch, persist_timeout_ticks="1")
     got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
     assert got["pk"][1] == 1 and got["team"] == 1          # launched once, gave up, never tried again
     assert bits_equal(ref["poses"], got["poses"]) and ref["stats"].tobytes() == got["stats"].tobytes()

@@ -26,7 +26,7 @@ import numpy as np
 import pytest
 
 from bpvo_amd import synth
-from util import ROT_TOL, bits_equal, make_params, pose_error, setup_pair, trans_tol
+from util import ROT_TOL, bits_equal, make_params, pose_error, setup_pair, trans_tol, set_options
 
 pytestmark = pytest.mark.gpu
 
@@ -76,7 +76,7 @@ def test_gpu_iterates_follow_the_reference_iteration_by_iteration(hip, orc, rows
     # ---- 1. the trace of the chain and of the persistent kernel; the estimate is untouched by tracing
     runs = {}
     for pk in ("0", "1"):
-        monkeypatch.setenv("BPVO_HIP_PERSISTENT", pk)
+        set_options(monkeypatch, persistent=pk)
         ctx, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor=descriptor, loss=loss)
         T_plain, st_plain = ctx.estimate_pose(0, 0, 1)
         T, st, rec = ctx.estimate_pose_trace(0, 0, 1)

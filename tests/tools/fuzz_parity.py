@@ -130,7 +130,7 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
     kw = dict(kw)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
     formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
-    os.environ["BPVO_HIP_FUSE_FROZEN"] = "1" if fuse else "0"
+    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0")
     for bind in (hip, orc):
         ctx = bind.create(K, b, rows, cols, make_params(bind, **kw), n_frames=2, n_pairs=1)
         if formulation:
@@ -311,7 +311,7 @@ def check_batch_case(hip, rows, cols, kw, seed, ctxs):
     kw = dict(kw)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
     formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
-    os.environ["BPVO_HIP_FUSE_FROZEN"] = "1" if fuse else "0"
+    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0")
     n = 2 + seed % 4
     b = synth.make_batch(rows, cols, n, first_index=seed % 3000)
     bc = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)

@@ -30,7 +30,7 @@ for line in open(path):
     K, b, imgA, dispA, imgB, dispB, slack = fz.make_inputs(rows, cols, scene, seed)
     kw2 = {k: v for k, v in kw.items() if not k.startswith("_")}
     form = 2 if kw.get("_dspace") else (1 if kw.get("_fast_warp") else 0)
-    os.environ["BPVO_HIP_FUSE_FROZEN"] = "1" if kw.get("_fuse_frozen") else "0"
+    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if kw.get("_fuse_frozen") else "0")
     out = {}
     for name, bind, red in (("hip", hip, 0), ("f32", orc, 0), ("f64", orc, 1)):
         ctx = bind.create(K, b, rows, cols, make_params(bind, **kw2), n_frames=2, n_pairs=1)

@@ -33,7 +33,7 @@ def main():
         K, b, imgA, dispA, imgB, dispB, slack = fz.make_inputs(rows, cols, scene, seed)
         fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
         formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
-        os.environ["BPVO_HIP_FUSE_FROZEN"] = "1" if fuse else "0"
+        os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0")
         print(rows, cols, kw, "formulation", formulation, "fuse", fuse, "slack", slack, "fx", K[0][0])
         cs = []
         for bind in (hip, orc):

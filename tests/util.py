@@ -1,4 +1,6 @@
 """Helpers shared by the parity tests."""
+import os
+
 import numpy as np
 
 from bpvo_amd import capi, synth
@@ -53,3 +55,14 @@ def bits_equal(a, b):
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     return a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def options_string(**kw):
+    """BPVO_HIP_OPTIONS: bpvo_hip_set_option(key, value) for every context created from here on, merged with what is already set."""
+    cur = dict(kv.split("=", 1) for kv in os.environ.get("BPVO_HIP_OPTIONS", "").split(",") if kv)
+    cur.update({k: str(v) for k, v in kw.items()})
+    return ",".join(f"{k}={v}" for k, v in cur.items())
+
+
+def set_options(monkeypatch, **kw):
+    monkeypatch.setenv("BPVO_HIP_OPTIONS", options_string(**kw))
