@@ -29,21 +29,28 @@ struct UploadRun {
 int upload_prepare(bpvo_hip_ctx* c, int n_pairs)
 {
   const size_t npix = c->geom[0].npix;
-  if((int) c->up_streams.size() < c->up_workers) {
-    for(int w = (int) c->up_streams.size(); w < c->up_workers; ++w) {
-      hipStream_t st = nullptr;
-      HIP_CK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      c->up_streams.push_back(st);
-      c->up_slot_bytes = (size_t) kUploadChunkPairs * npix * (2 + 4);
-      uint8_t* pin = nullptr;
-      HIP_CK(c, hipHostMalloc((void**) &pin, 2 * c->up_slot_bytes));
-      c->up_pinned.push_back(pin);
-      for(int sl = 0; sl < 2; ++sl) {
-        hipEvent_t e = nullptr;
-        HIP_CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        c->up_slot_free.push_back(e);
-      }
+  // one worker = one pinned block of two slots + the events that free them (the copy stream is shared: up_streams[0]).  A worker's
+  // resources are taken into the context only when all of them exist: a failed pinned allocation leaves the vectors in step
+  c->up_slot_bytes = (size_t) kUploadChunkPairs * npix * (2 + 4);
+  if(c->up_streams.empty()) {
+    hipStream_t st = nullptr;
+    HIP_CK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->up_streams.push_back(st);
+  }
+  while((int) c->up_pinned.size() < c->up_workers) {
+    uint8_t* pin = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t e = hipHostMalloc((void**) &pin, 2 * c->up_slot_bytes);
+    for(int sl = 0; sl < 2 && e == hipSuccess; ++sl) e = hipEventCreateWithFlags(&ev[sl], hipEventDisableTiming);
+    if(e != hipSuccess) {
+      if(pin) (void) hipHostFree(pin);
+      for(auto x : ev) if(x) (void) hipEventDestroy(x);
+      c->err = std::string("upload pipeline: ") + hipGetErrorString(e);
+      return BPVO_ERR_DEVICE;
     }
+    c->up_pinned.push_back(pin);
+    c->up_slot_free.push_back(ev[0]);
+    c->up_slot_free.push_back(ev[1]);
   }
   if(n_pairs > c->up_cap_pairs) {
     HIP_CK(c, hipDeviceSynchronize());

@@ -99,22 +99,44 @@ __global__ void sgm_pixel_cost_kernel(const uint8_t* __restrict__ sl, const uint
   pc[((size_t) cols * y + x) * D + d0] = (uint8_t) (sad + (int) (uint8_t) ((double) ham * cweight));
 }
 
-// (2r+1)^2 box sums with clamped coordinates; rows y + r >= rows and (for y >= 1) column 0 stay 0 (S1)
-__global__ void sgm_box_cost_kernel(const uint8_t* __restrict__ pc, uint16_t* __restrict__ cost, int rows, int cols, int D, int wrad)
+// (2r+1)^2 box sums with clamped coordinates; rows y + r >= rows and (for y >= 1) column 0 stay 0 (S1).  Separable: the sum over the
+// window's columns first (u16, at most (2r+1) * 255), then over its rows — 2 (2r+1) reads per output instead of (2r+1)^2; integer sums,
+// any order (round 3 evaluated the 25 clamped taps per output directly: 0.6 ms per 1241 x 376 x 128 frame, profiles/r03_stereo.txt).
+// A thread owns four consecutive disparities of one pixel: 4-byte / 8-byte accesses, coalesced along d.
+__global__ __launch_bounds__(256) void sgm_box_rows_kernel(const uint8_t* __restrict__ pc, uint16_t* __restrict__ rowsum, int rows, int cols, int D, int wrad)
 {
-  const int x = blockIdx.x, y = blockIdx.y, d = threadIdx.x;
-  if(d >= D) return;
-  int s = 0;
+  const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;          // (pixel, group of 4 disparities)
+  const int dq = D >> 2;
+  const size_t p = t / dq;
+  if(p >= (size_t) rows * cols) return;
+  const int d = (int) (t - p * dq) * 4;
+  const int x = (int) (p % cols);
+  const size_t row0 = p - x;
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for(int ox = -wrad; ox <= wrad; ++ox) {
+    const int xx = min(max(x + ox, 0), cols - 1);
+    const uchar4 v = *reinterpret_cast<const uchar4*>(pc + (row0 + xx) * D + d);
+    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+  }
+  *reinterpret_cast<ushort4*>(rowsum + p * D + d) = make_ushort4((uint16_t) s0, (uint16_t) s1, (uint16_t) s2, (uint16_t) s3);
+}
+__global__ __launch_bounds__(256) void sgm_box_cols_kernel(const uint16_t* __restrict__ rowsum, uint16_t* __restrict__ cost, int rows, int cols, int D, int wrad)
+{
+  const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+  const int dq = D >> 2;
+  const size_t p = t / dq;
+  if(p >= (size_t) rows * cols) return;
+  const int d = (int) (t - p * dq) * 4;
+  const int x = (int) (p % cols), y = (int) (p / cols);
+  int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   if(y + wrad < rows && (y == 0 || x >= 1)) {
     for(int oy = -wrad; oy <= wrad; ++oy) {
       const int yy = min(max(y + oy, 0), rows - 1);
-      for(int ox = -wrad; ox <= wrad; ++ox) {
-        const int xx = min(max(x + ox, 0), cols - 1);
-        s += pc[((size_t) cols * yy + xx) * D + d];
-      }
+      const ushort4 v = *reinterpret_cast<const ushort4*>(rowsum + ((size_t) cols * yy + x) * D + d);
+      s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
     }
   }
-  cost[((size_t) cols * y + x) * D + d] = (uint16_t) s;
+  *reinterpret_cast<ushort4*>(cost + p * D + d) = make_ushort4((uint16_t) s0, (uint16_t) s1, (uint16_t) s2, (uint16_t) s3);
 }
 
 __global__ void sgm_right_cost_kernel(const uint16_t* __restrict__ lcost, uint16_t* __restrict__ rcost, int rows, int cols, int D)
@@ -211,6 +233,92 @@ __global__ __launch_bounds__(64) void sgm_path_kernel(const uint16_t* __restrict
   }
 }
 
+// The same scanline kernel with the path costs of a lane held as PAIRS of 16-bit values in 32-bit registers (2 NP disparities per lane):
+// the recurrence is int16 saturating arithmetic — v_pk_add_i16 / v_pk_sub_i16 with clamp, v_pk_min_i16 do two disparities per instruction
+// and the saturation for free, where the scalar form spends a min + max on every sat16.  The kernel is bound by VALU issue (6 wavefronts per
+// SIMD, ~150 instructions per step in the scalar form: 1.13 ms per 1241 x 376 x 128 frame), not by latency.  Same values: every operation
+// of the scalar form is an int16 saturating one (the costs are below 2^15: stereo_check rejects window radii whose box sums are not).
+typedef short sgm_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sgm_s16x2 sgm_pk(unsigned u) { return __builtin_bit_cast(sgm_s16x2, u); }
+__device__ __forceinline__ unsigned sgm_bits(sgm_s16x2 v) { return __builtin_bit_cast(unsigned, v); }
+template <int NP>
+__global__ __launch_bounds__(64) void sgm_path_packed_kernel(const uint16_t* __restrict__ cost_l, const uint16_t* __restrict__ cost_r, int16_t* __restrict__ Lvol,
+                                                             int rows, int cols, int D, int P1, int P2)
+{
+  constexpr int PF = 4, V = 2 * NP;
+  const int per_side = 2 * rows + 2 * cols;
+  const int side = blockIdx.x / per_side;
+  int q = blockIdx.x - side * per_side;
+  int path, line;
+  if(q < rows) { path = 0; line = q; }
+  else if(q < 2 * rows) { path = 2; line = q - rows; }
+  else if(q < 2 * rows + cols) { path = 1; line = q - 2 * rows; }
+  else { path = 3; line = q - 2 * rows - cols; }
+  const int vertical = path & 1, dir = path < 2 ? 1 : -1;
+  const uint16_t* __restrict__ cost = side ? cost_r : cost_l;
+  const size_t vol = (size_t) rows * cols * D;
+  int16_t* __restrict__ L = Lvol + (size_t) (side * 4 + path) * vol;
+
+  const int lane = threadIdx.x;
+  const int nsteps = vertical ? rows : cols;
+  const size_t step_stride = (vertical ? (size_t) cols * D : (size_t) D);
+  const size_t base = vertical ? (size_t) line * D : (size_t) line * cols * D;
+  const int d0 = lane * V;
+  const bool live = d0 < D;                                    // (D is a multiple of 16 and V divides it: a lane is all in or all out)
+  unsigned prev[NP];
+#pragma unroll
+  for(int j = 0; j < NP; ++j) prev[j] = 0u;
+  int prev_min = 0;
+  const sgm_s16x2 P1v = {(short) P1, (short) P1};
+  auto offset = [&](int st) { return base + (size_t) (dir > 0 ? st : nsteps - 1 - st) * step_stride + d0; };
+  using word_t = typename std::conditional<NP == 1, uint32_t, uint64_t>::type;
+  word_t cw[PF];
+#pragma unroll
+  for(int i = 0; i < PF; ++i) {
+    cw[i] = 0;
+    if(live && i < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(i));
+  }
+  for(int s0 = 0; s0 < nsteps; s0 += PF) {
+#pragma unroll
+    for(int i = 0; i < PF; ++i) {
+      const int st = s0 + i;
+      if(st >= nsteps) break;
+      const word_t cword = cw[i];
+      const size_t off = offset(st);
+      if(live && st + PF < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(st + PF));
+      const short pm = (short) (prev_min + P2);
+      const sgm_s16x2 pmv = {pm, pm};
+      // the neighbours across lanes: the previous lane's last pair (its high half is d0 - 1), the next lane's first pair (low half: d0 + V)
+      const unsigned left = lane == 0 ? 0x7fff0000u : (unsigned) __shfl_up((int) prev[NP - 1], 1);
+      const unsigned right = (unsigned) __shfl_down((int) prev[0], 1);
+      unsigned cur[NP];
+      int mn = 32767;
+#pragma unroll
+      for(int j = 0; j < NP; ++j) {
+        const unsigned below = j > 0 ? prev[j - 1] : left;
+        unsigned above = j < NP - 1 ? prev[j + 1] : right;
+        if(d0 + 2 * j + 2 >= D) above = 0x7fffu;              // the sentinel behind the last disparity
+        const sgm_s16x2 lm = sgm_pk((below >> 16) | (prev[j] << 16));      // (d - 1) of both halves
+        const sgm_s16x2 lp = sgm_pk((prev[j] >> 16) | (above << 16));      // (d + 1) of both halves
+        const sgm_s16x2 c = sgm_pk((unsigned) (cword >> (32 * j)));
+        sgm_s16x2 a = __builtin_elementwise_min(sgm_pk(prev[j]), __builtin_elementwise_add_sat(lm, P1v));
+        a = __builtin_elementwise_min(a, __builtin_elementwise_add_sat(lp, P1v));
+        a = __builtin_elementwise_min(a, pmv);
+        a = __builtin_elementwise_add_sat(__builtin_elementwise_sub_sat(a, pmv), c);
+        cur[j] = sgm_bits(a);
+        if(live) mn = min(mn, min((int) a.x, (int) a.y));
+      }
+#pragma unroll
+      for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+      prev_min = mn;
+      word_t out = 0;
+#pragma unroll
+      for(int j = 0; j < NP; ++j) { prev[j] = cur[j]; out |= (word_t) cur[j] << (32 * j); }
+      if(live) *reinterpret_cast<word_t*>(L + off) = out;
+    }
+  }
+}
+
 // winner takes all (first minimum) + the sub-pixel expression of the original in double.  A wavefront per pixel: the D sums are read
 // coalesced (V per lane), the first minimum is the wave minimum of (sum, d) packed into one integer.
 // The sum of the four path costs in the original's order and saturating arithmetic: ((((0 + rows forward) + columns forward) + rows
@@ -275,11 +383,27 @@ __device__ __forceinline__ void uf_union(int* __restrict__ lab, int a, int b)
     a = old;
   }
 }
-__global__ __launch_bounds__(256) void sgm_cc_init_kernel(const uint16_t* __restrict__ img, int* __restrict__ lab, int* __restrict__ size, int npix)
+// Two pixels are connected when both are non-zero and differ by at most max_diff.  Labels START as the first pixel of the horizontal run
+// a pixel belongs to, found inside the wavefront by a ballot of the run starts (no atomics; a run that enters the wavefront from the left
+// starts, for now, at the wavefront's first pixel): one union per wavefront ties such a run to its left part, and a vertical pair
+// (p, p + cols) needs a union only where its left neighbour pair does not already imply it — (p - 1, p), (p - 1 + cols, p + cols) and
+// (p - 1, p - 1 + cols) all connected — i.e. about once per pair of overlapping runs instead of once per pixel.  Same components as
+// linking every neighbour pair (round 3: 0.27 ms per launch on a 1241 x 376 plane, every pixel of which is one component).
+__device__ __forceinline__ bool sgm_connected(int a, int b, int max_diff) { return a != 0 && b != 0 && abs(a - b) <= max_diff; }
+__global__ __launch_bounds__(256) void sgm_cc_init_kernel(const uint16_t* __restrict__ img, int* __restrict__ lab, int* __restrict__ size, int rows, int cols,
+                                                         int max_diff)
 {
   const int p = blockIdx.x * 256 + threadIdx.x;
+  const int npix = rows * cols;
+  const int lane = threadIdx.x & 63;
+  const int v = p < npix ? (int) img[p] : 0;
+  const int x = p < npix ? p % cols : 0;
+  const bool start = p >= npix || v == 0 || x == 0 || !sgm_connected(v, (int) img[p - 1], max_diff);     // (a zero pixel "starts" nothing: it breaks runs)
+  const unsigned long long starts = __ballot(start) | 1ull;          // lane 0 stands in for a run that comes in from the left
   if(p >= npix) return;
-  lab[p] = img[p] != 0 ? p : -1;
+  const unsigned long long upto = starts & (~0ull >> (63 - lane));   // run starts at lanes <= this one
+  const int first = 63 - __clzll((long long) upto);
+  lab[p] = v != 0 ? p - (lane - first) : -1;
   size[p] = 0;
 }
 __global__ __launch_bounds__(256) void sgm_cc_merge_kernel(const uint16_t* __restrict__ img, int* __restrict__ lab, int rows, int cols, int max_diff)
@@ -289,8 +413,19 @@ __global__ __launch_bounds__(256) void sgm_cc_merge_kernel(const uint16_t* __res
   const int v = img[p];
   if(v == 0) return;
   const int x = p % cols, y = p / cols;
-  if(x < cols - 1) { const int q = img[p + 1]; if(q != 0 && abs(v - q) <= max_diff) uf_union(lab, p, p + 1); }
-  if(y < rows - 1) { const int q = img[p + cols]; if(q != 0 && abs(v - q) <= max_diff) uf_union(lab, p, p + cols); }
+  // a run cut by the wavefront boundary: its first pixel of this wavefront and the pixel before it
+  if((threadIdx.x & 63) == 0 && x > 0 && sgm_connected(v, (int) img[p - 1], max_diff)) uf_union(lab, p, p - 1);
+  if(y < rows - 1) {
+    const int q = img[p + cols];
+    if(sgm_connected(v, q, max_diff)) {
+      bool implied = false;
+      if(x > 0) {
+        const int vl = img[p - 1], ql = img[p + cols - 1];
+        implied = sgm_connected(vl, v, max_diff) && sgm_connected(ql, q, max_diff) && sgm_connected(vl, ql, max_diff);
+      }
+      if(!implied) uf_union(lab, p, p + cols);
+    }
+  }
 }
 __global__ __launch_bounds__(256) void sgm_cc_count_kernel(int* __restrict__ lab, int* __restrict__ size, int npix)
 {
@@ -379,13 +514,19 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
     hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, L, sob_l, cen_l, rows, cols, pitch, cap, g.census_radius, 0);
     hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, R, sob_r, cen_r, rows, cols, pitch, cap, g.census_radius, 1);
     hipLaunchKernelGGL(sgm_pixel_cost_kernel, gxy, dim3(dthreads), 0, s, sob_l, sob_r, cen_l, cen_r, pc, rows, cols, pitch, D, g.census_weight);
-    hipLaunchKernelGGL(sgm_box_cost_kernel, gxy, dim3(dthreads), 0, s, pc, cost_l, rows, cols, D, g.window_radius);
+    {
+      // (the row sums borrow the first path-cost volume: the scanline kernel overwrites it later on the same stream)
+      uint16_t* rowsum = reinterpret_cast<uint16_t*>(Lvol);
+      const unsigned nbq = (unsigned) ((npix * (size_t) (D / 4) + 255) / 256);
+      hipLaunchKernelGGL(sgm_box_rows_kernel, dim3(nbq), dim3(256), 0, s, pc, rowsum, rows, cols, D, g.window_radius);
+      hipLaunchKernelGGL(sgm_box_cols_kernel, dim3(nbq), dim3(256), 0, s, rowsum, cost_l, rows, cols, D, g.window_radius);
+    }
     hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
     {
       const dim3 gp((unsigned) (2 * (2 * rows + 2 * cols)));
       if(D <= 64) hipLaunchKernelGGL(sgm_path_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
-      else if(D <= 128) hipLaunchKernelGGL(sgm_path_kernel<2>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
-      else hipLaunchKernelGGL(sgm_path_kernel<4>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+      else if(D <= 128) hipLaunchKernelGGL(sgm_path_packed_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+      else hipLaunchKernelGGL(sgm_path_packed_kernel<2>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
     }
     for(int side = 0; side < 2; ++side) {
       uint16_t* disp = side == 0 ? disp_l : disp_r;
@@ -397,7 +538,7 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
         else hipLaunchKernelGGL(sgm_wta_kernel<4>, gw, dim3(256), 0, s, L4, disp, npix, D, g.disparity_factor);
       }
       // speckleFilter(100, 2 * factor) (utils/sgm.cc:898)
-      hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix);
+      hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, rows, cols, (int) (2 * g.disparity_factor));
       hipLaunchKernelGGL(sgm_cc_merge_kernel, dim3(nb), dim3(256), 0, s, disp, lab, rows, cols, (int) (2 * g.disparity_factor));
       hipLaunchKernelGGL(sgm_cc_count_kernel, dim3(nb), dim3(256), 0, s, lab, size, (int) npix);
       hipLaunchKernelGGL(sgm_cc_apply_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix, 100);

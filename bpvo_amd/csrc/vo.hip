@@ -82,7 +82,9 @@ static int stereo_check(bpvo_hip_ctx* c, const bpvo_hip_stereo_params* sp)
     if(sp->consistencyThreshold < 0) return fail(c, BPVO_ERR_INVALID_ARG, "threshold for LR consistency must be positive");
     if(!(sp->disparityFactor > 0)) return fail(c, BPVO_ERR_INVALID_ARG, "disparity factor is less than zero");
     if(sp->numberOfDisparities > 256) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: numberOfDisparities <= 256 are on the device path");
-    if(sp->windowRadius < 0 || sp->windowRadius > 7 || c->rows <= sp->windowRadius) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: windowRadius 0..7 (and fewer than image rows) are on the device path");
+    // (2r+1)^2 * 255 must stay below 2^15: the original's sliding sums are int16 saturating additions (_mm_adds_epi16) and the cost is read
+    // back as int16; up to radius 5 (121 * 255 = 30855) nothing saturates and the plain integer sums of the device path are the same numbers
+    if(sp->windowRadius < 0 || sp->windowRadius > 5 || c->rows <= sp->windowRadius) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: windowRadius 0..5 (and fewer than image rows) are on the device path");
     // int16 path costs: the sums of four paths stay clear of saturation for penalties below this (the original saturates silently)
     if(sp->smoothnessPenaltyLarge > 4000) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: smoothnessPenaltyLarge <= 4000 on the device path");
     return BPVO_OK;

@@ -43,7 +43,7 @@ typedef std::vector<float> WeightsVector;
 
 enum LossFunctionType { kHuber = BPVO_LOSS_HUBER, kTukey = BPVO_LOSS_TUKEY, kL2 = BPVO_LOSS_L2 };
 enum VerbosityType { kIteration = BPVO_VERB_ITERATION, kFinal, kSilent, kDebug };
-/* all eight values of the reference (bpvo/types.h:142-152); all but kLatch are on the device path */
+/* all eight values of the reference (bpvo/types.h:142-152), all on the device path */
 enum DescriptorType { kIntensity = BPVO_DESC_INTENSITY, kIntensityAndGradient, kDescriptorFieldsFirstOrder, kDescriptorFieldsSecondOrder,
                       kLatch, kCentralDifference, kLaplacian, kBitPlanes = BPVO_DESC_BITPLANES };
 static_assert(kLaplacian + 1 == kBitPlanes, "DescriptorType numbering follows the reference");

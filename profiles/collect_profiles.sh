@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'bash profiles/collect_profiles.sh r01'
 # 1. kernel trace + stats of the default bench command (two estimation lanes, the run `value` comes from) and of the same
-#    command with BPVO_HIP_LANES=1 (the per-launch durations bench.py's single-lane roofline pass is compared with);
+#    command with BPVO_HIP_OPTIONS=lanes=1 (the per-launch durations bench.py's single-lane roofline pass is compared with);
 # 2. PMC passes (counters in their own runs, --kernel-trace only) on the BENCHED workload itself — 1024 pairs, converge mode,
 #    2 steps, one lane — and on the timing-tolerance batch (conf/perf_*.cfg tolerances, 3 levels); synthetic pairs read from a
 #    cache rendered beforehand, each pass under its own timeout.
@@ -20,7 +20,7 @@ CACHE=/tmp/bpvo_bench_inputs
 timeout 300 python3 "$R/bench.py" --steps 1 --warmup 0 --cpu-pairs 0 --other-configs 0 --no-profile --input-cache $CACHE > /dev/null 2> "$O/cache_default.err"; echo "inputs rc=$?"
 timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache $CACHE \
     > "$O/trace_bench.json" 2> "$O/trace.err"; echo "trace rc=$?"
-export BPVO_HIP_LANES=1
+export BPVO_HIP_OPTIONS=lanes=1
 timeout 400 rocprofv3 --kernel-trace --stats -d "$O/trace1" -- python3 "$R/bench.py" --steps 3 --warmup 1 --cpu-pairs 0 --other-configs 0 --gen-workers 1 --input-cache $CACHE \
     > "$O/trace1_bench.json" 2> "$O/trace1.err"; echo "trace (one lane) rc=$?"
 i=0

@@ -19,7 +19,7 @@ def db_of(sub):
     return sqlite3.connect(fs[-1]) if fs else None
 
 
-for sub, suffix, env in (("trace", "", ""), ("trace1", "_1lane", "BPVO_HIP_LANES=1 ")):
+for sub, suffix, env in (("trace", "", ""), ("trace1", "_1lane", "BPVO_HIP_OPTIONS=lanes=1 ")):
     db = db_of(sub)
     if not db:
         continue
@@ -51,7 +51,7 @@ for sub in sorted(glob.glob(os.path.join(src, "pmc*"))):
         if "bpvo_hip" not in k:
             continue
         per.setdefault(k, {})[c] = dict(launches=n, avg=v, avg_duration_ns=dur)
-lines = ["PMC averages per launch on the benched workload: BPVO_HIP_LANES=1 bench.py --steps 2 --warmup 0 (1024 pairs, converge mode, AlgorithmParameters()",
+lines = ["PMC averages per launch on the benched workload: BPVO_HIP_OPTIONS=lanes=1 bench.py --steps 2 --warmup 0 (1024 pairs, converge mode, AlgorithmParameters()",
          "tolerances; the launches shrink as pairs converge: averages are over all launches).  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them."]
 for k in sorted(per):
     lines.append("")

@@ -1146,3 +1146,30 @@ def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotati
     if hip_err is None:
         rot, trans = pose_error(Th, To)
         assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+
+
+def test_current_frames_of_a_pair_batch_keep_no_disparity_unless_asked(hip):
+    """bpvo_hip_batch_run neither uploads nor stores the disparity of the CURRENT frame (B) of a pair — nothing on the path reads it (the
+    reference's setData copies whatever it is handed, bpvo/vo_frame.cc:48-55; the difference is stated in c_api.h).  Making such a slot a
+    template therefore fails with BPVO_ERR_NO_DATA; with the option keep_current_disparity = 1 it works, and the poses are the same."""
+    rows, cols, n = 96, 128, 4
+    b = synth.make_batch(rows, cols, n, first_index=3)
+    outs = []
+    for keep in (0, 1):
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=2), n_frames=2 * n, n_pairs=n)
+        assert ctx.get_option("keep_current_disparity") == 0.0
+        ctx.set_option("keep_current_disparity", keep)
+        poses, _ = ctx.batch_run(b["images"], b["disparities"])
+        outs.append(poses)
+        if keep:
+            ctx.frame_set_template(1)                                   # B of pair 0 becomes the template of a later estimate
+            T, _ = ctx.estimate_pose(0, 1, 2)
+            assert np.isfinite(T).all()
+        else:
+            with pytest.raises(capi.BpvoError, match="status -3"):      # BPVO_ERR_NO_DATA
+                ctx.frame_set_template(1)
+        ctx.close()
+    assert bits_equal(outs[0], outs[1])
+    with pytest.raises(capi.BpvoError):
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=2), n_frames=2, n_pairs=1)
+        ctx.set_option("no_such_option", 1)

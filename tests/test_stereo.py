@@ -384,7 +384,10 @@ def _sgm_params(ctx, **kw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("rows,cols,kw", [(376, 1241, dict(ndisp=128)), (480, 640, dict(ndisp=64)), (121, 163, dict(ndisp=32, crad=1, wrad=1, p1=60, p2=900)),
                                           (97, 203, dict(ndisp=48, cap=40, thr=2, cw=0.5)), (64, 300, dict(ndisp=256, factor=64.0)),
-                                          (50, 70, dict(ndisp=16, wrad=3))])
+                                          (50, 70, dict(ndisp=16, wrad=3)),
+                                          # the largest window and Sobel cap the device path admits: box sums up to 121 * 255 = 30855, just
+                                          # below the int16 range in which the original's saturating additions would start to clip
+                                          (90, 160, dict(ndisp=32, wrad=5, cap=127, cw=1.0 / 6.0)), (80, 140, dict(ndisp=144, wrad=4, cap=99))])
 def test_hip_sgm_bit_exact(hip, orc, rows, cols, kw):
     d = synth.make_stereo_pair(rows, cols, 4, z0=8.0 if cols > 700 else 4.0)
     rng = np.random.default_rng(cols)
@@ -410,7 +413,7 @@ def test_hip_sgm_batch_errors_and_add_frame(hip, orc):
     got = ctx.stereo_bm(L, R, _sgm_params(ctx, ndisp=32))
     for k in range(n):
         assert np.array_equal(got[k], orc_sgm(orc, L[k], R[k], ndisp=32)), k
-    for bad in (dict(ndisp=24), dict(crad=3), dict(p1=200, p2=100), dict(thr=-1), dict(factor=0.0), dict(ndisp=512), dict(p2=5000)):
+    for bad in (dict(ndisp=24), dict(crad=3), dict(p1=200, p2=100), dict(thr=-1), dict(factor=0.0), dict(ndisp=512), dict(p2=5000), dict(wrad=6)):
         with pytest.raises(capi.BpvoError):
             ctx.stereo_bm(L[0], R[0], _sgm_params(ctx, **bad))
     # addFrame fed by the matcher on the device = addFrame fed the oracle's map from the host
