@@ -8,18 +8,18 @@
 // their definitions, the sequential part reduced to what is sequential in the algorithm:
 //   sgm_census_sobel   capped x-Sobel (right image mirrored, as the original stores it) and the 5x5 / 3x3 census code       per pixel
 //   sgm_pixel_cost     Birchfield-Tomasi style sampling-insensitive |dSobel| + weighted census Hamming distance            per (y, x, d)
-//   sgm_box_cost       (2r+1)^2 box sum with clamped coordinates = the sliding row / column sums of the original, incl. the rows and
-//                      the column the original never writes (S1 in the oracle)                                                per (y, x, d)
+//   sgm_box_rows/cols  (2r+1)^2 box sum with clamped coordinates = the sliding row / column sums of the original, incl. the rows and
+//                      the column the original never writes (S1 in the oracle); separable, four disparities per thread      per (y, x, d)
 //   sgm_right_cost     the right image's cost volume: right(x, d) = left(x + d, d), clamped                                  per (y, x, d)
-//   sgm_path_kernel    one scanline (a row for the horizontal paths, a column for the vertical ones) per wavefront, lanes = disparities,
-//                      sequential along the line: L(p, d) = min(L'(d), L'(d +- 1) + P1, min L' + P2) - (min L' + P2) + C(p, d), int16
-//                      saturating, neighbours by wave shuffles, the minimum by a DPP tree; adds L into the sum volume         per line
+//   sgm_path_packed    one scanline (a row for the horizontal paths, a column for the vertical ones) per wavefront, lanes = pairs of
+//                      disparities, sequential along the line: L(p, d) = min(L'(d), L'(d +- 1) + P1, min L' + P2) - (min L' + P2) +
+//                      C(p, d) in packed int16 saturating arithmetic, neighbours and the wave minimum by DPP                   per line
 //   sgm_wta            winner takes all + the original's sub-pixel expression in double                                      per pixel
-//   speckle filter     connected components (|difference| <= 2 * factor between 4-neighbours) by lock-free union-find, sizes by
+//   speckle filter     connected components (|difference| <= 2 * factor between 4-neighbours) by lock-free union-find over run labels, sizes by
 //                      atomics, regions of <= 100 pixels zeroed — the flood fill of the original finds the same components
 //   sgm_lr_check       left-right consistency of the left map, conversion to float
-// Bounds: sgm_pixel_cost / sgm_box_cost are VALU / L1-bound (25 window terms per output), the path kernels latency-bound chains of
-// width x ~60 instructions with H (or W) wavefronts in flight, everything else streams the 2-byte volumes once.
+// Bounds (profiles/r04_stereo_pmc.txt): the scanline kernel is a chain of `width` (or `height`) dependent steps per wavefront with
+// 2 (2 H + 2 W) wavefronts in flight; everything else streams the 1- and 2-byte volumes once or twice.
 #include <algorithm>
 #include <type_traits>
 
@@ -150,94 +150,17 @@ __global__ void sgm_right_cost_kernel(const uint16_t* __restrict__ lcost, uint16
 // One scanline per wavefront.  The four directions of a cost volume — along the rows left to right and back, along the columns down and
 // up — depend on the cost volume alone, and so do the two volumes (left, right image): ALL EIGHT sets of scanlines run in ONE launch,
 // 2 * (2 rows + 2 cols) wavefronts, every direction writing its path costs L into a volume of its own (the original adds them into one
-// sum volume as it goes; the winner-takes-all kernel adds the four in the original's order).  V disparities per lane (d = lane * V + k).
-// The loads of a step do not depend on the step before it: they are requested PF steps ahead, so the chain that is sequential is the
-// arithmetic alone.  (First version: one launch per direction, loads inside the chain, read-modify-write of the sum volume: 780 us per
-// launch, 8 launches per frame at 1241 x 376 x 128; with the prefetch 577 us; profiles/r03_stereo_first.txt.)
-template <int V>
-__global__ __launch_bounds__(64) void sgm_path_kernel(const uint16_t* __restrict__ cost_l, const uint16_t* __restrict__ cost_r, int16_t* __restrict__ Lvol,
-                                                      int rows, int cols, int D, int P1, int P2)
-{
-  constexpr int PF = 4;
-  // which scanline: per side [rows: along x, +1 | rows: along x, -1 | cols: along y, +1 | cols: along y, -1]
-  const int per_side = 2 * rows + 2 * cols;
-  const int side = blockIdx.x / per_side;
-  int q = blockIdx.x - side * per_side;
-  int path, line;
-  if(q < rows) { path = 0; line = q; }
-  else if(q < 2 * rows) { path = 2; line = q - rows; }
-  else if(q < 2 * rows + cols) { path = 1; line = q - 2 * rows; }
-  else { path = 3; line = q - 2 * rows - cols; }
-  // path: 0 = rows forward (pass 0, path 0 of the original), 1 = columns forward (pass 0, path 2), 2 = rows backward, 3 = columns backward
-  const int vertical = path & 1, dir = path < 2 ? 1 : -1;
-  const uint16_t* __restrict__ cost = side ? cost_r : cost_l;
-  const size_t vol = (size_t) rows * cols * D;
-  int16_t* __restrict__ L = Lvol + (size_t) (side * 4 + path) * vol;
-
-  const int lane = threadIdx.x;
-  const int nsteps = vertical ? rows : cols;
-  const size_t step_stride = (vertical ? (size_t) cols * D : (size_t) D);
-  const size_t base = vertical ? (size_t) line * D : (size_t) line * cols * D;
-  const int d0 = lane * V;
-  const bool live = d0 < D;                                    // (D is a multiple of 16 and V divides it: a lane is all in or all out)
-  int prev[V];
-#pragma unroll
-  for(int k = 0; k < V; ++k) prev[k] = 0;                      // before the first pixel: all path costs and their minimum 0
-  int prev_min = 0;
-  auto offset = [&](int s) { return base + (size_t) (dir > 0 ? s : nsteps - 1 - s) * step_stride + d0; };
-  // V consecutive 16-bit values of this lane as one 16- / 32- / 64-bit word
-  using word_t = typename std::conditional<V == 1, uint16_t, typename std::conditional<V == 2, uint32_t, uint64_t>::type>::type;
-  word_t cw[PF];
-#pragma unroll
-  for(int i = 0; i < PF; ++i) {
-    cw[i] = 0;
-    if(live && i < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(i));
-  }
-  for(int s0 = 0; s0 < nsteps; s0 += PF) {
-#pragma unroll
-    for(int i = 0; i < PF; ++i) {
-      const int s = s0 + i;
-      if(s >= nsteps) break;
-      const word_t cword = cw[i];
-      const size_t off = offset(s);
-      if(live && s + PF < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(s + PF));      // refill the slot for step s + PF
-      const int pm = (int) (int16_t) (prev_min + P2);
-      // neighbours across lanes: d - 1 of k = 0 is the previous lane's last, d + 1 of k = V - 1 the next lane's first
-      const int from_left = __shfl_up(prev[V - 1], 1), from_right = __shfl_down(prev[0], 1);
-      int cur[V];
-      int mn = 32767;
-      word_t out = 0;
-#pragma unroll
-      for(int k = 0; k < V; ++k) {
-        const int d = d0 + k;
-        const int c = (int) (uint16_t) (cword >> (16 * k));
-        int lm = k > 0 ? prev[k - 1] : (lane == 0 ? 32767 : from_left);
-        int lp = k < V - 1 ? prev[k + 1] : from_right;
-        if(d + 1 >= D) lp = 32767;                             // the sentinel behind the last disparity
-        if(d == 0) lm = 32767;
-        int a = min(prev[k], sat16(lm + P1));
-        a = min(a, sat16(lp + P1));
-        a = min(a, pm);
-        a = sat16(sat16(a - pm) + c);
-        cur[k] = a;
-        if(live) mn = min(mn, a);
-        out |= (word_t) (uint16_t) (int16_t) a << (16 * k);
-      }
-#pragma unroll
-      for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
-      prev_min = mn;
-#pragma unroll
-      for(int k = 0; k < V; ++k) prev[k] = cur[k];
-      if(live) *reinterpret_cast<word_t*>(L + off) = out;
-    }
-  }
-}
-
-// The same scanline kernel with the path costs of a lane held as PAIRS of 16-bit values in 32-bit registers (2 NP disparities per lane):
-// the recurrence is int16 saturating arithmetic — v_pk_add_i16 / v_pk_sub_i16 with clamp, v_pk_min_i16 do two disparities per instruction
-// and the saturation for free, where the scalar form spends a min + max on every sat16.  The kernel is bound by VALU issue (6 wavefronts per
-// SIMD, ~150 instructions per step in the scalar form: 1.13 ms per 1241 x 376 x 128 frame), not by latency.  Same values: every operation
-// of the scalar form is an int16 saturating one (the costs are below 2^15: stereo_check rejects window radii whose box sums are not).
+// sum volume as it goes; the winner-takes-all kernel adds the four in the original's order).
+// L(p, d) = min(L'(d), L'(d +- 1) + P1, min L' + P2) - (min L' + P2) + C(p, d) in int16 saturating arithmetic.  A lane holds 2 NP
+// consecutive disparities as PAIRS of 16-bit values in 32-bit registers: v_pk_add_i16 / v_pk_sub_i16 with clamp and v_pk_min_i16 do two
+// disparities per instruction and the saturation for free (the costs are below 2^15: stereo_check rejects window radii whose box sums
+// are not).  What is sequential is a step's dependent chain — neighbours across lanes, the recurrence, the wave minimum that the next
+// step needs — so the chain is kept on the VALU: neighbours by DPP wave shifts, the minimum by the DPP row ladder + v_readlane (__shfl
+// compiles to ds_bpermute, an LDS round trip each, eight in a row per step).  Memory: batches of SGM_PF steps, see the loop.
+#ifndef SGM_PF_VALUE
+#define SGM_PF_VALUE 16
+#endif
+constexpr int SGM_PF = SGM_PF_VALUE;
 typedef short sgm_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ sgm_s16x2 sgm_pk(unsigned u) { return __builtin_bit_cast(sgm_s16x2, u); }
 __device__ __forceinline__ unsigned sgm_bits(sgm_s16x2 v) { return __builtin_bit_cast(unsigned, v); }
@@ -245,7 +168,7 @@ template <int NP>
 __global__ __launch_bounds__(64) void sgm_path_packed_kernel(const uint16_t* __restrict__ cost_l, const uint16_t* __restrict__ cost_r, int16_t* __restrict__ Lvol,
                                                              int rows, int cols, int D, int P1, int P2)
 {
-  constexpr int PF = 4, V = 2 * NP;
+  constexpr int PF = SGM_PF, V = 2 * NP;
   const int per_side = 2 * rows + 2 * cols;
   const int side = blockIdx.x / per_side;
   int q = blockIdx.x - side * per_side;
@@ -271,26 +194,30 @@ __global__ __launch_bounds__(64) void sgm_path_packed_kernel(const uint16_t* __r
   int prev_min = 0;
   const sgm_s16x2 P1v = {(short) P1, (short) P1};
   auto offset = [&](int st) { return base + (size_t) (dir > 0 ? st : nsteps - 1 - st) * step_stride + d0; };
+  // The cost loads are UNCONDITIONAL — the step clamped to the line's last one, the lanes beyond D reading disparity 0: a load inside a
+  // branch makes the compiler wait for it at the end of the branch (s_waitcnt vmcnt(0) right behind every load: the first version of this
+  // kernel spent a full memory round trip per step, 1241 of them per row — that, not arithmetic or shuffles, was its 1.1 ms).
+  const int d0_load = live ? d0 : 0;
+  auto load_offset = [&](int st) { st = min(st, nsteps - 1); return base + (size_t) (dir > 0 ? st : nsteps - 1 - st) * step_stride + d0_load; };
   using word_t = typename std::conditional<NP == 1, uint32_t, uint64_t>::type;
-  word_t cw[PF];
-#pragma unroll
-  for(int i = 0; i < PF; ++i) {
-    cw[i] = 0;
-    if(live && i < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(i));
-  }
+  // A scanline is walked in BATCHES of PF steps: the PF cost words of a batch are requested back to back, the PF steps run on registers,
+  // the PF words of path costs are stored back to back.  Loads and stores share one counter on this hardware and may complete out of
+  // order with respect to each other, so the compiler can only wait for "everything" (vmcnt(0)) once both kinds are in flight: a load per
+  // step next to a store per step — the software pipeline of the first versions — degenerates into one full memory round trip per STEP
+  // (1241 of them per row).  In batches the round trip is paid once per PF steps.
   for(int s0 = 0; s0 < nsteps; s0 += PF) {
+    word_t cw[PF], ow[PF];
+#pragma unroll
+    for(int i = 0; i < PF; ++i) cw[i] = *reinterpret_cast<const word_t*>(cost + load_offset(s0 + i));
 #pragma unroll
     for(int i = 0; i < PF; ++i) {
-      const int st = s0 + i;
-      if(st >= nsteps) break;
       const word_t cword = cw[i];
-      const size_t off = offset(st);
-      if(live && st + PF < nsteps) cw[i] = *reinterpret_cast<const word_t*>(cost + offset(st + PF));
       const short pm = (short) (prev_min + P2);
       const sgm_s16x2 pmv = {pm, pm};
-      // the neighbours across lanes: the previous lane's last pair (its high half is d0 - 1), the next lane's first pair (low half: d0 + V)
-      const unsigned left = lane == 0 ? 0x7fff0000u : (unsigned) __shfl_up((int) prev[NP - 1], 1);
-      const unsigned right = (unsigned) __shfl_down((int) prev[0], 1);
+      // neighbours by DPP wave shifts (a VALU move: ~10 cycles; ds_bpermute, what __shfl compiles to, is an LDS round trip of ~120): lane
+      // 0 / lane 63 keep the `old` operand — the sentinel 32767 below disparity 0 / (for D = 64 V) behind the last one
+      const unsigned left = (unsigned) __builtin_amdgcn_update_dpp((int) 0x7fff0000u, (int) prev[NP - 1], 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+      const unsigned right = (unsigned) __builtin_amdgcn_update_dpp((int) 0x00007fffu, (int) prev[0], 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
       unsigned cur[NP];
       int mn = 32767;
 #pragma unroll
@@ -308,13 +235,28 @@ __global__ __launch_bounds__(64) void sgm_path_packed_kernel(const uint16_t* __r
         cur[j] = sgm_bits(a);
         if(live) mn = min(mn, min((int) a.x, (int) a.y));
       }
-#pragma unroll
-      for(int o = 32; o >= 1; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
-      prev_min = mn;
+      // wave minimum by the DPP ladder (row shifts inside the rows of 16 lanes, then the two row broadcasts): lane 63 ends up with it
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x111 /*row_shr:1*/, 0xf, 0xf, false));
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x112 /*row_shr:2*/, 0xf, 0xf, false));
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x114 /*row_shr:4*/, 0xf, 0xf, false));
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x118 /*row_shr:8*/, 0xf, 0xf, false));
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x142 /*row_bcast:15*/, 0xa, 0xf, false));
+      mn = min(mn, __builtin_amdgcn_update_dpp(mn, mn, 0x143 /*row_bcast:31*/, 0xc, 0xf, false));
       word_t out = 0;
 #pragma unroll
-      for(int j = 0; j < NP; ++j) { prev[j] = cur[j]; out |= (word_t) cur[j] << (32 * j); }
-      if(live) *reinterpret_cast<word_t*>(L + off) = out;
+      for(int j = 0; j < NP; ++j) out |= (word_t) cur[j] << (32 * j);
+      ow[i] = out;
+      // (steps past the end of the line — the last batch of a ragged line — leave the state alone: nothing follows them)
+      if(s0 + i < nsteps) {
+        prev_min = __builtin_amdgcn_readlane(mn, 63);
+#pragma unroll
+        for(int j = 0; j < NP; ++j) prev[j] = cur[j];
+      }
+    }
+    if(live) {
+#pragma unroll
+      for(int i = 0; i < PF; ++i)
+        if(s0 + i < nsteps) *reinterpret_cast<word_t*>(L + offset(s0 + i)) = ow[i];
     }
   }
 }
@@ -524,8 +466,7 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
     hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
     {
       const dim3 gp((unsigned) (2 * (2 * rows + 2 * cols)));
-      if(D <= 64) hipLaunchKernelGGL(sgm_path_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
-      else if(D <= 128) hipLaunchKernelGGL(sgm_path_packed_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
+      if(D <= 128) hipLaunchKernelGGL(sgm_path_packed_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
       else hipLaunchKernelGGL(sgm_path_packed_kernel<2>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
     }
     for(int side = 0; side < 2; ++side) {

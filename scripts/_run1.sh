@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r04f
-python -m pytest tests -m gpu -x -q > gpurun_out/r04f/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> gpurun_out/r04f/pytest_gpu.txt
-tail -5 gpurun_out/r04f/pytest_gpu.txt
-python scripts/shard_ab.py --pairs 128 --ref-pairs 1024 --steps 10 --repeat 1 -- "" "lanes=1" "lanes=3" > gpurun_out/r04f/shard_ab.txt 2>&1; cat gpurun_out/r04f/shard_ab.txt
+mkdir -p gpurun_out/r04h
+python tests/tools/sgm_bisect.py bpvo_amd/csrc/libbpvo_hip.so bpvo_amd/csrc/exp/libbpvo_hip_pf8.so > gpurun_out/r04h/bisect4.txt 2>&1; cat gpurun_out/r04h/bisect4.txt
+python tests/tools/sgm_speed.py bpvo_amd/csrc/libbpvo_hip.so bpvo_amd/csrc/exp/libbpvo_hip_pf8.so bpvo_amd/csrc/exp/libbpvo_hip_pf32.so > gpurun_out/r04h/speed4.txt 2>&1; cat gpurun_out/r04h/speed4.txt
