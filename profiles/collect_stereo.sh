@@ -44,7 +44,9 @@ for i in (1, 2, 3):
     db = sqlite3.connect(fs[-1])
     q = "select kernel_name, counter_name, count(*), avg(value), avg(duration), max(grid_size) from counters_collection where kernel_name like '%sgm_%' or kernel_name like '%stereo_%' group by kernel_name, counter_name, grid_size"
     for k, c, n, v, dur, grid in db.execute(q):
-        per.setdefault((k.split("(")[0].split("::")[-1], grid), {})[c] = (v, n, dur)
+        import re
+        m = re.search(r"(sgm_\w+|stereo_\w+)(<[^>]*>)?", k)
+        per.setdefault((m.group(0) if m else k[:40], grid), {})[c] = (v, n, dur)
 print("PMC averages per launch of the stereo kernels, scripts/stereo_bench.py 2 (1241x376 / 128 and 640x480 / 64 disparities), one rocprofv3 --pmc pass per counter set.")
 print("HBM bytes from the request-size counters: read = 32 * RDREQ_32B + 64 * RDREQ_64B + 128 * RDREQ_128B, written = 64 * WRREQ_64B + 32 * (WRREQ - WRREQ_64B).")
 for (k, grid), cs in sorted(per.items(), key=lambda kv: -(kv[1].get("SQ_WAVE_CYCLES", (0, 0, 0))[2] or 0)):
