@@ -128,6 +128,7 @@ FrameJob make_frame_job(bpvo_hip_ctx* c, FrameSlot& f, int l)
   std::memcpy(j.K, g.K, sizeof(j.K));
   j.b = g.b;
   j.dspace = c->dspace;
+  j.lazy = f.lazy[l] ? 1 : 0;
   return j;
 }
 
@@ -249,6 +250,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("stagger", stagger, 0, 1),
     OPT_INT("upload_workers", up_workers, 0, 32),
     OPT_INT("keep_current_disparity", keep_current_disparity, 0, 1),
+    OPT_INT("lazy_template_descriptor", lazy_template, 0, 1),
     OptionDef{"tapcache_max_density", 0.0, 1e9, [](bpvo_hip_ctx* c) { return c->tapcache_max_density; },
               [](bpvo_hip_ctx* c, double v) { c->tapcache_max_density = v; return BPVO_OK; }},
     OptionDef{"upload_plan_first", 0.0, 0.9, [](bpvo_hip_ctx* c) { return c->up_plan[0]; },

@@ -253,6 +253,7 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(refs[i] < 0 || refs[i] >= c->n_frames || curs[i] < 0 || curs[i] >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot");
     if(!c->frames[refs[i]].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+    if(int rc = ensure_dense_descriptor(c, curs[i])) return rc;      // (a batch's template frame as the current frame of this estimate)
   }
   const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
   int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
@@ -430,6 +431,7 @@ static int linearize_impl(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, i
   CHECK_CTX(c); CHECK_WS(c, ws); CHECK_SLOT(c, ref_slot); CHECK_SLOT(c, cur_slot); CHECK_LEVEL(c, level);
   if(!c->frames[ref_slot].has_template) return fail(c, BPVO_ERR_NO_TEMPLATE, "reference frame has no template");
   if(!c->frames[cur_slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
+  if(int rc0 = ensure_dense_descriptor(c, cur_slot)) return rc0;
   if(c->frames[ref_slot].n_host[level] <= 0) return fail(c, BPVO_ERR_NO_TEMPLATE, "you should call setData before calling computeResiduals");
   c->frac_valid = false;
   (void) hipSetDevice(c->device);

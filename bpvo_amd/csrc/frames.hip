@@ -54,6 +54,12 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
   // pair batches: the compact channel-0 plane serves the saliency map of TEMPLATE frames only; the current frames' descriptor kernel
   // skips its store (the selection reads channel 0 from the records should such a frame be made a template later)
   for(int i = 0; i < count; ++i) c->frames[first + i * stride].ch0_valid = !(skip_odd_disp && (i & 1));
+  // ... and the TEMPLATE frames (A, even) of a pair batch keep no records at the NMS levels (FrameSlot::lazy): bit-planes with the census
+  // fused into the blur kernel, CD3 gradients.  Every other frame, and every frame set through the frame API, is dense.
+  const bool lazy_ok = skip_odd_disp != 0 && c->lazy_template && c->params.descriptor == BPVO_DESC_BITPLANES && c->C == 8 &&
+                       !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f && c->params.gradientEstimation == BPVO_GRAD_CD3;
+  for(int i = 0; i < count; ++i)
+    for(int l = 0; l < c->L; ++l) c->frames[first + i * stride].lazy[l] = lazy_ok && !(i & 1) && c->geom[l].nms_radius > 0;
   const FrameJob* tab = nullptr;
   int rc = upload_frame_jobs(c, first, stride, count, fr, 0, &tab);
   if(rc) return rc;
@@ -168,7 +174,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   }
   for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
     ScopedTimer t(c, KC_TEMPLATE, 0.0, fr.ln);
-    launch_template_build(s, tab + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5);
+    launch_template_build(s, tab + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5, c->gauss_k);
   }
   if(!fr.own_thread) {      // (a lane thread goes straight on to its estimation on the same stream)
     FR_CK(c, fr, hipStreamSynchronize(s));
@@ -187,6 +193,25 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count)
     if(!c->frames[first + i * stride].has_disp) return fail(c, BPVO_ERR_NO_DATA, "no disparity in frame (the current frame of a pair batch)");
   }
   return frames_set_template(c, first, stride, count, ctx_run(c));
+}
+
+// The full records of a slot's lazy levels, from the image the slot still holds: the descriptor kernel again, for this frame alone,
+// with the flag cleared (accessors; a template frame of a batch used as the current frame of a later estimate).
+int ensure_dense_descriptor(bpvo_hip_ctx* c, int slot)
+{
+  FrameSlot& f = c->frames[slot];
+  bool any = false;
+  for(int l = 0; l < c->L; ++l) any = any || f.lazy[l];
+  if(!any) return BPVO_OK;
+  for(int l = 0; l < c->L; ++l) f.lazy[l] = false;
+  const FrameRun fr = ctx_run(c);
+  const FrameJob* tab = nullptr;
+  const int rc = upload_frame_jobs(c, slot, 1, 1, fr, 0, &tab);
+  if(rc) return rc;
+  for(int l = c->L - 1; l >= c->params.maxTestLevel; --l)
+    launch_bitplanes(c->stream, tab + (size_t) l * c->n_frames, c->geom[l].cols, c->geom[l].rows, 1, c->params.sigmaBitPlanes, c->gauss_k, 1);
+  HIP_CK(c, hipStreamSynchronize(c->stream));
+  return BPVO_OK;
 }
 
 }  // namespace bpvo_hip_host
@@ -268,6 +293,7 @@ int bpvo_hip_get_descriptor_channel(bpvo_hip_ctx* c, int slot, int level, int ch
   if(channel < 0 || channel >= c->C) return fail(c, BPVO_ERR_INVALID_ARG, "bad channel");
   if(!c->frames[slot].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
   (void) hipSetDevice(c->device);
+  if(int rc = ensure_dense_descriptor(c, slot)) return rc;      // (a template frame of a pair batch: its NMS levels kept no records)
   const size_t npix = c->geom[level].npix;
   // de-interleave one channel: 2-D copy with a source pitch of C floats
   HIP_CK(c, hipMemcpy2DAsync(out, sizeof(float), c->frames[slot].desc[level] + channel, sizeof(float) * c->C, sizeof(float), npix,

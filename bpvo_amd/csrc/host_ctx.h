@@ -59,6 +59,7 @@ struct FrameSlot {
   uint8_t* img[kMaxLevels] = {};
   uint8_t* cen[kMaxLevels] = {};
   float* ch0[kMaxLevels] = {};
+  bool lazy[kMaxLevels] = {};     // levels whose descriptor records were not stored (FrameJob::lazy): census bytes + channel 0 only
   bool ch0_valid = true;          // false: the descriptor of the slot's current data was computed without the compact channel-0 plane
   float* desc[kMaxLevels] = {};
   float* disp = nullptr;
@@ -224,6 +225,8 @@ struct bpvo_hip_ctx {
   // host batches on two lanes: the pairs are cut into a SMALL first group (lane 0 starts its Gauss-Newton stage while most of the batch
   // is still crossing the bus), a large second one for lane 1, and the rest for lane 0 again (host_groups_plan); fractions of the batch
   double up_plan[2] = {0.19, 0.50};      // options "upload_plan_first" / "upload_plan_second"; first = 0: two equal groups.  Measured: profiles/r03_host_buffers_plan.txt
+  int lazy_template = 1;                 // option "lazy_template_descriptor": the template frames (A) of a pair batch keep census bytes + channel 0 at the NMS
+                                         // levels instead of 32-byte records nobody reads (bit-planes, CD3); template_build forms its stencils from the census
   int keep_current_disparity = 0;        // option: pair batches store the disparity of the CURRENT frames (B) too, so that a B slot can be made
                                          // a template later (frames_set_template); off by default: 1.9 GB per 1024-pair step never read
   double up_last_seconds = 0.0;          // wall time the workers of the last call needed for all chunks (measurement)
@@ -360,6 +363,7 @@ int fraction_good(bpvo_hip_ctx* c, int ws, float thr, float* frac);
 int get_weights_host(bpvo_hip_ctx* c, int ws, std::vector<float>& w_cm, int* n_out);
 int check_template_not_empty(bpvo_hip_ctx* c, int ref_slot);
 int ensure_lanes(bpvo_hip_ctx* c, int n);
+int ensure_dense_descriptor(bpvo_hip_ctx* c, int slot);      // a slot with lazy levels gets its full records (accessors, a template frame used as current)
 int set_option(bpvo_hip_ctx* c, const std::string& key, double v);
 int apply_options_string(bpvo_hip_ctx* c, const char* str);
 struct OptionDef { const char* key; double lo, hi; std::function<double(bpvo_hip_ctx*)> get; std::function<int(bpvo_hip_ctx*, double)> set; };

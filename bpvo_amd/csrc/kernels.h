@@ -56,7 +56,7 @@ void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
                           int num_levels, int with_normalization);
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
-void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5);
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3]);   // gauss_k: the bit-planes blur taps (lazy levels)
 
 // stereo front-end (kernels_stereo.hip): OpenCV 2.4 block matching with the reference's parameters, batched over frames
 struct StereoLaunch {

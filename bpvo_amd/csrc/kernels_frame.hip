@@ -269,6 +269,12 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   // job table), and on gfx9 the wait for such a load also waits for every store before it (vmcnt counts both, in order)
   float* __restrict__ const desc = j.desc;
   float* __restrict__ const ch0 = j.ch0;
+  // A LAZY level (FrameJob::lazy; template frames of a pair batch at the NMS levels): the records of such a level are read at the five
+  // stencil positions of one pixel in ~18 only — 72 % of them never — so the level keeps its census bytes and channel 0 (what the saliency
+  // map needs) and template_build forms the stencils' records from the census bytes: the kernel then runs the census stage, one plane of
+  // eight in the two passes, and stores 5 bytes per pixel instead of 36.
+  const bool lazy = FROM_IMAGE && j.lazy != 0;
+  uint8_t* __restrict__ const cen_out = j.cen;
   if(tid < 18) {      // entry a + 3 b + 9 S0 (visible after the first barrier below)
     const float S0 = (float) (tid / 9), A = (float) (tid % 3), B = (float) ((tid / 3) % 3);
     s_lut[tid] = S0 * k0 + A * k1 + B * k2;
@@ -331,12 +337,37 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
                            ((p[1] >= c) << 4) | ((p[IW - 1] >= c) << 5) | ((p[IW] >= c) << 6) | ((p[IW + 1] >= c) << 7));
         }
         s_cen[ly * CW + lx] = spread_planes(out);
+        // lazy level: the census byte image is what template_build works from (the position's own pixel: no reflection inside the tile)
+        if(lazy && ly >= BP_HALO && ly < BP_HALO + BP_TH && lx >= BP_HALO && lx < BP_HALO + BP_TW && y0 + ly - BP_HALO < R && x0 + lx - BP_HALO < W)
+          cen_out[(size_t) (y0 + ly - BP_HALO) * W + (x0 + lx - BP_HALO)] = out;
       }
       __syncthreads();
     }
     const bool more = t + 1 < stack && y0 + BP_TH < R;
     if(more) prefetch(y0 + BP_TH);
 
+    if(lazy) {
+      // plane 0 only: the same table entry, the same column expression as the full form below
+      for(int i = tid; i < CR * BP_TW; i += 256) {
+        const int ly = i / BP_TW, lx = i - ly * BP_TW;
+        const uint2* c = s_cen + ly * CW + lx;
+        const unsigned ilo = (c[1].x + c[3].x) + 3u * (c[0].x + c[4].x) + 9u * c[2].x;
+        s_row[i] = s_lut[ilo & 0xffu];
+      }
+      __syncthreads();
+      if(more) stage();
+      for(int i = tid; i < BP_TH * BP_TW; i += 256) {
+        const int ly = i / BP_TW, lx = i - ly * BP_TW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if(gx >= W || gy >= R) continue;
+        const float* Th = s_row + ly * BP_TW + lx;
+        constexpr int pitch = BP_TW;
+        float o = k0 * Th[2 * pitch]; o += k1 * (Th[3 * pitch] + Th[pitch]); o += k2 * (Th[4 * pitch] + Th[0]);
+        ch0[(size_t) gy * W + gx] = o;
+      }
+      __syncthreads();
+      continue;
+    }
     // horizontal pass: (BP_TH + 4) rows x BP_TW columns, 5 positions per thread
     for(int i = tid; i < CR * BP_TW; i += 256) {
       const int ly = i / BP_TW, lx = i - ly * BP_TW;
@@ -973,10 +1004,47 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
 // (reference: bpvo/template_data.cc:102-137; Jacobian = bpvo/rigid_body_warp.cc:60-315 in the SSE code's operation
 // gradients pre-multiplied by fx, fy).  The 1x6 Jacobian rows themselves are recomputed on the fly by irls_reduce (types.h
 // jac_row), so only pix and (Ix, Iy) are stored, in the tiled layout of types.h.
+// One row-pass value vector of the bit-planes blur at census position (px, r) from the census byte image: the five bytes of the row
+// window (REFLECT_101 on the census coordinates, as bitplanes_blur_kernel stages them), spread to a byte per plane, combined into the
+// table index of all eight planes, looked up — the operations of that kernel's row pass, value for value.
+__device__ __forceinline__ void bp_row_from_census(const uint8_t* __restrict__ cen, int W, int R, int px, int r, const float* __restrict__ lut, float (&T)[8])
+{
+  const uint8_t* row = cen + (size_t) reflect101(r, R) * W;
+  const uint2 cm2 = spread_planes(row[reflect101(px - 2, W)]), cm1 = spread_planes(row[reflect101(px - 1, W)]), c0 = spread_planes(row[reflect101(px, W)]),
+              cp1 = spread_planes(row[reflect101(px + 1, W)]), cp2 = spread_planes(row[reflect101(px + 2, W)]);
+  const unsigned ilo = (cm1.x + cp1.x) + 3u * (cm2.x + cp2.x) + 9u * c0.x;
+  const unsigned ihi = (cm1.y + cp1.y) + 3u * (cm2.y + cp2.y) + 9u * c0.y;
+#pragma unroll
+  for(int b = 0; b < 4; ++b) {
+    T[b] = lut[(ilo >> (8 * b)) & 0xffu];
+    T[4 + b] = lut[(ihi >> (8 * b)) & 0xffu];
+  }
+}
+// ... and the column pass over five of them (rows y-2 .. y+2 of one column): bitplanes_blur_kernel's expression
+__device__ __forceinline__ void bp_col_pass(const float (&Tm2)[8], const float (&Tm1)[8], const float (&T0)[8], const float (&Tp1)[8], const float (&Tp2)[8],
+                                            float k0, float k1, float k2, float (&out)[8])
+{
+#pragma unroll
+  for(int c = 0; c < 8; ++c) {
+    float o = k0 * T0[c];
+    o += k1 * (Tp1[c] + Tm1[c]);
+    o += k2 * (Tp2[c] + Tm2[c]);
+    out[c] = o;
+  }
+}
+
 template <int C>
-__global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5)
+__global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5, float k0, float k1, float k2)
 {
   const FrameJob& j = jobs[blockIdx.z];
+  __shared__ float s_lut[18];
+  if(C == 8 && j.lazy) {      // (uniform over the workgroup: a frame's level is lazy or it is not)
+    if(threadIdx.x < 18) {    // the row-pass table of bitplanes_blur_kernel: entry a + 3 b + 9 S0
+      const float S0 = (float) (threadIdx.x / 9), A = (float) (threadIdx.x % 3), B = (float) ((threadIdx.x / 3) % 3);
+      s_lut[threadIdx.x] = S0 * k0 + A * k1 + B * k2;
+    }
+    __syncthreads();
+  }
   const int N = *j.n_out;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if(i >= N) return;
@@ -997,8 +1065,32 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     };
     float xp[8], xm[8], yp[8], ym[8];
-    load8(0, pixv);
-    load8(2, xp); load8(-2, xm); load8(rs, yp); load8(-rs, ym);
+    if(j.lazy) {
+      // the five records of the CD3 stencil, formed from the census bytes exactly as bitplanes_blur_kernel forms them (lazy levels are
+      // CD3 only: the host keeps CD5 templates dense): column x over rows y-3 .. y+3 serves (x, y-1), (x, y), (x, y+1); columns x -+ 1
+      // over rows y-2 .. y+2 serve (x-1, y), (x+1, y)
+      const int R = j.rows, x = ii % W, y = ii / W;
+      const uint8_t* __restrict__ cen = j.cen;
+      {
+        float Tc[7][8];
+#pragma unroll
+        for(int r = 0; r < 7; ++r) bp_row_from_census(cen, W, R, x, y - 3 + r, s_lut, Tc[r]);
+        bp_col_pass(Tc[0], Tc[1], Tc[2], Tc[3], Tc[4], k0, k1, k2, ym);
+        bp_col_pass(Tc[1], Tc[2], Tc[3], Tc[4], Tc[5], k0, k1, k2, pixv);
+        bp_col_pass(Tc[2], Tc[3], Tc[4], Tc[5], Tc[6], k0, k1, k2, yp);
+      }
+#pragma unroll
+      for(int side = 0; side < 2; ++side) {
+        float Ts[5][8];
+#pragma unroll
+        for(int r = 0; r < 5; ++r) bp_row_from_census(cen, W, R, x + (side ? 1 : -1), y - 2 + r, s_lut, Ts[r]);
+        if(side) bp_col_pass(Ts[0], Ts[1], Ts[2], Ts[3], Ts[4], k0, k1, k2, xp);
+        else bp_col_pass(Ts[0], Ts[1], Ts[2], Ts[3], Ts[4], k0, k1, k2, xm);
+      }
+    } else {
+      load8(0, pixv);
+      load8(2, xp); load8(-2, xm); load8(rs, yp); load8(-rs, ym);
+    }
     if(!grad_cd5) {
 #pragma unroll
       for(int c = 0; c < 8; ++c) {
@@ -1177,11 +1269,13 @@ void launch_gather_counts(hipStream_t s, const FrameJob* jobs, int job_pitch, in
   hipLaunchKernelGGL(gather_counts_kernel, dim3((nframes * kMaxLevels + 255) / 256), dim3(256), 0, s, jobs, job_pitch, nframes, first_level,
                      num_levels, out);
 }
-void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5)
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3])
 {
   if(max_points <= 0) return;
   const dim3 g((max_points + 255) / 256, 1, nframes);
-  dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5); });
+  dispatch_channels(C, [&](auto c) {
+    hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5, gauss_k[0], gauss_k[1], gauss_k[2]);
+  });
 }
 
 void launch_export_jacobians(hipStream_t s, const FrameJob* job, int C, int n, float* out)

@@ -219,6 +219,9 @@ struct FrameJob {
   float          K[9];
   float          b;
   int            dspace;    // 1: DisparitySpaceWarp points / raw gradients (see PairJob)
+  int            lazy;      // 1 (C = 8 bit-planes, template frames of a pair batch at the NMS levels): the level's 32-byte records are NOT
+                            // stored — `cen` holds the census bytes and `ch0` channel 0 (all the selection needs); template_build
+                            // forms the records of its stencils from the census bytes (kernels_frame.hip)
 };
 
 }  // namespace bpvo_hip

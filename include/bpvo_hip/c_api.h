@@ -354,6 +354,11 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "upload_workers"         6         host threads that stage a HOST-buffer batch in pinned chunks (0: plain copies)
  *   "upload_plan_first"      0.19      fractions of a host batch in the first (lane 0) and second (lane 1) group of the upload plan;
  *   "upload_plan_second"     0.50      first = 0: two equal groups
+ *   "lazy_template_descriptor" 1       bpvo_hip_batch_run keeps, for the TEMPLATE frame (A) of every pair, census bytes + channel 0 instead of the
+ *                                      32-byte descriptor records at the pyramid levels with non-maximum suppression (bit-planes, CD3 gradients):
+ *                                      one pixel in ~18 is a template point there, template_build forms the records of its stencils from the census
+ *                                      bytes (same operations, same bits).  The accessors and a later estimate with such a slot as the CURRENT frame
+ *                                      rebuild the records on demand.
  *   "keep_current_disparity" 0         bpvo_hip_batch_run stores the disparity of the CURRENT frame (B) of every pair too.  By default it is
  *                                      neither uploaded nor stored — nothing on the path reads it — and bpvo_hip_frame(s)_set_template on
  *                                      such a slot returns BPVO_ERR_NO_DATA; set 1 before batches whose B frames become templates later.

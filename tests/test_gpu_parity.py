@@ -1173,3 +1173,33 @@ def test_current_frames_of_a_pair_batch_keep_no_disparity_unless_asked(hip):
     with pytest.raises(capi.BpvoError):
         ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=2), n_frames=2, n_pairs=1)
         ctx.set_option("no_such_option", 1)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(376, 1241, 4, id="kitti-1241x376-L4"), pytest.param(243, 651, 3, id="651x243-L3-ragged")])
+def test_lazy_template_descriptor_is_bit_identical(hip, rows, cols, levels):
+    """Pair batches keep, for their TEMPLATE frames, census bytes + channel 0 instead of descriptor records at the levels with non-maximum
+    suppression (option lazy_template_descriptor, default on); template_build forms the records of its stencils from the census bytes.
+    Against the dense form: template pixels and Jacobians of every level, poses and statistics, bit for bit; the accessor rebuilds the
+    records of a lazy level on demand (= the descriptor of the same image set through the frame API)."""
+    n = 3
+    b = synth.make_batch(rows, cols, n, first_index=40)
+    out = {}
+    for lazy in (0, 1):
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels, minNumPixelsForNonMaximaSuppression=100 * 100), n_frames=2 * n, n_pairs=n)
+        ctx.set_option("lazy_template_descriptor", lazy)
+        poses, stats = ctx.batch_run(b["images"], b["disparities"])
+        rec = dict(poses=poses, stats=stats, pix=[ctx.get_pixels(2, l) for l in range(levels)], jac=[ctx.get_jacobians(2, l) for l in range(levels)],
+                   npts=[ctx.num_points(2, l) for l in range(levels)], sal=[ctx.get_saliency(2, l) for l in range(levels)])
+        rec["desc"] = [np.stack([ctx.get_descriptor_channel(2, l, c) for c in range(8)]) for l in range(levels)]      # (lazy: rebuilt on demand)
+        rec["desc_b"] = ctx.get_descriptor_channel(3, 0, 5)
+        out[lazy] = rec
+        ctx.close()
+    a, z = out[0], out[1]
+    assert a["npts"] == z["npts"] and min(a["npts"]) > 0
+    assert bits_equal(a["poses"], z["poses"]) and a["stats"].tobytes() == z["stats"].tobytes()
+    for l in range(levels):
+        assert bits_equal(a["sal"][l], z["sal"][l]), l
+        assert bits_equal(a["pix"][l], z["pix"][l]), l
+        assert bits_equal(a["jac"][l], z["jac"][l]), l
+        assert bits_equal(a["desc"][l], z["desc"][l]), l
+    assert bits_equal(a["desc_b"], z["desc_b"])

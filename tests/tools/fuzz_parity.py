@@ -58,6 +58,9 @@ def draw(rng):
         kw.update(centralDifferenceRadius=int(rng.choice([1, 1, 2, 3])),
                   centralDifferenceSigmaBefore=float(rng.choice([-1.0, 0.75, 2.7])),
                   centralDifferenceSigmaAfter=float(rng.choice([-1.0, 1.75, 3.4])))
+    elif descriptor == "latch":                       # (soaks with --latch only: the draw of the fixed-seed suite is unchanged)
+        kw.update(latchNumBytes=int(rng.choice([1, 1, 2, 4])), latchHalfSsdSize=int(rng.choice([0, 1, 1, 2, 3])),
+                  latchRotationInvariance=int(rng.integers(0, 2)))
     elif descriptor == "gradient":                    # pre-smoothing with OpenCV's automatic kernel size: 5 / 9 taps
         kw.update(sigmaPriorToCensusTransform=float(rng.choice([-1.0, -1.0, 0.5, 1.0])))
     scene = int(rng.integers(0, 3))       # 0: synthetic plane pair, 1: tiled texture + shift, 2: same with noise disparity
@@ -352,9 +355,12 @@ def main():
     ap.add_argument("--max-rows", type=int, default=200)
     ap.add_argument("--max-cols", type=int, default=300)
     ap.add_argument("--batch-every", type=int, default=0)
+    ap.add_argument("--latch", action="store_true", help="LATCH among the descriptors drawn (levels too small for a key point give an empty template on both sides)")
     args = ap.parse_args()
     global MAX_ROWS, MAX_COLS
     MAX_ROWS, MAX_COLS = args.max_rows, args.max_cols
+    if args.latch:
+        DESCRIPTORS.append("latch")
     import bpvo_amd
     import __graft_entry__ as ge
     hip = bpvo_amd.load()
