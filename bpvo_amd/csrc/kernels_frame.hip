@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   // stencil positions of one pixel in ~18 only — 72 % of them never — so the level keeps its census bytes and channel 0 (what the saliency
   // map needs) and template_build forms the stencils' records from the census bytes: the kernel then runs the census stage, one plane of
   // eight in the two passes, and stores 5 bytes per pixel instead of 36.
-  const bool lazy = FROM_IMAGE && j.lazy != 0;
+  // The tile columns at the right edge stay dense: the saliency of the columns the reference's SIMD body treats apart — x < 4 (formed from
+  // columns n - 4 + x) and x >= n = W & ~3 (Q7) — reads whole records of columns n - 5 .. W - 1 (saliency_generic).
+  const bool lazy_level = FROM_IMAGE && j.lazy != 0;
+  const bool lazy = lazy_level && x0 + BP_TW + 8 <= (W & ~3);
   uint8_t* __restrict__ const cen_out = j.cen;
   if(tid < 18) {      // entry a + 3 b + 9 S0 (visible after the first barrier below)
     const float S0 = (float) (tid / 9), A = (float) (tid % 3), B = (float) ((tid / 3) % 3);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
         }
         s_cen[ly * CW + lx] = spread_planes(out);
         // lazy level: the census byte image is what template_build works from (the position's own pixel: no reflection inside the tile)
-        if(lazy && ly >= BP_HALO && ly < BP_HALO + BP_TH && lx >= BP_HALO && lx < BP_HALO + BP_TW && y0 + ly - BP_HALO < R && x0 + lx - BP_HALO < W)
+        if(lazy_level && ly >= BP_HALO && ly < BP_HALO + BP_TH && lx >= BP_HALO && lx < BP_HALO + BP_TW && y0 + ly - BP_HALO < R && x0 + lx - BP_HALO < W)
           cen_out[(size_t) (y0 + ly - BP_HALO) * W + (x0 + lx - BP_HALO)] = out;
       }
       __syncthreads();
