@@ -156,6 +156,9 @@ class Device {
   bpvo_hip_ctx* ctx() const { return _ctx; }
   ImageSize imageSize() const { return _size; }
   void check(int rc) const { if(rc != BPVO_OK) throw Error(bpvo_hip_last_error(_ctx)); }
+  /* how the device schedules its work (c_api.h "Options"); no counterpart in the reference */
+  void setOption(const std::string& name, double value) { check(bpvo_hip_set_option(_ctx, name.c_str(), value)); }
+  double getOption(const std::string& name) const { double v = 0.0; check(bpvo_hip_get_option(_ctx, name.c_str(), &v)); return v; }
  private:
   bpvo_hip_ctx* _ctx;
   ImageSize _size;
@@ -331,6 +334,9 @@ class VisualOdometry {
     return _points;
   }
   const Trajectory& trajectory() const { return _trajectory; }   // bpvo/vo.h:98
+  /* scheduling options of the device context (c_api.h "Options"; the reference has none) */
+  void setOption(const std::string& name, double value) { _dev->setOption(name, value); }
+  double getOption(const std::string& name) const { return _dev->getOption(name); }
 
  private:
   Result makeResult(const bpvo_hip_result& r)

@@ -46,6 +46,7 @@ int facade_surface()
   (void) vo.numPointsAtLevel();
   (void) vo.pointsAtLevel(-1).size();
   (void) vo.trajectory().size();
+  vo.setOption("lanes", 1); (void) vo.getOption("lanes");
   auto dev = std::make_shared<bpvo::detail::Device>(K, 0.1f, bpvo::ImageSize(64, 64), p, 2, 1);
   bpvo::VisualOdometryFrame ref(dev, 0), cur(dev, 1);
   ref.setData(nullptr, nullptr); ref.setTemplate(); (void) ref.hasTemplate(); (void) cur.empty(); cur.clear(); (void) ref.numLevels();
