@@ -159,6 +159,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.partials = c->ws[ws].partials;
   j.st = c->d_states + ws;
   j.cnt = c->d_counters + kWsCounters * (size_t) ws;
+  j.ticket = c->d_tickets + ws;
   if(ws == c->trace_ws) { j.trace = c->d_trace; j.trace_cap = c->trace_cap; }
   return j;
 }
@@ -247,6 +248,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_size", team_size_env, 0, 256),
     OPT_INT("team_cus", num_cus, 1, 1 << 16),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
+    OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),
     OPT_INT("upload_workers", up_workers, 0, 32),
     OPT_INT("keep_current_disparity", keep_current_disparity, 0, 1),
@@ -554,6 +556,8 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_wtmp, sizeof(float) * (size_t) cp->cap_max * cp->C));
   CREATE_CK(hipMalloc((void**) &cp->d_count, sizeof(unsigned int)));
+  CREATE_CK(hipMalloc((void**) &cp->d_tickets, sizeof(unsigned) * n_pairs));
+  CREATE_CK(hipMemset(cp->d_tickets, 0, sizeof(unsigned) * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_counters, kWsCounters * sizeof(unsigned long long) * n_pairs));
   CREATE_CK(hipMemset(cp->d_counters, 0, kWsCounters * sizeof(unsigned long long) * n_pairs));
   CREATE_CK(hipHostMalloc((void**) &cp->h_fjobs, 2 * sizeof(FrameJob) * (size_t) cp->L * n_frames));
@@ -578,7 +582,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
   (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1); (void) hipFree(c->d_latch_off);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
-  (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_trace);
+  (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_tickets); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);
   (void) hipFree(c->st_sgm);
   for(auto st : c->up_streams) if(st) { (void) hipStreamSynchronize(st); (void) hipStreamDestroy(st); }

@@ -99,6 +99,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
     g.fuse_frozen = c->fuse_frozen;
+    g.step_in_reduce = n <= c->step_in_reduce_max ? 1 : 0;
+    g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
     // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
     const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
     launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
@@ -151,8 +153,10 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         // level 2 times every kernel; level 3 (bench.py's single-lane roofline pass) every warp_residual AND every irls_reduce launch
         { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all && launch_median_k); if(launch_median_k) launch_median(ln->stream, g); }
         { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all || c->profile_k6_all); launch_irls_reduce(ln->stream, g); }
-        { ScopedTimer t(c, KC_GN_STEP, 0.0, ln, c->profile_all);
-          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance); }
+        if(!g.step_in_reduce) {
+          ScopedTimer t(c, KC_GN_STEP, 0.0, ln, c->profile_all);
+          launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+        }
       }
       const int slot = round % 3;
       launch_compact_active(ln->stream, g.jobs, g.active, n_cur, lists[slot], ln->d_active + 2 * slot);

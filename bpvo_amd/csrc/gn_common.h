@@ -21,6 +21,62 @@ constexpr int GN_BLOCK = 256;
 constexpr int K6_BLOCK = K6_BLOCK_VALUE;
 constexpr int K6_WAVES = K6_BLOCK / 64;
 
+// Sums of N <= 32 per-lane accumulators over the 64 lanes of a wavefront, every one with the pairing of
+//   for(o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
+// as lane 0 sees it — (i, i+32), then (i, i+16), (i, i+8) ... (i, i+1): the same additions in the same order, bit for bit — but as a
+// reduce-scatter on the VALU.  __shfl_down is ds_bpermute, an LDS round trip: 6 per accumulator, 180 per wave for the 30 sums of the
+// normal equations.  Here v_permlane32_swap folds the two halves of the wave for TWO accumulators per instruction (the lower half
+// goes on with accumulator k, the upper half with k + H), v_permlane16_swap folds the rows of 16 the same way, and the last four
+// steps are DPP row shifts inside the rows: 78 VALU instructions and no LDS for N = 30.  Afterwards lane 16 * r of a wave holds, in
+// out[k], the sum of accumulator wave_tree_index<N>(r, k) (-1: nothing).
+template <int N>
+__host__ __device__ constexpr int wave_tree_index(int row, int k)
+{
+  constexpr int H = (N + 1) / 2, Q = (H + 1) / 2;
+  const int ka = k + (row & 1) * Q;
+  const int a = ka + (row >> 1) * H;
+  return (ka < H && a < N) ? a : -1;
+}
+template <int N>
+__device__ __forceinline__ void wave_tree_sums(const float (&acc)[N], float (&out)[(((N + 1) / 2) + 1) / 2])
+{
+  static_assert(N >= 2 && N <= 32, "four rows of up to eight sums");
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  constexpr int H = (N + 1) / 2, Q = (H + 1) / 2;
+  float t[H];
+#pragma unroll
+  for(int k = 0; k < H; ++k) {
+    const u2 s = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[k]), __float_as_uint(acc[k + H < N ? k + H : k]), false, false);
+    t[k] = __uint_as_float(s.x) + __uint_as_float(s.y);
+  }
+#pragma unroll
+  for(int k = 0; k < Q; ++k) {
+    const u2 s = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[k]), __float_as_uint(t[k + Q < H ? k + Q : k]), false, false);
+    float v = __uint_as_float(s.x) + __uint_as_float(s.y);
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x108, 0xf, 0xf, false));   // row_shl:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x104, 0xf, 0xf, false));   // row_shl:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x102, 0xf, 0xf, false));   // row_shl:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x101, 0xf, 0xf, false));   // row_shl:1
+    out[k] = v;
+  }
+}
+// ... and into the per-wave row of an LDS table: part[a] = sum of accumulator a
+template <int N>
+__device__ __forceinline__ void wave_tree_sums_to(const float (&acc)[N], int lane, float* part)
+{
+  constexpr int Q = (((N + 1) / 2) + 1) / 2;
+  float out[Q];
+  wave_tree_sums<N>(acc, out);
+  if((lane & 15) == 0) {
+    const int row = lane >> 4;
+#pragma unroll
+    for(int k = 0; k < Q; ++k) {
+      const int a = wave_tree_index<N>(row, k);
+      if(a >= 0) part[a] = out[k];
+    }
+  }
+}
+
 // workspace of a workgroup: k-th entry of the active list, or k itself without a list
 __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
 

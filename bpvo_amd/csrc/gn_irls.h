@@ -39,7 +39,7 @@ __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
 typedef float IrlsPartLds[4][kPartialStride];
 template <int C, int LOSS, bool FUSED>
 __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
-                                          IrlsPartLds& s_part, bool has, float* __restrict__ partials)
+                                          IrlsPartLds& s_part, bool has, float* __restrict__ partials, bool agent_store = false)
 {
   // Fused path (C = 8): the robust scale is frozen for the rest of the level, so nothing separates the residuals from
   // their weights any more — they are recomputed here exactly as warp_residual does (same warp_point, same tap cache) and
@@ -150,34 +150,27 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
     }
   }
 
-  // wavefront tree (64 lanes; the compiler lowers these shuffles to DPP adds — a reduce-scatter over ds_bpermute was 2.5x
-  // slower), then LDS across the 4 waves
-#pragma unroll
-  for(int k = 0; k < kNumAcc; ++k) {
-    float v = acc[k];
-#pragma unroll
-    for(int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
-    acc[k] = v;
-  }
+  // wavefront tree (64 lanes, the pairing of a __shfl_down ladder without its LDS round trips: wave_tree_sums), then LDS across
+  // the 4 waves
   const int lane = vtid & 63, wave = vtid >> 6;
-  if(lane == 0) {
-#pragma unroll
-    for(int k = 0; k < kNumAcc; ++k) s_part[wave][k] = acc[k];
-  }
+  wave_tree_sums_to<kNumAcc>(acc, lane, s_part[wave]);
   __syncthreads();
   if(vtid < kNumAcc && has) {
     const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
-    partials[(size_t) tile * kPartialStride + vtid] = v;
+    // agent_store (step_in_reduce: another workgroup of the SAME launch reads the partial): written through to where every XCD sees
+    // it, instead of a release fence that writes back the whole L2
+    if(agent_store) __hip_atomic_store(partials + (size_t) tile * kPartialStride + vtid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partials[(size_t) tile * kPartialStride + vtid] = v;
   }
 }
 
 // the form irls_reduce uses: one 256-thread workgroup = one tile
 template <int C, int LOSS, bool FUSED>
-__device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __restrict__ st, int pts_per_block)
+__device__ __forceinline__ void irls_block(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, bool agent_store = false)
 {
   if((int) blockIdx.x * pts_per_block >= j.n) return;
   __shared__ IrlsPartLds s_part;
-  irls_tile<C, LOSS, FUSED>(j, st, pts_per_block, blockIdx.x, threadIdx.x, s_part, true, j.partials);
+  irls_tile<C, LOSS, FUSED>(j, st, pts_per_block, blockIdx.x, threadIdx.x, s_part, true, j.partials, agent_store);
 }
 
 // irls_tile for LATENCY-bound launches (persistent kernel, C = 8): the same per-point arithmetic and the same accumulation order
@@ -360,18 +353,8 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
     if(has1) point(i1, d1);
   }
 
-#pragma unroll
-  for(int k = 0; k < kNumAcc; ++k) {
-    float v = acc[k];
-#pragma unroll
-    for(int o = 32; o >= 1; o >>= 1) v += __shfl_down(v, o);
-    acc[k] = v;
-  }
   const int lane = vtid & 63, wave = vtid >> 6;
-  if(lane == 0) {
-#pragma unroll
-    for(int k = 0; k < kNumAcc; ++k) s_part[wave][k] = acc[k];
-  }
+  wave_tree_sums_to<kNumAcc>(acc, lane, s_part[wave]);
   __syncthreads();
   if(vtid < kNumAcc && has) {
     const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);

@@ -75,7 +75,8 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 
   const float sqrt_eps = sqrtf(FLT_EPSILON);
 
-  if(st->phase == PHASE_FIRST) {
+  const bool first = st->phase == PHASE_FIRST;
+  if(first) {
     const float g_norm = inf_norm6(st->G);
     st->g_norm = g_norm;
     st->g_tol = g_tol_param * fmaxf(g_norm, sqrt_eps);
@@ -86,7 +87,12 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
       st->phase = PHASE_DONE; st->active = 0;
       return false;
     }
-    if(!solve_system(st->H, st->G, st->dp, scratch)) {           // :356-362
+  }
+  // ONE call site for both phases: the solve is then inlined where it is used (a shared out-of-line copy saves its callee-saved
+  // registers to scratch, and every kernel that holds the step — irls_reduce with step_in_reduce — would carry a private segment)
+  const bool solved = solve_system(st->H, st->G, st->dp, scratch);
+  if(first) {
+    if(!solved) {                                                // :356-362
       bpvo_hip_stats& s = st->stats[st->level];
       s.status = BPVO_STATUS_SOLVER_ERROR; s.finalError = f_norm; s.numIterations = 0; s.firstOrderOptimality = 0.0f;
       st->status = BPVO_STATUS_SOLVER_ERROR;
@@ -99,7 +105,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
     gn_update_pose(st, nrm);                            // :371
   } else {
     // runIteration's solve (pose_estimator_gn.h:89-97)
-    if(!solve_system(st->H, st->G, st->dp, scratch)) {
+    if(!solved) {
       st->status = BPVO_STATUS_SOLVER_ERROR;
       gn_finalize(st);                                  // `break`: no ++ on the way out
       return false;
@@ -143,6 +149,7 @@ __device__ bool gn_logic(GNState* st, const float* nrm, const float* s_sum, Solv
 // The loads of 32 tiles are issued back to back, UNCONDITIONALLY (the tile index is clamped, the add is what the bound selects: a
 // conditional load makes the compiler wait per branch), so a level costs one global-memory round trip per 32 tiles instead of one per
 // 8: 2.2 -> 1.3 us of the serial step at the finest level of a 1241x376 pair (profiles/r02_persistent_phases.txt).  Same order of additions.
+template <bool COHERENT = false>
 __device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/,
                                                 const float* __restrict__ partials)
 {
@@ -155,7 +162,11 @@ __device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_bl
       for(int b0 = 0; b0 < nblk; b0 += U) {
         float v[U];
 #pragma unroll
-        for(int u = 0; u < U; ++u) v[u] = pp[(size_t) min(b0 + u, nblk - 1) * kPartialStride];
+        for(int u = 0; u < U; ++u) {
+          const float* q = pp + (size_t) min(b0 + u, nblk - 1) * kPartialStride;
+          if constexpr(COHERENT) v[u] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else v[u] = *q;
+        }
 #pragma unroll
         for(int u = 0; u < U; ++u) {
           const double t = s + (double) v[u];
@@ -201,6 +212,58 @@ __device__ __forceinline__ void gn_serial_step(const PairJob& j, GNState* st, co
       j.cnt[10] += (unsigned long long) j.n;
     }
   }
+}
+
+// The step of one workspace by ONE wavefront (lanes 0..63 of the calling workgroup's first wave; nobody else may touch `s`): the state
+// lives in HBM between launches, the serial bookkeeping runs on an LDS copy (global-memory round trips would otherwise dominate:
+// every field access is a dependent ~1 us load).  Lanes 0 .. kNumAcc-1 sum the partials, lane 0 runs the serial step.  COHERENT: the
+// partials were stored by other workgroups of the launch that is still running (gn_last_tile) and are read past the caches.
+struct GNStepLds {
+  uint32_t state[sizeof(GNState) / sizeof(uint32_t)];
+  float sum[kPartialStride];
+  float nrm[5];
+  SolveScratch scratch;
+};
+static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
+__device__ __forceinline__ void wave_lds_sync()      // LDS written by some lanes of the wave, read by others: program order is enough for the
+{                                                    // hardware (one wave's LDS operations complete in order), the compiler must keep it
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool COHERENT>
+__device__ __forceinline__ void gn_step_wave(const PairJob& j, GNStepLds& s, int pts_per_block, int mode, const GNParams& prm, int fuse_frozen)
+{
+  constexpr int kWords = (int) (sizeof(GNState) / sizeof(uint32_t));
+  const int lane = threadIdx.x;
+  GNState* gst = j.st;
+  for(int i = lane; i < kWords; i += 64) s.state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
+  if(lane < 4) s.nrm[lane] = j.nrm[lane];
+  if(lane == 4) s.nrm[4] = j.dspace ? 1.0f : 0.0f;
+  gn_sum_partials<COHERENT>(j, pts_per_block, lane, s.sum, j.partials);
+  wave_lds_sync();
+  if(lane == 0)
+    gn_serial_step(j, reinterpret_cast<GNState*>(s.state), s.nrm, s.sum, &s.scratch, mode, prm.max_iterations, prm.max_fun_evals, prm.p_tol, prm.f_tol,
+                   prm.g_tol, fuse_frozen, true);
+  wave_lds_sync();
+  for(int i = lane; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s.state[i];
+}
+
+// K8 + K9 in one launch.  The first wave of every tile of a workspace, once its partial is stored THROUGH the caches (irls_tile,
+// agent_store) and acknowledged, draws a ticket; the wave that draws the LAST one has all partials of the workspace in reach — read
+// past the caches, gn_sum_partials<true> — and takes the step: summed in tile order as ever, so the result does not depend on which
+// tile that is.  No fences: an agent-scope release writes back the whole L2 of the XCD and an acquire invalidates it, once per tile —
+// measured, the launch took twice as long (profiles/r04_step_in_reduce.txt).  Called by the first wave only (the others are done);
+// true for the wave that takes the step.  `tiles`: tickets of the workspace in this launch.
+__device__ __forceinline__ bool gn_last_tile(const PairJob& j, int tiles)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the partial has arrived where the other XCDs read it
+  unsigned ticket = 0;
+  if(threadIdx.x == 0) ticket = __hip_atomic_fetch_add(j.ticket.p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = (unsigned) __builtin_amdgcn_readfirstlane((int) ticket);
+  if(ticket != (unsigned) (tiles - 1)) return false;
+  if(threadIdx.x == 0) __hip_atomic_store(j.ticket.p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+  return true;
 }
 
 }  // namespace bpvo_hip

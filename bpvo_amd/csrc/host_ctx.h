@@ -162,6 +162,7 @@ struct bpvo_hip_ctx {
   float* d_records = nullptr;      // [n_pairs][kRecordFloats]
   float* d_wtmp = nullptr;         // [cap_max * C] weights scratch
   unsigned int* d_count = nullptr;
+  unsigned* d_tickets = nullptr;             // [n_pairs] PairJob::ticket
   unsigned long long* d_counters = nullptr;   // [4] points, linearisations, bracketed / full median selections
   // pinned staging
   FrameJob* h_fjobs = nullptr;
@@ -181,6 +182,10 @@ struct bpvo_hip_ctx {
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  Option "fuse_frozen".  (C = 8: ONE irls_reduce launch serves the plain and
                                // the fused workspaces with a per-workspace branch; the two-launch form measured slower at every batch size, round 2)
+  int step_in_reduce_max = 128; // groups of up to this many pairs run the four-kernel chain as three: the last tile of a workspace in irls_reduce takes
+                               // the Gauss-Newton step (gn_step.h gn_last_tile; same sums in the same order).  Worth +2 % at 64 pairs per lane (the
+                               // 128-pair shard), nothing at 128, -3 % at 512: the first wave of every tile waits for its write-through store and its
+                               // ticket.  Option "step_in_reduce_max_pairs" (0: never)
   // Groups of at most persist_max_ws workspaces (a single pair: sequential addFrame) run every pyramid level in ONE persistent
   // launch (kernels_gn.hip, gn_persistent_kernel) instead of rounds of four kernels per iteration; bit-identical results.
   // Options "persistent" (0 turns it off), "persist_max_ws", "persist_grid" size it.  persistent_failed: a launch gave up at a barrier

@@ -103,6 +103,10 @@ struct GNLaunch {
   int fuse_frozen = 0;   // estimate loops, C = 8, kLinear, f64 formulation: once a workspace's scale is frozen, irls_reduce
                          // recomputes the residuals itself and warp_residual skips the workspace
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
+  // 1: the tile of a workspace that stores its partial LAST in an irls_reduce launch also takes the Gauss-Newton step (what
+  // gn_step_kernel does, with step_prm) — the chain is then three kernels per iteration and launch_gn_step is not called
+  int step_in_reduce = 0;
+  GNParams step_prm = {0, 0, 0.0f, 0.0f, 0.0f};
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);

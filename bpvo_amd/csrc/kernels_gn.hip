@@ -212,30 +212,48 @@ __global__ __launch_bounds__(NT) void median_finish_kernel(const PairJob* __rest
 
 // Two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves, FUSED =
 // true (136 VGPRs instead of 103: kept out of the plain kernel's register budget) the frozen ones.
+// step.on (only without fuse_frozen, where one launch serves every workspace): the last tile of a workspace takes the Gauss-Newton
+// step (gn_last_tile); a workspace without points still has its tile 0 for that.
+struct GNStepArgs { int on; GNParams prm; };
+// (waves per SIMD the reduction had on its own: left alone the compiler gives the step's serial code 180 registers, and the whole
+// launch its occupancy)
+constexpr int irls_min_waves(int C) { return C <= 10 ? 4 : C <= 24 ? 3 : 2; }
 template <int C, int LOSS, bool FUSED>
-__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen)
+__global__ __launch_bounds__(GN_BLOCK, irls_min_waves(C)) void irls_reduce_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, int fuse_frozen,
+                                                               GNStepArgs step)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
   if(fuse_frozen && (FUSED != !(st->delta_scale > 1e-6f))) return;
-  irls_block<C, LOSS, FUSED>(j, st, pts_per_block);
+  if(!step.on) { irls_block<C, LOSS, FUSED>(j, st, pts_per_block); return; }
+  const int tiles = max(1, (j.n + pts_per_block - 1) / pts_per_block);
+  if((int) blockIdx.x >= tiles) return;
+  irls_block<C, LOSS, FUSED>(j, st, pts_per_block, true);
+  if(threadIdx.x >= 64) return;
+  __shared__ GNStepLds s_step;
+  if(gn_last_tile(j, tiles)) gn_step_wave<true>(j, s_step, pts_per_block, 0, step.prm, 0);
 }
 // ... or ONE launch serves both kinds with a per-workspace branch (C = 8): every workgroup then runs at the fused form's
 // register budget (3 waves per SIMD instead of 4), but small launches — the 128-pair shard of config 5, single pairs — do not
 // pay a second, half-empty launch per iteration (each costs its ramp and drain: at 128 pairs the two launches took 59 us where
 // the bytes are worth 38).
 template <int LOSS>
-__global__ __launch_bounds__(GN_BLOCK) void irls_reduce_both_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block)
+__global__ __launch_bounds__(GN_BLOCK, 3) void irls_reduce_both_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, GNStepArgs step)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
-  if(st->delta_scale > 1e-6f) irls_block<8, LOSS, false>(j, st, pts_per_block);
-  else irls_block<8, LOSS, true>(j, st, pts_per_block);
+  const int tiles = max(1, (j.n + pts_per_block - 1) / pts_per_block);
+  if(step.on && (int) blockIdx.x >= tiles) return;
+  if(st->delta_scale > 1e-6f) irls_block<8, LOSS, false>(j, st, pts_per_block, step.on != 0);
+  else irls_block<8, LOSS, true>(j, st, pts_per_block, step.on != 0);
+  if(!step.on || threadIdx.x >= 64) return;
+  __shared__ GNStepLds s_step;
+  if(gn_last_tile(j, tiles)) gn_step_wave<true>(j, s_step, pts_per_block, 0, step.prm, 1);
 }
 
-__global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
+__global__ __launch_bounds__(64, 4) void gn_step_kernel(const PairJob* __restrict__ jobs, int pts_per_block, int mode,
                                                      int max_iterations, int max_fun_evals, float p_tol, float f_tol,
                                                      float g_tol_param, ActiveSet act, int fuse_frozen)
 {
@@ -243,24 +261,9 @@ __global__ __launch_bounds__(64) void gn_step_kernel(const PairJob* __restrict__
   GNState* gst = j.st;
   if(!gst->active) return;
 
-  // the state lives in HBM between launches; the serial bookkeeping runs on an LDS copy (global-memory round trips
-  // would otherwise dominate this kernel: every field access is a dependent ~1 us load)
-  constexpr int kWords = (int) (sizeof(GNState) / sizeof(uint32_t));
-  static_assert(sizeof(GNState) % sizeof(uint32_t) == 0, "GNState must be word sized");
-  __shared__ uint32_t s_state[kWords];
-  __shared__ float s_sum[kPartialStride];
-  __shared__ float s_nrm[5];
-  __shared__ SolveScratch s_scratch;
-  for(int i = threadIdx.x; i < kWords; i += 64) s_state[i] = reinterpret_cast<const uint32_t*>(gst)[i];
-  if(threadIdx.x < 4) s_nrm[threadIdx.x] = j.nrm[threadIdx.x];
-  if(threadIdx.x == 4) s_nrm[4] = j.dspace ? 1.0f : 0.0f;
-  gn_sum_partials(j, pts_per_block, threadIdx.x, s_sum, j.partials);
-  __syncthreads();
-  if(threadIdx.x == 0)
-    gn_serial_step(j, reinterpret_cast<GNState*>(s_state), s_nrm, s_sum, &s_scratch, mode, max_iterations, max_fun_evals, p_tol, f_tol,
-                   g_tol_param, fuse_frozen, true);
-  __syncthreads();
-  for(int i = threadIdx.x; i < kWords; i += 64) reinterpret_cast<uint32_t*>(gst)[i] = s_state[i];
+  __shared__ GNStepLds s_step;
+  const GNParams prm = {max_iterations, max_fun_evals, p_tol, f_tol, g_tol_param};
+  gn_step_wave<false>(j, s_step, pts_per_block, mode, prm, fuse_frozen);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -528,20 +531,23 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 {
   const dim3 grid((g.max_points + ppb - 1) / ppb, g.npairs);
   const int fuse = (C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
+  GNStepArgs step;
+  step.on = g.step_in_reduce;
+  step.prm = g.step_prm;
   if constexpr(C == 8) {
     if(fuse) {      // one launch serves the workspaces with a moving scale and the frozen ones (per-workspace branch)
       switch(g.loss) {
-        case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
-        case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
-        default: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_L2>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb); break;
+        case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_HUBER>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, step); break;
+        case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_TUKEY>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, step); break;
+        default: hipLaunchKernelGGL((irls_reduce_both_kernel<BPVO_LOSS_L2>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, step); break;
       }
       return;
     }
   }
   switch(g.loss) {
-    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
-    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse); break;
+    case BPVO_LOSS_HUBER: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_HUBER, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, step); break;
+    case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_TUKEY, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, step); break;
+    default: hipLaunchKernelGGL((irls_reduce_kernel<C, BPVO_LOSS_L2, false>), grid, dim3(GN_BLOCK), 0, s, g.jobs, g.active, ppb, fuse, step); break;
   }
 }
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)

@@ -41,7 +41,6 @@ static_assert(K6_BLOCK == 256 && GN_BLOCK == 256, "the persistent kernel's virtu
 static_assert(PK_THREADS / 64 >= kPersistMaxWs, "pk_step_phase: one wave per workspace");
 
 
-struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
 
 // The phases are separate NON-inlined functions: inlined into one body the compiler hoists every workspace's addresses and job
 // fields across all of them and spills hundreds of bytes per lane; as functions each gets its own register allocation.  Their

@@ -112,6 +112,9 @@ struct GNState {
   int   trace_n;                             // records written to PairJob::trace since set_pose (bpvo_hip_estimate_pose_trace)
 };
 
+// PoseEstimatorParameters as the device-side state machine reads them (gn_step.h)
+struct GNParams { int max_iterations, max_fun_evals; float p_tol, f_tol, g_tol; };
+
 // Streaming (non-temporal) 16-byte accesses for data that is read or written exactly once per launch and is far larger
 // than the caches: keeps such streams from evicting each other in L2 (measured +15 % on the access pattern of
 // warp_residual, scripts/micro/streams.hip).
@@ -186,6 +189,7 @@ struct PairJob {
                            // [7] / [8] the same over the first 8 linearisations of a level, [10] points linearised through the
                            // fused path; written by one thread each: no atomics
   GPtr<GNState> st;
+  GPtr<unsigned> ticket;   // tiles of the running irls_reduce launch that have stored their partial (the last one takes the step; back to 0 by then)
   // per-linearisation trace of the Gauss-Newton run (bpvo_hip_estimate_pose_trace; null otherwise): trace_cap records of
   // kTraceFloats floats, written by the thread that runs the serial step — the table the reference prints per iteration at
   // kIteration verbosity (bpvo/pose_estimator_base.h:231-247), with the pose, H, G and dp added

@@ -349,6 +349,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_size"              0         workgroups per team; 0 = CUs / pairs
  *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
+ *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair
+ *                                      inside the reduction launch — three kernels per iteration instead of four, same bits (0: never)
  *   "stagger"                1         lanes run their pairs end to end (frame stage of one lane under the estimation of another)
  *   "tapcache_max_density"   0.5       pyramid levels with more template points per pixel than this gather straight from the descriptor
  *   "upload_workers"         6         host threads that stage a HOST-buffer batch in pinned chunks (0: plain copies)

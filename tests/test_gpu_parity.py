@@ -1203,3 +1203,39 @@ def test_lazy_template_descriptor_is_bit_identical(hip, rows, cols, levels):
         assert bits_equal(a["jac"][l], z["jac"][l]), l
         assert bits_equal(a["desc"][l], z["desc"][l]), l
     assert bits_equal(a["desc_b"], z["desc_b"])
+
+
+@pytest.mark.parametrize("kw", [pytest.param(dict(descriptor="bitplanes", loss="tukey"), id="bitplanes-tukey"),
+                                pytest.param(dict(descriptor="bitplanes", loss="l2"), id="bitplanes-l2"),
+                                pytest.param(dict(descriptor="intensity", loss="huber"), id="intensity-huber"),
+                                pytest.param(dict(descriptor="bitplanes", loss="tukey", interp=capi.INTERP_CUBIC), id="bitplanes-cubic"),
+                                pytest.param(dict(descriptor="gradient", loss="tukey"), id="gradient-tukey"),
+                                pytest.param(dict(descriptor="bitplanes", loss="huber", fuse_frozen=0), id="bitplanes-unfused")])
+def test_step_taken_by_the_last_reduction_tile_is_bit_identical(hip, kw):
+    """Option step_in_reduce_max_pairs (groups of up to 128 pairs by default): the four-kernel chain of a batch runs as three — the tile of a pair that stores its partial sums
+    last in an irls_reduce launch sums them (in tile order, as gn_step_kernel does) and takes the Gauss-Newton step.  Poses, statistics,
+    residuals and weights against the four-kernel form, bit for bit; the batch holds a pair whose template is empty at every level (its
+    tile 0 takes the step: solver error, like the separate kernel) and is run twice on the same context (the tickets are back at zero)."""
+    kw = dict(kw)
+    fuse = kw.pop("fuse_frozen", 1)
+    rows, cols, levels, n = 120, 160, 3, 6
+    b = synth.make_batch(rows, cols, n, first_index=11)
+    disp = b["disparities"].copy()
+    disp[2 * 4] = 0.0                      # pair 4: no valid disparity in its template frame -> no points
+    out = {}
+    for step in (0, 1):
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels, **kw), n_frames=2 * n, n_pairs=n)
+        ctx.set_option("team", 0)           # the chain, not the team kernel of small batches
+        ctx.set_option("fuse_frozen", fuse)
+        ctx.set_option("step_in_reduce_max_pairs", 1000 * step)
+        assert ctx.get_option("step_in_reduce_max_pairs") == 1000.0 * step
+        for _ in range(2):
+            poses, stats = ctx.batch_run(b["images"], disp)
+        out[step] = dict(poses=poses, stats=stats, r=ctx.get_residuals(1), w=ctx.get_weights(1), n4=ctx.num_points(2 * 4, 0))
+        ctx.close()
+    a, z = out[0], out[1]
+    assert a["n4"] == 0 and z["n4"] == 0
+    assert bits_equal(a["poses"], z["poses"])
+    assert a["stats"].tobytes() == z["stats"].tobytes()
+    assert bits_equal(a["r"], z["r"]) and bits_equal(a["w"], z["w"])
+    assert np.isfinite(z["poses"][[0, 1, 2, 3, 5]]).all()
