@@ -274,9 +274,11 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   // map needs) and template_build forms the stencils' records from the census bytes: the kernel then runs the census stage, one plane of
   // eight in the two passes, and stores 5 bytes per pixel instead of 36.
   // The tile columns at the right edge stay dense: the saliency of the columns the reference's SIMD body treats apart — x < 4 (formed from
-  // columns n - 4 + x) and x >= n = W & ~3 (Q7) — reads whole records of columns n - 5 .. W - 1 (saliency_generic).
+  // columns n - 4 + x) and x >= n = W & ~3 (Q7) — reads whole records of columns n - 5 .. W - 1 (saliency_generic).  And when W is a
+  // multiple of 4, column x = 3 is formed at xs = W - 1, whose right neighbour is the reference's read past the end of the row: the
+  // record of column 0 of the NEXT row — so the first tile column stays dense too.
   const bool lazy_level = FROM_IMAGE && j.lazy != 0;
-  const bool lazy = lazy_level && x0 + BP_TW + 8 <= (W & ~3);
+  const bool lazy = lazy_level && x0 + BP_TW + 8 <= (W & ~3) && !(x0 == 0 && (W & 3) == 0);
   uint8_t* __restrict__ const cen_out = j.cen;
   if(tid < 18) {      // entry a + 3 b + 9 S0 (visible after the first barrier below)
     const float S0 = (float) (tid / 9), A = (float) (tid % 3), B = (float) ((tid / 3) % 3);

@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r04p
-python scripts/shard_ab.py --pairs 128 --ref-pairs 1024 --steps 10 --repeat 2 -- "" "BPVO_AB_LIB=bpvo_amd/csrc/exp/libbpvo_hip_w4.so" > gpurun_out/r04p/shard_ab.txt 2>&1; cat gpurun_out/r04p/shard_ab.txt
+mkdir -p gpurun_out/r04s
+python -m pytest tests -m gpu -q > gpurun_out/r04s/pytest_full.txt 2>&1; tail -8 gpurun_out/r04s/pytest_full.txt
+python bench.py > gpurun_out/r04s/bench.json 2> gpurun_out/r04s/bench.err; tail -2 gpurun_out/r04s/bench.err; cut -c1-400 gpurun_out/r04s/bench.json

@@ -1175,17 +1175,24 @@ def test_current_frames_of_a_pair_batch_keep_no_disparity_unless_asked(hip):
         ctx.set_option("no_such_option", 1)
 
 
-@pytest.mark.parametrize("rows,cols,levels", [pytest.param(376, 1241, 4, id="kitti-1241x376-L4"), pytest.param(243, 651, 3, id="651x243-L3-ragged")])
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(376, 1241, 4, id="kitti-1241x376-L4"), pytest.param(243, 651, 3, id="651x243-L3-ragged"),
+                                              pytest.param(112, 144, 1, id="144x112-L1-width-multiple-of-4"), pytest.param(480, 640, 4, id="640x480-L4")])
 def test_lazy_template_descriptor_is_bit_identical(hip, rows, cols, levels):
     """Pair batches keep, for their TEMPLATE frames, census bytes + channel 0 instead of descriptor records at the levels with non-maximum
     suppression (option lazy_template_descriptor, default on); template_build forms the records of its stencils from the census bytes.
     Against the dense form: template pixels and Jacobians of every level, poses and statistics, bit for bit; the accessor rebuilds the
-    records of a lazy level on demand (= the descriptor of the same image set through the frame API)."""
+    records of a lazy level on demand (= the descriptor of the same image set through the frame API).  Every context first runs a batch
+    of OTHER images with dense records, so that a record the lazy form does not write but something reads — the saliency of column 3 reads
+    the record of column 0 of the next row when the width is a multiple of 4 (the reference's read past the row, Q7) — is a stale one."""
     n = 3
     b = synth.make_batch(rows, cols, n, first_index=40)
+    other = synth.make_batch(rows, cols, n, first_index=77)
     out = {}
     for lazy in (0, 1):
-        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels, minNumPixelsForNonMaximaSuppression=100 * 100), n_frames=2 * n, n_pairs=n)
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels, minNumPixelsForNonMaximaSuppression=100 * 100 if levels > 1 else 1),
+                         n_frames=2 * n, n_pairs=n)
+        ctx.set_option("lazy_template_descriptor", 0)
+        ctx.batch_run(other["images"], other["disparities"])
         ctx.set_option("lazy_template_descriptor", lazy)
         poses, stats = ctx.batch_run(b["images"], b["disparities"])
         rec = dict(poses=poses, stats=stats, pix=[ctx.get_pixels(2, l) for l in range(levels)], jac=[ctx.get_jacobians(2, l) for l in range(levels)],
