@@ -12,6 +12,21 @@ namespace bpvo_hip {
 // then a wavefront shuffle tree, then LDS across the 4 waves; per-block partials are combined in fixed order in f64 by
 // gn_step, so the result is deterministic run to run.
 constexpr int kNumAcc = 30;   // 21 H + 6 G + e + #valid points + tap-cache hits (fused path)
+// The sums of the normal equations are accumulated with fused multiply-adds: H, G and the function value are tolerance-compared with
+// the reference (its own summation order and SSE lanes differ from any one here; the rank-2 form above already regroups
+// them), a fused multiply-add is the more accurate of the two, and the reduction is co-limited by its VALU work: ~100 of the ~330 flops
+// per point go.  Residuals, weights and valid flags — the bit-exact quantities — do not pass through here.
+#ifndef K8_FMA
+#define K8_FMA 1
+#endif
+__device__ __forceinline__ float irls_mad(float a, float b, float c)
+{
+#if K8_FMA
+  return __builtin_fmaf(a, b, c);
+#else
+  return a * b + c;
+#endif
+}
 
 template <int LOSS>
 __device__ __forceinline__ float mest_weight(float r, float sigma_inv)
@@ -116,12 +131,12 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
       const float r = rr[c];
       const float w = mest_weight<LOSS>(r, sigma_inv) * v;
       const float wx = w * Ix[c], wy = w * Iy[c];
-      Sxx += wx * Ix[c];
-      Sxy += wx * Iy[c];
-      Syy += wy * Iy[c];
-      Gx += wx * r;
-      Gy += wy * r;
-      acc[27] += (w * r) * r;
+      Sxx = irls_mad(wx, Ix[c], Sxx);
+      Sxy = irls_mad(wx, Iy[c], Sxy);
+      Syy = irls_mad(wy, Iy[c], Syy);
+      Gx = irls_mad(wx, r, Gx);
+      Gy = irls_mad(wy, r, Gy);
+      acc[27] = irls_mad(w * r, r, acc[27]);
     }
     float A[6], B[6];
     if(!dspace) {
@@ -140,13 +155,13 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
       int idx = 0;
 #pragma unroll
       for(int a = 0; a < 6; ++a) {
-        const float pa = Sxx * A[a] + Sxy * B[a];      // coefficient of A[b]
-        const float qa = Sxy * A[a] + Syy * B[a];      // coefficient of B[b]
+        const float pa = irls_mad(Sxy, B[a], Sxx * A[a]);      // coefficient of A[b]
+        const float qa = irls_mad(Syy, B[a], Sxy * A[a]);      // coefficient of B[b]
 #pragma unroll
-        for(int b = a; b < 6; ++b) acc[idx++] += pa * A[b] + qa * B[b];
+        for(int b = a; b < 6; ++b) { acc[idx] = irls_mad(qa, B[b], irls_mad(pa, A[b], acc[idx])); ++idx; }
       }
 #pragma unroll
-      for(int a = 0; a < 6; ++a) acc[21 + a] += Gx * A[a] + Gy * B[a];
+      for(int a = 0; a < 6; ++a) acc[21 + a] = irls_mad(Gy, B[a], irls_mad(Gx, A[a], acc[21 + a]));
     }
   }
 
@@ -311,12 +326,12 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
       const float r = rr[c];
       const float w = mest_weight<LOSS>(r, sigma_inv) * v;
       const float wx = w * Ix[c], wy = w * Iy[c];
-      Sxx += wx * Ix[c];
-      Sxy += wx * Iy[c];
-      Syy += wy * Iy[c];
-      Gx += wx * r;
-      Gy += wy * r;
-      acc[27] += (w * r) * r;
+      Sxx = irls_mad(wx, Ix[c], Sxx);
+      Sxy = irls_mad(wx, Iy[c], Sxy);
+      Syy = irls_mad(wy, Iy[c], Syy);
+      Gx = irls_mad(wx, r, Gx);
+      Gy = irls_mad(wy, r, Gy);
+      acc[27] = irls_mad(w * r, r, acc[27]);
     }
     const float4 Pt = d.Pt;
     float A[6], B[6];
@@ -334,13 +349,13 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
     int idx = 0;
 #pragma unroll
     for(int a = 0; a < 6; ++a) {
-      const float pa = Sxx * A[a] + Sxy * B[a];
-      const float qa = Sxy * A[a] + Syy * B[a];
+      const float pa = irls_mad(Sxy, B[a], Sxx * A[a]);
+      const float qa = irls_mad(Syy, B[a], Sxy * A[a]);
 #pragma unroll
-      for(int b = a; b < 6; ++b) acc[idx++] += pa * A[b] + qa * B[b];
+      for(int b = a; b < 6; ++b) { acc[idx] = irls_mad(qa, B[b], irls_mad(pa, A[b], acc[idx])); ++idx; }
     }
 #pragma unroll
-    for(int a = 0; a < 6; ++a) acc[21 + a] += Gx * A[a] + Gy * B[a];
+    for(int a = 0; a < 6; ++a) acc[21 + a] = irls_mad(Gy, B[a], irls_mad(Gx, A[a], acc[21 + a]));
   };
 
   for(int i0 = p_begin + vtid; i0 < p_end; i0 += 2 * GN_BLOCK) {
