@@ -239,7 +239,8 @@ __global__ __launch_bounds__(GN_BLOCK, irls_min_waves(C)) void irls_reduce_kerne
 // pay a second, half-empty launch per iteration (each costs its ramp and drain: at 128 pairs the two launches took 59 us where
 // the bytes are worth 38).
 #ifndef K8_BOTH_WAVES
-#define K8_BOTH_WAVES 3   // 4 (128 registers, 12 of them spilled): -1.5 % at 1024 pairs, -2 % at 128 (profiles/r04_step_in_reduce.txt)
+#define K8_BOTH_WAVES 3   // the floor; with the fused multiply-adds of irls_mad the kernel takes 127 registers and gets four (FORCED to four before them, 12
+                          // registers spilled: -1.5 % at 1024 pairs, -2 % at 128, profiles/r04_step_in_reduce.txt)
 #endif
 template <int LOSS>
 __global__ __launch_bounds__(GN_BLOCK, K8_BOTH_WAVES) void irls_reduce_both_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int pts_per_block, GNStepArgs step)

@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r04t
-python scripts/shard_ab.py --pairs 128 --ref-pairs 1024 --steps 10 --repeat 2 -- "" "BPVO_AB_LIB=bpvo_amd/csrc/exp/libbpvo_hip_nofma.so" > gpurun_out/r04t/shard_ab.txt 2>&1; cat gpurun_out/r04t/shard_ab.txt
-python -m pytest tests -m gpu -q > gpurun_out/r04t/pytest_full.txt 2>&1; tail -8 gpurun_out/r04t/pytest_full.txt
+mkdir -p gpurun_out/r04u
+bash profiles/collect_profiles.sh r04 > gpurun_out/r04u/collect.log 2>&1; tail -4 gpurun_out/r04u/collect.log | cut -c1-300
+python bench.py > gpurun_out/r04u/bench.json 2> gpurun_out/r04u/bench.err; tail -2 gpurun_out/r04u/bench.err; cut -c1-300 gpurun_out/r04u/bench.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r04u/smoke.txt 2>&1; tail -3 gpurun_out/r04u/smoke.txt
