@@ -241,13 +241,20 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
             vol = float(n) * rows * cols * ndisp
             out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "pixel_disparities_per_s": vol / dt,
                          "valid_fraction_frame0": valid, "disparities": ndisp,
-                         "bound": "the cost / sum volumes through HBM: ~57 B per (pixel, disparity) = %.0f GB/s achieved; the scanline kernels are latency-bound chains" % (57 * vol / dt / 1e9)}
+                         "accounted_GBps": 57 * vol / dt / 1e9,      # ~57 B per (pixel, disparity) by the accounting above, over the whole matcher
+                         "bound": "measured, profiles/r04_stereo_pmc.txt (rocprofv3 --pmc over scripts/stereo_bench.py): the scanline kernel "
+                                  "(26 % of the matcher) moves 4.2 TB/s of HBM = 0.52 of the peak with its waves issue-stalled 43 % of their cycles "
+                                  "(one dependent DPP / packed-min chain per step); the vertical box sums run at 0.90 of the peak; the right-view cost, "
+                                  "winner-take-all and pixel cost kernels wait on memory (waves waiting 73 - 89 %, L2 hit 0.82 - 0.85 for the "
+                                  "transposing ones): the matcher as a whole is latency-, not bandwidth-bound"}
         else:
             valid = float((dd[0] >= 0).float().mean().item())
             sums = float(n) * rows * (cols - ndisp + 1) * ndisp
             out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "window_sums_per_s": sums / dt,
                          "valid_fraction_frame0": valid, "disparities": ndisp, "SADWindowSize": sp.SADWindowSize,
-                         "bound": "VALU (integer SAD, wave prefix sums): 2 u8 images in + 1 f32 map out are " + "%.1f" % ((2 + 4) * rows * cols * n / dt / 1e9) + " GB/s of HBM traffic"}
+                         "bound": "measured, profiles/r04_stereo_pmc.txt: " + "%.1f" % ((2 + 4) * rows * cols * n / dt / 1e9) + " GB/s of HBM traffic by the accounting (2 u8 "
+                                  "images in, 1 f32 map out; counters: 17 - 41 GB/s), VALU active 25 % of the wave cycles, waves waiting 57 % (LDS prefix "
+                                  "sums of the integer SAD): an instruction- and LDS-latency-bound integer kernel, three orders below the HBM roofline"}
         ctx.close()
     seq = stereo_in.get("sequence")
     if seq is not None:
