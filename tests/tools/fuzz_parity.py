@@ -300,28 +300,35 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
     return "noise-floor-minimum"
 
 
-def check_batch(hip, rows, cols, kw, seed):
-    """bpvo_hip_batch_run of 2-5 pairs against the same pairs estimated one at a time on a fresh context: bit for bit."""
+def check_batch(hip, rows, cols, kw, seed, options="", dirty=False, n=None):
+    """bpvo_hip_batch_run of 2-5 pairs (or n) against the same pairs estimated one at a time on a fresh context: bit for bit.  `options`: more
+    settings of the batch context ("team=0,lanes=1"); `dirty`: the batch context runs a batch of OTHER images first (what a buffer the run
+    does not rewrite holds is then somebody else's data, not zeros)."""
     ctxs = []
     try:
-        return check_batch_case(hip, rows, cols, kw, seed, ctxs)
+        return check_batch_case(hip, rows, cols, kw, seed, ctxs, options, dirty, n)
     finally:
+        os.environ.pop("BPVO_HIP_OPTIONS", None)
         for ctx in ctxs:
             ctx.close()
 
 
-def check_batch_case(hip, rows, cols, kw, seed, ctxs):
+def check_batch_case(hip, rows, cols, kw, seed, ctxs, options="", dirty=False, n=None):
     kw = dict(kw)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
     formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
-    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0")
-    n = 2 + seed % 4
+    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0") + ("," + options if options else "")
+    n = n or 2 + seed % 4
     b = synth.make_batch(rows, cols, n, first_index=seed % 3000)
     bc = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)
     ctxs.append(bc)
+    os.environ["BPVO_HIP_OPTIONS"] = "fuse_frozen=" + ("1" if fuse else "0")
     if formulation:
         bc.set_warp_formulation(formulation)
     try:
+        if dirty:
+            o = synth.make_batch(rows, cols, n, first_index=(seed + 1234) % 3000)
+            bc.batch_run(o["images"], o["disparities"])
         poses, stats = bc.batch_run(b["images"], b["disparities"])
     except capi.BpvoError:
         return "batch-error"
