@@ -47,61 +47,112 @@ __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const
 // BORDER_REFLECT_101, dst = ((W+1)/2, (R+1)/2).  Integer arithmetic: evaluation order is irrelevant.
 // Through LDS: a workgroup stages the (2*64+3) x (2*16+3) source pixels of a 64 x 16 output
 // tile with row-contiguous loads (whole dwords where the tile allows: see below), forms the horizontal [1 4 6 4 1] sums once per (source row, output column) and the vertical ones from
-// those.  Integer arithmetic, same values.  1024 pairs of 1241x376: 2.5 -> see profiles/README.md ms per step for the three levels.
+// those.  Integer arithmetic, same values.  1024 pairs of 1241x376, the three levels of a step: 2.5 ms (one thread per output from HBM) -> 1.8 (LDS) ->
+// 1.46 (dword staging) -> 0.81 ms (round 4: four sums per thread from two 8-byte LDS reads, v_alignbyte + v_dot4; dword stores; four tiles per
+// workgroup with the next tile's loads in flight).
 constexpr int PDT_W = 64, PDT_H = 16;
 constexpr int PDS_W = 2 * PDT_W + 3, PDS_H = 2 * PDT_H + 3;
 constexpr int PDS_DW = (PDS_W + 3 + 3) / 4;        // dwords that cover PDS_W bytes starting at any byte of a dword (34)
 constexpr int PDS_PITCH = 4 * (PDS_DW + 2);        // bytes per staged row (144)
+constexpr int PD_STACK = 4;                        // vertically adjacent tiles a workgroup walks: the next tile's loads fly under the current one's passes
+constexpr int PD_NPRE = (PDS_H * PDS_DW + 255) / 256;
 __global__ __launch_bounds__(256) void pyrdown_u8_lds_kernel(const FrameJob* src_jobs, const FrameJob* dst_jobs)
 {
   __shared__ __attribute__((aligned(16))) uint8_t s_src[PDS_H][PDS_PITCH];
-  __shared__ uint16_t s_h[PDS_H][PDT_W];      // <= 16 * 255
+  __shared__ __attribute__((aligned(8))) uint16_t s_h[PDS_H][PDT_W];      // <= 16 * 255
+  __shared__ int s_off[PDS_H];
   const FrameJob& sj = src_jobs[blockIdx.z];
   const FrameJob& dj = dst_jobs[blockIdx.z];
-  const int sw = sj.cols, sh = sj.rows;
-  const int dx0 = blockIdx.x * PDT_W, dy0 = blockIdx.y * PDT_H;
+  const int sw = sj.cols, sh = sj.rows, dw = dj.cols, dh = dj.rows;
+  const int dx0 = blockIdx.x * PDT_W;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint8_t* __restrict__ s = sj.img;
+  uint8_t* __restrict__ const d = const_cast<uint8_t*>(dj.img.get());
   const int c_first = 2 * dx0 - 2;
   // Tiles whose source columns (and the up to three bytes either side that whole-dword loads add) lie inside one image row: the window
   // is fetched as aligned dwords, 34 per row, and a row's bytes start `off` (0..3, its address modulo 4) into its LDS row.  The
   // others (the first and last tile of a row of tiles, narrow images) go byte by byte through REFLECT_101.
   const bool fast = c_first >= 3 && c_first + PDS_W + 3 <= sw;
-  if(fast) {
-    for(int i = threadIdx.x; i < PDS_H * PDS_DW; i += 256) {
-      const int r = i / PDS_DW, l = i - r * PDS_DW;
-      const uint8_t* p = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw + c_first;
-      const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-      if(4u * (unsigned) l < (unsigned) (a & 3u) + PDS_W)
-        reinterpret_cast<uint32_t*>(&s_src[r][0])[l] = *reinterpret_cast<const uint32_t*>(a - (a & 3u) + 4u * (unsigned) l);
-    }
-  } else {
-    for(int r = wave; r < PDS_H; r += 4) {
-      const uint8_t* row = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw;
+  auto row_ptr = [&](int dy0, int r) { return s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw + c_first; };
+  uint32_t pre[PD_NPRE];
+  auto prefetch = [&](int dy0) {      // (every lane loads: clamped index, no branch around the loads)
 #pragma unroll
-      for(int c0 = 0; c0 < PDS_W; c0 += 64) {
-        const int c = c0 + lane;
-        if(c < PDS_W) s_src[r][c] = row[reflect101(min(c_first + c, sw + 1), sw)];
+    for(int k = 0; k < PD_NPRE; ++k) {
+      const int i = min((int) threadIdx.x + k * 256, PDS_H * PDS_DW - 1);
+      const int r = i / PDS_DW, l = i - r * PDS_DW;
+      const uintptr_t a = reinterpret_cast<uintptr_t>(row_ptr(dy0, r));
+      // (dwords past the row's window are not staged; the address stays inside the frame's image: a row's window ends 3 bytes before the row does)
+      const unsigned ll = min((unsigned) l, ((unsigned) (a & 3u) + PDS_W - 1) / 4u);
+      pre[k] = *reinterpret_cast<const uint32_t*>(a - (a & 3u) + 4u * ll);
+    }
+  };
+  const int dy_first = blockIdx.y * (PDT_H * PD_STACK);
+  if(fast) prefetch(dy_first);
+  for(int t = 0; t < PD_STACK; ++t) {
+    const int dy0 = dy_first + t * PDT_H;
+    if(dy0 >= dh) break;
+    if(fast) {
+#pragma unroll
+      for(int k = 0; k < PD_NPRE; ++k) {
+        const int i = (int) threadIdx.x + k * 256;
+        if(i < PDS_H * PDS_DW) { const int r = i / PDS_DW, l = i - r * PDS_DW; reinterpret_cast<uint32_t*>(&s_src[r][0])[l] = pre[k]; }
+      }
+      if(t + 1 < PD_STACK && dy0 + PDT_H < dh) prefetch(dy0 + PDT_H);
+    } else {
+      for(int r = wave; r < PDS_H; r += 4) {
+        const uint8_t* row = s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw;
+#pragma unroll
+        for(int c0 = 0; c0 < PDS_W; c0 += 64) {
+          const int c = c0 + lane;
+          if(c < PDS_W) s_src[r][c] = row[reflect101(min(c_first + c, sw + 1), sw)];
+        }
       }
     }
-  }
-  __syncthreads();
-  for(int idx = threadIdx.x; idx < PDS_H * PDT_W; idx += 256) {
-    const int r = idx >> 6, x = idx & 63;
-    int off = 0;
-    if(fast) off = (int) (reinterpret_cast<uintptr_t>(s + (size_t) reflect101(min(2 * dy0 - 2 + r, sh + 1), sh) * sw + c_first) & 3u);
-    const uint8_t* q = &s_src[r][2 * x + off];
-    s_h[r][x] = (uint16_t) (q[2] * 6 + (q[1] + q[3]) * 4 + q[0] + q[4]);
-  }
-  __syncthreads();
-  const int x = dx0 + lane;
-  if(x >= dj.cols) return;
+    // byte offset of every staged row inside its LDS row (its address modulo 4 in the dword path, 0 otherwise)
+    if(threadIdx.x < PDS_H) s_off[threadIdx.x] = fast ? (int) (reinterpret_cast<uintptr_t>(row_ptr(dy0, threadIdx.x)) & 3u) : 0;
+    __syncthreads();
+    // horizontal [1 4 6 4 1]: a thread forms FOUR neighbouring sums of one staged row from the 11 bytes they cover — two 8-byte LDS reads,
+    // the window shifted to the row's byte offset with v_alignbyte, every sum a v_dot4 over (1 4 6 4) plus its fifth byte (each staged
+    // byte was read five times, one byte per LDS instruction, before)
+    for(int idx = threadIdx.x; idx < PDS_H * (PDT_W / 4); idx += 256) {
+      const int r = idx >> 4, xq = idx & 15;
+      const uint2* q = reinterpret_cast<const uint2*>(&s_src[r][8 * xq]);
+      const uint2 lo = q[0], hi = q[1];
+      const unsigned off = (unsigned) s_off[r];
+      const unsigned d0 = __builtin_amdgcn_alignbyte(lo.y, lo.x, off), d1 = __builtin_amdgcn_alignbyte(hi.x, lo.y, off),
+                     d2 = __builtin_amdgcn_alignbyte(hi.y, hi.x, off);
+      const unsigned kW = 0x04060401u;      // bytes (1, 4, 6, 4), lowest first
+      const unsigned h0 = __builtin_amdgcn_udot4(d0, kW, d1 & 0xffu, false);
+      const unsigned h1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), kW, (d1 >> 16) & 0xffu, false);
+      const unsigned h2 = __builtin_amdgcn_udot4(d1, kW, d2 & 0xffu, false);
+      const unsigned h3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), kW, (d2 >> 16) & 0xffu, false);
+      *reinterpret_cast<uint2*>(&s_h[r][4 * xq]) = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+    }
+    __syncthreads();
+    // vertical pass: a thread finishes four neighbouring pixels of one output row and stores them as one (possibly unaligned) dword
+    const int ty = threadIdx.x >> 4, xq = threadIdx.x & 15;
+    const int y = dy0 + ty, x = dx0 + 4 * xq;
+    if(y < dh && x < dw) {
+      unsigned v[4];
+      uint2 tt[5];
 #pragma unroll
-  for(int q = 0; q < PDT_H / 4; ++q) {
-    const int ty = wave * (PDT_H / 4) + q, y = dy0 + ty;
-    if(y >= dj.rows) break;
-    const int acc = s_h[2 * ty][lane] + 4 * s_h[2 * ty + 1][lane] + 6 * s_h[2 * ty + 2][lane] + 4 * s_h[2 * ty + 3][lane] + s_h[2 * ty + 4][lane];
-    const_cast<uint8_t*>(dj.img.get())[(size_t) y * dj.cols + x] = (uint8_t) ((acc + 128) >> 8);
+      for(int k = 0; k < 5; ++k) tt[k] = *reinterpret_cast<const uint2*>(&s_h[2 * ty + k][4 * xq]);
+#pragma unroll
+      for(int e = 0; e < 4; ++e) {
+        unsigned a[5];
+#pragma unroll
+        for(int k = 0; k < 5; ++k) { const unsigned w = (e < 2) ? tt[k].x : tt[k].y; a[k] = (e & 1) ? (w >> 16) : (w & 0xffffu); }
+        v[e] = (a[0] + 4u * a[1] + 6u * a[2] + 4u * a[3] + a[4] + 128u) >> 8;
+      }
+      uint8_t* o = d + (size_t) y * dw + x;
+      if(x + 3 < dw) {
+        typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+        *reinterpret_cast<u32_unaligned*>(o) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+      } else {
+        for(int e = 0; e < 4 && x + e < dw; ++e) o[e] = (uint8_t) v[e];
+      }
+    }
+    __syncthreads();      // (the next tile's staging overwrites s_src / s_h)
   }
 }
 
@@ -1199,7 +1250,7 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 }
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes)
 {
-  hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H - 1) / PDT_H, nframes), dim3(256), 0, s, src, dst);
+  hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H * PD_STACK - 1) / (PDT_H * PD_STACK), nframes), dim3(256), 0, s, src, dst);
 }
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
 {
