@@ -243,10 +243,10 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
                          "valid_fraction_frame0": valid, "disparities": ndisp,
                          "accounted_GBps": 57 * vol / dt / 1e9,      # ~57 B per (pixel, disparity) by the accounting above, over the whole matcher
                          "bound": "measured, profiles/r04_stereo_pmc.txt (rocprofv3 --pmc over scripts/stereo_bench.py): the scanline kernel "
-                                  "(26 % of the matcher) moves 4.2 TB/s of HBM = 0.52 of the peak with its waves issue-stalled 43 % of their cycles "
-                                  "(one dependent DPP / packed-min chain per step); the vertical box sums run at 0.90 of the peak; the right-view cost, "
-                                  "winner-take-all and pixel cost kernels wait on memory (waves waiting 73 - 89 %, L2 hit 0.82 - 0.85 for the "
-                                  "transposing ones): the matcher as a whole is latency-, not bandwidth-bound"}
+                                  "(37 % of the matcher) moves 4.2 TB/s of HBM = 0.53 of the peak with its waves issue-stalled 44 % of their cycles "
+                                  "(one dependent DPP / packed-min chain per step); the vertical box sums run at 0.91 of the peak; winner-take-all "
+                                  "reads its four path volumes at 2.9 TB/s (waves waiting 78 %), the right-view cost moves exactly its volume through "
+                                  "LDS tiles at 2.7 TB/s: the matcher as a whole is latency-, not bandwidth-bound"}
         else:
             valid = float((dd[0] >= 0).float().mean().item())
             sums = float(n) * rows * (cols - ndisp + 1) * ndisp

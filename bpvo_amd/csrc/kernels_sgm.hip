@@ -75,28 +75,72 @@ __device__ __forceinline__ void half_minmax(const uint8_t* __restrict__ row, int
   mx = max(max(l, r), c);
 }
 
-// pixel-wise cost u8 [rows][cols][D]: threads = disparities of one pixel (blockDim.x = D rounded up to 64), blockIdx.x = x, blockIdx.y = y
-__global__ void sgm_pixel_cost_kernel(const uint8_t* __restrict__ sl, const uint8_t* __restrict__ sr, const int* __restrict__ cl, const int* __restrict__ cr,
-                                      uint8_t* __restrict__ pc, int rows, int cols, int pitch, int D, double cweight)
+// pixel-wise cost u8 [rows][cols][D] per ROW TILE: a workgroup handles SPC_TX pixels of one row; what a cost needs of the left pixel (centre,
+// half-pixel minimum and maximum, census word) and of the SPC_TX + D - 1 right positions the tile's disparities reach is formed ONCE in LDS (one
+// workgroup per pixel recomputing it per disparity from six loads: 200 us per 1241 x 376 x 128 frame, now 47), the weighted Hamming term
+// (uint8) ((double) ham * cweight) comes from a 33-entry table of that very expression, and a thread writes four consecutive disparities as
+// one dword.  D a multiple of 4, D <= 256.
+constexpr int SPC_TX = 32, SPC_MAXD = 256;
+__global__ __launch_bounds__(256) void sgm_pixel_cost_tile_kernel(const uint8_t* __restrict__ sl, const uint8_t* __restrict__ sr, const int* __restrict__ cl,
+                                                                   const int* __restrict__ cr, uint8_t* __restrict__ pc, int rows, int cols, int pitch, int D,
+                                                                   double cweight)
 {
-  const int x = blockIdx.x, y = blockIdx.y, d0 = threadIdx.x;
-  if(d0 >= D) return;
-  const int d = min(d0, x);                                   // costs beyond d = x repeat the one at d = x (S2)
+  __shared__ uint8_t s_lc[SPC_TX], s_lmin[SPC_TX], s_lmax[SPC_TX];
+  __shared__ int s_cl[SPC_TX];
+  __shared__ uint8_t s_rc[SPC_TX + SPC_MAXD], s_rmin[SPC_TX + SPC_MAXD], s_rmax[SPC_TX + SPC_MAXD];
+  __shared__ int s_cr[SPC_TX + SPC_MAXD];
+  __shared__ uint8_t s_ham[33];
+  const int y = blockIdx.y, x0 = blockIdx.x * SPC_TX, tid = threadIdx.x;
   const uint8_t* lrow = sl + (size_t) pitch * y;
   const uint8_t* rrow = sr + (size_t) pitch * y;               // mirrored: original column x - d sits at cols - 1 - x + d
-  const int lc = lrow[x];
-  int lmin, lmax, rmin, rmax;
-  half_minmax(lrow, x, cols, lmin, lmax);
-  const int ri = cols - 1 - x + d;
-  half_minmax(rrow, ri, cols, rmin, rmax);
-  const int rc = rrow[ri];
-  int l2r = max(0, lc - rmax);
-  l2r = max(l2r, rmin - lc);
-  int r2l = max(0, rc - lmax);
-  r2l = max(r2l, lmin - rc);
-  const int sad = min(l2r, r2l);
-  const int ham = __popc((unsigned) (cl[(size_t) cols * y + x] ^ cr[(size_t) cols * y + x - d]));
-  pc[((size_t) cols * y + x) * D + d0] = (uint8_t) (sad + (int) (uint8_t) ((double) ham * cweight));
+  const int nr = SPC_TX + D - 1;
+  // right positions ri0 + k, k = 0 .. nr - 1, with ri0 = cols - 1 - (x0 + SPC_TX - 1) (those outside the row are never indexed: d <= x)
+  const int ri0 = cols - SPC_TX - x0;
+  // census words of the right image at columns cx0 + k, cx0 = x0 - (D - 1)
+  const int cx0 = x0 - D + 1;
+  for(int k = tid; k < nr; k += 256) {
+    const int ri = ri0 + k;
+    if(ri >= 0 && ri < cols) {
+      int mn, mx;
+      half_minmax(rrow, ri, cols, mn, mx);
+      s_rc[k] = rrow[ri]; s_rmin[k] = (uint8_t) mn; s_rmax[k] = (uint8_t) mx;
+    }
+    const int cx = cx0 + k;
+    if(cx >= 0 && cx < cols) s_cr[k] = cr[(size_t) cols * y + cx];
+  }
+  if(tid < SPC_TX && x0 + tid < cols) {
+    const int x = x0 + tid;
+    int mn, mx;
+    half_minmax(lrow, x, cols, mn, mx);
+    s_lc[tid] = lrow[x]; s_lmin[tid] = (uint8_t) mn; s_lmax[tid] = (uint8_t) mx;
+    s_cl[tid] = cl[(size_t) cols * y + x];
+  }
+  if(tid >= 64 && tid < 64 + 33) s_ham[tid - 64] = (uint8_t) ((double) (tid - 64) * cweight);
+  __syncthreads();
+  const int dq = D >> 2;
+  for(int it = tid; it < SPC_TX * dq; it += 256) {
+    const int xi = it / dq, q = it - xi * dq;
+    const int x = x0 + xi;
+    if(x >= cols) break;                                       // (items are ordered by pixel)
+    const int lc = s_lc[xi], lmin = s_lmin[xi], lmax = s_lmax[xi];
+    const unsigned lcen = (unsigned) s_cl[xi];
+    unsigned out = 0;
+#pragma unroll
+    for(int e = 0; e < 4; ++e) {
+      const int d = min(4 * q + e, x);                          // costs beyond d = x repeat the one at d = x (S2)
+      const int kr = (SPC_TX - 1 - xi) + d;                     // = cols - 1 - x + d - ri0
+      const int kc = (xi + D - 1) - d;                          // = x - d - cx0
+      const int rc = s_rc[kr], rmin = s_rmin[kr], rmax = s_rmax[kr];
+      int l2r = max(0, lc - rmax);
+      l2r = max(l2r, rmin - lc);
+      int r2l = max(0, rc - lmax);
+      r2l = max(r2l, lmin - rc);
+      const int sad = min(l2r, r2l);
+      const int ham = __popc(lcen ^ (unsigned) s_cr[kc]);
+      out |= (unsigned) (uint8_t) (sad + (int) s_ham[ham]) << (8 * e);
+    }
+    *reinterpret_cast<unsigned*>(pc + ((size_t) cols * y + x) * D + 4 * q) = out;
+  }
 }
 
 // (2r+1)^2 box sums with clamped coordinates; rows y + r >= rows and (for y >= 1) column 0 stay 0 (S1).  Separable: the sum over the
@@ -145,6 +189,44 @@ __global__ void sgm_right_cost_kernel(const uint16_t* __restrict__ lcost, uint16
   if(d >= D) return;
   const int dd = min(d, cols - 1 - x);                         // past the image the last valid disparity's cost repeats
   rcost[((size_t) cols * y + x) * D + d] = lcost[((size_t) cols * y + x + dd) * D + dd];
+}
+
+// The same through LDS (D <= 128): the gather above reads one 2-byte value per lane, every lane from another 256-byte row (eight times
+// the volume in requests: profiles/r04_stereo_pmc.txt).  Here a workgroup fetches the SRC_TX + D - 1 rows its SRC_TX pixels reach as
+// whole rows (16-byte loads; neighbouring tiles share most of them in the L2) and reads the diagonal from LDS.
+constexpr int SRC_TX = 64, SRC_MAXD = 128, SRC_PITCH = SRC_MAXD + 8;      // halfwords per staged row: 272 bytes, 16-byte aligned, banks spread along the diagonal
+__global__ __launch_bounds__(256) void sgm_right_cost_tile_kernel(const uint16_t* __restrict__ lcost, uint16_t* __restrict__ rcost, int rows, int cols, int D)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t s_rows[(SRC_TX + SRC_MAXD - 1) * SRC_PITCH];
+  // Workgroups are handed to the XCDs round robin, and every XCD has its own L2: consecutive tiles of a row, which share all but SRC_TX of
+  // their rows, go to ONE XCD (each takes a contiguous eighth of the tiles): 563 -> 119.5 MB read per 1241 x 376 x 128 frame, the volume itself.
+  // (a 1-D grid of 8 * per workgroups, per = ceil(tiles / 8))
+  const int gx = (cols + SRC_TX - 1) / SRC_TX, ntile = gx * rows, per = (int) gridDim.x >> 3;
+  const int tile = ((int) blockIdx.x & 7) * per + ((int) blockIdx.x >> 3);
+  if(tile >= ntile) return;
+  const int y = tile / gx, x0 = (tile - y * gx) * SRC_TX, tid = threadIdx.x;
+  const int nrow = min(SRC_TX + D - 1, cols - x0);             // rows of pixels x0 .. x0 + nrow - 1 (past the image nothing is read: dd <= cols - 1 - x)
+  const int v8 = D >> 3;                                       // 16-byte vectors per row
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(lcost + ((size_t) cols * y + x0) * D);
+  for(int i = tid; i < nrow * v8; i += 256) {
+    const int r = i / v8, c = i - r * v8;
+    *reinterpret_cast<uint4*>(&s_rows[r * SRC_PITCH + 8 * c]) = src[(size_t) r * v8 + c];
+  }
+  __syncthreads();
+  const int dq = D >> 2;
+  for(int it = tid; it < SRC_TX * dq; it += 256) {
+    const int xl = it / dq, q = it - xl * dq;
+    const int x = x0 + xl;
+    if(x >= cols) break;
+    const int last = cols - 1 - x;                             // past the image the last valid disparity's cost repeats
+    uint16_t v[4];
+#pragma unroll
+    for(int e = 0; e < 4; ++e) {
+      const int dd = min(4 * q + e, last);
+      v[e] = s_rows[(xl + dd) * SRC_PITCH + dd];
+    }
+    *reinterpret_cast<ushort4*>(rcost + ((size_t) cols * y + x) * D + 4 * q) = make_ushort4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 // One scanline per wavefront.  The four directions of a cost volume — along the rows left to right and back, along the columns down and
@@ -287,13 +369,28 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(const int16_t* __restrict_
     v[k] = d < D ? sgm_sum4(L4, vol, p * D + d) : 32767;
     if(d < D) key = min(key, ((v[k] + 32768) << 9) | d);      // (d < 512)
   }
+  // minimum over the wave on the VALU (DPP row ladder + v_readlane: six ds_bpermute round trips as __shfl_xor), and the three sums the
+  // sub-pixel step needs out of the lanes' registers instead of twelve more dependent loads by lane 0
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x111 /*row_shr:1*/, 0xf, 0xf, false));
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x112 /*row_shr:2*/, 0xf, 0xf, false));
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x114 /*row_shr:4*/, 0xf, 0xf, false));
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x118 /*row_shr:8*/, 0xf, 0xf, false));
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x142 /*row_bcast:15*/, 0xa, 0xf, false));
+  key = min(key, __builtin_amdgcn_update_dpp(key, key, 0x143 /*row_bcast:31*/, 0xc, 0xf, false));
+  const int bd = __builtin_amdgcn_readlane(key, 63) & 511;
+  auto sum_at = [&](int dsel) {      // dsel uniform over the wave
+    const int li = __builtin_amdgcn_readfirstlane(dsel / V), rem = dsel % V;
+    int r = 0;
 #pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) key = min(key, __shfl_xor(key, o));
-  const int bd = key & 511;
-  if(lane != 0) return;
+    for(int k = 0; k < V; ++k) {
+      const int t = __builtin_amdgcn_readlane(v[k], li);
+      r = (k == rem) ? t : r;
+    }
+    return r;
+  };
   int out;
   if(bd > 0 && bd < D - 1) {
-    const int c = sgm_sum4(L4, vol, p * D + bd), l = sgm_sum4(L4, vol, p * D + bd - 1), r = sgm_sum4(L4, vol, p * D + bd + 1);
+    const int c = sum_at(bd), l = sum_at(bd - 1), r = sum_at(bd + 1);
     double w;
     if(r < l) w = (double) bd * factor + (double) (r - l) / (double) (c - l) / 2.0 * factor + 0.5;
     else w = (double) bd * factor + (double) (r - l) / (double) (c - r) / 2.0 * factor + 0.5;
@@ -303,7 +400,7 @@ __global__ __launch_bounds__(256) void sgm_wta_kernel(const int16_t* __restrict_
   } else {
     out = (int) ((double) bd * factor);
   }
-  disp[p] = (uint16_t) out;
+  if(lane == 0) disp[p] = (uint16_t) out;
 }
 
 // ---- speckle filter: connected components by lock-free union-find (roots = smallest pixel index of the component)
@@ -378,15 +475,25 @@ __global__ __launch_bounds__(256) void sgm_cc_count_kernel(int* __restrict__ lab
     lab[p] = r;                                            // (path compression; roots never change after the merge kernel)
   }
   // the pixels of a wavefront mostly share one root (a plane is ONE component of 400 k pixels: one atomic per pixel on one address took
-  // 4.3 ms): the lanes with the leader's root are counted with one atomic, then the next root, ...
+  // 4.3 ms): the lanes with the leader's root are counted with one atomic, then the next root, ... — and the root the workgroup's first
+  // lanes have is counted in LDS first, one global atomic per workgroup (7 300 waves on one address were 90 us of queueing)
+  __shared__ int s_root, s_cnt;
+  if(threadIdx.x == 0) { s_root = r; s_cnt = 0; }
+  __syncthreads();
+  const int wg_root = s_root;
   unsigned long long todo = __ballot(r >= 0);
   while(todo) {
     const int leader = __ffsll((long long) todo) - 1;
-    const int lr = __shfl(r, leader);
+    const int lr = __builtin_amdgcn_readlane(r, leader);
     const unsigned long long same = __ballot(r == lr) & todo;
-    if((threadIdx.x & 63) == leader) atomicAdd(&size[lr], (int) __popcll(same));
+    if((threadIdx.x & 63) == leader) {
+      if(lr == wg_root) atomicAdd(&s_cnt, (int) __popcll(same));
+      else atomicAdd(&size[lr], (int) __popcll(same));
+    }
     todo &= ~same;
   }
+  __syncthreads();
+  if(threadIdx.x == 0 && s_cnt > 0) atomicAdd(&size[wg_root], s_cnt);
 }
 __global__ __launch_bounds__(256) void sgm_cc_apply_kernel(uint16_t* __restrict__ img, const int* __restrict__ lab, const int* __restrict__ size, int npix,
                                                           int max_size)
@@ -455,7 +562,8 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
     const uint8_t* R = g.right + npix * f;
     hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, L, sob_l, cen_l, rows, cols, pitch, cap, g.census_radius, 0);
     hipLaunchKernelGGL(sgm_census_sobel_kernel, gpix, dim3(256), 0, s, R, sob_r, cen_r, rows, cols, pitch, cap, g.census_radius, 1);
-    hipLaunchKernelGGL(sgm_pixel_cost_kernel, gxy, dim3(dthreads), 0, s, sob_l, sob_r, cen_l, cen_r, pc, rows, cols, pitch, D, g.census_weight);
+    hipLaunchKernelGGL(sgm_pixel_cost_tile_kernel, dim3((cols + SPC_TX - 1) / SPC_TX, rows), dim3(256), 0, s, sob_l, sob_r, cen_l, cen_r, pc, rows, cols, pitch, D,
+                       g.census_weight);
     {
       // (the row sums borrow the first path-cost volume: the scanline kernel overwrites it later on the same stream)
       uint16_t* rowsum = reinterpret_cast<uint16_t*>(Lvol);
@@ -463,7 +571,8 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
       hipLaunchKernelGGL(sgm_box_rows_kernel, dim3(nbq), dim3(256), 0, s, pc, rowsum, rows, cols, D, g.window_radius);
       hipLaunchKernelGGL(sgm_box_cols_kernel, dim3(nbq), dim3(256), 0, s, rowsum, cost_l, rows, cols, D, g.window_radius);
     }
-    hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
+    if(D <= SRC_MAXD) hipLaunchKernelGGL(sgm_right_cost_tile_kernel, dim3(8u * (unsigned) (((cols + SRC_TX - 1) / SRC_TX * rows + 7) / 8)), dim3(256), 0, s, cost_l, cost_r, rows, cols, D);
+    else hipLaunchKernelGGL(sgm_right_cost_kernel, gxy, dim3(dthreads), 0, s, cost_l, cost_r, rows, cols, D);
     {
       const dim3 gp((unsigned) (2 * (2 * rows + 2 * cols)));
       if(D <= 128) hipLaunchKernelGGL(sgm_path_packed_kernel<1>, gp, dim3(64), 0, s, cost_l, cost_r, Lvol, rows, cols, D, g.P1, g.P2);
