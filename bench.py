@@ -423,7 +423,7 @@ def main():
     all_kstats = {k["name"]: k for k in ctx.kernel_stats()}
     points_linearized = all_kstats["irls_reduce"]["units"]     # device-side count: sum over linearisations of N
     kstats = all_kstats if not args.no_profile else {}
-    # The timed steps run the batch on two estimation lanes (streams): faster, but the per-launch durations of one lane then
+    # The timed steps run the batch on several estimation lanes (streams; three for bit-planes, two for intensity): faster, but the per-launch durations of one lane then
     # include time shared with the other lane's kernels.  The roofline of warp_residual is therefore taken from ONE more,
     # untimed step of the same workload on a single lane (same kernels, same launches, HIP events on the library's stream);
     # what the events saw inside the timed region is reported next to it (roofline_timed_region).
@@ -483,7 +483,7 @@ def main():
             kt = kernels["warp_residual"]
             roofline_timed = {"achieved": kt["algorithmic_GBps"], "frac": kt["algorithmic_GBps"] / HBM_PEAK_GBS, "avg_launch_ms": kt["avg_ms"],
                               "points_per_launch": kt["units_per_launch"],
-                              "note": "HIP events inside the timed region: two lanes, a launch shares the chip with the other lane's kernels"}
+                              "note": "HIP events inside the timed region: the batch runs on several lanes (three for 8 channels), a launch shares the chip with the other lanes' kernels"}
         if "warp_residual" in kernels_1lane:
             k = kernels_1lane["warp_residual"]
             # HBM bytes per launch from the PMC passes (profiles/collect_profiles.sh): measured per template point on a
@@ -501,7 +501,7 @@ def main():
                         "bytes_per_point": 18 + 24 * (8 if args.descriptor == "bitplanes" else 1),
                         "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"],
                         "measured": "one untimed step of the same workload on a single estimation lane, HIP events around EVERY launch on the "
-                                    "library's stream (the timed steps overlap two lanes: roofline_timed_region)"}
+                                    "library's stream (the timed steps overlap the lanes: roofline_timed_region)"}
 
         # The second chip-filling kernel, irls_reduce (since round 2 the larger share of the GPU time), in MOVED bytes: what its
         # loads request.  SURVEY.md 8d's algorithmic 2 + 28 C does not describe it — the Jacobian rows are recomputed, not read,
@@ -544,7 +544,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_bytes / secs / 1e9 / HBM_PEAK_GBS,
                           "share_of_step": secs / (elapsed / args.steps),
                           "note": "HBM traffic by the PMC counters over the summed launch durations of the two kernels (single-lane pass); "
-                                  "share_of_step compares that sum with one timed two-lane step"}
+                                  "share_of_step compares that sum with one timed step (lanes overlapped)"}
 
         cpu = None
         pose_vs_cpu = None

@@ -262,7 +262,8 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   // host buffers: batches of at least two chunks go through the upload pipeline
   // (keep_current_disparity: the staging area of the pipeline holds the A frames' disparities only; such batches take plain copies)
   const bool use_pipe = !on_device && c->up_workers > 0 && !c->keep_current_disparity && n_pairs >= 2 * kUploadChunkPairs;
-  if(c->stagger && nl > 1 && !c->profile_all) {
+  if(use_pipe) nl = std::min(nl, 2);      // (the upload plan is a two-lane plan)
+  if(c->stagger && n_pairs >= c->stagger_min_pairs && nl > 1 && !c->profile_all) {
     if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr, nullptr);
     // (groups of at least 64 pairs: smaller ones cost more in launch floors than their earlier start is worth)
     std::vector<std::pair<int, int>> groups;

@@ -250,6 +250,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),
+    OPT_INT("stagger_min_pairs", stagger_min_pairs, 0, 1 << 20),
     OPT_INT("upload_workers", up_workers, 0, 32),
     OPT_INT("keep_current_disparity", keep_current_disparity, 0, 1),
     OPT_INT("lazy_template_descriptor", lazy_template, 0, 1),

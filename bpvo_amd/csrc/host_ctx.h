@@ -125,7 +125,7 @@ struct Lane {
 // 1241x376 bit-planes, +3.7 % at 128, +7 % for 640x480 intensity; four lanes lose at every size.  Per-launch durations of
 // overlapping lanes include the time shared with the other lane: measurements that need clean per-kernel times run with
 // bpvo_hip_set_max_lanes(ctx, 1) / BPVO_HIP_LANES=1.  Results do not depend on the number of lanes (test_gpu_parity.py).
-constexpr int kDefaultLanes = 2;
+constexpr int kDefaultLanes = 3;          // C = 8: +1 ... +2.6 % over two at 128 - 512 pairs and at 640x480, +0.5 % at 1024 (profiles/r04_small_batch_model.txt); C = 1: -2 %
 constexpr int kDefaultLanesNarrow = 2;
 constexpr int kMinPairsPerLane = 8;
 constexpr int kPkCtlWords = 32;    // one 128-byte line per level
@@ -243,6 +243,8 @@ struct bpvo_hip_ctx {
   bool frac_valid = false; int frac_ws = -1; float frac_thr = 0.0f; unsigned frac_cnt = 0; int frac_n = 0;
   double tapcache_max_density = 0.5;   // option: levels with more template points per pixel than this run without the tap cache (batches)
   bool stagger = true;         // option (0: batches run stage by stage over all pairs instead of lane by lane, batch_run_staggered)
+  int stagger_min_pairs = 192; // ... for batches of at least this many pairs: below, the lanes' short frame stages are not worth their serialisation
+                               // (128 pairs on three lanes: +4.5 % without, +1.4 % with).  Option "stagger_min_pairs"
   int census_taps[2] = {0, 0}; // fixed-point {centre, side} taps of the 3x3 u8 blur before the census (sigma_ct > 0)
   bool profiling = false;      // HIP events around warp_residual (the roofline kernel) and the frame stages
   bool profile_all = false;    // ... and around every GN kernel (diagnostics; costs ~10 % throughput)

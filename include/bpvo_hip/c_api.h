@@ -335,7 +335,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  * thread that drives the context.  Unknown key or value out of range: BPVO_ERR_INVALID_ARG (bpvo_hip_last_error names the key).
  *
  *   key                      default   meaning
- *   "lanes"                  2         estimation lanes (HIP streams driven by host threads) a pair batch fans out over, 1 .. 8 (at least 8
+ *   "lanes"                  3 / 2     (8-channel / single-channel descriptors) estimation lanes (HIP streams driven by host threads) a pair batch fans out over, 1 .. 8 (at least 8
  *                                      pairs per lane).  The narrow per-pair kernels of one lane overlap the chip-filling kernels of another;
  *                                      per-launch timings are only clean with 1.  Lanes beyond those the context holds are allocated here.
  *   "persistent"             1         single pairs (estimatePose, addFrame) run every pyramid level in ONE persistent launch; 0: the
@@ -351,7 +351,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
  *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair
  *                                      inside the reduction launch — three kernels per iteration instead of four, same bits (0: never)
- *   "stagger"                1         lanes run their pairs end to end (frame stage of one lane under the estimation of another)
+ *   "stagger"                1         lanes run their pairs end to end (frame stage of one lane under the estimation of another) ...
+ *   "stagger_min_pairs"      192       ... for batches of at least this many pairs (smaller ones: the frame stage of all pairs first, then the lanes)
  *   "tapcache_max_density"   0.5       pyramid levels with more template points per pixel than this gather straight from the descriptor
  *   "upload_workers"         6         host threads that stage a HOST-buffer batch in pinned chunks (0: plain copies)
  *   "upload_plan_first"      0.19      fractions of a host batch in the first (lane 0) and second (lane 1) group of the upload plan;

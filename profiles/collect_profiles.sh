@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
 #   gpurun --timeout 900 -- 'bash profiles/collect_profiles.sh r01'
-# 1. kernel trace + stats of the default bench command (two estimation lanes, the run `value` comes from) and of the same
+# 1. kernel trace + stats of the default bench command (the default estimation lanes, the run `value` comes from) and of the same
 #    command with BPVO_HIP_OPTIONS=lanes=1 (the per-launch durations bench.py's single-lane roofline pass is compared with);
 # 2. PMC passes (counters in their own runs, --kernel-trace only) on the BENCHED workload itself — 1024 pairs, converge mode,
 #    2 steps, one lane — and on the timing-tolerance batch (conf/perf_*.cfg tolerances, 3 levels); synthetic pairs read from a
