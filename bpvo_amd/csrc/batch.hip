@@ -256,13 +256,12 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   if(n_pairs < 0 || 2 * n_pairs > c->n_frames || n_pairs > c->n_pairs) return fail(c, BPVO_ERR_INVALID_ARG, "batch exceeds ctx capacity");
   (void) hipSetDevice(c->device);
   if(n_pairs > 0 && (!images || !disparities)) return fail(c, BPVO_ERR_INVALID_ARG, "nullptr image/disparity");
-  const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
-  int nl = std::max(1, std::min(lanes_ok, n_pairs / kMinPairsPerLane));
-  if(team_serves(c, n_pairs)) nl = 1;
   // host buffers: batches of at least two chunks go through the upload pipeline
   // (keep_current_disparity: the staging area of the pipeline holds the A frames' disparities only; such batches take plain copies)
   const bool use_pipe = !on_device && c->up_workers > 0 && !c->keep_current_disparity && n_pairs >= 2 * kUploadChunkPairs;
-  if(use_pipe) nl = std::min(nl, 2);      // (the upload plan is a two-lane plan)
+  int nl = lanes_for(c, n_pairs, use_pipe ? 2 : 8);      // (the upload plan is a two-lane plan)
+  if(nl < 0) return nl;
+  if(team_serves(c, n_pairs)) nl = 1;
   if(c->stagger && n_pairs >= c->stagger_min_pairs && nl > 1 && !c->profile_all) {
     if(!use_pipe) return batch_run_staggered(c, n_pairs, nl, images, disparities, on_device != 0, poses, stats, nullptr, nullptr);
     // (groups of at least 64 pairs: smaller ones cost more in launch floors than their earlier start is worth)

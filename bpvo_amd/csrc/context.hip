@@ -193,7 +193,18 @@ void resolve_events(bpvo_hip_ctx* c)   // call from the API thread after the lan
   }
 }
 
-// ---- estimation lanes: allocated on demand (create: the default number; option "lanes": more) -------------------------------------------
+// ---- estimation lanes: allocated on demand (create: up to two; option "lanes" and the first batch that wants more: the rest) ---------------
+// lanes a batch of n pairs fans out over (at most `cap`), allocating those the context does not hold yet; a (negative) error code on failure
+int lanes_for(bpvo_hip_ctx* c, int n, int cap)
+{
+  if(g_live_ctx[c->device & 63].load() > 1) return 1;      // several contexts on the device: one lane each
+  const int want = std::max(1, std::min(std::min(c->max_lanes_now, cap), n / kMinPairsPerLane));
+  if(want > (int) c->lanes.size()) {
+    const int rc = ensure_lanes(c, want);
+    if(rc) return rc;
+  }
+  return want;
+}
 int ensure_lanes(bpvo_hip_ctx* c, int n)
 {
   const int n_pairs = c->n_pairs;
@@ -232,7 +243,7 @@ const std::vector<OptionDef>& option_table()
                                                   [](bpvo_hip_ctx* c, double v) { c->field_ = (decltype(c->field_)) v; return BPVO_OK; }}
   static const std::vector<OptionDef> t = {
     // estimation lanes a batch may fan out over (streams driven by host threads); more than the context holds are allocated here
-    OptionDef{"lanes", 1, 8, [](bpvo_hip_ctx* c) { return (double) std::min((int) c->lanes.size(), c->max_lanes_now); },
+    OptionDef{"lanes", 1, 8, [](bpvo_hip_ctx* c) { return (double) std::max(1, std::min(c->max_lanes_now, std::max(1, c->n_pairs / kMinPairsPerLane))); },
               [](bpvo_hip_ctx* c, double v) {
                 const int n = std::max(1, std::min((int) v, std::max(1, c->n_pairs / kMinPairsPerLane)));
                 const int rc = ensure_lanes(c, n);
@@ -551,7 +562,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(rc) { g_create_error = "BPVO_HIP_OPTIONS: " + cp->err; return rc; }
   }
   {
-    const int rc = ensure_lanes(cp, std::max(1, std::min(cp->max_lanes_now, n_pairs / kMinPairsPerLane)));
+    // (a third lane — the default for eight channels — gets its stream when a batch first wants it: a context that only ever runs
+    // host-buffer batches, which stay on their two-lane upload plan, then holds three streams + the copy stream, not four + one: the
+    // streams of a process share four hardware queues by default, and a fifth busy one made the host-buffer step 1.33 x instead of 1.15 x)
+    const int rc = ensure_lanes(cp, std::max(1, std::min(std::min(cp->max_lanes_now, 2), n_pairs / kMinPairsPerLane)));
     if(rc) { g_create_error = cp->err; return rc; }
   }
   CREATE_CK(hipMalloc((void**) &cp->d_records, sizeof(float) * kRecordFloats * n_pairs));

@@ -259,8 +259,8 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
     if(!c->frames[curs[i]].has_data) return fail(c, BPVO_ERR_NO_DATA, "no data in frame");
     if(int rc = ensure_dense_descriptor(c, curs[i])) return rc;      // (a batch's template frame as the current frame of this estimate)
   }
-  const int lanes_ok = g_live_ctx[c->device & 63].load() > 1 ? 1 : std::min((int) c->lanes.size(), c->max_lanes_now);
-  int nl = std::max(1, std::min(lanes_ok, n / kMinPairsPerLane));
+  int nl = lanes_for(c, n, 8);
+  if(nl < 0) return nl;
   if(team_serves(c, n)) nl = 1;      // the team-persistent kernel takes the whole chip
   // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).

@@ -370,6 +370,7 @@ int fraction_good(bpvo_hip_ctx* c, int ws, float thr, float* frac);
 int get_weights_host(bpvo_hip_ctx* c, int ws, std::vector<float>& w_cm, int* n_out);
 int check_template_not_empty(bpvo_hip_ctx* c, int ref_slot);
 int ensure_lanes(bpvo_hip_ctx* c, int n);
+int lanes_for(bpvo_hip_ctx* c, int n, int cap);
 int ensure_dense_descriptor(bpvo_hip_ctx* c, int slot);      // a slot with lazy levels gets its full records (accessors, a template frame used as current)
 int set_option(bpvo_hip_ctx* c, const std::string& key, double v);
 int apply_options_string(bpvo_hip_ctx* c, const char* str);

@@ -337,7 +337,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   key                      default   meaning
  *   "lanes"                  3 / 2     (8-channel / single-channel descriptors) estimation lanes (HIP streams driven by host threads) a pair batch fans out over, 1 .. 8 (at least 8
  *                                      pairs per lane).  The narrow per-pair kernels of one lane overlap the chip-filling kernels of another;
- *                                      per-launch timings are only clean with 1.  Lanes beyond those the context holds are allocated here.
+ *                                      per-launch timings are only clean with 1.  A context is created with up to two; more are allocated by this option
+ *                                      or by the first batch that fans out over them (host-buffer batches stay on their two-lane upload plan).
  *   "persistent"             1         single pairs (estimatePose, addFrame) run every pyramid level in ONE persistent launch; 0: the
  *                                      four-kernel chain.  Also the master switch of "team".
  *   "persist_max_ws"         1         groups of up to this many pairs take the persistent kernel (1 .. 8; more than 1 measured slower)
