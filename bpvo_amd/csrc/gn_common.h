@@ -77,6 +77,22 @@ __device__ __forceinline__ void wave_tree_sums_to(const float (&acc)[N], int lan
   }
 }
 
+// 32-bit integer inclusive scan / sum over the 64 lanes of a wavefront on the VALU: row_shr 1, 2, 4, 8 inside the rows of 16 (lanes without
+// a source add 0), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  The sum is the scan's last lane, read with
+// v_readlane (uniform over the wave).
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned x)
+{
+  int v = (int) x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, true);
+  return (unsigned) v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned x) { return (unsigned) __builtin_amdgcn_readlane((int) wave_incl_scan_u32(x), 63); }
+
 // workspace of a workgroup: k-th entry of the active list, or k itself without a list
 __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { return a.list ? a.list[k] : k; }
 
@@ -110,20 +126,14 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
     mask |= (mask_t) (in ? 1u : 0u) << c;
   }
   const int lane = threadIdx.x & 63;
-  unsigned incl = cnt, sum_below = below, sum_valid = (v ? 1u : 0u) | (hit ? 0x10000u : 0u);   // valid points | tap-cache hits << 16
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
-  }
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) {
-    sum_below += __shfl_down(sum_below, o);
-    sum_valid += __shfl_down(sum_valid, o);
-  }
+  // the inclusive scan of the counts and the two wave sums on the VALU (DPP row shifts + the two row broadcasts: 18 ds_bpermute round
+  // trips as __shfl_up / __shfl_down ladders, per 64 points); integer sums — any order
+  const unsigned incl = wave_incl_scan_u32(cnt);
+  const unsigned sum_below = wave_sum_u32(below);
+  const unsigned sum_valid = wave_sum_u32((v ? 1u : 0u) | (hit ? 0x10000u : 0u));      // valid points | tap-cache hits << 16 (wave-uniform results)
   unsigned woff = 0;
   if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
-    const unsigned t_in = __shfl(incl, 63);
+    const unsigned t_in = (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
     if(lane == 0 && write) reinterpret_cast<uint4*>(j.med_blk.get())[blk] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
   } else {
     if(lane == 63) s.in[wave] = incl;
