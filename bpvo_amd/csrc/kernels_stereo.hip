@@ -47,14 +47,16 @@ __global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __
   dst[(size_t) y * cols + x] = out;
 }
 
+// inclusive scan over the 64 lanes on the VALU: DPP row shifts inside the rows of 16 (lanes without a source add 0), then the two row
+// broadcasts — six ds_bpermute round trips as a __shfl_up ladder, once per (disparity, row) of the matcher's inner loop; integer sums
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o);
-    if(lane >= o) v += t;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, true);
   return v;
 }
 
