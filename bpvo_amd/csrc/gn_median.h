@@ -32,12 +32,7 @@ template <int NT = 1024>
 __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* s_wave /*[16]*/, unsigned& total)
 {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned incl = v;
-#pragma unroll
-  for(int o = 1; o < 64; o <<= 1) {
-    const unsigned t = __shfl_up(incl, o);
-    if(lane >= o) incl += t;
-  }
+  const unsigned incl = wave_incl_scan_u32(v);      // (DPP: gn_common.h)
   __syncthreads();
   if(lane == 63) s_wave[wave] = incl;
   __syncthreads();
@@ -196,13 +191,7 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     }
     unsigned t_below, t_in, t_valid;
     {   // four block sums with one LDS round
-#pragma unroll
-      for(int o = 32; o >= 1; o >>= 1) {
-        c_below += __shfl_down(c_below, o);
-        c_in += __shfl_down(c_in, o);
-        c_valid += __shfl_down(c_valid, o);
-        c_hit += __shfl_down(c_hit, o);
-      }
+      c_below = wave_sum_u32(c_below); c_in = wave_sum_u32(c_in); c_valid = wave_sum_u32(c_valid); c_hit = wave_sum_u32(c_hit);
       __syncthreads();
       if((tid & 63) == 0) { unsigned* w4 = cache + (tid >> 6) * 4; w4[0] = c_below; w4[1] = c_in; w4[2] = c_valid; w4[3] = c_hit; }
       __syncthreads();
