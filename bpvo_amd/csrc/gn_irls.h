@@ -230,7 +230,7 @@ __device__ __forceinline__ void irls_lat_load(const PairJob& j, int i, IrlsPoint
 
 template <int LOSS, bool FUSED>
 __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* __restrict__ st, int pts_per_block, int tile, int vtid,
-                                              IrlsPartLds& s_part, bool has, float* __restrict__ partials)
+                                              IrlsPartLds& s_part, bool has, float* __restrict__ partials, bool agent_store = false)
 {
   float P[12];
   if constexpr(FUSED) {
@@ -373,7 +373,8 @@ __device__ __forceinline__ void irls_tile_lat(const PairJob& j, const GNState* _
   __syncthreads();
   if(vtid < kNumAcc && has) {
     const float v = (s_part[0][vtid] + s_part[1][vtid]) + (s_part[2][vtid] + s_part[3][vtid]);
-    partials[(size_t) tile * kPartialStride + vtid] = v;
+    if(agent_store) __hip_atomic_store(partials + (size_t) tile * kPartialStride + vtid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else partials[(size_t) tile * kPartialStride + vtid] = v;
   }
 }
 

@@ -195,7 +195,7 @@ struct bpvo_hip_ctx {
   // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
   // Options "team" (0 turns it off), "team_max_pairs", "team_size" (0 = CUs / pairs), "team_cus" (CUs the grid may claim: tests).
-  int team_mode = 1, team_max_pairs = 64, team_size_env = 0, num_cus = 0;
+  int team_mode = 1, team_max_pairs = 80, team_size_env = 0, num_cus = 0;
   std::atomic<uint64_t> team_launches{0};
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
   std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)

@@ -264,8 +264,10 @@ __device__ __forceinline__ void pk_irls_phase(const PairJob* __restrict__ jobs, 
   float* const partials = pk_partials(j, pts_per_block, parity);
   for(int base = 0; base < ntiles; base += nwg * PK_VB) {
     const int tile = base + vsub * nwg + pk_member;
-    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
-    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials);
+    // (the partials are stored THROUGH the caches and read past them by the step: the barrier between the two phases then needs no
+    // release / acquire pair — an L2 write-back and an invalidation per workgroup and iteration for 30 floats per tile)
+    if constexpr(C == 8) irls_tile_lat<LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials, true);
+    else irls_tile<C, LOSS, FUSED>(j, pk_st(ws), pts_per_block, tile, vtid, pk_part[vsub], tile < ntiles, partials, true);
     __syncthreads();
   }
 }
@@ -279,7 +281,7 @@ __device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restric
 #ifdef BPVO_PK_TIMING
   long long sub_t = wall_clock64();
 #endif
-  if(mine) gn_sum_partials(jobs[ws], pts_per_block, lane, pk_sum[ws], pk_partials(jobs[ws], pts_per_block, parity));
+  if(mine) gn_sum_partials<true>(jobs[ws], pts_per_block, lane, pk_sum[ws], pk_partials(jobs[ws], pts_per_block, parity));
   __syncthreads();
 #ifdef BPVO_PK_TIMING
   if(threadIdx.x == 0) GN_SUBTICK(4);
@@ -291,11 +293,13 @@ __device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restric
 }
 
 // returns false when the barrier gave up (timeout, or another workgroup's abort)
-__device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigned epoch, long long timeout)
+// `light`: what crosses the barrier was stored through the caches and will be read past them (the reduction's partials): arrival and
+// departure only, no release / acquire of the L2
+__device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigned epoch, long long timeout, bool light = false)
 {
   __syncthreads();
   if(threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if(!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -309,7 +313,7 @@ __device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigne
         if(wall_clock64() - t0 > timeout) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if(!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     pk_ok = ok;
   }
   __syncthreads();
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
       }
     }
     PK_TICK(3);
-    ok = pk_grid_barrier(ctl, ++epoch, timeout);
+    ok = pk_grid_barrier(ctl, ++epoch, timeout, true);
     PK_TICK(4);
     if(!ok) break;
     pk_step_phase(jobs, nws, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
@@ -437,11 +441,11 @@ constexpr int TEAM_WARP_U = TEAM_WARP_U_VALUE;      // points a thread of the te
 constexpr int kTeamCtlWords = 32;       // one 128-byte line per team: [0] arrivals, [1] next pair broadcast slot; global line 0: [1] abort, [2] next pair
 __shared__ int pk_next_pair;
 
-__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout)
+__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, bool light = false)
 {
   __syncthreads();
   if(threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if(!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -455,7 +459,7 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
         if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if(!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     pk_ok = ok;
   }
   __syncthreads();
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
           pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
         }
         TEAM_TICK(3);
-        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, true)) return;      // (only the partials cross: light)
         TEAM_TICK(4);
         pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
         TEAM_TICK(5);
