@@ -258,6 +258,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_max_pairs", team_max_pairs, 0, 1 << 20),
     OPT_INT("team_size", team_size_env, 0, 256),
     OPT_INT("team_cus", num_cus, 1, 1 << 16),
+    OPT_INT("team_local_barriers", team_local_barriers, 0, 1),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),

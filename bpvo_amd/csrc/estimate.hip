@@ -78,6 +78,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     t.n_teams = std::max(1, std::min(std::min(n, slots / ts), kMaxTeams));
     t.ctl = ln->d_team_ctl;
     t.timeout_ticks = c->persist_timeout;
+    t.local_barriers = c->team_local_barriers;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
     const hipError_t te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
     if(te == hipSuccess) {

@@ -139,6 +139,7 @@ struct GNTeamLaunch {
   int team_size, n_teams;
   unsigned* ctl;
   long long timeout_ticks;
+  int local_barriers = 1;    // teams whose workgroups share one XCD (checked on the device) keep their barriers inside that XCD's L2
 };
 int  gn_team_ctl_words(int n_teams);
 hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol);

@@ -440,12 +440,20 @@ constexpr bool TEAM_NT = TEAM_NT_VALUE != 0;        // streaming (non-temporal) 
 constexpr int TEAM_WARP_U = TEAM_WARP_U_VALUE;      // points a thread of the team kernel's warp phase carries at once
 constexpr int kTeamCtlWords = 32;       // one 128-byte line per team: [0] arrivals, [1] next pair broadcast slot; global line 0: [1] abort, [2] next pair
 __shared__ int pk_next_pair;
+__shared__ unsigned pk_team_xccs;      // XCDs the team's workgroups run on (bit mask)
 
-__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, bool light = false)
+// mode 0: release / acquire at agent scope — the L2 of the workgroup's XCD written back before the arrival, invalidated after the
+//   departure: what crosses the barrier may be read by a workgroup on another XCD through plain loads.
+// mode 1 (light): what crosses was stored through the caches and is read past them (the reduction's partials): arrival and departure only.
+// mode 2 (local): every workgroup of the team sits on ONE XCD (verified at the start of the kernel from the hardware's XCC id): they share
+//   its L2, so the writers' plain stores only have to have arrived there (the vmcnt(0) of the workgroup barrier below: the vector L1 is
+//   write-through) — no L2 write-back — and the readers drop what their L1 holds with the acquire's own invalidation (buffer_inv sc1).
+//   (The workgroup-scope form, buffer_inv sc0, was 5 % faster still and is NOT enough: the one-channel team test read stale residuals.)
+__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, int mode = 0)
 {
   __syncthreads();
   if(threadIdx.x == 0) {
-    if(!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -459,7 +467,8 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
         if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
       }
     }
-    if(!light) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else if(mode == 2) asm volatile("buffer_inv sc1" ::: "memory");
     pk_ok = ok;
   }
   __syncthreads();
@@ -504,7 +513,7 @@ __device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int 
 template <int C, int LOSS>
 __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
                                                              int team_size, int n_teams, int level_hi, int level_lo, int pts_per_block,
-                                                             GNParams prm, int fuse_frozen, int scale_is_moot, unsigned* ctl, long long timeout)
+                                                             GNParams prm, int fuse_frozen, int scale_is_moot, unsigned* ctl, long long timeout, int local_ok)
 {
   constexpr bool kCanFuse = (C == 8);
   const int tid = threadIdx.x;
@@ -526,6 +535,10 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
   unsigned* const global_ctl = ctl;                                           // [1] abort, [2] next pair to hand out
   unsigned* const team_ctl = ctl + (size_t) (1 + team) * kTeamCtlWords;       // [0] arrivals, [1] pair slot
   unsigned epoch = 0, epoch_it = 0;
+  // which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0), registered in the team's line [2] before the first barrier; behind it every
+  // member knows whether the team shares one L2 (team_mode 2: pk_team_barrier) — whatever the dispatcher did with the grid
+  if(tid == 0) (void) __hip_atomic_fetch_or(team_ctl + 2, 1u << (__builtin_amdgcn_s_getreg(63508) & 0xf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int team_mode = 0;
   // BPVO_PK_TIMING: workgroup 0 of team 0 accumulates the 100 MHz ticks of its phases, per pyramid level, in ctl[4 .. 31]: 7 words per level
   // {warp, barrier1, median, irls, barrier2, step, iterations}
 #ifdef BPVO_PK_TIMING
@@ -546,8 +559,12 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
-    if(tid == 0) pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(tid == 0) {
+      pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
+    team_mode = (local_ok && __popc(pk_team_xccs) == 1) ? 2 : 0;
     const int pair = pk_next_pair;
     if(pair >= n_pairs) return;
 
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
     for(int level = level_hi; level >= level_lo; --level) {
       const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
       pk_level_begin(jobs[0], level, scale_is_moot);
-      if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;         // keys reset before any phase reads them
+      if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;         // keys reset before any phase reads them
       for(;;) {
         const GNState* st = pk_st(0);
         if(!st->active) break;
@@ -572,7 +589,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
           if constexpr(C == 8) pk_warp_phase_staged<TEAM_WARP_U, TEAM_NT>(jobs, 0, stats_wg);
           else pk_warp_phase<C>(jobs, 0, stats_wg);
           TEAM_TICK(0);
-          if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+          if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;
           TEAM_TICK(1);
           if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
           TEAM_TICK(2);
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
           pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
         }
         TEAM_TICK(3);
-        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, true)) return;      // (only the partials cross: light)
+        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, 1)) return;      // (only the partials cross: light)
         TEAM_TICK(4);
         pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
         TEAM_TICK(5);
@@ -675,7 +692,7 @@ static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const G
     });
     if(status[dev] != hipSuccess) return status[dev];
     hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
-                       t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks);
+                       t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks, t.local_barriers);
     return hipGetLastError();
   };
   switch(t.loss) {

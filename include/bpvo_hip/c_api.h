@@ -349,6 +349,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_max_pairs"         80        (the chain is faster from ~96 pairs on: DESIGN.md §4)
  *   "team_size"              0         workgroups per team; 0 = CUs / pairs
  *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
+ *   "team_local_barriers"    1         teams whose workgroups all run on one XCD (checked on the device) skip the L2 write-back of their barriers
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
  *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair
  *                                      inside the reduction launch — three kernels per iteration instead of four, same bits (0: never)

@@ -42,7 +42,7 @@ def main():
             continue
         n += 1
         opts = OPTION_SETS[int(rng.integers(len(OPTION_SETS)))]
-        npairs = int(rng.choice([2, 3, 5, 9, 17, 40]))
+        npairs = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 24, 32, 40]))      # (multiples of 8: teams that sit on one XCD each)
         if npairs * rows * cols > 40 * 120 * 160:
             npairs = max(2, (40 * 120 * 160) // (rows * cols))
         try:
