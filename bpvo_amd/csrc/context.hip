@@ -256,6 +256,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("persist_timeout_ticks", persist_timeout, 1, 1e15),
     OPT_INT("team", team_mode, 0, 1),
     OPT_INT("team_max_pairs", team_max_pairs, 0, 1 << 20),
+    OPT_INT("team_full_pairs", team_full_pairs, 0, 1 << 20),
     OPT_INT("team_size", team_size_env, 0, 256),
     OPT_INT("team_cus", num_cus, 1, 1 << 16),
     OPT_INT("team_local_barriers", team_local_barriers, 0, 1),

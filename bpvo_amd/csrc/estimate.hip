@@ -15,7 +15,13 @@ namespace bpvo_hip_host {
 // while per-kernel timings are being collected: there are no kernels to time)
 bool team_serves(const bpvo_hip_ctx* c, int n)
 {
-  const bool size_ok = n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs;
+  bool size_ok = n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs;
+  // above team_full_pairs only when the teams fill the chip: the kernel runs CUs / n workgroups per pair, and what that division leaves over
+  // idles for the whole launch (96 pairs: 2 x 96 of 256 CUs, 770 k GN it/s against the chain's 840 k; 128 pairs: 2 x 128, 935 k against 890 k)
+  if(size_ok && n > c->team_full_pairs && c->team_size_env <= 0 && c->num_cus > 0) {
+    const int ts = std::max(1, std::min(64, c->num_cus / n));
+    size_ok = 20 * ts * std::min(n, c->num_cus / ts) >= 19 * c->num_cus;
+  }
   return c->team_mode && c->persistent && !c->persistent_failed.load() && size_ok &&
          (c->C == 8 || c->C == 1) && c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !c->profile_all && !c->profile_k6_all &&
          c->num_cus >= 2 && g_live_ctx[c->device & 63].load() <= 1;

@@ -346,7 +346,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "persist_timeout_ticks"  5e7       100 MHz ticks a device-side barrier waits before the launch gives up and the call falls back to
  *                                      the chain (0.5 s; the tests of that path set 1)
  *   "team"                   1         batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in one team-persistent launch
- *   "team_max_pairs"         80        (the chain is faster from ~96 pairs on: DESIGN.md §4)
+ *   "team_max_pairs"         128       ... up to this many pairs; above "team_full_pairs" (80) only when CUs / pairs workgroups per pair fill at least
+ *                                      95 % of the CUs (128 pairs on 256 CUs do, 96 do not: the chain is faster there)
  *   "team_size"              0         workgroups per team; 0 = CUs / pairs
  *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
  *   "team_local_barriers"    1         teams whose workgroups all run on one XCD (checked on the device) skip the L2 write-back of their barriers
