@@ -167,3 +167,39 @@ def test_team_kernel_gives_up_cleanly(hip, monkeypatch):
     assert got["pk"][1] == 1 and got["team"] == 1          # launched once, gave up, never tried again
     assert bits_equal(ref["poses"], got["poses"]) and ref["stats"].tobytes() == got["stats"].tobytes()
     assert bits_equal(ref["poses2"], got["poses2"]) and bits_equal(ref["r"], got["r"]) and bits_equal(ref["w"], got["w"])
+
+
+@pytest.mark.parametrize("n", [16, 40])
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
+def test_team_kernel_with_a_team_per_xcd(hip, n, descriptor, loss, monkeypatch):
+    """Team counts that divide over the eight XCDs: a team's workgroups are dealt to ONE XCD, every workgroup registers the XCD it runs on
+    (HW_REG_XCC_ID), and a team that finds itself on one XCD drops the L2 write-back of its barriers (option team_local_barriers; its
+    barrier between reduction and step carries the partials past the caches either way).  Against the agent-scope fences and against the
+    chain, bit for bit — with one channel too (whose plain residual loads read stale lines under a weaker invalidation)."""
+    rows, cols, levels = 120, 160, 3
+    set_options(monkeypatch, team="0")
+    ref = run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=310)
+    assert ref["team"] == 0
+    set_options(monkeypatch, team="1")
+    for local in ("0", "1"):
+        set_options(monkeypatch, team_local_barriers=local)
+        got = run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=310)
+        assert got["team"] == 2 and got["pk"][1] == 0, (local, got["team"], got["pk"])
+        assert_same_batch(ref, got)
+
+
+def test_team_kernel_above_80_pairs_only_where_it_fills_the_chip(hip):
+    """Up to 80 pairs (team_full_pairs) a batch takes the team kernel whatever its size; up to 128 (team_max_pairs) only when CUs / pairs
+    workgroups per pair use at least 95 % of the CUs: on 256 CUs 128 pairs (2 x 128) and 85 (3 x 85) do, 96 (2 x 96) do not."""
+    rows, cols, levels = 96, 128, 2
+    for n, team in ((128, True), (96, False), (85, True)):
+        b = synth.make_batch(rows, cols, n, first_index=5, workers=8)
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels), n_frames=2 * n, n_pairs=n)
+        cus = int(ctx.get_option("team_cus"))
+        ctx.batch_run(b["images"], b["disparities"])
+        ts = max(1, min(64, cus // n))
+        fills = 20 * ts * min(n, cus // ts) >= 19 * cus
+        assert (ctx.team_counts() == 1) == fills, (n, cus, ctx.team_counts())
+        if cus == 256:
+            assert fills == team, (n, fills)
+        ctx.close()
