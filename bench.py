@@ -13,8 +13,10 @@ ranks — strong scaling: `--gpus N` gives every rank 1024 / N pairs (N = 1: the
 --pairs on EVERY rank.  There is no data-path collective.  value = GN iterations (linearise + solve + pose update, counted
 like the reference's _num_fun_evals, bpvo/pose_estimator_gn.h:78) of the whole job per second of step time.
 
-Launch: `python bench.py` (1 GPU) or
+Launch: `python bench.py` (1 GPU), `python bench.py --gpus N` (this process starts the N ranks as children of itself, before it
+touches the GPU, and passes rank 0's line through), or the ranks started from outside:
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Every rank checks WORLD_SIZE == --gpus; the line carries `ranks_seen` (an all-reduced count) and the RCCL version.
 """
 from __future__ import annotations
 
@@ -116,7 +118,7 @@ def cpu_baseline(args, batch, n_sample):
                   f"(= the reference's default build, WITH_TBB OFF): {one['gn_iters']} GN iterations in {one['seconds']:.2f} s",
         "frames_per_s": n / one["seconds"],
         "_poses": one["poses"],
-        "all_cores": {"value": allc["gn_iters"] / allc["seconds"], "cores": allc["threads"], "seconds": allc["seconds"],
+        "all_cores": {"value": allc["gn_iters"] / allc["seconds"], "cores": allc["threads"], "seconds": allc["seconds"], "kind": "port, OpenMP over channels",
                       "host_cores": os.cpu_count(),
                       "note": "OpenMP over the 8 channels / range-split reduction = the reference's TBB decomposition (max 8-way)"},
     }
@@ -313,11 +315,37 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as CHILD processes (python -m torch.distributed.run
+    ... bench.py <the same arguments>), before this process has imported torch.cuda or the HIP library — nothing here touches the
+    GPU, and nothing is exec'd.  Rank 0's JSON line is the children's stdout, passed through; the exit code is theirs."""
+    import socket
+    import subprocess
+    import torch                       # device_count() does not initialise the GPU on this image
+    ndev = torch.cuda.device_count()
+    if args.gpus > ndev and not args.single_device:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible (functional test on one device: --single-device --dist-backend gloo)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); pass --gpus {world}")
 
     from bpvo_amd import synth
     from bpvo_amd.distributed import RECORD_FLOATS, gather_records, records_to_poses, shard_range
@@ -441,15 +469,23 @@ def main():
     # pairs and levels of the LAST step; `gn_local` counts linearisations (= _num_fun_evals, pose_estimator_gn.h:78), 1-2 more per level
     numit_last_step = float(stats["numIterations"].sum())
     frame_ms_local = sum(all_kstats[k]["total_ms"] for k in ("pyramid", "descriptor", "saliency_select", "normalization", "template_build"))
-    t = torch.tensor([elapsed, float(gn_local), numit_last_step, frame_ms_local], dtype=torch.float64, device=coll_dev)
+    t = torch.tensor([elapsed, float(gn_local), numit_last_step, frame_ms_local, 1.0], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed_max, gn_total, numit_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
+        elapsed_max, gn_total, numit_total, ranks_seen = float(tmax[0]), float(tsum[1]), float(tsum[2]), int(round(float(tsum[4])))
     else:
-        elapsed_max, gn_total, numit_total = elapsed, float(gn_local), numit_last_step
+        elapsed_max, gn_total, numit_total, ranks_seen = elapsed, float(gn_local), numit_last_step, 1
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: {ranks_seen} rank(s) took part in the all-reduce, --gpus {args.gpus}")
+    rccl_version = None
+    if world > 1 and args.dist_backend == "nccl":
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl_version = "unknown"
 
     if rank == 0:
         n_pairs_total = P * world
@@ -591,7 +627,7 @@ def main():
                       "linearisation + solve + pose update, counted like the reference's _num_fun_evals)"
             if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s",
             "value": gn_total / elapsed_max, "unit": "GN iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "dist_backend": (args.dist_backend if world > 1 else None),
+            "dist_backend": (args.dist_backend if world > 1 else None), "ranks_seen": ranks_seen, "rccl_version": rccl_version,
             "ms_per_step": 1e3 * elapsed_max / args.steps, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "f32 (+f64 projection/interpolation)", "data": "synthetic",
             "config": {"workload": f"batch of {n_pairs_total} independent {args.cols}x{args.rows} stereo pairs "

@@ -250,7 +250,9 @@ const std::vector<OptionDef>& option_table()
                 if(rc == BPVO_OK) c->max_lanes_now = (int) v;
                 return rc;
               }},
-    OPT_INT("persistent", persistent, 0, 1),
+    // "persistent" = 1 also re-arms a context whose persistent / team launch once gave up at a barrier (persistent_failed is sticky otherwise)
+    OptionDef{"persistent", 0, 1, [](bpvo_hip_ctx* c) { return (double) c->persistent; },
+              [](bpvo_hip_ctx* c, double v) { c->persistent = (int) v; if(c->persistent) c->persistent_failed.store(false); return BPVO_OK; }},
     OPT_INT("persist_max_ws", persist_max_ws, 1, kPersistMaxWs),
     OPT_INT("persist_grid", persist_grid, 1, 128),
     OPT_INT("persist_timeout_ticks", persist_timeout, 1, 1e15),
@@ -258,7 +260,13 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_max_pairs", team_max_pairs, 0, 1 << 20),
     OPT_INT("team_full_pairs", team_full_pairs, 0, 1 << 20),
     OPT_INT("team_size", team_size_env, 0, 256),
-    OPT_INT("team_cus", num_cus, 1, 1 << 16),
+    // CUs the team grid may claim: never more than the device has (a larger grid cannot be co-resident and would only time out)
+    OptionDef{"team_cus", 1, 1 << 16, [](bpvo_hip_ctx* c) { return (double) c->num_cus; },
+              [](bpvo_hip_ctx* c, double v) {
+                if(c->device_cus > 0 && (int) v > c->device_cus) { c->err = "option team_cus: more CUs than the device has"; return BPVO_ERR_INVALID_ARG; }
+                c->num_cus = (int) v;
+                return BPVO_OK;
+              }},
     OPT_INT("team_local_barriers", team_local_barriers, 0, 1),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
@@ -554,7 +562,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   }
   {
     hipDeviceProp_t prop;
-    if(hipGetDeviceProperties(&prop, device) == hipSuccess) cp->num_cus = prop.multiProcessorCount;
+    if(hipGetDeviceProperties(&prop, device) == hipSuccess) cp->num_cus = cp->device_cus = prop.multiProcessorCount;
   }
   cp->max_lanes_now = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
   // BPVO_HIP_OPTIONS="key=value,key=value": bpvo_hip_set_option applied to every context the process creates (measurement scripts and

@@ -203,14 +203,21 @@ int ensure_dense_descriptor(bpvo_hip_ctx* c, int slot)
   bool any = false;
   for(int l = 0; l < c->L; ++l) any = any || f.lazy[l];
   if(!any) return BPVO_OK;
-  for(int l = 0; l < c->L; ++l) f.lazy[l] = false;
+  // The job table is built from the flags, so they are cleared for it and put back if anything fails: the slot counts as dense
+  // only once the kernels that fill its records have run.
+  bool was[kMaxLevels];
+  for(int l = 0; l < c->L; ++l) { was[l] = f.lazy[l]; f.lazy[l] = false; }
+  auto restore = [&]() { for(int l = 0; l < c->L; ++l) f.lazy[l] = was[l]; };
   const FrameRun fr = ctx_run(c);
   const FrameJob* tab = nullptr;
   const int rc = upload_frame_jobs(c, slot, 1, 1, fr, 0, &tab);
-  if(rc) return rc;
+  if(rc) { restore(); return rc; }
   for(int l = c->L - 1; l >= c->params.maxTestLevel; --l)
     launch_bitplanes(c->stream, tab + (size_t) l * c->n_frames, c->geom[l].cols, c->geom[l].rows, 1, c->params.sigmaBitPlanes, c->gauss_k, 1);
-  HIP_CK(c, hipStreamSynchronize(c->stream));
+  if(hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+    restore();
+    return fail(c, BPVO_ERR_DEVICE, "ensure_dense_descriptor: descriptor kernels failed");
+  }
   return BPVO_OK;
 }
 

@@ -195,7 +195,7 @@ struct bpvo_hip_ctx {
   // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
   // Options "team" (0 turns it off), "team_max_pairs", "team_size" (0 = CUs / pairs), "team_cus" (CUs the grid may claim: tests).
-  int team_mode = 1, team_max_pairs = 128, team_full_pairs = 80, team_size_env = 0, num_cus = 0;   // (team_full_pairs: up to here whatever the fill)
+  int team_mode = 1, team_max_pairs = 128, team_full_pairs = 80, team_size_env = 0, num_cus = 0, device_cus = 0;   // (team_full_pairs: up to here whatever the fill)
   int team_local_barriers = 1;   // option "team_local_barriers": kernels_gn_team.hip pk_team_barrier mode 2 for teams on one XCD (0: agent-scope fences always)
   std::atomic<uint64_t> team_launches{0};
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)

@@ -297,6 +297,9 @@ __device__ __attribute__((noinline)) void pk_step_phase(const PairJob* __restric
 // departure only, no release / acquire of the L2
 __device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigned epoch, long long timeout, bool light = false)
 {
+  // EVERY wave waits for its own global stores to have left (the vector L1 is write-through: vmcnt(0) = they are in the L2) before
+  // the workgroup barrier: s_barrier alone does not wait for vmcnt, and thread 0's wait below covers thread 0's wave only.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if(threadIdx.x == 0) {
     if(!light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -446,11 +449,12 @@ __shared__ unsigned pk_team_xccs;      // XCDs the team's workgroups run on (bit
 //   departure: what crosses the barrier may be read by a workgroup on another XCD through plain loads.
 // mode 1 (light): what crosses was stored through the caches and is read past them (the reduction's partials): arrival and departure only.
 // mode 2 (local): every workgroup of the team sits on ONE XCD (verified at the start of the kernel from the hardware's XCC id): they share
-//   its L2, so the writers' plain stores only have to have arrived there (the vmcnt(0) of the workgroup barrier below: the vector L1 is
-//   write-through) — no L2 write-back — and the readers drop what their L1 holds with the acquire's own invalidation (buffer_inv sc1).
+//   its L2, so the writers' plain stores only have to have arrived there (the explicit s_waitcnt vmcnt(0) every wave executes ahead of
+//   the workgroup barrier below: the vector L1 is write-through) — no L2 write-back — and the readers drop what their L1 holds with the acquire's own invalidation (buffer_inv sc1).
 //   (The workgroup-scope form, buffer_inv sc0, was 5 % faster still and is NOT enough: the one-channel team test read stale residuals.)
 __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, int mode = 0)
 {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores in the L2 before the arrival (see pk_grid_barrier)
   __syncthreads();
   if(threadIdx.x == 0) {
     if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -576,6 +580,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
 
     for(int level = level_hi; level >= level_lo; --level) {
       const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
+      __syncthreads();      // every wave has read `active` of the level it leaves before thread 0 rewrites the LDS state
       pk_level_begin(jobs[0], level, scale_is_moot);
       if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;         // keys reset before any phase reads them
       for(;;) {

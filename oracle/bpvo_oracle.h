@@ -35,6 +35,7 @@ void bpvo_orc_destroy(bpvo_orc_ctx* ctx);
 const char* bpvo_orc_last_error(const bpvo_orc_ctx* ctx);
 int bpvo_orc_set_num_threads(bpvo_orc_ctx* ctx, int n);
 int bpvo_orc_set_reduction(bpvo_orc_ctx* ctx, int mode);   /* 0: reference (f32 accumulation); 1: f64 accumulation — test instrument only */
+int bpvo_orc_set_perturbation(bpvo_orc_ctx* ctx, int seed, double rel);   /* test instrument: (H, G) .* (1 + rel N(0,1)) per linearisation; 0 = off */
 int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* ctx, int mode);   /* 0: PhotoError f64 (active), 1: projectPoints f32 (inactive branch) */
 int bpvo_orc_num_levels(const bpvo_orc_ctx* ctx);
 int bpvo_orc_num_channels(const bpvo_orc_ctx* ctx);

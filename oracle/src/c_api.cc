@@ -103,6 +103,13 @@ int bpvo_orc_set_reduction(bpvo_orc_ctx* c, int mode)
   c->vo.vo_pose.est.reduction = mode;
   return 0;
 }
+// test instrument (orc.h PoseEstimator::perturb_rel): relative noise on every linearisation's (H, G); rel = 0 switches it off
+int bpvo_orc_set_perturbation(bpvo_orc_ctx* c, int seed, double rel)
+{
+  for(auto& w : c->ws) { w.est.perturb_rel = (float) rel; w.est.perturb_seed = (uint32_t) seed; w.est.perturb_count = 0; }
+  c->vo.vo_pose.est.perturb_rel = (float) rel; c->vo.vo_pose.est.perturb_seed = (uint32_t) seed; c->vo.vo_pose.est.perturb_count = 0;
+  return 0;
+}
 int bpvo_orc_set_warp_formulation(bpvo_orc_ctx* c, int mode)
 {
   if(mode != 0 && mode != 1 && mode != 2) return fail(c, "unknown warp formulation");

@@ -172,6 +172,11 @@ struct PoseEstimator {
   // mode of the reference: a test instrument that shows what a reduction without f32 accumulation noise (the GPU's tree +
   // f64 combine is within 4e-6 of it) does to the termination tests (tests/test_oracle_cpu.py, tests/tools/fuzz_regressions.txt)
   int reduction = 0;
+  // Test instrument, NOT a mode of the reference: every linearisation's (H, G) multiplied entry by entry (H symmetrically) by
+  // 1 + perturb_rel * n, n ~ N(0, 1) from a generator seeded with (perturb_seed, linearisation count) — the size of the difference
+  // between two f32 summation orders.  The randomised parity tool asks the oracle with it whether a problem's final pose is
+  // decided by such differences (tests/tools/fuzz_parity.py, rule "solver-fallback-edge").
+  float perturb_rel = 0.0f; uint32_t perturb_seed = 0; uint32_t perturb_count = 0;
   AutoScaleEstimator scale_estimator;
   std::vector<float> residuals, weights;
   std::vector<uint16_t> valid;        // replicated to C*N after linearize (Q12 / base.h:307-320)

@@ -21,6 +21,30 @@ void PoseEstimator::setParameters(const Params& p)
   maxFuncEvals = 6 * 200;
 }
 
+// test instrument (orc.h, PoseEstimator::perturb_rel): (H, G) <- (H, G) .* (1 + rel * n), H kept symmetric
+static void perturbSystem(float H[36], float G[6], float rel, uint32_t seed, uint32_t count)
+{
+  uint64_t s = 0x9e3779b97f4a7c15ull * (uint64_t) (seed + 1) + 0xbf58476d1ce4e5b9ull * (uint64_t) (count + 1);
+  auto next = [&]() {      // splitmix64
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+  };
+  auto gauss = [&]() {     // sum of 12 uniforms - 6
+    double a = 0.0;
+    for(int i = 0; i < 12; ++i) a += (double) (next() >> 11) * (1.0 / 9007199254740992.0);
+    return a - 6.0;
+  };
+  for(int i = 0; i < 6; ++i)
+    for(int j = i; j < 6; ++j) {
+      const float v = (float) ((double) H[i * 6 + j] * (1.0 + (double) rel * gauss()));
+      H[i * 6 + j] = v;
+      H[j * 6 + i] = v;
+    }
+  for(int i = 0; i < 6; ++i) G[i] = (float) ((double) G[i] * (1.0 + (double) rel * gauss()));
+}
+
 // PoseEstimatorGN::linearize (bpvo/pose_estimator_gn.h:70-81) incl. replicateValidFlags (pose_estimator_base.h:307-320).
 float PoseEstimator::linearize(TemplateData* tdata, const Descriptor& desc, const M44& T, float H[36], float G[6])
 {
@@ -38,7 +62,9 @@ float PoseEstimator::linearize(TemplateData* tdata, const Descriptor& desc, cons
   last_sigma = sigma;
   computeWeights(lossFunction, residuals, valid, sigma, weights);
   num_fun_evals += 1;
-  return linearSystemRun(tdata->jacobians, residuals, weights, valid, H, G, reduction == 1 ? -1 : nthreads);
+  const float f = linearSystemRun(tdata->jacobians, residuals, weights, valid, H, G, reduction == 1 ? -1 : nthreads);
+  if(perturb_rel > 0.0f) perturbSystem(H, G, perturb_rel, perturb_seed, perturb_count++);
+  return f;
 }
 
 static inline float infNorm6(const float* g)

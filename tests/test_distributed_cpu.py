@@ -84,3 +84,19 @@ def test_two_rank_gather_equals_single_process(tmp_path, orc):
 def test_gather_is_identity_without_process_group():
     t = torch.arange(64, dtype=torch.float32).reshape(2, 32)
     assert gather_records(t) is t
+
+
+def test_bench_gpus_flag_is_read():
+    """bench.py --gpus N is not a no-op: without a launcher it wants to start N ranks itself (and says so when the box has fewer
+    devices); under a launcher every rank refuses a WORLD_SIZE that disagrees with it.  No GPU is touched by either path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 64:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "--gpus 64: only" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "--gpus 1 but the launcher started 2" in (r.stdout + r.stderr)

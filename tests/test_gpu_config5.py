@@ -253,6 +253,32 @@ def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_
     assert np.array_equal(it[:, :LEVELS], stats["numIterations"]) and np.array_equal(st[:, :LEVELS], stats["status"])
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it — the shape of the driver's command — starts N ranks as children
+    (before it touches the GPU) and passes rank 0's line through: n_gpus = ranks_seen = N, the batch split over the ranks.  With one
+    visible device the two ranks share it over gloo; with more they sit on distinct devices and the gather is RCCL."""
+    ndev = _device_count_without_touching_the_gpu()
+    world = min(ndev, 8) if ndev > 1 else 2
+    dump = str(tmp_path / "records.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--pairs", str(3 * world),
+           "--cpu-pairs", "0", "--other-configs", "0", "--gen-workers", "2", "--dump-records", dump]
+    if ndev <= 1:
+        cmd += ["--dist-backend", "gloo", "--single-device"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == world and out["ranks_seen"] == world and out["config"]["pairs_per_gpu"] == 3
+    rec = np.load(dump)
+    assert np.array_equal(rec[:, 30], np.repeat(np.arange(world), 3).astype(np.float32))
+    if ndev > 1:
+        assert out["dist_backend"] == "nccl" and out["rccl_version"] and np.array_equal(rec[:, 31], rec[:, 30])
+    # a launcher that disagrees with --gpus is refused by every rank
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 1 but the launcher started 2" in (r.stdout + r.stderr)
+
+
 # ---- bounded soak (tests/tools/soak_parity.py in the suite) ----------------------------------------------------------
 @pytest.mark.parametrize("rows,cols,descriptor,loss,n", [pytest.param(376, 1241, "bitplanes", "tukey", 64, id="kitti-bitplanes-tukey-64"),
                                                          pytest.param(480, 640, "intensity", "huber", 64, id="640x480-intensity-huber-64")])

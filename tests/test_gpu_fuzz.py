@@ -1,9 +1,12 @@
 """A bounded run of the randomised stage-by-stage parity tool (tests/tools/fuzz_parity.py) inside the suite: fixed seeds, the
-configurations the reference can be configured to (withNormalization = 1, every descriptor on the device path, the four interpolation
-types, CD3 / CD5, three losses, NMS on / off, ragged sizes, 1-4 levels, the three warp formulations, the fused path), every stage up to
-the weights bit-identical with the oracle, every final pose inside the bar or explained by one of the tool's rules — each of which asks
-the ORACLE ITSELF (its other summation orders, a perturbed start, its f64 trace) whether the difference is the problem's, not the
-implementation's.  Plus the committed regression cases, replayed."""
+configurations the reference can be configured to — every descriptor on the device path, the four interpolation types, CD3 / CD5, three
+losses, NMS on / off, ragged sizes, 1-5 levels, maxIterations 50 / 100 / 400, the three warp formulations, the fused path, and, for a
+third of the cases, the UN-NORMALISED class: withNormalization = 0 (conf/tsukuba_eval.cfg:8 — the default configuration of
+apps/eval_descriptors.cc:130, the app that runs every descriptor of the factory) and the DisparitySpaceWarp formulation, whose
+setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90).  Every stage up to the weights bit-identical with the oracle, every
+final pose inside the bar or explained by one of the tool's rules — each of which asks the ORACLE ITSELF (its other summation orders, a
+perturbed start, perturbed normal equations, its f64 trace) whether the difference is the problem's, not the implementation's.  Plus
+the committed regression cases, replayed."""
 import ast
 import os
 import sys
@@ -23,31 +26,47 @@ pytestmark = pytest.mark.gpu
 # finding, not an explanation.
 AGREED = {"template-error", "estimate-error", "non-finite"}
 EXPLAINED = {"unstable-problem", "iteration-limit", "stops-where-the-oracle-would", "function-tol-at-the-noise-floor", "genuine-function-tol-stop",
-             "genuine-scale-freeze", "noise-floor-minimum"}
+             "genuine-scale-freeze", "noise-floor-minimum", "solver-fallback-edge"}
 ACCEPTED = {"ok"} | AGREED | EXPLAINED
-RULE_CAP, EXPLAINED_CAP, AGREED_CAP = 0.03, 0.08, 0.10      # fractions of the normalised cases of a run
+RULE_CAP, EXPLAINED_CAP, AGREED_CAP = 0.03, 0.08, 0.05      # fractions of the cases of a run
+UNNORMALISED_SHARE = 1.0 / 3.0                              # of the cases of a run
+# (case, level) cells whose numIterations AND status equal the oracle's under the reference's timing tolerances (conf/perf_*.cfg):
+# measured on the Gauss-Newton code of round 4 (unchanged since: profiles/r05_fuzz_outcomes.txt); the suite does not fall below it
+ITERATION_CELLS_FLOOR = 0.90
 
 
-@pytest.mark.parametrize("seed,n_cases", [(20261001, 160), (20261002, 160)])
-def test_bounded_fuzz_of_normalised_configurations(hip, orc, seed, n_cases):
+@pytest.mark.parametrize("seed,n_cases", [(20261001, 165), (20261002, 165)])
+def test_bounded_fuzz_with_the_unnormalised_class(hip, orc, seed, n_cases):
     import fuzz_parity as fz
     rng = np.random.default_rng(seed)
-    outcomes = {}
+    quota = {True: int(round(UNNORMALISED_SHARE * n_cases)), False: n_cases - int(round(UNNORMALISED_SHARE * n_cases))}
+    taken = {True: 0, False: 0}
+    outcomes, by_class = {}, {True: {}, False: {}}
+    cells = [0, 0]
     n = 0
     while n < n_cases:
         rows, cols, kw, scene, s = fz.draw(rng)
-        if not kw["withNormalization"] or kw.get("_dspace"):     # no configuration of the reference switches the normalisation off
+        un = fz.is_unnormalised(kw)
+        if taken[un] >= quota[un]:
             continue
+        taken[un] += 1
         n += 1
         out = fz.check(hip, orc, rows, cols, kw, scene, s)        # raises AssertionError with the stage that differs
         assert out in ACCEPTED, (rows, cols, scene, s, kw, out)
         outcomes[out] = outcomes.get(out, 0) + 1
+        by_class[un][out] = by_class[un].get(out, 0) + 1
         if n % 5 == 0 and out == "ok":
             outb = fz.check_batch(hip, rows, cols, kw, s, dirty=True)      # (the batch context has run other images before)
             outcomes["batch-" + outb] = outcomes.get("batch-" + outb, 0) + 1
-    table = f"fuzz seed {seed}: {n} cases, outcomes {dict(sorted(outcomes.items()))}"
+        if n % 3 == 0 and out == "ok":
+            e, t = fz.iteration_cells(hip, orc, rows, cols, kw, scene, s)
+            cells[0] += e; cells[1] += t
+    frac = cells[0] / max(1, cells[1])
+    table = (f"fuzz seed {seed}: {n} cases ({taken[True]} un-normalised), outcomes {dict(sorted(outcomes.items()))}; "
+             f"normalised {dict(sorted(by_class[False].items()))}; un-normalised {dict(sorted(by_class[True].items()))}; "
+             f"iteration cells equal under the timing tolerances {cells[0]}/{cells[1]} = {frac:.4f}")
     print("\n" + table)
-    out_dir = os.path.join(ROOT, "gpurun_out")       # (scratch that travels back from the GPU box; the committed copy: profiles/r04_fuzz_outcomes.txt)
+    out_dir = os.path.join(ROOT, "gpurun_out")       # (scratch that travels back from the GPU box; the committed copy: profiles/r05_fuzz_outcomes.txt)
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "fuzz_outcomes.txt"), "a") as f:
         f.write(table + "\n")
@@ -56,7 +75,31 @@ def test_bounded_fuzz_of_normalised_configurations(hip, orc, seed, n_cases):
     assert sum(explained.values()) <= EXPLAINED_CAP * n_cases, outcomes
     assert sum(v for k, v in outcomes.items() if k in AGREED) <= AGREED_CAP * n_cases, outcomes
     assert outcomes.get("ok", 0) >= (1.0 - EXPLAINED_CAP - AGREED_CAP) * n_cases, outcomes
+    # the un-normalised class on its own: most of its poses are inside the bar, the rest explained by the capped rules above
+    assert by_class[True].get("ok", 0) >= 0.80 * taken[True], by_class[True]
     assert not [k for k in outcomes if k.startswith("batch-") and k != "batch-ok"], outcomes
+    assert cells[1] >= 40 and frac >= ITERATION_CELLS_FLOOR, (cells, frac)
+
+
+def test_the_unnormalised_regression_cases_are_explained(hip, orc):
+    """tests/tools/fuzz_regressions.txt: the un-normalised cases (withNormalization = 0 or the d-space warp) that rounds 2-4 listed as
+    'beyond the bar, no rule': every one is now inside the bar or explained by a rule that asks the oracle — most by
+    'solver-fallback-edge' (the oracle's own final pose moves beyond the bar under 2e-7 perturbations of its normal equations and its
+    other summation orders, and the GPU's pose lies within 3x that spread or is a fixed point of the oracle)."""
+    import fuzz_parity as fz
+    seen = {}
+    for line in open(os.path.join(ROOT, "tests", "tools", "fuzz_regressions.txt")):
+        line = line.strip()
+        if not line or line.startswith("#") or not ("'withNormalization': 0" in line or "'_dspace': True" in line):
+            continue
+        head, brace = line.split("{", 1)
+        rows, cols, scene, seed = (int(v) for v in head.split()[-4:])
+        kw = ast.literal_eval("{" + brace.split("}", 1)[0] + "}")
+        seen[(rows, cols, seed)] = fz.check(hip, orc, rows, cols, kw, scene, seed)
+    print("\nun-normalised regression cases:", seen)
+    with open(os.path.join(ROOT, "gpurun_out", "fuzz_outcomes.txt"), "a") as f:
+        f.write("un-normalised regression cases: " + repr(seen) + "\n")
+    assert len(seen) >= 12 and all(v in ACCEPTED for v in seen.values()), seen
 
 
 def test_the_normalised_regression_cases_are_explained(hip, orc):

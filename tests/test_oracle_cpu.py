@@ -780,7 +780,7 @@ def _fuzz_regression_cases():
 
 def test_unnormalised_fuzz_cases_sit_on_the_solver_fallback_edge(orc):
     """tests/tools/fuzz_regressions.txt: the randomised parity cases whose final poses differ beyond the bar although every stage up to
-    the weights is bit-identical.  The ones with withNormalization = 0 (no configuration of the reference switches it off) share one
+    the weights is bit-identical.  The ones with withNormalization = 0 (conf/tsukuba_eval.cfg:8, the default configuration of apps/eval_descriptors.cc:130) share one
     mechanism, shown here on the oracle alone: PoseEstimatorData_::solve (bpvo/pose_estimator_base.h:90-111) accepts the f32 LDLT
     solution iff (H dp).isApprox(G) and otherwise solves H + 1e-3 max(diag) I in f64 — a step that is 10-100x shorter along the weak
     directions.  For these un-normalised 6x6 systems (condition numbers of 1e5 ... 1e7) that acceptance test is a knife edge: along
