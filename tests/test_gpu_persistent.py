@@ -5,7 +5,7 @@ FOR BIT — poses, statistics, residuals, valid masks, weights, robust scale —
 import numpy as np
 import pytest
 
-from bpvo_amd import synth
+from bpvo_amd import capi, synth
 from util import bits_equal, make_params, setup_pair, set_options
 
 pytestmark = pytest.mark.gpu
@@ -138,7 +138,7 @@ def test_team_kernel_is_bit_identical_to_the_chain(hip, rows, cols, levels, n, d
     assert len(np.unique(ref["stats"]["numIterations"][:, 0])) > 1            # the pairs really finish at different iterations
 
 
-@pytest.mark.parametrize("cus,team_size", [(6, 0), (7, 3), (4, 4), (300, 0)])
+@pytest.mark.parametrize("cus,team_size", [(6, 0), (7, 3), (4, 4), (200, 0)])
 def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
     """Fewer teams than pairs (pairs are handed out dynamically: option team_cus caps the grid), teams of 1, 3 and 4 workgroups
     (ragged chunk / tile splits), more CUs claimed than pairs need."""
@@ -152,6 +152,28 @@ def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
     got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
     assert got["team"] == 2 and got["pk"][1] == 0
     assert_same_batch(ref, got)
+
+
+def test_team_cus_above_the_device_is_refused_and_persistent_rearms(hip, monkeypatch):
+    """Option team_cus is clamped by refusal (a grid larger than the device cannot be co-resident and would only time out); and
+    set_option("persistent", 1) re-arms a context whose team launch once gave up (persistent_failed is sticky otherwise)."""
+    rows, cols, levels, n = 120, 160, 3, 9
+    b = synth.make_batch(rows, cols, n, first_index=31)
+    ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, descriptor="bitplanes", loss="tukey", levels=levels), n_frames=2 * n, n_pairs=n)
+    with pytest.raises(capi.BpvoError):
+        ctx.set_option("team_cus", 100000)
+    assert ctx.get_option("team_cus") <= 1024
+    ctx.set_option("team_size", 4)
+    ctx.set_option("persist_timeout_ticks", 1)
+    ctx.batch_run(b["images"], b["disparities"])
+    assert ctx.persistent_counts()[1] == 1            # gave up at the first barrier, ran on the chain
+    ctx.set_option("persist_timeout_ticks", 50000000)
+    ctx.set_option("persistent", 1)
+    assert ctx.persistent_counts()[1] == 0
+    before = ctx.team_counts()
+    ctx.batch_run(b["images"], b["disparities"])
+    assert ctx.persistent_counts()[1] == 0 and ctx.team_counts() > before
+    ctx.close()
 
 
 def test_team_kernel_gives_up_cleanly(hip, monkeypatch):
