@@ -21,7 +21,7 @@ STATUS_PARAMETER_TOL, STATUS_FUNCTION_TOL, STATUS_GRADIENT_TOL, STATUS_MAX_ITERA
 KF_LARGE_TRANSLATION, KF_LARGE_ROTATION, KF_SMALL_FRAC_GOOD, KF_NO_KEYFRAMING, KF_FIRST_FRAME = range(0x40, 0x45)
 MAX_LEVELS = 8
 TRACE_FLOATS = 68
-STEREO_BM, STEREO_SGM = 0, 1
+STEREO_BM, STEREO_SGM, STEREO_SGBM = 0, 1, 2
 
 
 class Params(C.Structure):
@@ -61,7 +61,10 @@ class StereoParams(C.Structure):
                 # StereoAlgorithm: 0 block matching, 1 SgmStereo (utils/sgm.h:33-46) with the fields below
                 ("algorithm", C.c_int), ("sobelCapValue", C.c_int), ("censusRadius", C.c_int), ("windowRadius", C.c_int),
                 ("smoothnessPenaltySmall", C.c_int), ("smoothnessPenaltyLarge", C.c_int), ("consistencyThreshold", C.c_int), ("reserved_", C.c_int),
-                ("disparityFactor", C.c_double), ("censusWeightFactor", C.c_double)]
+                ("disparityFactor", C.c_double), ("censusWeightFactor", C.c_double),
+                # StereoAlgorithm 2: cv::StereoSGBM (OpenCV 2.4) — its fields; it also reads minDisparity, numberOfDisparities, SADWindowSize,
+                # preFilterCap, uniquenessRatio above
+                ("P1", C.c_int), ("P2", C.c_int), ("disp12MaxDiff", C.c_int), ("speckleWindowSize", C.c_int), ("speckleRange", C.c_int), ("fullDP", C.c_int)]
 
 
 class KernelStat(C.Structure):
@@ -308,6 +311,14 @@ class Context:
         sp = StereoParams()
         self.b.fn("default_stereo_params", None)(C.byref(sp))
         sp.numberOfDisparities = int(ndisp)
+        return sp
+
+    def sgbm_params_from_config(self, minDisparity, numberOfDisparities, SADWindowSize=3, P1=0, P2=0, uniquenessRatio=0, speckleWindowSize=0,
+                                speckleRange=0, fullDP=0):
+        """bpvo_hip_stereo_params_sgbm_from_config: the struct the reference's StereoSGBM constructor call builds from the config KEYS."""
+        sp = StereoParams()
+        self.b.fn("stereo_params_sgbm_from_config", None)(C.byref(sp), int(minDisparity), int(numberOfDisparities), int(SADWindowSize), int(P1), int(P2),
+                                                          int(uniquenessRatio), int(speckleWindowSize), int(speckleRange), int(fullDP))
         return sp
 
     def stereo_bm(self, left, right, sp):

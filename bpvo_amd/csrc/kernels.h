@@ -81,6 +81,22 @@ struct SgmLaunch {
 };
 size_t sgm_scratch_bytes(int rows, int cols, int ndisp);
 bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g);   // false: disparity range outside what the kernels serve (multiple of 16, <= 256)
+// filterSpeckles on a u16 map whose invalid value is 0 (kernels_sgm.hip's union-find kernels): 4-connected regions (neighbours both non-zero,
+// |difference| <= max_diff) of at most max_size pixels are zeroed; lab / size: rows * cols ints each
+void launch_speckle_filter_u16(hipStream_t s, uint16_t* img, int* lab, int* size, int rows, int cols, int max_diff, int max_size);
+
+// semi-global block matching (kernels_sgbm.hip): cv::StereoSGBM of OpenCV 2.4, single-pass mode, + medianBlur(3) + filterSpeckles + / 16
+struct SgbmLaunch {
+  const uint8_t* left; const uint8_t* right;   // [nframes][rows*cols] u8 (device)
+  float* disp;                                 // [nframes][rows*cols] f32 (device)
+  void* scratch;                               // sgbm_scratch_bytes(rows, cols, min_disp, ndisp) bytes, shared by the frames
+  int rows, cols, nframes;
+  // the cv::StereoSGBM fields (their "<= 0 means" defaults are applied by the launcher like computeDisparitySGBM does)
+  int min_disp, ndisp, sad_window, P1, P2, disp12_max_diff, pre_filter_cap, uniqueness_ratio, speckle_window, speckle_range, full_dp;
+};
+size_t sgbm_scratch_bytes(int rows, int cols, int min_disp, int ndisp);
+bool sgbm_serves(const SgbmLaunch& g, const char** why);      // false + the reason: what the device path does not take
+bool launch_stereo_sgbm(hipStream_t s, const SgbmLaunch& g);
 
 // Gauss-Newton stage (batched over workspaces / pairs)
 // Compacted list of the workspaces of a launch that are still iterating (estimate loops).  The host rebuilds it (on the

@@ -524,6 +524,16 @@ __global__ __launch_bounds__(256) void sgm_lr_check_kernel(const uint16_t* __res
 
 }  // namespace
 
+void launch_speckle_filter_u16(hipStream_t s, uint16_t* img, int* lab, int* size, int rows, int cols, int max_diff, int max_size)
+{
+  const size_t npix = (size_t) rows * cols;
+  const unsigned nb = (unsigned) ((npix + 255) / 256);
+  hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, img, lab, size, rows, cols, max_diff);
+  hipLaunchKernelGGL(sgm_cc_merge_kernel, dim3(nb), dim3(256), 0, s, img, lab, rows, cols, max_diff);
+  hipLaunchKernelGGL(sgm_cc_count_kernel, dim3(nb), dim3(256), 0, s, lab, size, (int) npix);
+  hipLaunchKernelGGL(sgm_cc_apply_kernel, dim3(nb), dim3(256), 0, s, img, lab, size, (int) npix, max_size);
+}
+
 size_t sgm_scratch_bytes(int rows, int cols, int D)
 {
   const size_t npix = (size_t) rows * cols, pitch = (size_t) cols + 15 - (cols - 1) % 16;
@@ -588,10 +598,7 @@ bool launch_stereo_sgm(hipStream_t s, const SgmLaunch& g)
         else hipLaunchKernelGGL(sgm_wta_kernel<4>, gw, dim3(256), 0, s, L4, disp, npix, D, g.disparity_factor);
       }
       // speckleFilter(100, 2 * factor) (utils/sgm.cc:898)
-      hipLaunchKernelGGL(sgm_cc_init_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, rows, cols, (int) (2 * g.disparity_factor));
-      hipLaunchKernelGGL(sgm_cc_merge_kernel, dim3(nb), dim3(256), 0, s, disp, lab, rows, cols, (int) (2 * g.disparity_factor));
-      hipLaunchKernelGGL(sgm_cc_count_kernel, dim3(nb), dim3(256), 0, s, lab, size, (int) npix);
-      hipLaunchKernelGGL(sgm_cc_apply_kernel, dim3(nb), dim3(256), 0, s, disp, lab, size, (int) npix, 100);
+      launch_speckle_filter_u16(s, disp, lab, size, rows, cols, (int) (2 * g.disparity_factor), 100);
     }
     hipLaunchKernelGGL(sgm_lr_check_kernel, dim3(nb), dim3(256), 0, s, disp_l, disp_r, g.disp + npix * f, rows, cols, g.disparity_factor, g.consistency_threshold);
   }

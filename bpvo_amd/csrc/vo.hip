@@ -89,7 +89,18 @@ static int stereo_check(bpvo_hip_ctx* c, const bpvo_hip_stereo_params* sp)
     if(sp->smoothnessPenaltyLarge > 4000) return fail(c, BPVO_ERR_UNSUPPORTED, "SGM: smoothnessPenaltyLarge <= 4000 on the device path");
     return BPVO_OK;
   }
-  if(sp->algorithm != BPVO_STEREO_BLOCK_MATCHING) return fail(c, BPVO_ERR_UNSUPPORTED, "StereoAlgorithm: BlockMatching and SGM are on the device path (SGBM is OpenCV's, RSGM is not built)");
+  if(sp->algorithm == BPVO_STEREO_SGBM) {
+    if(sp->numberOfDisparities <= 0 || sp->numberOfDisparities % 16) return fail(c, BPVO_ERR_INVALID_ARG, "numberOfDisparities must be a positive multiple of 16");   // CV_Assert(D % 16 == 0)
+    SgbmLaunch g = {};
+    g.rows = c->rows; g.cols = c->cols;
+    g.min_disp = sp->minDisparity; g.ndisp = sp->numberOfDisparities; g.sad_window = sp->SADWindowSize; g.P1 = sp->P1; g.P2 = sp->P2;
+    g.disp12_max_diff = sp->disp12MaxDiff; g.pre_filter_cap = sp->preFilterCap; g.uniqueness_ratio = sp->uniquenessRatio;
+    g.speckle_window = sp->speckleWindowSize; g.speckle_range = sp->speckleRange; g.full_dp = sp->fullDP;
+    const char* why = nullptr;
+    if(!sgbm_serves(g, &why)) return fail(c, BPVO_ERR_UNSUPPORTED, why);
+    return BPVO_OK;
+  }
+  if(sp->algorithm != BPVO_STEREO_BLOCK_MATCHING) return fail(c, BPVO_ERR_UNSUPPORTED, "StereoAlgorithm: BlockMatching, SGM and SGBM are on the device path (RSGM is GPL-gated in the reference and not built)");
   if(sp->preFilterCap < 1 || sp->preFilterCap > 63) return fail(c, BPVO_ERR_INVALID_ARG, "preFilterCap must be within 1..63");
   if(sp->SADWindowSize < 5 || sp->SADWindowSize > 255 || sp->SADWindowSize % 2 == 0 || sp->SADWindowSize >= std::min(c->cols, c->rows))
     return fail(c, BPVO_ERR_INVALID_ARG, "SADWindowSize must be odd, be within 5..255 and be not larger than image width or height");
@@ -150,6 +161,26 @@ static int stereo_run(bpvo_hip_ctx* c, int count, const uint8_t* left, const uin
     if(d_left) *d_left = dl;
     return BPVO_OK;
   }
+  if(sp->algorithm == BPVO_STEREO_SGBM) {
+    const size_t need = sgbm_scratch_bytes(c->rows, c->cols, sp->minDisparity, sp->numberOfDisparities);
+    if(need > c->st_sgm_bytes) {
+      HIP_CK(c, hipStreamSynchronize(c->stream));
+      (void) hipFree(c->st_sgm);
+      c->st_sgm = nullptr; c->st_sgm_bytes = 0;
+      HIP_CK(c, hipMalloc(&c->st_sgm, need));
+      c->st_sgm_bytes = need;
+    }
+    SgbmLaunch g = {};
+    g.left = dl; g.right = dr; g.disp = c->st_disp; g.scratch = c->st_sgm;
+    g.rows = c->rows; g.cols = c->cols; g.nframes = count;
+    g.min_disp = sp->minDisparity; g.ndisp = sp->numberOfDisparities; g.sad_window = sp->SADWindowSize; g.P1 = sp->P1; g.P2 = sp->P2;
+    g.disp12_max_diff = sp->disp12MaxDiff; g.pre_filter_cap = sp->preFilterCap; g.uniqueness_ratio = sp->uniquenessRatio;
+    g.speckle_window = sp->speckleWindowSize; g.speckle_range = sp->speckleRange; g.full_dp = sp->fullDP;
+    if(!launch_stereo_sgbm(c->stream, g)) return fail(c, BPVO_ERR_UNSUPPORTED, "semi-global block matching: parameters not served by the kernels");
+    HIP_CK(c, hipGetLastError());
+    if(d_left) *d_left = dl;
+    return BPVO_OK;
+  }
   launch_stereo_prefilter(c->stream, dl, c->st_left_pre, c->rows, c->cols, sp->preFilterCap, count);
   launch_stereo_prefilter(c->stream, dr, c->st_right_pre, c->rows, c->cols, sp->preFilterCap, count);
   StereoLaunch g;
@@ -171,6 +202,23 @@ void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p)   // utils/stereo
   p->algorithm = BPVO_STEREO_BLOCK_MATCHING;
   p->sobelCapValue = 15; p->censusRadius = 2; p->windowRadius = 2; p->smoothnessPenaltySmall = 100; p->smoothnessPenaltyLarge = 1600;
   p->consistencyThreshold = 1; p->disparityFactor = 256.0; p->censusWeightFactor = 1.0 / 6.0;
+}
+void bpvo_hip_stereo_params_sgbm_from_config(bpvo_hip_stereo_params* p, int minDisparity, int numberOfDisparities, int SADWindowSize, int P1, int P2,
+                                             int uniquenessRatio, int speckleWindowSize, int speckleRange, int fullDP)
+{
+  // make_unique<cv::StereoSGBM>(minDisparity, numberOfDisparities, SADWindowSize, P1, P2, uniquenessRatio, speckleWindowSize, speckleRange,
+  // (bool) fullDP) against StereoSGBM(minDisparity, numDisparities, SADWindowSize, P1, P2, disp12MaxDiff, preFilterCap, uniquenessRatio,
+  // speckleWindowSize, speckleRange = 0, fullDP = false)  (utils/stereo_algorithm.cc:30-39)
+  bpvo_hip_default_stereo_params(p);
+  p->algorithm = BPVO_STEREO_SGBM;
+  p->minDisparity = minDisparity; p->numberOfDisparities = numberOfDisparities; p->SADWindowSize = SADWindowSize; p->P1 = P1; p->P2 = P2;
+  p->disp12MaxDiff = uniquenessRatio;
+  p->preFilterCap = speckleWindowSize;
+  p->uniquenessRatio = speckleRange;
+  p->speckleWindowSize = fullDP ? 1 : 0;
+  p->speckleRange = 0;
+  p->fullDP = 0;
+  p->textureThreshold = 0;
 }
 int bpvo_hip_stereo_bm(bpvo_hip_ctx* c, int count, const uint8_t* left, const uint8_t* right, int on_device, const bpvo_hip_stereo_params* sp,
                        float* disparity, int disparity_on_device)

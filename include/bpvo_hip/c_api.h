@@ -260,7 +260,7 @@ int bpvo_hip_batch_copy_records_device(bpvo_hip_ctx* ctx, float* d_dst, int n_pa
  * linear addressing, clamped at the end of the image; and for minDisparity > 0 the original's column loop runs past the end of the
  * row (its results there depend on the next row's bytes) — here and in the oracle that overrun is CUT at the last column, not
  * reproduced. */
-enum { BPVO_STEREO_BLOCK_MATCHING = 0, BPVO_STEREO_SGM = 1 };
+enum { BPVO_STEREO_BLOCK_MATCHING = 0, BPVO_STEREO_SGM = 1, BPVO_STEREO_SGBM = 2 };
 typedef struct bpvo_hip_stereo_params {
   int preFilterCap;          /* 31 */
   int SADWindowSize;         /* 15; odd, 5..21 on the device path */
@@ -283,8 +283,30 @@ typedef struct bpvo_hip_stereo_params {
   int    reserved_;
   double disparityFactor;          /* 256.0 */
   double censusWeightFactor;       /* 1.0 / 6.0 */
+  /* BPVO_STEREO_SGBM — `StereoAlgorithm = SGBM | SemiGlobalBlockMatching` (utils/stereo_algorithm.cc:25-40, run :113-121; selected by
+   * conf/kitti_seq_0.cfg:6): cv::StereoSGBM of OpenCV 2.4 + its medianBlur(3) + filterSpeckles + convertTo(CV_32F, 1/16).  These are the
+   * FIELDS OF cv::StereoSGBM; it also reads minDisparity, numberOfDisparities, SADWindowSize, preFilterCap and uniquenessRatio above.
+   * The reference's constructor call passes nine positional arguments to a constructor of eleven, so its config keys land one slot off
+   * (uniquenessRatio -> disp12MaxDiff, speckleWindowSize -> preFilterCap, speckleRange -> uniquenessRatio, (bool) fullDP -> speckleWindowSize):
+   * bpvo_hip_stereo_params_sgbm_from_config fills the struct from the KEYS exactly like that call.  `<= 0 means` rules of
+   * computeDisparitySGBM apply (SADWindowSize <= 0: 5, P1 <= 0: 2, P2 <= 0: 5 then max(P2, P1 + 1), disp12MaxDiff <= 0: 1, uniquenessRatio < 0:
+   * 10, preFilterCap: max(cap, 15) | 1).  Invalid pixels carry minDisparity - 1.  OpenCV's source is absent from the reference tree:
+   * restated, parity unpinned; the GPU tests hold the kernels to that restatement bit for bit.  Device path: single-pass mode (fullDP = 0: the only mode the
+   * reference's call can reach), minDisparity >= 0, numberOfDisparities <= 256, window and penalties that keep the int16 buffers of the
+   * original from wrapping (BPVO_ERR_UNSUPPORTED names the limit otherwise). */
+  int    P1;                       /* 0 */
+  int    P2;                       /* 0 */
+  int    disp12MaxDiff;            /* 0 */
+  int    speckleWindowSize;        /* 0 */
+  int    speckleRange;             /* 0 */
+  int    fullDP;                   /* 0 */
 } bpvo_hip_stereo_params;
 void bpvo_hip_default_stereo_params(bpvo_hip_stereo_params* p);
+/* StereoAlgorithm::Impl's SGBM branch (utils/stereo_algorithm.cc:27-40): the struct the reference's constructor call produces from the config
+ * KEYS minDisparity, numberOfDisparities, SADWindowSize (3), P1 (0), P2 (0), uniquenessRatio (0), speckleWindowSize (0), speckleRange (0),
+ * fullDP (0) — defaults in brackets; algorithm = BPVO_STEREO_SGBM */
+void bpvo_hip_stereo_params_sgbm_from_config(bpvo_hip_stereo_params* p, int minDisparity, int numberOfDisparities, int SADWindowSize, int P1, int P2,
+                                             int uniquenessRatio, int speckleWindowSize, int speckleRange, int fullDP);
 /* StereoAlgorithm::run for `count` rectified pairs of the ctx's image size ([count][rows*cols] u8 each, host or device) ->
  * f32 disparities [count][rows*cols] (host or device); sp->algorithm selects the matcher (the entry point keeps its name) */
 int bpvo_hip_stereo_bm(bpvo_hip_ctx* ctx, int count, const uint8_t* left, const uint8_t* right, int on_device,

@@ -272,6 +272,17 @@ struct StereoParameters : bpvo_hip_stereo_params {
     p.algorithm = BPVO_STEREO_SGM;
     return p;
   }
+  /* `StereoAlgorithm = SGBM` (utils/stereo_algorithm.cc:27-40; conf/kitti_seq_0.cfg:6): cv::StereoSGBM as the reference's constructor call
+   * builds it from the config KEYS (defaults of the cf.get calls) — nine positional arguments into a constructor of eleven, the keys land one
+   * slot off (include/bpvo_hip/c_api.h).  Set the cv::StereoSGBM fields of the struct directly for the matcher as OpenCV documents it. */
+  static StereoParameters SemiGlobalBlockMatching(int minDisparity, int numberOfDisparities, int SADWindowSize = 3, int P1 = 0, int P2 = 0,
+                                                  int uniquenessRatio = 0, int speckleWindowSize = 0, int speckleRange = 0, int fullDP = 0)
+  {
+    StereoParameters p(numberOfDisparities);
+    bpvo_hip_stereo_params_sgbm_from_config(&p, minDisparity, numberOfDisparities, SADWindowSize, P1, P2, uniquenessRatio, speckleWindowSize,
+                                            speckleRange, fullDP);
+    return p;
+  }
 };
 
 /* bpvo::VisualOdometry (bpvo/vo.h:31-105).  The keyframe state machine of bpvo/vo.cc:125-224 runs inside the library

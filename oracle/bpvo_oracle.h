@@ -98,6 +98,7 @@ void bpvo_orc_twist_to_matrix(const float p[6], float T[16]);
 int bpvo_orc_stereo_bm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int params[6], float* dmap);
 int bpvo_orc_stereo_prefilter(const uint8_t* src, int rows, int cols, int cap, uint8_t* dst);
 int bpvo_orc_stereo_sgm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int iparams[7], const double dparams[2], float* dmap);
+int bpvo_orc_stereo_sgbm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int params[11], float* dmap);
 int bpvo_orc_compute_weights(int loss, const float* r, const uint16_t* valid, size_t n, float sigma, float* w);
 
 #ifdef __cplusplus

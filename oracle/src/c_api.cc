@@ -460,6 +460,16 @@ int bpvo_orc_stereo_sgm(const uint8_t* left, const uint8_t* right, int rows, int
   sp.disparityFactor = dparams[0]; sp.censusWeightFactor = dparams[1];
   return stereoSGM(left, right, rows, cols, sp, dmap) ? 0 : 1;
 }
+// StereoAlgorithm::run (SemiGlobalBlockMatching): params = the cv::StereoSGBM fields {minDisparity, numberOfDisparities, SADWindowSize, P1, P2,
+// disp12MaxDiff, preFilterCap, uniquenessRatio, speckleWindowSize, speckleRange, fullDP}; 1 = arguments outside what is restated
+int bpvo_orc_stereo_sgbm(const uint8_t* left, const uint8_t* right, int rows, int cols, const int params[11], float* dmap)
+{
+  SgbmParams sp;
+  sp.minDisparity = params[0]; sp.numberOfDisparities = params[1]; sp.SADWindowSize = params[2]; sp.P1 = params[3]; sp.P2 = params[4];
+  sp.disp12MaxDiff = params[5]; sp.preFilterCap = params[6]; sp.uniquenessRatio = params[7]; sp.speckleWindowSize = params[8];
+  sp.speckleRange = params[9]; sp.fullDP = params[10];
+  return stereoSGBM(left, right, rows, cols, sp, dmap) ? 0 : 1;
+}
 // MEstimator::ComputeWeights on raw arrays (r [n], valid [n] u16 -> w [n]); n a multiple of 16 runs the SIMD body only
 int bpvo_orc_compute_weights(int loss, const float* r, const uint16_t* valid, size_t n, float sigma, float* w)
 {

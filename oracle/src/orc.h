@@ -98,6 +98,13 @@ struct SgmParams {
   double disparityFactor = 256.0, censusWeightFactor = 1.0 / 6.0;
 };
 bool stereoSGM(const uint8_t* left, const uint8_t* right, int rows, int cols, const SgmParams& sp, float* dmap);
+// sgbm.cc — cv::StereoSGBM of OpenCV 2.4 (the fields of the class; the reference's positional constructor call that fills them:
+// utils/stereo_algorithm.cc:27-40, Q22 in sgbm.cc)
+struct SgbmParams {
+  int minDisparity = 0, numberOfDisparities = 64, SADWindowSize = 3, P1 = 0, P2 = 0, disp12MaxDiff = 0, preFilterCap = 0, uniquenessRatio = 0,
+      speckleWindowSize = 0, speckleRange = 0, fullDP = 0;
+};
+bool stereoSGBM(const uint8_t* left, const uint8_t* right, int rows, int cols, const SgbmParams& sp, float* dmap);
 
 // ---- descriptor (dense_descriptor.*, intensity_descriptor.cc, bitplanes_descriptor.cc)
 struct Descriptor {

@@ -230,6 +230,37 @@ def test_tsukuba_stereo_cfg_sequence_with_its_block_matcher(hip, orc):
     a.close(); c.close()
 
 
+def orc_sgbm(orc, left, right, prm):
+    out = np.empty(left.shape, np.float32)
+    rc = orc.fn("stereo_sgbm")(left.ctypes.data_as(C.c_void_p), right.ctypes.data_as(C.c_void_p), left.shape[0], left.shape[1], (C.c_int * 11)(*prm), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out
+
+
+def test_kitti_seq_0_cfg_sequence_with_its_sgbm_front_end(hip, orc):
+    """conf/kitti_seq_0.cfg at 1241x376: StereoAlgorithm = SemiGlobalBlockMatching (minDisparity 0, 128 disparities, SADWindowSize 7, fullDP 0,
+    everything else the defaults of the cf.get calls, utils/stereo_algorithm.cc:30-39), Intensity, SIX pyramid levels, 400 iterations, Tukey,
+    parameterTolerance 5e-7, minSaliency 2.5, goodPointThreshold 0.85, minValidDisparity 1."""
+    rows, cols, n = 376, 1241, 5
+    K, b, frames = stereo_sequence(rows, cols, n, seed=53, z0=8.0, step_rot=0.004, step_trans=0.12)
+    CONFIGS["kitti_seq_0"] = dict(levels=6, maxTestLevel=0, loss="tukey", maxIterations=400, minTranslationMagToKeyFrame=0.5, minRotationMagToKeyFrame=5.0,
+                                  parameterTolerance=5e-7, functionTolerance=1e-6, goodPointThreshold=0.85, maxFractionOfGoodPointsToKeyFrame=0.6,
+                                  minSaliency=2.5, relaxTolerancesForCoarseLevels=0, minValidDisparity=1.0)
+    ph, _ = params_of(hip, "kitti_seq_0")
+    po, _ = params_of(orc, "kitti_seq_0")
+    a = hip.create(K, b, rows, cols, ph, n_frames=3, n_pairs=1)
+    c = orc.create(K, b, rows, cols, po, n_frames=3, n_pairs=1)
+    assert a.L == c.L == 6
+    sp = a.sgbm_params_from_config(0, 128, SADWindowSize=7, fullDP=0)
+    # StereoSGBM(0, 128, 7, P1 0, P2 0, disp12MaxDiff 0, preFilterCap 0, uniquenessRatio 0, speckleWindowSize 0, speckleRange 0, fullDP false)
+    prm = (0, 128, 7, 0, 0, 0, 0, 0, 0, 0, 0)
+    oh = [a.add_frame_stereo(left, right, sp) for left, right, _ in frames]
+    oo = [c.add_frame(left, orc_sgbm(orc, left, right, prm)) for left, right, _ in frames]
+    worst = compare_sequences("kitti_seq_0", K, oh, oo, [a.vo_num_points_at_level(l) for l in range(6)], [c.vo_num_points_at_level(l) for l in range(6)])
+    note(f"conf/kitti_seq_0.cfg 1241x376 x {n} frames (SGBM front-end, 6 levels): key frames {[int(r['isKeyFrame']) for r in oh]}, worst pose difference {worst[0]:.2e} rad / {worst[1]:.2e} m")
+    a.close(); c.close()
+
+
 EVAL_DESCRIPTORS = {"Intensity": "intensity", "IntensityAndGradient": "gradient", "DescriptorFields": "fields1", "Latch": "latch",
                     "Laplacian": "laplacian", "CentralDifference": "centraldiff", "BitPlanes": "bitplanes"}      # apps/eval_descriptors.cc:136-145, types.cc:146-164
 

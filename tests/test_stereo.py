@@ -426,3 +426,247 @@ def test_hip_sgm_batch_errors_and_add_frame(hip, orc):
         ra = a.add_frame_stereo(left, right, sp)
         rc = c.add_frame(left, orc_sgm(orc, left, right, ndisp=32))
         assert np.array_equal(ra["pose"].view(np.uint32), rc["pose"].view(np.uint32)) and ra["isKeyFrame"] == rc["isKeyFrame"] and ra["stats"] == rc["stats"]
+
+
+# ---- semi-global block matching: cv::StereoSGBM of OpenCV 2.4 as the reference constructs it (utils/stereo_algorithm.cc:27-40), BPVO_STEREO_SGBM ----
+SGBM_DEFAULT = dict(mind=0, ndisp=64, wsz=3, p1=0, p2=0, d12=0, cap=0, uniq=0, spw=0, spr=0, fulldp=0)      # StereoSGBM(minD, nD, SADWindowSize, 0, 0, 0, 0, 0, 0, 0, false)
+
+
+def orc_sgbm(orc, left, right, **kw):
+    q = dict(SGBM_DEFAULT, **kw)
+    out = np.empty(left.shape, np.float32)
+    prm = (C.c_int * 11)(q["mind"], q["ndisp"], q["wsz"], q["p1"], q["p2"], q["d12"], q["cap"], q["uniq"], q["spw"], q["spr"], q["fulldp"])
+    rc = orc.fn("stereo_sgbm")(np.ascontiguousarray(left).ctypes.data_as(C.c_void_p), np.ascontiguousarray(right).ctypes.data_as(C.c_void_p),
+                               left.shape[0], left.shape[1], prm, out.ctypes.data_as(C.c_void_p))
+    return out if rc == 0 else None
+
+
+def np_sgbm(Limg, Rimg, mind=0, ndisp=64, wsz=3, p1=0, p2=0, d12=0, cap=0, uniq=0, spw=0, spr=0, fulldp=0):
+    """cv::StereoSGBM (OpenCV 2.4, single-pass mode) + medianBlur(3) + filterSpeckles + / 16, evaluated from its definition with whole-array
+    operations: Birchfield-Tomasi pixel costs on the clipped x-Sobel plane and (a quarter of) the raw plane, clamped SAD window with the two
+    rows / columns the original never refreshes, five path recurrences (each one a plain scan over all its lines at once), sum, winner takes
+    all, uniqueness, right-view voting, sub-pixel parabola, left-right check."""
+    Li, Ri = Limg.astype(np.int64), Rimg.astype(np.int64)
+    H, W = Li.shape
+    minD, maxD, D = mind, mind + ndisp, ndisp
+    SW = wsz if wsz > 0 else 5
+    ft = max(cap, 15) | 1
+    uniq = uniq if uniq >= 0 else 10
+    d12 = d12 if d12 > 0 else 1
+    P1 = p1 if p1 > 0 else 2
+    P2 = max(p2 if p2 > 0 else 5, P1 + 1)
+    minX1, maxX1 = max(maxD, 0), W + min(minD, 0)
+    W1 = maxX1 - minX1
+    INV = (minD - 1) * 16
+    out = np.full((H, W), INV, np.int64)
+    if W1 > 0:
+        def planes(I):
+            up, dn = I[np.maximum(np.arange(H) - 1, 0)], I[np.minimum(np.arange(H) + 1, H - 1)]
+            sob = np.full((H, W), ft, np.int64)
+            g = lambda A: A[:, 2:] - A[:, :-2]
+            sob[:, 1:-1] = np.clip(2 * g(I) + g(up) + g(dn), -ft, ft) + ft
+            raw = I.copy(); raw[:, 0] = ft; raw[:, -1] = ft
+            return sob, raw
+
+        def interval(P):      # min / max over the half-sample neighbourhood, the image edge replicated
+            l = np.concatenate([P[:, :1], (P[:, 1:] + P[:, :-1]) // 2], axis=1)
+            r = np.concatenate([(P[:, :-1] + P[:, 1:]) // 2, P[:, -1:]], axis=1)
+            return np.minimum(np.minimum(l, r), P), np.maximum(np.maximum(l, r), P)
+
+        pix = np.zeros((H, W1, D), np.int64)
+        xs = np.arange(minX1, maxX1)
+        for k, (pl, pr) in enumerate(zip(planes(Li), planes(Ri))):
+            u0, u1 = interval(pl)
+            v0, v1 = interval(pr)
+            for d in range(D):
+                xr = xs - (d + minD)
+                u, v = pl[:, xs], pr[:, xr]
+                c0 = np.maximum(np.maximum(0, u - v1[:, xr]), v0[:, xr] - u)
+                c1 = np.maximum(np.maximum(0, v - u1[:, xs]), u0[:, xs] - v)
+                pix[:, :, d] += np.minimum(c0, c1) >> (0 if k == 0 else 2)
+        s2 = SW // 2
+        xi = np.clip(np.arange(W1)[:, None] + np.arange(-s2, s2 + 1)[None, :], 0, W1 - 1)
+        hs = pix[:, xi, :].sum(axis=2)
+        yi = np.clip(np.arange(H)[:, None] + np.arange(-s2, s2 + 1)[None, :], 0, H - 1)
+        Cv = hs[yi].sum(axis=1)
+        Cv[max(H - s2, 1):] = Cv[max(H - s2, 1) - 1]             # the rows whose window would pass the last image row keep the last cost computed
+        Cv[1:, 0, :] = Cv[0, 0, :]                               # the first cost column is only ever computed for row 0
+        Cv = ((Cv + 32768) % 65536) - 32768                      # int16 buffers
+
+        def recur(Lp, mp, Cc):
+            big = np.full(Lp.shape[:-1] + (1,), 1 << 20, np.int64)
+            lm = np.concatenate([big, Lp[..., :-1]], axis=-1) + P1
+            lp = np.concatenate([Lp[..., 1:], big], axis=-1) + P1
+            delta = (mp + P2)[..., None]
+            Lv = Cc + np.minimum(np.minimum(Lp, lm), np.minimum(lp, delta)) - delta
+            return ((Lv + 32768) % 65536) - 32768, Lv.min(axis=-1)
+
+        def horizontal(step):
+            Lo = np.zeros((H, W1, D), np.int64)
+            Lp, mp = np.zeros((H, D), np.int64), np.zeros(H, np.int64)
+            for x in (range(W1) if step > 0 else range(W1 - 1, -1, -1)):
+                Lp, mp = recur(Lp, mp, Cv[:, x, :])
+                Lo[:, x, :] = Lp
+            return Lo
+
+        def from_above(dx):      # predecessor (x + dx, y - 1); outside the buffer: L = 0, min L = 0
+            Lo = np.zeros((H, W1, D), np.int64)
+            Lp, mp = np.zeros((W1, D), np.int64), np.zeros(W1, np.int64)
+            for y in range(H):
+                if dx:
+                    Ls, ms = np.zeros_like(Lp), np.zeros_like(mp)
+                    if dx < 0: Ls[1:], ms[1:] = Lp[:-1], mp[:-1]
+                    else: Ls[:-1], ms[:-1] = Lp[1:], mp[1:]
+                else:
+                    Ls, ms = Lp, mp
+                Lp, mp = recur(Ls, ms, Cv[y])
+                Lo[y] = Lp
+            return Lo
+
+        S = np.clip(horizontal(+1) + from_above(-1) + from_above(0) + from_above(+1), -32768, 32767)
+        S = np.clip(S + horizontal(-1), -32768, 32767)
+        best = S.argmin(axis=2)
+        minS = S.min(axis=2)
+        dd = np.arange(D)[None, None, :]
+        unique = ~((S * (100 - uniq) < (minS * 100)[..., None]) & (np.abs(best[..., None] - dd) > 1)).any(axis=2)
+        cdiv = lambda a, b: np.sign(a) * (np.abs(a) // b)        # C integer division (b > 0)
+        bm, bp = np.clip(best - 1, 0, D - 1), np.clip(best + 1, 0, D - 1)
+        Sm, Sp_, S0 = np.take_along_axis(S, bm[..., None], 2)[..., 0], np.take_along_axis(S, bp[..., None], 2)[..., 0], minS
+        den = np.maximum(Sm + Sp_ - 2 * S0, 1)
+        sub = np.where((best > 0) & (best < D - 1), best * 16 + cdiv((Sm - Sp_) * 16 + den, den * 2), best * 16) + minD * 16
+        for y in range(H):
+            d2, c2 = np.full(W, INV, np.int64), np.full(W, 32767, np.int64)
+            for x in range(W1 - 1, -1, -1):
+                if not unique[y, x]:
+                    continue
+                x2 = x + minX1 - best[y, x] - minD
+                if c2[x2] > minS[y, x]:
+                    c2[x2], d2[x2] = minS[y, x], best[y, x] + minD
+                out[y, x + minX1] = sub[y, x]
+            for x in range(minX1, maxX1):
+                v = out[y, x]
+                if v == INV:
+                    continue
+                lo, hi = v >> 4, (v + 15) >> 4
+                xa, xb = x - lo, x - hi
+                if 0 <= xa < W and d2[xa] >= minD and abs(d2[xa] - lo) > d12 and 0 <= xb < W and d2[xb] >= minD and abs(d2[xb] - hi) > d12:
+                    out[y, x] = INV
+    pad = np.pad(out, 1, mode="edge")
+    out = np.median(np.stack([pad[1 + dy: 1 + dy + H, 1 + dx: 1 + dx + W] for dy in (-1, 0, 1) for dx in (-1, 0, 1)]), axis=0).astype(np.int64)
+    if spw > 0:
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        idx = np.arange(H * W).reshape(H, W)
+        ok = out != INV
+        md = 16 * spr
+        eh = ok[:, :-1] & ok[:, 1:] & (np.abs(out[:, :-1] - out[:, 1:]) <= md)
+        ev = ok[:-1] & ok[1:] & (np.abs(out[:-1] - out[1:]) <= md)
+        a = np.concatenate([idx[:, :-1][eh], idx[:-1][ev]]); b = np.concatenate([idx[:, 1:][eh], idx[1:][ev]])
+        _, lab = connected_components(coo_matrix((np.ones(a.size), (a, b)), shape=(H * W, H * W)), directed=False)
+        size = np.bincount(lab)
+        out = np.where(ok & (size[lab].reshape(H, W) <= spw), INV, out)
+    return (out.astype(np.float32) * np.float32(1.0 / 16.0)).astype(np.float32)
+
+
+def _sgbm_pair(rows, cols, seed, z0=4.0):
+    d = synth.make_stereo_pair(rows, cols, seed, z0=z0)
+    rng = np.random.default_rng(seed)
+    left, right = d["left"].copy(), d["right"].copy()
+    right[: rows // 5] = rng.integers(0, 256, (rows // 5, cols), dtype=np.uint8)      # a band where nothing matches: uniqueness, left-right check
+    left[rows // 2: rows // 2 + 6, 20: 20 + cols // 4] = 100                         # a textureless patch
+    right[rows // 2: rows // 2 + 6, 20: 20 + cols // 4] = 100
+    return left, right, d
+
+
+@pytest.mark.parametrize("rows,cols,kw", [(40, 90, dict(ndisp=16, wsz=7)),                                        # conf/kitti_seq_0.cfg's shape: window 7, everything else 0
+                                          (33, 75, dict(ndisp=32, wsz=3, p1=8, p2=32, uniq=10, d12=1)),
+                                          (36, 96, dict(ndisp=16, wsz=5, p1=24, p2=96, cap=31, uniq=5, spw=20, spr=2)),
+                                          (30, 80, dict(ndisp=16, wsz=9, mind=3, p1=50, p2=200, uniq=15, d12=2, spw=1)),
+                                          (28, 70, dict(ndisp=16, wsz=0, uniq=-1, d12=-1, cap=63))])
+def test_sgbm_oracle_against_a_numpy_evaluation_of_the_definition(orc, rows, cols, kw):
+    left, right, _ = _sgbm_pair(rows, cols, 7)
+    got = orc_sgbm(orc, left, right, **kw)
+    want = np_sgbm(left, right, **kw)
+    assert got is not None and np.array_equal(got, want), (np.argwhere(got != want)[:8], got[got != want][:8], want[got != want][:8])
+    inv = (kw.get("mind", 0) - 1)
+    assert (got == inv).any() and (got > inv).mean() > 0.2
+
+
+def test_sgbm_recovers_the_disparity_of_a_plane_and_rejects_what_is_not_restated(orc):
+    rows, cols = 60, 200
+    d = synth.make_stereo_pair(rows, cols, 3, z0=4.0)
+    got = orc_sgbm(orc, d["left"], d["right"], ndisp=32, wsz=7, p1=8 * 49, p2=32 * 49, uniq=10)
+    ok = got >= 0
+    ok[:, :32] = False
+    assert ok.mean() > 0.5 and np.abs(got[ok] - d["disp"][ok]).mean() < 0.6
+    for bad in (dict(ndisp=24), dict(mind=-2), dict(fulldp=1), dict(ndisp=0)):
+        assert orc_sgbm(orc, d["left"], d["right"], **dict(dict(ndisp=32, wsz=7), **bad)) is None, bad
+
+
+def _hip_sgbm_params(ctx, **kw):
+    """the cv::StereoSGBM fields, set directly"""
+    q = dict(SGBM_DEFAULT, **kw)
+    sp = ctx.default_stereo_params(q["ndisp"])
+    sp.algorithm = capi.STEREO_SGBM
+    sp.minDisparity, sp.SADWindowSize, sp.P1, sp.P2, sp.disp12MaxDiff = q["mind"], q["wsz"], q["p1"], q["p2"], q["d12"]
+    sp.preFilterCap, sp.uniquenessRatio, sp.speckleWindowSize, sp.speckleRange, sp.fullDP = q["cap"], q["uniq"], q["spw"], q["spr"], q["fulldp"]
+    return sp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,kw", [(376, 1241, dict(ndisp=128, wsz=7)),                                   # conf/kitti_seq_0.cfg at KITTI size
+                                          (480, 640, dict(ndisp=64, wsz=7)),
+                                          (480, 640, dict(ndisp=64, wsz=5, p1=8 * 25, p2=32 * 25, uniq=10, d12=1, spw=100, spr=2, cap=63)),   # OpenCV's documented set-up
+                                          (121, 163, dict(ndisp=32, wsz=3, p1=8, p2=32, uniq=10, d12=1)),
+                                          (97, 203, dict(ndisp=48, wsz=9, mind=3, p1=50, p2=200, uniq=15, d12=2, spw=1)),
+                                          (64, 300, dict(ndisp=256, wsz=5, p1=10, p2=120, uniq=5)),
+                                          (50, 70, dict(ndisp=16, wsz=0, uniq=-1, d12=-1, cap=63)),
+                                          (40, 90, dict(ndisp=16, wsz=11, p1=3, p2=4)),
+                                          (33, 60, dict(ndisp=64, wsz=3))])                                      # no cost column: every pixel invalid
+def test_hip_sgbm_bit_exact(hip, orc, rows, cols, kw):
+    left, right, d = _sgbm_pair(rows, cols, 4, z0=8.0 if cols > 700 else 4.0)
+    p = hip.default_params(); p.numPyramidLevels = 2; p.verbosity = capi.VERB_SILENT
+    ctx = hip.create(d["K"], d["b"], rows, cols, p, n_frames=3, n_pairs=1)
+    got = ctx.stereo_bm(left, right, _hip_sgbm_params(ctx, **kw))
+    want = orc_sgbm(orc, left, right, **kw)
+    assert want is not None
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (np.argwhere(got != want)[:8], got[got != want][:8], want[got != want][:8], (got != want).sum())
+    inv = kw.get("mind", 0) - 1
+    if cols > kw["ndisp"] + kw.get("mind", 0) + 8:
+        cost_columns = (cols - kw["ndisp"] - kw.get("mind", 0)) / cols
+        assert (got == inv).any() and (got > inv).mean() > 0.2 * cost_columns
+    else:
+        assert (got == inv).all()
+
+
+@pytest.mark.gpu
+def test_hip_sgbm_reference_constructor_call_batch_errors_and_add_frame(hip, orc):
+    """The reference's own construction (utils/stereo_algorithm.cc:30-39): nine positional arguments into cv::StereoSGBM's eleven-argument
+    constructor — the config keys land one slot off.  bpvo_hip_stereo_params_sgbm_from_config reproduces it; batches; what the device
+    path refuses; addFrame fed by the matcher."""
+    rows, cols, n = 120, 200, 3
+    pairs = [synth.make_stereo_pair(rows, cols, k, z0=4.0) for k in range(n)]
+    L = np.stack([q["left"] for q in pairs]); R = np.stack([q["right"] for q in pairs])
+    p = hip.default_params(); p.numPyramidLevels = 2; p.verbosity = capi.VERB_SILENT
+    ctx = hip.create(pairs[0]["K"], pairs[0]["b"], rows, cols, p, n_frames=3, n_pairs=1)
+    # keys of a config: uniquenessRatio = 12 -> disp12MaxDiff, speckleWindowSize = 40 -> preFilterCap, speckleRange = 7 -> uniquenessRatio, fullDP = 1 -> speckleWindowSize 1
+    sp = ctx.sgbm_params_from_config(0, 32, SADWindowSize=5, P1=20, P2=90, uniquenessRatio=12, speckleWindowSize=40, speckleRange=7, fullDP=1)
+    assert (sp.algorithm, sp.disp12MaxDiff, sp.preFilterCap, sp.uniquenessRatio, sp.speckleWindowSize, sp.speckleRange, sp.fullDP) == (capi.STEREO_SGBM, 12, 40, 7, 1, 0, 0)
+    got = ctx.stereo_bm(L, R, sp)
+    for k in range(n):
+        assert np.array_equal(got[k], orc_sgbm(orc, L[k], R[k], ndisp=32, wsz=5, p1=20, p2=90, d12=12, cap=40, uniq=7, spw=1, spr=0)), k
+    # conf/kitti_seq_0.cfg: minDisparity 0, numberOfDisparities 128 (here 32), SADWindowSize 7, fullDP 0, nothing else
+    sp0 = ctx.sgbm_params_from_config(0, 32, SADWindowSize=7)
+    assert np.array_equal(ctx.stereo_bm(L[0], R[0], sp0), orc_sgbm(orc, L[0], R[0], ndisp=32, wsz=7))
+    for bad in (dict(ndisp=24), dict(mind=-1), dict(fulldp=1), dict(ndisp=512), dict(wsz=21), dict(wsz=7, p2=32000), dict(ndisp=0)):
+        with pytest.raises(capi.BpvoError):
+            ctx.stereo_bm(L[0], R[0], _hip_sgbm_params(ctx, **dict(dict(ndisp=32, wsz=7), **bad)))
+    seq = synth.make_stereo_sequence(240, 320, 4, index=9)
+    pp = hip.default_params(); pp.numPyramidLevels = 3; pp.verbosity = capi.VERB_SILENT; pp.descriptor = capi.DESC_BITPLANES
+    a = hip.create(seq["K"], seq["b"], 240, 320, pp, n_frames=3, n_pairs=1)
+    c = hip.create(seq["K"], seq["b"], 240, 320, pp, n_frames=3, n_pairs=1)
+    sps = a.sgbm_params_from_config(0, 32, SADWindowSize=7)
+    for left, right in seq["frames"]:
+        ra = a.add_frame_stereo(left, right, sps)
+        rc = c.add_frame(left, orc_sgbm(orc, left, right, ndisp=32, wsz=7))
+        assert np.array_equal(ra["pose"].view(np.uint32), rc["pose"].view(np.uint32)) and ra["isKeyFrame"] == rc["isKeyFrame"] and ra["stats"] == rc["stats"]
