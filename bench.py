@@ -225,6 +225,8 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
         ctx = hip.create(K, b, rows, cols, p, device=dev_index, n_frames=1, n_pairs=1)
         sp = ctx.default_stereo_params(ndisp)
         sp.algorithm = capi.STEREO_SGM if algorithm == "sgm" else capi.STEREO_BM
+        if algorithm == "sgbm":      # conf/kitti_seq_0.cfg: SemiGlobalBlockMatching, SADWindowSize 7, every other key at the default of its cf.get
+            sp = ctx.sgbm_params_from_config(0, ndisp, SADWindowSize=7)
         dl, dr = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)
         dd = torch.empty((n, rows, cols), dtype=torch.float32, device=dev)
         for _ in range(2):
@@ -236,7 +238,16 @@ def stereo_lines(hip, torch, dev, dev_index, stereo_in):
             ctx.stereo_bm_device(n, dl.data_ptr(), dr.data_ptr(), sp, dd.data_ptr())
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        if algorithm == "sgm":
+        if algorithm == "sgbm":
+            valid = float((dd[0] >= 0).float().mean().item())
+            width1 = cols - ndisp
+            vol = float(n) * rows * width1 * ndisp
+            # per (cost pixel, disparity): pixel cost 1 B written, read ~7 x by the row sums (L1 / L2) -> 2 B row sums written and read -> 2 B cost
+            # written, read by 5 path families that write 2 B each, read again by the selection: 1 + 2 + 2 + 2 + 2 + 5 * (2 + 2) + 5 * 2 = 39 B
+            out[name] = {"frames": n, "frames_per_s": n / dt, "ms_per_frame": 1e3 * dt / n, "pixel_disparities_per_s": vol / dt,
+                         "valid_fraction_frame0": valid, "disparities": ndisp, "SADWindowSize": 7, "accounted_GBps": 39 * vol / dt / 1e9,
+                         "bound": "per-kernel HBM traffic and stall fractions: profiles/r05_stereo_pmc.txt (rocprofv3 --pmc over scripts/stereo_bench.py)"}
+        elif algorithm == "sgm":
             valid = float((dd[0] > 0).float().mean().item())
             # per frame: pixel cost (1 B) written + read 25 x by the box sum (L1 / L2), two 2-byte cost volumes written and read by 4 path
             # passes each together with the 2-byte sum volume (read + write): ~ (1 + 2 + 2 + 2 * 4 * (2 + 2 + 2) + 2 * 2) B per (pixel, disparity)
@@ -390,7 +401,9 @@ def main():
         seq640["stereo"] = {"batches": {"block matching 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, st_k, "bm"),
                                         "block matching 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "bm"),
                                         "SGM (SgmStereo, conf/kitti_eval.cfg) 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, st_k, "sgm"),
-                                        "SGM 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "sgm")},
+                                        "SGM 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "sgm"),
+                                        "SGBM (cv::StereoSGBM as conf/kitti_seq_0.cfg builds it) 1241x376, 128 disparities, batch of 16 pairs": (376, 1241, 128, st_k, "sgbm"),
+                                        "SGBM 640x480, 64 disparities, batch of 16 pairs": (480, 640, 64, st_t, "sgbm")},
                             "sequence": (480, 640, 64, st_seq["frames"], st_seq["K"], st_seq["b"])}
 
     import torch

@@ -13,9 +13,9 @@
 //   sgbm_path          one scanline per wavefront — rows both ways, columns down, both down-going diagonals — lanes = pairs of
 //                      disparities in packed int16, neighbours and the wave minimum by DPP; a path starts from L = 0, min L = 0
 //                      (the zeroed borders of the original's buffers)                                                    per line
-//   sgbm_select        one workgroup per image row: S = sat(sat(L0 + L1 + L2 + L3) + L4), first minimum, uniqueness, sub-pixel parabola
-//                      (C division), the right view's votes (LDS atomics on (cost, column) keys: smallest cost, then the column the
-//                      original meets first), left-right check                                                           per row
+//   sgbm_wta / sgbm_lr a wavefront per cost pixel: S = sat(sat(L0 + L1 + L2 + L3) + L4), first minimum, uniqueness, sub-pixel parabola
+//                      (C division), the right view's votes (atomics on (cost, column) keys: smallest cost, then the column the
+//                      original meets first); then the left-right check per pixel                                        per pixel
 //   sgbm_median3       3 x 3 median of the int16 map, replicated border; filterSpeckles by the union-find kernels of kernels_sgm.hip
 // Bounds: the scanline kernel is a chain of `width1` (or `height`) dependent steps per wavefront; everything else streams the volumes.
 #include <algorithm>
@@ -266,92 +266,99 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(const int16_t* __restrict
   }
 }
 
-// ---- one workgroup per image row: sum, winner takes all, uniqueness, sub-pixel, right-view votes, left-right check -> int16 map
+// ---- selection in two launches that fill the chip.
+// sgbm_wta: a WAVEFRONT per cost pixel — S = sat(sat(L0 + L1 + L2 + L3) + L4) (the original's order), first minimum, uniqueness, sub-pixel
+// parabola (C division) -> the candidate map (int, scaled by 16), and the pixel's vote for the right view: a global atomicMin on a
+// (cost, column) key per right-image column — smallest cost wins, among equals the column the original meets first (it walks the row from
+// the right with a strict `>`).  (Round 5, first form: one workgroup per image row with the votes in LDS — 376 workgroups, 252 us per
+// 1241 x 376 x 128 frame at 2 TB/s; profiles/r05_stereo_pmc_first.txt.)
 __device__ __forceinline__ int sat16i(int v) { return min(max(v, -32768), 32767); }
-constexpr int SEL_THREADS = 512;
 template <int V>      // disparities per lane: D <= 64 V
-__global__ __launch_bounds__(SEL_THREADS) void sgbm_select_kernel(const int16_t* __restrict__ Lvol, int16_t* __restrict__ disp, int rows, int cols, int width1, int D,
-                                                                 int minD, int minX1, int uniqueness, int disp12MaxDiff)
+__global__ __launch_bounds__(256) void sgbm_wta_kernel(const int16_t* __restrict__ Lvol, int* __restrict__ cand, unsigned* __restrict__ votes, int rows, int cols,
+                                                      int width1, int D, int minD, int minX1, int uniqueness)
 {
-  extern __shared__ int s_sel[];      // [cols] disparity candidates (scaled), [cols] votes of the right view
-  int* s_d1 = s_sel;
-  unsigned* s_vote = reinterpret_cast<unsigned*>(s_sel + cols);
-  const int y = blockIdx.x;
-  const int INVALID_SCALED = (minD - 1) * 16;
-  for(int x = threadIdx.x; x < cols; x += SEL_THREADS) { s_d1[x] = INVALID_SCALED; s_vote[x] = 0xffffffffu; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const size_t p = (size_t) blockIdx.x * 4 + (threadIdx.x >> 6);      // cost pixel
+  if(p >= (size_t) rows * width1) return;
+  const int y = (int) (p / width1), x = (int) (p % width1);
   const size_t vol = (size_t) rows * width1 * D;
-  for(int x = wave; x < width1; x += SEL_THREADS / 64) {
-    const size_t at = ((size_t) y * width1 + x) * D;
-    int S[V];
-    unsigned best = 0xffffffffu;       // (S + 32768) << 16 | d: the first minimum
+  const size_t at = p * D;
+  int S[V];
+  unsigned best = 0xffffffffu;       // (S + 32768) << 16 | d: the first minimum
+#pragma unroll
+  for(int k = 0; k < V; ++k) {
+    const int d = lane + 64 * k;
+    int s = kInvalidCost;
+    if(d < D) {
+      const int l0 = Lvol[at + d], l1 = Lvol[vol + at + d], l2 = Lvol[2 * vol + at + d], l3 = Lvol[3 * vol + at + d], l4 = Lvol[4 * vol + at + d];
+      s = sat16i(sat16i(l0 + l1 + l2 + l3) + l4);
+      best = min(best, ((unsigned) (s + 32768) << 16) | (unsigned) d);
+    }
+    S[k] = s;
+  }
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) best = min(best, (unsigned) __shfl_xor((int) best, o));
+  const int minS = (int) (best >> 16) - 32768, bestDisp = (int) (best & 0xffffu);
+  if(minS >= kInvalidCost) return;                        // (every sum saturated: the original's strict `<` finds no minimum)
+  bool clash = false;
+#pragma unroll
+  for(int k = 0; k < V; ++k) {
+    const int d = lane + 64 * k;
+    if(d < D && S[k] * (100 - uniqueness) < minS * 100 && abs(bestDisp - d) > 1) clash = true;
+  }
+  if(__any(clash)) return;
+  int sm = 0, sp = 0;      // neighbours of the minimum for the parabola
+  {
+    const int dm = bestDisp - 1, dp = bestDisp + 1;
 #pragma unroll
     for(int k = 0; k < V; ++k) {
-      const int d = lane + 64 * k;
-      int s = kInvalidCost;
-      if(d < D) {
-        const int l0 = Lvol[at + d], l1 = Lvol[vol + at + d], l2 = Lvol[2 * vol + at + d], l3 = Lvol[3 * vol + at + d], l4 = Lvol[4 * vol + at + d];
-        s = sat16i(sat16i(l0 + l1 + l2 + l3) + l4);
-        best = min(best, ((unsigned) (s + 32768) << 16) | (unsigned) d);
-      }
-      S[k] = s;
-    }
-#pragma unroll
-    for(int o = 32; o >= 1; o >>= 1) best = min(best, (unsigned) __shfl_xor((int) best, o));
-    const int minS = (int) (best >> 16) - 32768, bestDisp = (int) (best & 0xffffu);
-    if(minS >= kInvalidCost) continue;                        // (every sum saturated: the original's strict `<` finds no minimum)
-    bool clash = false;
-#pragma unroll
-    for(int k = 0; k < V; ++k) {
-      const int d = lane + 64 * k;
-      if(d < D && S[k] * (100 - uniqueness) < minS * 100 && abs(bestDisp - d) > 1) clash = true;
-    }
-    if(__any(clash)) continue;
-    // neighbours of the minimum for the parabola
-    int sm = 0, sp = 0;
-    {
-      const int dm = bestDisp - 1, dp = bestDisp + 1;
-#pragma unroll
-      for(int k = 0; k < V; ++k) {
-        const int vm = __shfl(S[k], dm & 63), vp = __shfl(S[k], dp & 63);
-        if((dm >> 6) == k) sm = vm;
-        if((dp >> 6) == k) sp = vp;
-      }
-    }
-    if(lane == 0) {
-      int d = bestDisp;
-      const int x2 = x + minX1 - d - minD;
-      // smallest cost wins, among equals the largest cost column (the original walks the row from the right with a strict `>`)
-      atomicMin(&s_vote[x2], ((unsigned) (minS + 32768) << 16) | (unsigned) (65535 - x));
-      if(0 < d && d < D - 1) {
-        const int denom2 = max(sm + sp - 2 * minS, 1);
-        d = d * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
-      } else {
-        d *= 16;
-      }
-      s_d1[x + minX1] = d + minD * 16;
+      const int vm = __shfl(S[k], dm & 63), vp = __shfl(S[k], dp & 63);
+      if((dm >> 6) == k) sm = vm;
+      if((dp >> 6) == k) sp = vp;
     }
   }
-  __syncthreads();
-  for(int x = threadIdx.x; x < cols; x += SEL_THREADS) {
-    int d1 = s_d1[x];
-    if(d1 != INVALID_SCALED && x >= minX1 && x < minX1 + width1) {
-      const int dlo = d1 >> 4, dhi = (d1 + 15) >> 4;
-      const int xa = x - dlo, xb = x - dhi;
-      auto vote = [&](int xx) -> int {      // disp2ptr[xx]: d + minD of the winning column, or the (negative) invalid value
-        const unsigned v = s_vote[xx];
-        if(v == 0xffffffffu) return INVALID_SCALED;
-        const int xw = 65535 - (int) (v & 0xffffu);
-        return xw + minX1 - xx;             // x2 = x + minX1 - d - minD  =>  d + minD = x + minX1 - x2
-      };
-      if(0 <= xa && xa < cols && 0 <= xb && xb < cols) {
-        const int va = vote(xa), vb = vote(xb);
-        if(va >= minD && abs(va - dlo) > disp12MaxDiff && vb >= minD && abs(vb - dhi) > disp12MaxDiff) d1 = INVALID_SCALED;
-      }
+  if(lane == 0) {
+    int d = bestDisp;
+    const int x2 = x + minX1 - d - minD;
+    atomicMin(&votes[(size_t) y * cols + x2], ((unsigned) (minS + 32768) << 16) | (unsigned) (65535 - x));
+    if(0 < d && d < D - 1) {
+      const int denom2 = max(sm + sp - 2 * minS, 1);
+      d = d * 16 + ((sm - sp) * 16 + denom2) / (denom2 * 2);
+    } else {
+      d *= 16;
     }
-    disp[(size_t) y * cols + x] = (int16_t) d1;
+    cand[(size_t) y * cols + x + minX1] = d + minD * 16;
   }
+}
+// left-right check of the candidates against the right view's votes (both roundings of the sub-pixel disparity get a chance) -> int16 map
+__global__ __launch_bounds__(256) void sgbm_lr_kernel(const int* __restrict__ cand, const unsigned* __restrict__ votes, int16_t* __restrict__ disp, int rows, int cols,
+                                                     int width1, int minD, int minX1, int disp12MaxDiff)
+{
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if(x >= cols) return;
+  const int INVALID_SCALED = (minD - 1) * 16;
+  const size_t row = (size_t) y * cols;
+  int d1 = cand[row + x];
+  if(d1 != INVALID_SCALED && x >= minX1 && x < minX1 + width1) {
+    const int dlo = d1 >> 4, dhi = (d1 + 15) >> 4;
+    const int xa = x - dlo, xb = x - dhi;
+    auto vote = [&](int xx) -> int {      // disp2ptr[xx]: d + minD of the winning column, or the invalid value (scaled: the original's own mix)
+      const unsigned v = votes[row + xx];
+      if(v == 0xffffffffu) return INVALID_SCALED;
+      const int xw = 65535 - (int) (v & 0xffffu);
+      return xw + minX1 - xx;             // x2 = x + minX1 - d - minD  =>  d + minD = x + minX1 - x2
+    };
+    if(0 <= xa && xa < cols && 0 <= xb && xb < cols) {
+      const int va = vote(xa), vb = vote(xb);
+      if(va >= minD && abs(va - dlo) > disp12MaxDiff && vb >= minD && abs(vb - dhi) > disp12MaxDiff) d1 = INVALID_SCALED;
+    }
+  }
+  disp[row + x] = (int16_t) d1;
+}
+__global__ __launch_bounds__(256) void sgbm_init_select_kernel(int* __restrict__ cand, unsigned* __restrict__ votes, size_t npix, int invalid_scaled)
+{
+  const size_t p = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if(p < npix) { cand[p] = invalid_scaled; votes[p] = 0xffffffffu; }
 }
 
 // medianBlur(disp, disp, 3) on int16, replicated border; also writes the speckle filter's view (u16, 0 = invalid) when asked
@@ -477,10 +484,15 @@ bool launch_stereo_sgbm(hipStream_t s, const SgbmLaunch& g)
       for(int fam = 0; fam < 5; ++fam) lines += sgbm_family_lines(fam, rows, width1);
       if(D <= 128) hipLaunchKernelGGL(sgbm_path_kernel<1>, dim3((unsigned) lines), dim3(64), 0, s, cost, Lvol, rows, width1, D, P1, P2);
       else hipLaunchKernelGGL(sgbm_path_kernel<2>, dim3((unsigned) lines), dim3(64), 0, s, cost, Lvol, rows, width1, D, P1, P2);
-      const size_t sel_lds = sizeof(int) * 2 * (size_t) cols;
-      if(D <= 64) hipLaunchKernelGGL(sgbm_select_kernel<1>, dim3(rows), dim3(SEL_THREADS), sel_lds, s, Lvol, d16a, rows, cols, width1, D, minD, minX1, uniq, d12);
-      else if(D <= 128) hipLaunchKernelGGL(sgbm_select_kernel<2>, dim3(rows), dim3(SEL_THREADS), sel_lds, s, Lvol, d16a, rows, cols, width1, D, minD, minX1, uniq, d12);
-      else hipLaunchKernelGGL(sgbm_select_kernel<4>, dim3(rows), dim3(SEL_THREADS), sel_lds, s, Lvol, d16a, rows, cols, width1, D, minD, minX1, uniq, d12);
+      // (candidates and votes borrow the speckle filter's label / size planes: they are consumed before that filter runs)
+      int* cand = lab;
+      unsigned* votes = reinterpret_cast<unsigned*>(size);
+      hipLaunchKernelGGL(sgbm_init_select_kernel, dim3(nb), dim3(256), 0, s, cand, votes, npix, invalid_scaled);
+      const dim3 gw((unsigned) (((size_t) rows * width1 + 3) / 4));
+      if(D <= 64) hipLaunchKernelGGL(sgbm_wta_kernel<1>, gw, dim3(256), 0, s, Lvol, cand, votes, rows, cols, width1, D, minD, minX1, uniq);
+      else if(D <= 128) hipLaunchKernelGGL(sgbm_wta_kernel<2>, gw, dim3(256), 0, s, Lvol, cand, votes, rows, cols, width1, D, minD, minX1, uniq);
+      else hipLaunchKernelGGL(sgbm_wta_kernel<4>, gw, dim3(256), 0, s, Lvol, cand, votes, rows, cols, width1, D, minD, minX1, uniq);
+      hipLaunchKernelGGL(sgbm_lr_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, s, cand, votes, d16a, rows, cols, width1, minD, minX1, d12);
     } else {
       // no cost column at all (the image is narrower than the disparity range): every pixel invalid
       hipLaunchKernelGGL(sgbm_fill_kernel, dim3(nb), dim3(256), 0, s, d16a, npix, (int16_t) invalid_scaled);

@@ -17,7 +17,7 @@ fs = sorted(glob.glob("/tmp/st_prof/*/*_results.db"))
 db = sqlite3.connect(fs[-1])
 print()
 print("rocprofv3 --kernel-trace --stats -- python3 scripts/stereo_bench.py 4   (4 pairs per batch, 2 + 5 calls per configuration; kernel, calls, total us, average us, percent)")
-for r in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 18"):
+for r in db.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 30"):
     print("%-100s %6d %12.1f %10.2f %6.2f" % (r[0][:100], r[1], r[2], r[3], r[4]))
 PY
 cat "$OUT" | cut -c1-250
@@ -42,10 +42,10 @@ for i in (1, 2, 3):
     if not fs:
         continue
     db = sqlite3.connect(fs[-1])
-    q = "select kernel_name, counter_name, count(*), avg(value), avg(duration), max(grid_size) from counters_collection where kernel_name like '%sgm_%' or kernel_name like '%stereo_%' group by kernel_name, counter_name, grid_size"
+    q = "select kernel_name, counter_name, count(*), avg(value), avg(duration), max(grid_size) from counters_collection where kernel_name like '%sgm_%' or kernel_name like '%sgbm_%' or kernel_name like '%stereo_%' group by kernel_name, counter_name, grid_size"
     for k, c, n, v, dur, grid in db.execute(q):
         import re
-        m = re.search(r"(sgm_\w+|stereo_\w+)(<[^>]*>)?", k)
+        m = re.search(r"(sgbm_\w+|sgm_\w+|stereo_\w+)(<[^>]*>)?", k)
         per.setdefault((m.group(0) if m else k[:40], grid), {})[c] = (v, n, dur)
 print("PMC averages per launch of the stereo kernels, scripts/stereo_bench.py 2 (1241x376 / 128 and 640x480 / 64 disparities), one rocprofv3 --pmc pass per counter set.")
 print("HBM bytes from the request-size counters: read = 32 * RDREQ_32B + 64 * RDREQ_64B + 128 * RDREQ_128B, written = 64 * WRREQ_64B + 32 * (WRREQ - WRREQ_64B).")

@@ -19,7 +19,8 @@ hip = bpvo_amd.load()
 dev = torch.device("cuda", 0)
 torch.cuda.init()
 out = bench.stereo_lines(hip, torch, dev, 0, {"batches": {"block matching 1241x376 / 128": (376, 1241, 128, k, "bm"), "block matching 640x480 / 64": (480, 640, 64, t, "bm"),
-                                                           "SGM 1241x376 / 128": (376, 1241, 128, k, "sgm"), "SGM 640x480 / 64": (480, 640, 64, t, "sgm")},
+                                                           "SGM 1241x376 / 128": (376, 1241, 128, k, "sgm"), "SGM 640x480 / 64": (480, 640, 64, t, "sgm"),
+                                                           "SGBM 1241x376 / 128": (376, 1241, 128, k, "sgbm"), "SGBM 640x480 / 64": (480, 640, 64, t, "sgbm")},
                                                "sequence": (480, 640, 64, seq["frames"], seq["K"], seq["b"])})
 for name, v in out.items():
     print(name, json.dumps(v))
