@@ -85,6 +85,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     t.ctl = ln->d_team_ctl;
     t.timeout_ticks = c->persist_timeout;
     t.local_barriers = c->team_local_barriers;
+    // (nobody can join where the teams start at the admission cap or there is one team only: the leaders' looks at the tickets are then
+    // skipped altogether — a 16-pair batch, teams of 16, lost 1.5 % to them)
+    t.join_mode = (t.team_size < gn_team_max_size() && t.n_teams > 1 && n >= c->team_join_from_pairs) ? c->team_join : 0;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
     const hipError_t te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
     if(te == hipSuccess) {
@@ -229,6 +232,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     }
   }
 #endif
+  if(team_ran) c->team_joins.fetch_add(ln->h_team_ctl[3]);      // workgroups that joined another team in this launch (measurement)
   if(team_ran && ln->h_team_ctl[1] != 0) {
     // a team barrier timed out (teams not co-resident): rerun the group through the four-kernel chain and stay on it
     c->persistent_failed.store(true);

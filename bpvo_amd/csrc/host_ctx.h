@@ -196,8 +196,12 @@ struct bpvo_hip_ctx {
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
   // Options "team" (0 turns it off), "team_max_pairs", "team_size" (0 = CUs / pairs), "team_cus" (CUs the grid may claim: tests).
   int team_mode = 1, team_max_pairs = 128, team_full_pairs = 80, team_size_env = 0, num_cus = 0, device_cus = 0;   // (team_full_pairs: up to here whatever the fill)
+  int team_join = 2;             // option "team_join": workgroups of a team that has run out of pairs join the teams still at work (kernels_gn_team.hip
+                                 // pk_join_team): 0 never, 1 teams on the workgroup's own XCD, 2 any team
+  int team_join_from_pairs = 48; // option "team_join_from_pairs": smaller batches run the fixed-size team kernel (A/B: profiles/r05_team_join.txt)
   int team_local_barriers = 1;   // option "team_local_barriers": kernels_gn_team.hip pk_team_barrier mode 2 for teams on one XCD (0: agent-scope fences always)
   std::atomic<uint64_t> team_launches{0};
+  std::atomic<uint64_t> team_joins{0};            // workgroups that left a team without pairs and joined one at work (measurement)
   std::atomic<bool> persistent_failed{false};      // (atomics: estimate_group runs on the lane threads)
   std::atomic<uint64_t> persistent_levels{0};      // levels run by the persistent kernel (measurement)
   // bpvo_hip_estimate_pose_trace: while trace_ws >= 0 the jobs of that workspace carry the device trace buffer

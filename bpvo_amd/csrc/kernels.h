@@ -156,8 +156,10 @@ struct GNTeamLaunch {
   unsigned* ctl;
   long long timeout_ticks;
   int local_barriers = 1;    // teams whose workgroups share one XCD (checked on the device) keep their barriers inside that XCD's L2
+  int join_mode = 2;         // workgroups whose team has run out of pairs join the teams still at work: 0 never, 1 teams on their own XCD, 2 any team
 };
 int  gn_team_ctl_words(int n_teams);
+int  gn_team_max_size();       // teams stop admitting newcomers at this size
 hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);
 int  gn_pts_per_block(int C);

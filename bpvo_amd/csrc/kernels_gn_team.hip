@@ -452,15 +452,24 @@ __shared__ unsigned pk_team_xccs;      // XCDs the team's workgroups run on (bit
 //   its L2, so the writers' plain stores only have to have arrived there (the explicit s_waitcnt vmcnt(0) every wave executes ahead of
 //   the workgroup barrier below: the vector L1 is write-through) — no L2 write-back — and the readers drop what their L1 holds with the acquire's own invalidation (buffer_inv sc1).
 //   (The workgroup-scope form, buffer_inv sc0, was 5 % faster still and is NOT enough: the one-channel team test read stale residuals.)
-__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, int mode = 0)
+// `target`: the value the team's arrival counter reaches when every member of the team has arrived at THIS barrier — the running sum of the
+// team sizes over its barriers so far (pk_arrivals: a team grows when idle workgroups join it, see pk_join_team).
+__shared__ unsigned pk_arrivals;
+// What the team kernel needs now and then (barrier budget, solver tolerances, the shape of the launch) lives in LDS, not in scalar registers
+// held across the reduction phase: that phase is inlined and takes every register there is — with the join logic's operands alive across
+// it the kernel spilled 55 vector registers (324 B of scratch per lane) and lost 2 % (profiles/r05_team_join.txt).
+struct TeamCfg { long long timeout; unsigned* abort_word; GNParams prm; int n_pairs, n_teams, team_size, level_lo, scale_is_moot, local_ok, join_mode; unsigned xcc_bit; };
+__shared__ TeamCfg pk_cfg;
+__device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, unsigned target, int mode = 0)
 {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores in the L2 before the arrival (see pk_grid_barrier)
   __syncthreads();
   if(threadIdx.x == 0) {
     if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned target = epoch * (unsigned) pk_nwg;
     __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* const abort_word = pk_cfg.abort_word;      // (read behind the arrival: off the path of the workgroups that wait for this one)
+    const long long timeout = pk_cfg.timeout;
     const long long t0 = wall_clock64();
     int ok = 1;
     unsigned spins = 0;
@@ -509,13 +518,40 @@ __device__ __forceinline__ void pk_level_begin(const PairJob& j, int level, int 
   }
 }
 
-// Grid: 1-D, n_teams * team_size workgroups.  Workgroups are dealt to the XCDs round robin by their linear index (guide: block b runs on
-// XCD b % 8 — observed, for speed only); when the teams divide evenly over the 8 XCDs a team's workgroups are taken from ONE XCD so that
-// the pair's taps, residuals and partials stay in that XCD's L2 between phases.  Any mapping is correct (the barriers are agent-scope).
-// (A WIDE form of this kernel — every phase under 128 VGPRs and 68 KB of LDS, two workgroups per CU — was built and measured in round 4:
-// slower at every batch size, profiles/r04_team_wide_rejected.txt.)
+// ---- the team kernel with teams of FIXED size (rounds 3 - 4), kept for the launches in which no team can grow — teams that start at the
+// admission cap (batches of up to 16 pairs), a single team — and for the batches below kTeamJoinFromPairs, where the growing form's
+// bookkeeping costs more than the little imbalance of a few large teams gives back (8 / 16 / 32 pairs: 3 - 4 % slower, 64: + 2 %, 80: + 5 %,
+// 128: + 7 %; profiles/r05_team_join.txt).  Same phases, same chunk and tile indices.  Its barrier counts epochs of a constant team size.
+__device__ __attribute__((noinline)) bool pk_team_barrier_fixed(unsigned* team_ctl, unsigned* abort_word, unsigned epoch, long long timeout, int mode = 0)
+{
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores in the L2 before the arrival (see pk_grid_barrier)
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned target = epoch * (unsigned) pk_nwg;
+    __hip_atomic_fetch_add(team_ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = wall_clock64();
+    int ok = 1;
+    unsigned spins = 0;
+    while(__hip_atomic_load(team_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if((++spins & 63u) == 0u || timeout < 64) {
+        if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else if(mode == 2) asm volatile("buffer_inv sc1" ::: "memory");
+    pk_ok = ok;
+  }
+  __syncthreads();
+  return pk_ok != 0;
+}
+
+
 template <int C, int LOSS>
-__global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
+__global__ __launch_bounds__(PK_THREADS) void gn_team_fixed_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
                                                              int team_size, int n_teams, int level_hi, int level_lo, int pts_per_block,
                                                              GNParams prm, int fuse_frozen, int scale_is_moot, unsigned* ctl, long long timeout, int local_ok)
 {
@@ -562,7 +598,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
+    if(!pk_team_barrier_fixed(team_ctl, global_ctl + 1, ++epoch, timeout)) return;
     if(tid == 0) {
       pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -582,7 +618,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
       __syncthreads();      // every wave has read `active` of the level it leaves before thread 0 rewrites the LDS state
       pk_level_begin(jobs[0], level, scale_is_moot);
-      if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;         // keys reset before any phase reads them
+      if(!pk_team_barrier_fixed(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;         // keys reset before any phase reads them
       for(;;) {
         const GNState* st = pk_st(0);
         if(!st->active) break;
@@ -594,7 +630,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
           if constexpr(C == 8) pk_warp_phase_staged<TEAM_WARP_U, TEAM_NT>(jobs, 0, stats_wg);
           else pk_warp_phase<C>(jobs, 0, stats_wg);
           TEAM_TICK(0);
-          if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;
+          if(!pk_team_barrier_fixed(team_ctl, global_ctl + 1, ++epoch, timeout, team_mode)) return;
           TEAM_TICK(1);
           if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
           TEAM_TICK(2);
@@ -606,7 +642,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
           pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
         }
         TEAM_TICK(3);
-        if(!pk_team_barrier(team_ctl, global_ctl + 1, ++epoch, timeout, 1)) return;      // (only the partials cross: light)
+        if(!pk_team_barrier_fixed(team_ctl, global_ctl + 1, ++epoch, timeout, 1)) return;      // (only the partials cross: light)
         TEAM_TICK(4);
         pk_step_phase(jobs, 1, pts_per_block, prm, fuse ? 1 : 0, stats_wg, epoch_it);
         TEAM_TICK(5);
@@ -623,6 +659,375 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[0][i];
     }
     __syncthreads();
+  }
+}
+
+
+// ---- teams that GROW: idle workgroups join the teams that are still working -------------------------------------------------------
+// A batch ends when its slowest pair does, and the pairs of a batch are far from equal (128 KITTI pairs: mean 17.4 ms per pair on its
+// two CUs, slowest 21.0: a fifth of the chip's time idle behind the last pairs, profiles/r05_team_join.txt).  When a team draws no more
+// pair, each of its workgroups looks for a team that is still at work, takes a ticket on that team's control line and waits; the
+// team's first workgroup (the leader) looks at the tickets once per iteration, right before it arrives at the barrier between
+// reduction and step, and publishes the new team size; after the step old members and newcomers meet at one ADMISSION barrier
+// (full release / acquire at agent scope: whatever the team wrote so far — tap cache, keys, state — becomes visible to the newcomers'
+// XCDs), the leader's copy of the state — all copies are identical — goes through HBM to the newcomers, and the next iteration deals
+// chunks and tiles over the larger team.  Chunk and tile indices, and with them every value, do not depend on the team size
+// (test_team_kernel_shapes); the barriers count arrivals against the running sum of the team sizes (pk_arrivals).
+// Team control line: [0] arrivals  [1] pair slot  [2] XCDs of the members (bit mask)  [3] team size, published by the leader (0: not yet)
+// [4] tickets taken  [5] closed (the team has drawn its last pair and dissolved)  [6] arrival target of the pending admission barrier
+// [7] pair  [8] level  [9] iteration parity counter for the newcomers  [10] level the team works on (for the choice of a team)
+#ifndef TEAM_ADMIT_EVERY_VALUE
+#define TEAM_ADMIT_EVERY_VALUE 1
+#endif
+#ifndef TEAM_MAX_SIZE_VALUE
+#define TEAM_MAX_SIZE_VALUE 16
+#endif
+constexpr unsigned kTeamAdmitEvery = TEAM_ADMIT_EVERY_VALUE;      // the leader looks at the tickets every so many iterations (a power of two): each look is an L2 round trip for every member (128 pairs: 976 k GN it/s with 4, 985 k with 2, 988 k with 1; profiles/r05_team_join.txt)
+constexpr int kTeamMaxSize = TEAM_MAX_SIZE_VALUE;       // a team stops admitting here: the serial phases and the barriers grow with it (team_size sweep, profiles/r05_team_join.txt)
+struct TeamSeat { int team, member, nwg, pair, level; unsigned epoch_it, arrivals; };
+__shared__ TeamSeat pk_seat;
+__shared__ int pk_joined;
+// thread 0 of an idle workgroup: find a team, take a ticket, wait for the admission; false: nothing left to join (or abort / timeout)
+__device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_team, TeamSeat* seat)
+{
+  unsigned* const abort_word = ctl + 1;
+  const int n_teams = pk_cfg.n_teams, own_team_size = pk_cfg.team_size;
+  const unsigned my_xcc_bit = pk_cfg.xcc_bit;
+  const bool same_xcd_only = pk_cfg.join_mode == 1;
+  const long long timeout = pk_cfg.timeout;
+  const long long t0 = wall_clock64();
+  for(;;) {
+    // choice: the open team on the coarsest level (most of its work ahead), then the smallest; teams on this workgroup's XCD first
+    int best = -1, best_score = -1;
+    for(int k = 1; k <= n_teams; ++k) {
+      const int t = (own_team + k) % n_teams;
+      unsigned* line = ctl + (size_t) (1 + t) * kTeamCtlWords;
+      if(__hip_atomic_load(line + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;       // dissolved
+      const unsigned size = __hip_atomic_load(line + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(size == 0u) continue;                                                                            // (has not started yet)
+      const unsigned tickets = __hip_atomic_load(line + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned crowd = (unsigned) own_team_size + tickets;      // (every team starts with own_team_size members)
+      if(crowd >= (unsigned) kTeamMaxSize) continue;
+      const unsigned xccs = __hip_atomic_load(line + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool local = xccs == my_xcc_bit;
+      if(same_xcd_only && !local) continue;
+      const int level = (int) __hip_atomic_load(line + 10, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int score = (local ? 1 << 20 : 0) + (level << 8) + (kTeamMaxSize - (int) crowd);
+      if(score > best_score) { best_score = score; best = t; }
+    }
+    if(best < 0) return false;
+    unsigned* line = ctl + (size_t) (1 + best) * kTeamCtlWords;
+    const unsigned ticket = __hip_atomic_fetch_add(line + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned my_index = (unsigned) own_team_size + ticket;
+    if(my_index >= (unsigned) kTeamMaxSize) continue;      // (lost a race for the last seat: the ticket stays unused — the leader never admits beyond the cap)
+    (void) __hip_atomic_fetch_or(line + 2, my_xcc_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // wait for the leader's word: admitted (size > my index) or dissolved
+    unsigned spins = 0;
+    for(;;) {
+      const unsigned size = __hip_atomic_load(line + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      if(size > my_index) {
+        seat->team = best; seat->member = (int) my_index; seat->nwg = (int) size;
+        seat->arrivals = __hip_atomic_load(line + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seat->pair = (int) __hip_atomic_load(line + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seat->level = (int) __hip_atomic_load(line + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seat->epoch_it = __hip_atomic_load(line + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+      if(__hip_atomic_load(line + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        // dissolved; an admission that included this ticket would have been published before that
+        if(__hip_atomic_load(line + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) > my_index) continue;
+        break;      // look for another team
+      }
+      __builtin_amdgcn_s_sleep(8);
+      if((++spins & 63u) == 0u) {
+        if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      }
+    }
+  }
+}
+
+// The whole workgroup: find a team and wait for the admission (thread 0, pk_join_team), wait until the team's barrier ahead of the admission
+// barrier is complete, meet the team at the admission barrier, take over the leader's state.  Leaves the seat in pk_seat and the team's
+// XCDs in pk_team_xccs; false: nothing left to join, abort or timeout.
+__device__ __attribute__((noinline)) bool pk_take_seat(unsigned* ctl, const PairJob* __restrict__ jobs_all, int job_pitch, int level_hi, int own_team)
+{
+  const int tid = threadIdx.x;
+  if(!pk_cfg.join_mode) return false;
+  if(tid == 0) pk_joined = pk_join_team(ctl, own_team, &pk_seat) ? 1 : 0;
+  __syncthreads();
+  if(!pk_joined) return false;
+  unsigned* const team_ctl = ctl + (size_t) (1 + pk_seat.team) * kTeamCtlWords;
+  if(tid == 0) {
+    pk_member = pk_seat.member; pk_nwg = pk_seat.nwg;
+    pk_arrivals = pk_seat.arrivals;      // the admission barrier's target: where the team's count stands once this workgroup is in
+    (void) __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Not before the team's own barrier between reduction and step is complete: the arrival counter is one running sum, and an
+    // arrival ahead of that barrier would be counted for it.  Its target is the admission barrier's minus the new team size.
+    const unsigned before = pk_seat.arrivals - (unsigned) pk_seat.nwg;
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    int ok = 1;
+    while((int) (__hip_atomic_load(team_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - before) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if((++spins & 63u) == 0u) {
+        if(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if(wall_clock64() - t0 > pk_cfg.timeout) { __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      }
+    }
+    pk_joined = ok;
+  }
+  __syncthreads();
+  if(!pk_joined) return false;
+  // the admission barrier (full release / acquire), then the state the leader put into HBM ahead of it
+  if(!pk_team_barrier(team_ctl, pk_seat.arrivals, 0)) return false;
+  {
+    const int pair = pk_seat.pair;
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+    for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[0][i] = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const PairJob& jl = jobs_all[(size_t) pk_seat.level * job_pitch + pair];
+    if(tid < 4) pk_nrm[0][tid] = jl.nrm[tid];
+    if(tid == 4) pk_nrm[0][4] = jl.dspace ? 1.0f : 0.0f;
+  }
+  if(tid == 0) pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return true;
+}
+
+// The leader (thread 0), every kTeamAdmitEvery-th iteration, right before it arrives at the barrier between reduction and step: newcomers
+// are told the size of the team from the next iteration on, the arrival target of the admission barrier behind this iteration's step,
+// and where the team stands — all of it ahead of the leader's own arrival, so that every old member reads the new size right behind
+// that barrier.
+__device__ __attribute__((noinline)) void pk_publish_admission(unsigned* team_ctl, int pair, int level, unsigned epoch_it, unsigned arrivals)
+{
+  const unsigned tickets = __hip_atomic_load(team_ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned want = min((unsigned) pk_cfg.team_size + tickets, (unsigned) kTeamMaxSize);
+  if(want <= (unsigned) pk_nwg) return;
+  __hip_atomic_store(team_ctl + 6, arrivals + (unsigned) pk_nwg + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(team_ctl + 7, (unsigned) pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(team_ctl + 8, (unsigned) level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(team_ctl + 9, epoch_it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(team_ctl + 3, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Every member, behind the step of such an iteration: has the team grown?  Then old members and newcomers meet once, with the full fences;
+// the leader's state goes ahead through HBM.  false: the barrier gave up.
+__device__ __attribute__((noinline)) bool pk_admit(unsigned* team_ctl, GNState* g_state, bool leader)
+{
+  const int tid = threadIdx.x;
+  if(tid == 0) pk_next_pair = (int) __hip_atomic_load(team_ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int new_nwg = pk_next_pair;
+  if(new_nwg == pk_nwg) return true;
+  if(leader) {
+    uint32_t* g = reinterpret_cast<uint32_t*>(g_state);
+    for(int i = tid; i < kStateWords; i += PK_THREADS) __hip_atomic_store(g + i, pk_state[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const unsigned target = pk_arrivals + (unsigned) new_nwg;
+  __syncthreads();
+  if(tid == 0) { pk_nwg = new_nwg; pk_arrivals = target; }
+  if(!pk_team_barrier(team_ctl, target, 0)) return false;
+  if(tid == 0) pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return true;
+}
+
+// Grid: 1-D, n_teams * team_size workgroups.  Workgroups are dealt to the XCDs round robin by their linear index (guide: block b runs on
+// XCD b % 8 — observed, for speed only); when the teams divide evenly over the 8 XCDs a team's workgroups are taken from ONE XCD so that
+// the pair's taps, residuals and partials stay in that XCD's L2 between phases.  Any mapping is correct (the barriers are agent-scope).
+// (A WIDE form of this kernel — every phase under 128 VGPRs and 68 KB of LDS, two workgroups per CU — was built and measured in round 4:
+// slower at every batch size, profiles/r04_team_wide_rejected.txt.)
+// One pair from `level` down, on this workgroup's team.  A function of its own, NOT inlined into the kernel's pair / join loop: the
+// reduction phase inside takes every register there is, and with the loop's bookkeeping (which team, leader or not, the seat of a
+// newcomer) alive across it the kernel spilled 50 vector registers; here those are plain arguments, fixed for the call, and the
+// call's save / restore is paid once per pair.  resume: this workgroup has just joined the team in the middle of `level`.
+// Returns false when a barrier gave up.
+struct TeamPairArgs { const PairJob* jobs_all; unsigned* team_ctl; int job_pitch, level_hi, pts_per_block, fuse, pair, level, leader, team_mode, resume; unsigned epoch_it; };
+__shared__ unsigned pk_epoch_it_out;
+template <int C, int LOSS, bool JOIN>
+__device__ __forceinline__ bool team_run_pair_body(const TeamPairArgs a)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  // Arguments of a non-inlined device function arrive in VECTOR registers: the compiler no longer knows that they are the same in every
+  // lane, and everything derived from them — the job's fields, every address of the phases — would be computed and loaded per lane (the
+  // first form of this function: 3 - 5 % slower than the inlined kernel at 8 - 32 pairs).  readfirstlane says it.
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto uni_ptr = [&](const void* q) {
+    const unsigned long long u = (unsigned long long) q;
+    return (unsigned long long) (unsigned) uni((int) (unsigned) u) | ((unsigned long long) (unsigned) uni((int) (unsigned) (u >> 32)) << 32);
+  };
+  const PairJob* __restrict__ const jobs_all = reinterpret_cast<const PairJob*>(uni_ptr(a.jobs_all));
+  unsigned* const team_ctl = reinterpret_cast<unsigned*>(uni_ptr(a.team_ctl));
+  const bool stats_wg = uni(a.leader) != 0, fuse = uni(a.fuse) != 0;
+  const int pair = uni(a.pair), pts_per_block = uni(a.pts_per_block), job_pitch = uni(a.job_pitch), level_hi = uni(a.level_hi);
+  int team_mode = uni(a.team_mode);
+  bool resume = uni(a.resume) != 0;
+  unsigned epoch_it = (unsigned) uni((int) a.epoch_it);
+  // arrivals: what the team's counter reads once every member has arrived at the barrier passed last (the running sum of the team
+  // sizes over its barriers); nwg: the team's size.  Register copies of pk_arrivals / pk_nwg, which the admission code updates.
+  unsigned arrivals = (unsigned) uni((int) pk_arrivals);
+  int nwg = uni(pk_nwg);
+#define TEAM_BARRIER(mode_) pk_team_barrier(team_ctl, arrivals += (unsigned) nwg, mode_)
+#ifdef BPVO_PK_TIMING
+  long long tk = wall_clock64();
+  unsigned acc_t[kMaxLevels][7];
+  for(int l = 0; l < kMaxLevels; ++l) for(int k = 0; k < 7; ++k) acc_t[l][k] = 0;
+#define TEAM_TICK(k) do { __syncthreads(); const long long t_ = wall_clock64(); acc_t[level][k] += (unsigned) (t_ - tk); tk = t_; } while(0)
+#else
+#define TEAM_TICK(k) do { } while(0)
+#endif
+  const int level_lo = uni(pk_cfg.level_lo), scale_is_moot = uni(pk_cfg.scale_is_moot), join_mode = JOIN ? uni(pk_cfg.join_mode) : 0;
+  for(int level = uni(a.level); level >= level_lo; --level) {
+    const PairJob* __restrict__ jobs = jobs_all + (size_t) level * job_pitch + pair;      // jobs[0]: this pair at this level
+    if(!resume) {
+      __syncthreads();      // every wave has read `active` of the level it leaves before thread 0 rewrites the LDS state
+      pk_level_begin(jobs[0], level, scale_is_moot);
+      if(stats_wg && tid == 0) __hip_atomic_store(team_ctl + 10, (unsigned) level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if(!TEAM_BARRIER(team_mode)) return false;         // keys reset before any phase reads them
+    }
+    resume = false;
+    for(;;) {
+      const GNState* st = pk_st(0);
+      if(!st->active) break;
+      const bool moving = st->delta_scale > 1e-6f;
+#ifdef BPVO_PK_TIMING
+      tk = wall_clock64(); acc_t[level][6] += 1;
+#endif
+      if(!fuse || moving) {
+        if constexpr(C == 8) pk_warp_phase_staged<TEAM_WARP_U, TEAM_NT>(jobs, 0, stats_wg);
+        else pk_warp_phase<C>(jobs, 0, stats_wg);
+        TEAM_TICK(0);
+        if(!TEAM_BARRIER(team_mode)) return false;
+        TEAM_TICK(1);
+        if(moving) pk_median_phase<C>(jobs, 0, stats_wg);
+        TEAM_TICK(2);
+      }
+      if constexpr(kCanFuse) {
+        if(fuse && !(pk_st(0)->delta_scale > 1e-6f)) pk_irls_phase<C, LOSS, true>(jobs, 0, pts_per_block, epoch_it);   // (after the median: the chain's rule)
+        else pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+      } else {
+        pk_irls_phase<C, LOSS, false>(jobs, 0, pts_per_block, epoch_it);
+      }
+      TEAM_TICK(3);
+      const bool admission_turn = JOIN && join_mode && (epoch_it & (kTeamAdmitEvery - 1u)) == 0u;      // (every member has the same epoch_it)
+      if(admission_turn && stats_wg && tid == 0) pk_publish_admission(team_ctl, pair, level, epoch_it, arrivals);
+      if(!TEAM_BARRIER(1)) return false;      // (only the partials cross: light)
+      TEAM_TICK(4);
+      pk_step_phase(jobs, 1, pts_per_block, pk_cfg.prm, fuse ? 1 : 0, stats_wg, epoch_it);
+      TEAM_TICK(5);
+      ++epoch_it;
+      if(admission_turn) {
+        if(tid == 0) pk_arrivals = arrivals;
+        if(!pk_admit(team_ctl, jobs_all[(size_t) level_hi * job_pitch + pair].st.get(), stats_wg)) return false;
+        arrivals = (unsigned) uni((int) pk_arrivals); nwg = uni(pk_nwg);
+        team_mode = (pk_cfg.local_ok && __popc(pk_team_xccs) == 1) ? 2 : 0;
+      }
+    }
+  }
+#ifdef BPVO_PK_TIMING
+  if(stats_wg && team_ctl == pk_cfg.abort_word - 1 + kTeamCtlWords && tid == 0)      // (team 0's leader)
+    for(int l = 0; l < 4; ++l) for(int k = 0; k < 7; ++k) (pk_cfg.abort_word - 1)[4 + l * 7 + k] += acc_t[l][k];      // words 4 .. 31 of the global line, summed over the team's pairs
+#endif
+  if(tid == 0) { pk_epoch_it_out = epoch_it; pk_arrivals = arrivals; }
+  // the pair is done: its state back to HBM (one copy; the others are identical)
+  if(stats_wg) {
+    uint32_t* g = reinterpret_cast<uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + pair].st.get());
+    for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[0][i];
+  }
+  __syncthreads();
+  return true;
+}
+
+template <int C, int LOSS>
+__device__ __attribute__((noinline)) bool team_run_pair(const TeamPairArgs a) { return team_run_pair_body<C, LOSS, true>(a); }
+
+// JOIN = false: the launches in which nobody can join anybody (teams that start at the admission cap — batches of up to 16 pairs — or a
+// single team): the pair's loops inlined into the kernel as they were before teams could grow, without the admission turns (3 % at 8 pairs,
+// where an iteration lasts 12 us).
+template <int C, int LOSS, bool JOIN>
+__global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __restrict__ jobs_all /*[levels][job_pitch]*/, int job_pitch, int n_pairs,
+                                                             int team_size, int n_teams, int level_hi, int level_lo, int pts_per_block,
+                                                             GNParams prm, int fuse_frozen, int scale_is_moot, unsigned* ctl, long long timeout, int local_ok,
+                                                             int join_mode)
+{
+  constexpr bool kCanFuse = (C == 8);
+  const int tid = threadIdx.x;
+  int team, member;
+  {
+    const int b = (int) blockIdx.x;
+    if((n_teams & 7) == 0) {
+      const int xcd = b & 7, slot = b >> 3;            // slot-th workgroup of its XCD
+      team = xcd * (n_teams >> 3) + slot / team_size;
+      member = slot % team_size;
+    } else {
+      team = b / team_size;
+      member = b % team_size;
+    }
+  }
+  if(tid == 0) {
+    pk_member = member; pk_nwg = team_size; pk_arrivals = 0u;
+    pk_cfg.timeout = timeout; pk_cfg.abort_word = ctl + 1; pk_cfg.prm = prm; pk_cfg.n_pairs = n_pairs; pk_cfg.n_teams = n_teams; pk_cfg.team_size = team_size;
+    pk_cfg.level_lo = level_lo; pk_cfg.scale_is_moot = scale_is_moot; pk_cfg.local_ok = local_ok; pk_cfg.join_mode = join_mode;
+    pk_cfg.xcc_bit = 1u << (__builtin_amdgcn_s_getreg(63508) & 0xf);
+  }
+  __syncthreads();
+  bool leader = member == 0;       // the team's first workgroup: draws pairs, keeps the counters, admits newcomers
+  unsigned* const global_ctl = ctl;                                     // [1] abort, [2] next pair to hand out, [3] workgroups that joined another team
+  unsigned* team_ctl = ctl + (size_t) (1 + team) * kTeamCtlWords;
+  // which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0), registered in the team's line [2] before the first barrier; behind it every
+  // member knows whether the team shares one L2 (team_mode 2: pk_team_barrier) — whatever the dispatcher did with the grid
+  if(tid == 0) {
+    (void) __hip_atomic_fetch_or(team_ctl + 2, pk_cfg.xcc_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(leader) __hip_atomic_store(team_ctl + 3, (unsigned) team_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  TeamPairArgs a;
+  a.jobs_all = jobs_all; a.job_pitch = job_pitch; a.level_hi = level_hi; a.pts_per_block = pts_per_block; a.fuse = (kCanFuse && fuse_frozen) ? 1 : 0;
+  a.epoch_it = 0;
+  for(;;) {
+    // next pair of this team: its leader draws, the barrier publishes the draw to the others
+    // (every workgroup reads the slot right after this barrier and before it arrives at the next one, which the drawing workgroup
+    // must pass before it can draw again: one slot is enough)
+    if(leader && tid == 0) {
+      const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // no pair left: the team dissolves — said BEFORE the barrier, behind every admission this leader ever published
+      if(p >= (unsigned) n_pairs) __hip_atomic_store(team_ctl + 5, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    {
+      const unsigned target = pk_arrivals + (unsigned) pk_nwg;
+      __syncthreads();
+      if(tid == 0) pk_arrivals = target;
+      if(!pk_team_barrier(team_ctl, target)) return;
+    }
+    if(tid == 0) {
+      pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    a.pair = pk_next_pair;
+    a.resume = 0;
+    a.level = level_hi;
+    if(a.pair >= n_pairs) {
+      // idle: join a team that still works (join_mode 0: leave; 1: teams on this workgroup's XCD only; 2: any)
+      if constexpr(!JOIN) return;
+      if(!pk_take_seat(ctl, jobs_all, job_pitch, level_hi, team)) return;
+      team = pk_seat.team;
+      team_ctl = ctl + (size_t) (1 + team) * kTeamCtlWords;
+      leader = false;
+      a.pair = pk_seat.pair; a.level = pk_seat.level; a.epoch_it = pk_seat.epoch_it;
+      a.resume = 1;
+    } else {
+      // the pair's state: HBM -> this workgroup's LDS copy (set_pose_kernel has run: T_out, statistics defaults)
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(jobs_all[(size_t) level_hi * job_pitch + a.pair].st.get());
+      for(int i = tid; i < kStateWords; i += PK_THREADS) pk_state[0][i] = g[i];
+    }
+    __syncthreads();
+    a.team_ctl = team_ctl; a.leader = leader ? 1 : 0;
+    a.team_mode = (local_ok && __popc(pk_team_xccs) == 1) ? 2 : 0;
+    if constexpr(JOIN) { if(!team_run_pair<C, LOSS>(a)) return; }
+    else { if(!team_run_pair_body<C, LOSS, false>(a)) return; }
+    a.epoch_it = pk_epoch_it_out;
   }
 }
 
@@ -676,6 +1081,7 @@ hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterat
 }
 // ---- team-persistent kernel for small batches
 int gn_team_ctl_words(int n_teams) { return (1 + n_teams) * kTeamCtlWords; }
+int gn_team_max_size() { return kTeamMaxSize; }
 template <int C>
 static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const GNParams& prm)
 {
@@ -697,13 +1103,37 @@ static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const G
     });
     if(status[dev] != hipSuccess) return status[dev];
     hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
+                       t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks, t.local_barriers, t.join_mode);
+    return hipGetLastError();
+  };
+  if(t.join_mode) {
+    switch(t.loss) {
+      case BPVO_LOSS_HUBER: return go(gn_team_kernel<C, BPVO_LOSS_HUBER, true>);
+      case BPVO_LOSS_TUKEY: return go(gn_team_kernel<C, BPVO_LOSS_TUKEY, true>);
+      default: return go(gn_team_kernel<C, BPVO_LOSS_L2, true>);
+    }
+  }
+  auto go_fixed = [&](auto kern) -> hipError_t {
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    dev &= 63;
+    std::call_once(once[dev], [&] {
+      status[dev] = hipFuncSetAttribute((const void*) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+      int per_cu = 0;
+      if(status[dev] == hipSuccess) status[dev] = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, PK_THREADS, lds);
+      if(status[dev] == hipSuccess && per_cu < need_per_cu) status[dev] = hipErrorLaunchOutOfResources;
+    });
+    if(status[dev] != hipSuccess) return status[dev];
+    hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
                        t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks, t.local_barriers);
     return hipGetLastError();
   };
   switch(t.loss) {
-    case BPVO_LOSS_HUBER: return go(gn_team_kernel<C, BPVO_LOSS_HUBER>);
-    case BPVO_LOSS_TUKEY: return go(gn_team_kernel<C, BPVO_LOSS_TUKEY>);
-    default: return go(gn_team_kernel<C, BPVO_LOSS_L2>);
+    case BPVO_LOSS_HUBER: return go_fixed(gn_team_fixed_kernel<C, BPVO_LOSS_HUBER>);
+    case BPVO_LOSS_TUKEY: return go_fixed(gn_team_fixed_kernel<C, BPVO_LOSS_TUKEY>);
+    default: return go_fixed(gn_team_fixed_kernel<C, BPVO_LOSS_L2>);
   }
 }
 hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol)

@@ -110,6 +110,7 @@ def run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=200, **k
     # a second batch on the same context (states, tap caches and counters of the first one are in place)
     rec["poses2"], rec["stats2"] = ctx.batch_run(b["images"][::-1].copy(), b["disparities"][::-1].copy())
     rec["team"], rec["pk"] = ctx.team_counts(), ctx.persistent_counts()
+    rec["joins"] = ctx.get_option("team_joins_seen")
     ctx.close()
     return rec
 
@@ -151,6 +152,28 @@ def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
         set_options(monkeypatch, team_size=str(team_size))
     got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=777)
     assert got["team"] == 2 and got["pk"][1] == 0
+    assert_same_batch(ref, got)
+
+
+@pytest.mark.parametrize("rows,cols,levels,n,cus,join", [pytest.param(120, 160, 3, 24, 48, 2, id="24-pairs-teams-of-2-any-team"),
+                                                        pytest.param(120, 160, 3, 24, 48, 1, id="24-pairs-teams-of-2-own-xcd"),
+                                                        pytest.param(120, 160, 3, 13, 39, 2, id="13-pairs-teams-of-3-across-xcds"),
+                                                        pytest.param(376, 1241, 4, 64, 0, 2, id="kitti-64-pairs-teams-of-4"),
+                                                        pytest.param(480, 640, 4, 40, 0, 2, id="640x480-40-pairs-teams-of-6")])
+@pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
+def test_teams_that_grow_are_bit_identical_to_the_chain(hip, rows, cols, levels, n, cus, join, descriptor, loss, monkeypatch):
+    """Workgroups of a team that has run out of pairs join the teams still at work (kernels_gn_team.hip, pk_join_team): the batch against the
+    four-kernel chain — poses, statistics, residuals, valid masks, weights, counters — with joins actually taking place (counter
+    team_joins_seen), on one XCD only and across XCDs (a newcomer from another XCD turns the team's barriers into agent-scope ones)."""
+    set_options(monkeypatch, team="0")
+    ref = run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=400)
+    assert ref["team"] == 0
+    set_options(monkeypatch, team="1", team_join=str(join), team_join_from_pairs="0", team_max_pairs="128", team_full_pairs="128")
+    if cus:
+        set_options(monkeypatch, team_cus=str(cus))
+    got = run_batch(hip, rows, cols, levels, n, descriptor, loss, first_index=400)
+    assert got["team"] == 2 and got["pk"][1] == 0, (got["team"], got["pk"])
+    assert got["joins"] > 0, "no workgroup joined another team: the case does not test what it says"
     assert_same_batch(ref, got)
 
 
