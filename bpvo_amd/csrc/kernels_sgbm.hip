@@ -214,10 +214,29 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(const int16_t* __restrict
   int prev_min = 0;
   const s16x2 P1v = {(short) P1, (short) P1};
   using word_t = typename std::conditional<NP == 1, uint32_t, uint64_t>::type;
+#ifndef SGBM_PIPE_VALUE
+#define SGBM_PIPE_VALUE 1
+#endif
+  // The cost words of the NEXT batch are requested before the steps of this one run (SGBM_PIPE_VALUE 1): a line is a chain of dependent
+  // steps, and a memory round trip per batch in the open was a third of its time (profiles/r05_stereo_pmc.txt).
+  word_t cnext[PF];
+  if(SGBM_PIPE_VALUE) {
+#pragma unroll
+    for(int i = 0; i < PF; ++i) cnext[i] = *reinterpret_cast<const word_t*>(cost + base + (long long) min(i, ln.n - 1) * step_stride + d0_load);
+  }
   for(int s0 = 0; s0 < ln.n; s0 += PF) {
     word_t cw[PF], ow[PF];
+    if(SGBM_PIPE_VALUE) {
 #pragma unroll
-    for(int i = 0; i < PF; ++i) cw[i] = *reinterpret_cast<const word_t*>(cost + base + (long long) min(s0 + i, ln.n - 1) * step_stride + d0_load);
+      for(int i = 0; i < PF; ++i) cw[i] = cnext[i];
+      if(s0 + PF < ln.n) {
+#pragma unroll
+        for(int i = 0; i < PF; ++i) cnext[i] = *reinterpret_cast<const word_t*>(cost + base + (long long) min(s0 + PF + i, ln.n - 1) * step_stride + d0_load);
+      }
+    } else {
+#pragma unroll
+      for(int i = 0; i < PF; ++i) cw[i] = *reinterpret_cast<const word_t*>(cost + base + (long long) min(s0 + i, ln.n - 1) * step_stride + d0_load);
+    }
 #pragma unroll
     for(int i = 0; i < PF; ++i) {
       const word_t cword = cw[i];

@@ -15,7 +15,9 @@ k, t = stack(376, 1241, n), stack(480, 640, n)
 seq = synth.make_stereo_sequence(480, 640, 9, index=23)
 import torch
 import bpvo_amd
-hip = bpvo_amd.load()
+from bpvo_amd import capi
+# BPVO_AB_LIB: an experimental build of the library (scripts/build_exp.sh) instead of the product's
+hip = capi.Binding(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["BPVO_AB_LIB"]), "bpvo_hip_") if os.environ.get("BPVO_AB_LIB") else bpvo_amd.load()
 dev = torch.device("cuda", 0)
 torch.cuda.init()
 out = bench.stereo_lines(hip, torch, dev, 0, {"batches": {"block matching 1241x376 / 128": (376, 1241, 128, k, "bm"), "block matching 640x480 / 64": (480, 640, 64, t, "bm"),

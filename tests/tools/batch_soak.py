@@ -21,7 +21,11 @@ import bpvo_amd
 import fuzz_parity as fz
 
 OPTION_SETS = ["", "team=0", "team=0,step_in_reduce_max_pairs=0", "lazy_template_descriptor=0", "team=0,lanes=1", "team=0,upload_workers=0",
-               "keep_current_disparity=1", "team=0,lanes=2"]
+               "keep_current_disparity=1", "team=0,lanes=2",
+               # teams that grow (round 5): forced on for every batch size, teams of 2 - 4 so that workgroups do run out of pairs and join others;
+               # joins on the workgroup's own XCD only, and a grid smaller than the chip
+               "team_join_from_pairs=0,team_size=2", "team_join_from_pairs=0,team_size=3,team_join=1", "team_join_from_pairs=0,team_size=4,team_cus=64",
+               "team_join_from_pairs=0,team_size=2,team_cus=24"]
 
 
 def main():
