@@ -18,7 +18,9 @@ bool team_serves(const bpvo_hip_ctx* c, int n)
   bool size_ok = n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs;
   // above team_full_pairs only when the teams fill the chip: the kernel runs CUs / n workgroups per pair, and what that division leaves over
   // idles for the whole launch (96 pairs: 2 x 96 of 256 CUs, 770 k GN it/s against the chain's 840 k; 128 pairs: 2 x 128, 935 k against 890 k)
-  if(size_ok && n > c->team_full_pairs && c->team_size_env <= 0 && c->num_cus > 0) {
+  // (with spare workgroups the chip is full whatever the division leaves: any batch of up to team_max_pairs pairs that is large enough to grow)
+  const bool spares_fill = c->team_join && c->team_spares && n >= c->team_join_from_pairs;
+  if(size_ok && n > c->team_full_pairs && c->team_size_env <= 0 && c->num_cus > 0 && !spares_fill) {
     const int ts = std::max(1, std::min(64, c->num_cus / n));
     size_ok = 20 * ts * std::min(n, c->num_cus / ts) >= 19 * c->num_cus;
   }
@@ -88,6 +90,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // (nobody can join where the teams start at the admission cap or there is one team only: the leaders' looks at the tickets are then
     // skipped altogether — a 16-pair batch, teams of 16, lost 1.5 % to them)
     t.join_mode = (t.team_size < gn_team_max_size() && t.n_teams > 1 && n >= c->team_join_from_pairs) ? c->team_join : 0;
+    // what the division CUs / pairs leaves over starts as spare workgroups that join the teams at their first admission
+    t.spare_workgroups = (t.join_mode && c->team_spares) ? std::max(0, slots - t.team_size * t.n_teams) : 0;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
     const hipError_t te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
     if(te == hipSuccess) {

@@ -156,6 +156,7 @@ struct GNTeamLaunch {
   unsigned* ctl;
   long long timeout_ticks;
   int local_barriers = 1;    // teams whose workgroups share one XCD (checked on the device) keep their barriers inside that XCD's L2
+  int spare_workgroups = 0;  // workgroups beyond n_teams * team_size that start without a team and join one (join_mode != 0 only): the grid fills the chip
   int join_mode = 2;         // workgroups whose team has run out of pairs join the teams still at work: 0 never, 1 teams on their own XCD, 2 any team
 };
 int  gn_team_ctl_words(int n_teams);

@@ -699,12 +699,13 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
   for(;;) {
     // choice: the open team on the coarsest level (most of its work ahead), then the smallest; teams on this workgroup's XCD first
     int best = -1, best_score = -1;
+    bool unstarted = false;
     for(int k = 1; k <= n_teams; ++k) {
       const int t = (own_team + k) % n_teams;
       unsigned* line = ctl + (size_t) (1 + t) * kTeamCtlWords;
       if(__hip_atomic_load(line + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;       // dissolved
       const unsigned size = __hip_atomic_load(line + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if(size == 0u) continue;                                                                            // (has not started yet)
+      if(size == 0u) { unstarted = true; continue; }      // (its leader has not said hello yet: a spare workgroup at the start of the launch)
       const unsigned tickets = __hip_atomic_load(line + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned crowd = (unsigned) own_team_size + tickets;      // (every team starts with own_team_size members)
       if(crowd >= (unsigned) kTeamMaxSize) continue;
@@ -715,7 +716,13 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
       const int score = (local ? 1 << 20 : 0) + (level << 8) + (kTeamMaxSize - (int) crowd);
       if(score > best_score) { best_score = score; best = t; }
     }
-    if(best < 0) return false;
+    if(best < 0) {
+      if(!unstarted) return false;
+      __builtin_amdgcn_s_sleep(32);
+      if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+      if(wall_clock64() - t0 > timeout) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+      continue;
+    }
     unsigned* line = ctl + (size_t) (1 + best) * kTeamCtlWords;
     const unsigned ticket = __hip_atomic_fetch_add(line + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned my_index = (unsigned) own_team_size + ticket;
@@ -954,9 +961,15 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
   constexpr bool kCanFuse = (C == 8);
   const int tid = threadIdx.x;
   int team, member;
+  // SPARE workgroups: the grid may be larger than n_teams * team_size (the launcher fills the chip: 96 pairs as teams of 2 leave 64 CUs
+  // over) — what is beyond the teams starts as a helper and joins a team at its first admission
+  const bool spare = (int) blockIdx.x >= n_teams * team_size;
   {
     const int b = (int) blockIdx.x;
-    if((n_teams & 7) == 0) {
+    if(spare) {
+      team = b % n_teams;       // (where its search for a team starts)
+      member = -1;
+    } else if((n_teams & 7) == 0) {
       const int xcd = b & 7, slot = b >> 3;            // slot-th workgroup of its XCD
       team = xcd * (n_teams >> 3) + slot / team_size;
       member = slot % team_size;
@@ -972,22 +985,24 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
     pk_cfg.xcc_bit = 1u << (__builtin_amdgcn_s_getreg(63508) & 0xf);
   }
   __syncthreads();
-  bool leader = member == 0;       // the team's first workgroup: draws pairs, keeps the counters, admits newcomers
+  bool leader = member == 0 && !spare;       // the team's first workgroup: draws pairs, keeps the counters, admits newcomers
   unsigned* const global_ctl = ctl;                                     // [1] abort, [2] next pair to hand out, [3] workgroups that joined another team
   unsigned* team_ctl = ctl + (size_t) (1 + team) * kTeamCtlWords;
   // which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0), registered in the team's line [2] before the first barrier; behind it every
   // member knows whether the team shares one L2 (team_mode 2: pk_team_barrier) — whatever the dispatcher did with the grid
-  if(tid == 0) {
+  if(tid == 0 && !spare) {
     (void) __hip_atomic_fetch_or(team_ctl + 2, pk_cfg.xcc_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if(leader) __hip_atomic_store(team_ctl + 3, (unsigned) team_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TeamPairArgs a;
   a.jobs_all = jobs_all; a.job_pitch = job_pitch; a.level_hi = level_hi; a.pts_per_block = pts_per_block; a.fuse = (kCanFuse && fuse_frozen) ? 1 : 0;
   a.epoch_it = 0;
+  bool idle = spare;       // a workgroup without a team: looks for one before anything else
   for(;;) {
     // next pair of this team: its leader draws, the barrier publishes the draw to the others
     // (every workgroup reads the slot right after this barrier and before it arrives at the next one, which the drawing workgroup
     // must pass before it can draw again: one slot is enough)
+    if(!idle) {
     if(leader && tid == 0) {
       const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1006,9 +1021,11 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
     }
     __syncthreads();
     a.pair = pk_next_pair;
+    }
     a.resume = 0;
     a.level = level_hi;
-    if(a.pair >= n_pairs) {
+    if(idle || a.pair >= n_pairs) {
+      idle = false;
       // idle: join a team that still works (join_mode 0: leave; 1: teams on this workgroup's XCD only; 2: any)
       if constexpr(!JOIN) return;
       if(!pk_take_seat(ctl, jobs_all, job_pitch, level_hi, team)) return;
@@ -1102,7 +1119,7 @@ static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const G
       if(status[dev] == hipSuccess && per_cu < need_per_cu) status[dev] = hipErrorLaunchOutOfResources;
     });
     if(status[dev] != hipSuccess) return status[dev];
-    hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
+    hipLaunchKernelGGL(kern, dim3(t.team_size * t.n_teams + t.spare_workgroups), dim3(PK_THREADS), lds, s, t.jobs_all, t.job_pitch, t.n_pairs, t.team_size, t.n_teams, t.level_hi,
                        t.level_lo, ppb, prm, fuse, t.scale_is_moot, t.ctl, t.timeout_ticks, t.local_barriers, t.join_mode);
     return hipGetLastError();
   };

@@ -215,10 +215,11 @@ __global__ __launch_bounds__(64) void sgbm_path_kernel(const int16_t* __restrict
   const s16x2 P1v = {(short) P1, (short) P1};
   using word_t = typename std::conditional<NP == 1, uint32_t, uint64_t>::type;
 #ifndef SGBM_PIPE_VALUE
-#define SGBM_PIPE_VALUE 1
+#define SGBM_PIPE_VALUE 0
 #endif
-  // The cost words of the NEXT batch are requested before the steps of this one run (SGBM_PIPE_VALUE 1): a line is a chain of dependent
-  // steps, and a memory round trip per batch in the open was a third of its time (profiles/r05_stereo_pmc.txt).
+  // SGBM_PIPE_VALUE 1: the cost words of the NEXT batch requested before the steps of this one run.  Measured: 0.719 against 0.715 ms per
+  // 1241 x 376 x 128 frame — no gain (the batch's own 16 loads are consumed with partial waits as they arrive; the chain of dependent steps
+  // is what a line costs), so the plain form is the default.
   word_t cnext[PF];
   if(SGBM_PIPE_VALUE) {
 #pragma unroll

@@ -376,6 +376,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_join"              2         workgroups of a team that has run out of pairs join the teams still at work (a batch ends with its slowest
  *                                      pair: + 7 % at 128 pairs): 0 never, 1 teams on the workgroup's own XCD only, 2 any team; same bits either way
  *   "team_join_from_pairs"   48        smaller batches (few, large teams: little to balance) run the team kernel with teams of fixed size
+ *   "team_spares"            1         the growing form's grid fills the chip: workgroups beyond pairs x (CUs / pairs) start without a team and join one
+ *                                      (96 pairs: 2 x 96 + 64 spares, + 4 %; 112: + 6 %) — with it every batch of up to team_max_pairs pairs takes the team kernel
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
  *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair

@@ -158,6 +158,9 @@ def test_team_kernel_shapes(hip, cus, team_size, monkeypatch):
 @pytest.mark.parametrize("rows,cols,levels,n,cus,join", [pytest.param(120, 160, 3, 24, 48, 2, id="24-pairs-teams-of-2-any-team"),
                                                         pytest.param(120, 160, 3, 24, 48, 1, id="24-pairs-teams-of-2-own-xcd"),
                                                         pytest.param(120, 160, 3, 13, 39, 2, id="13-pairs-teams-of-3-across-xcds"),
+                                                        pytest.param(120, 160, 3, 12, 32, 2, id="12-pairs-teams-of-2-and-8-spare-workgroups"),
+                                                        pytest.param(120, 160, 3, 16, 40, 1, id="16-pairs-teams-of-2-and-8-spares-own-xcd"),      # (own-XCD joins need teams that sit on one XCD: a multiple of 8 teams)
+                                                        pytest.param(376, 1241, 4, 96, 0, 2, id="kitti-96-pairs-teams-of-2-and-64-spares"),
                                                         pytest.param(376, 1241, 4, 64, 0, 2, id="kitti-64-pairs-teams-of-4"),
                                                         pytest.param(480, 640, 4, 40, 0, 2, id="640x480-40-pairs-teams-of-6")])
 @pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
@@ -175,6 +178,19 @@ def test_teams_that_grow_are_bit_identical_to_the_chain(hip, rows, cols, levels,
     assert got["team"] == 2 and got["pk"][1] == 0, (got["team"], got["pk"])
     assert got["joins"] > 0, "no workgroup joined another team: the case does not test what it says"
     assert_same_batch(ref, got)
+
+
+def test_growing_teams_give_up_cleanly(hip, monkeypatch):
+    """The growing form of the team kernel with a barrier budget of 10 ns: barriers and the newcomers' waiting loops all watch the abort word,
+    every workgroup leaves, the library reruns the batch through the chain and stays on it.  Same results, no hang."""
+    rows, cols, levels, n = 120, 160, 3, 24
+    set_options(monkeypatch, team="0")
+    ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    set_options(monkeypatch, team="1", team_join="2", team_join_from_pairs="0", team_cus="48", persist_timeout_ticks="1")
+    got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    assert got["pk"][1] == 1 and got["team"] == 1          # launched once, gave up, never tried again
+    assert bits_equal(ref["poses"], got["poses"]) and ref["stats"].tobytes() == got["stats"].tobytes()
+    assert bits_equal(ref["poses2"], got["poses2"]) and bits_equal(ref["r"], got["r"]) and bits_equal(ref["w"], got["w"])
 
 
 def test_team_cus_above_the_device_is_refused_and_persistent_rearms(hip, monkeypatch):
@@ -233,18 +249,25 @@ def test_team_kernel_with_a_team_per_xcd(hip, n, descriptor, loss, monkeypatch):
         assert_same_batch(ref, got)
 
 
-def test_team_kernel_above_80_pairs_only_where_it_fills_the_chip(hip):
-    """Up to 80 pairs (team_full_pairs) a batch takes the team kernel whatever its size; up to 128 (team_max_pairs) only when CUs / pairs
-    workgroups per pair use at least 95 % of the CUs: on 256 CUs 128 pairs (2 x 128) and 85 (3 x 85) do, 96 (2 x 96) do not."""
+def test_which_batches_take_the_team_kernel(hip):
+    """Up to 128 pairs (team_max_pairs) a batch takes the team kernel: since round 5 the grid always fills the chip — what the division CUs /
+    pairs leaves over starts as spare workgroups that join the teams (96 pairs: 2 x 96 + 64 spares).  With the spares (or the growing form)
+    switched off the round-4 rule holds: above 80 pairs (team_full_pairs) only when CUs / pairs workgroups per pair use at least 95 % of the
+    CUs — on 256 CUs 128 pairs (2 x 128) and 85 (3 x 85) do, 96 (2 x 96) do not."""
     rows, cols, levels = 96, 128, 2
-    for n, team in ((128, True), (96, False), (85, True)):
+    for n, team in ((128, True), (96, False), (85, True), (129, False)):
         b = synth.make_batch(rows, cols, n, first_index=5, workers=8)
-        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels), n_frames=2 * n, n_pairs=n)
-        cus = int(ctx.get_option("team_cus"))
-        ctx.batch_run(b["images"], b["disparities"])
-        ts = max(1, min(64, cus // n))
-        fills = 20 * ts * min(n, cus // ts) >= 19 * cus
-        assert (ctx.team_counts() == 1) == fills, (n, cus, ctx.team_counts())
-        if cus == 256:
-            assert fills == team, (n, fills)
-        ctx.close()
+        for spares in (1, 0):
+            ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels), n_frames=2 * n, n_pairs=n)
+            ctx.set_option("team_spares", spares)
+            cus = int(ctx.get_option("team_cus"))
+            ctx.batch_run(b["images"], b["disparities"])
+            ts = max(1, min(64, cus // n))
+            fills = 20 * ts * min(n, cus // ts) >= 19 * cus
+            want = (n <= 128) if spares else (n <= 128 and fills)
+            assert (ctx.team_counts() == 1) == want, (n, spares, cus, ctx.team_counts())
+            if cus == 256 and not spares:
+                assert fills == team or n > 128, (n, fills)
+            if spares and n == 96 and cus == 256:
+                assert ctx.get_option("team_joins_seen") >= 64      # the 64 spare workgroups found a team
+            ctx.close()
