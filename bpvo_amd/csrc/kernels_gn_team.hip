@@ -455,6 +455,7 @@ __shared__ unsigned pk_team_xccs;      // XCDs the team's workgroups run on (bit
 // `target`: the value the team's arrival counter reaches when every member of the team has arrived at THIS barrier — the running sum of the
 // team sizes over its barriers so far (pk_arrivals: a team grows when idle workgroups join it, see pk_join_team).
 __shared__ unsigned pk_arrivals;
+__shared__ int pk_size_seen;      // the team size published by the leader, as read with the count that completed the last barrier
 // What the team kernel needs now and then (barrier budget, solver tolerances, the shape of the launch) lives in LDS, not in scalar registers
 // held across the reduction phase: that phase is inlined and takes every register there is — with the join logic's operands alive across
 // it the kernel spilled 55 vector registers (324 B of scratch per lane) and lost 2 % (profiles/r05_team_join.txt).
@@ -473,7 +474,10 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
     const long long t0 = wall_clock64();
     int ok = 1;
     unsigned spins = 0;
-    while(__hip_atomic_load(team_ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    // the arrival counter and the team size its leader has published sit in one aligned 8-byte word: ONE load per poll reads both, and the
+    // size read together with the count that completes the barrier is the one the leader wrote ahead of its own arrival (pk_publish_admission)
+    unsigned long long both;
+    while((unsigned) (both = __hip_atomic_load(reinterpret_cast<unsigned long long*>(team_ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
       __builtin_amdgcn_s_sleep(1);
       if((++spins & 63u) == 0u || timeout < 64) {
         if(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
@@ -483,6 +487,7 @@ __device__ __attribute__((noinline)) bool pk_team_barrier(unsigned* team_ctl, un
     if(mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     else if(mode == 2) asm volatile("buffer_inv sc1" ::: "memory");
     pk_ok = ok;
+    pk_size_seen = (int) (both >> 32);
   }
   __syncthreads();
   return pk_ok != 0;
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_fixed_kernel(const PairJob
 // XCDs), the leader's copy of the state — all copies are identical — goes through HBM to the newcomers, and the next iteration deals
 // chunks and tiles over the larger team.  Chunk and tile indices, and with them every value, do not depend on the team size
 // (test_team_kernel_shapes); the barriers count arrivals against the running sum of the team sizes (pk_arrivals).
-// Team control line: [0] arrivals  [1] pair slot  [2] XCDs of the members (bit mask)  [3] team size, published by the leader (0: not yet)
+// Team control line: [0] arrivals  [1] team size, published by the leader (0: not yet; one 8-byte word with [0])  [2] XCDs of the members (bit mask)  [11] pair slot
 // [4] tickets taken  [5] closed (the team has drawn its last pair and dissolved)  [6] arrival target of the pending admission barrier
 // [7] pair  [8] level  [9] iteration parity counter for the newcomers  [10] level the team works on (for the choice of a team)
 #ifndef TEAM_ADMIT_EVERY_VALUE
@@ -704,7 +709,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
       const int t = (own_team + k) % n_teams;
       unsigned* line = ctl + (size_t) (1 + t) * kTeamCtlWords;
       if(__hip_atomic_load(line + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;       // dissolved
-      const unsigned size = __hip_atomic_load(line + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if(size == 0u) { unstarted = true; continue; }      // (its leader has not said hello yet: a spare workgroup at the start of the launch)
       const unsigned tickets = __hip_atomic_load(line + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned crowd = (unsigned) own_team_size + tickets;      // (every team starts with own_team_size members)
@@ -731,7 +736,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
     // wait for the leader's word: admitted (size > my index) or dissolved
     unsigned spins = 0;
     for(;;) {
-      const unsigned size = __hip_atomic_load(line + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
       if(size > my_index) {
         seat->team = best; seat->member = (int) my_index; seat->nwg = (int) size;
         seat->arrivals = __hip_atomic_load(line + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -742,7 +747,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
       }
       if(__hip_atomic_load(line + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         // dissolved; an admission that included this ticket would have been published before that
-        if(__hip_atomic_load(line + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) > my_index) continue;
+        if(__hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) > my_index) continue;
         break;      // look for another team
       }
       __builtin_amdgcn_s_sleep(8);
@@ -814,16 +819,14 @@ __device__ __attribute__((noinline)) void pk_publish_admission(unsigned* team_ct
   __hip_atomic_store(team_ctl + 7, (unsigned) pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(team_ctl + 8, (unsigned) level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(team_ctl + 9, epoch_it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(team_ctl + 3, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(team_ctl + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Every member, behind the step of such an iteration: has the team grown?  Then old members and newcomers meet once, with the full fences;
 // the leader's state goes ahead through HBM.  false: the barrier gave up.
 __device__ __attribute__((noinline)) bool pk_admit(unsigned* team_ctl, GNState* g_state, bool leader)
 {
   const int tid = threadIdx.x;
-  if(tid == 0) pk_next_pair = (int) __hip_atomic_load(team_ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const int new_nwg = pk_next_pair;
+  const int new_nwg = pk_size_seen;      // (read with the count that completed the barrier between reduction and step: pk_team_barrier)
   if(new_nwg == pk_nwg) return true;
   if(leader) {
     uint32_t* g = reinterpret_cast<uint32_t*>(g_state);
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
   // member knows whether the team shares one L2 (team_mode 2: pk_team_barrier) — whatever the dispatcher did with the grid
   if(tid == 0 && !spare) {
     (void) __hip_atomic_fetch_or(team_ctl + 2, pk_cfg.xcc_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if(leader) __hip_atomic_store(team_ctl + 3, (unsigned) team_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if(leader) __hip_atomic_store(team_ctl + 1, (unsigned) team_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   TeamPairArgs a;
   a.jobs_all = jobs_all; a.job_pitch = job_pitch; a.level_hi = level_hi; a.pts_per_block = pts_per_block; a.fuse = (kCanFuse && fuse_frozen) ? 1 : 0;
@@ -1005,7 +1008,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
     if(!idle) {
     if(leader && tid == 0) {
       const unsigned p = __hip_atomic_fetch_add(global_ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(team_ctl + 1, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(team_ctl + 11, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // no pair left: the team dissolves — said BEFORE the barrier, behind every admission this leader ever published
       if(p >= (unsigned) n_pairs) __hip_atomic_store(team_ctl + 5, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       if(!pk_team_barrier(team_ctl, target)) return;
     }
     if(tid == 0) {
-      pk_next_pair = (int) __hip_atomic_load(team_ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pk_next_pair = (int) __hip_atomic_load(team_ctl + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       pk_team_xccs = __hip_atomic_load(team_ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
