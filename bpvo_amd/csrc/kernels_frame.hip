@@ -964,6 +964,11 @@ __global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob*
 // ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
 // The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too (LDS-staged
 // chunks, one wave adding in point order).  It runs once per keyframe and level, all levels and frames side by side.
+// elements of the sequential sums per unrolled batch: the chain of dependent adds stops for an LDS round trip once per batch (setTemplate of one
+// 1241x376 frame: 470 / 387 / 350 / 336 / 358 / 384 us with 8 / 16 / 32 / 64 / 128 / 256; a register double buffer of the next batch: slower)
+#ifndef NRM_UNROLL
+#define NRM_UNROLL 64
+#endif
 constexpr int NRM_THREADS = 256, NRM_CHUNK = 512;   // 20 KB of LDS: seven workgroups per CU (1024-point chunks: three; 0.93 -> 0.59 ms per 1024-pair step)
 __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
                                                                     int with_normalization)
@@ -1006,7 +1011,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     if(ch + 1 < nchunks) fetch(ch + 1);
     if(tid < 64) {
       const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + comp;
-#pragma unroll 16
+#pragma unroll NRM_UNROLL
       for(int k = 0; k < cnt; ++k) c += sp[4 * k];
     }
     if(ch + 1 < nchunks) {
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) dists(ch + 1);
     if(tid < 64) {
-#pragma unroll 16
+#pragma unroll NRM_UNROLL
       for(int k = 0; k < cnt; ++k) m += s_dist[cur][k];
     }
     if(ch + 1 < nchunks) {
