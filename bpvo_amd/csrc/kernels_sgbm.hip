@@ -182,6 +182,9 @@ __host__ __device__ inline int sgbm_family_lines(int fam, int rows, int width1)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk(unsigned u) { return __builtin_bit_cast(s16x2, u); }
 __device__ __forceinline__ unsigned bits(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
+#ifndef SGBM_PRIO_VALUE
+#define SGBM_PRIO_VALUE 1
+#endif
 #ifndef SGBM_PF_VALUE
 #define SGBM_PF_VALUE 16
 #endif
@@ -193,13 +196,24 @@ template <int NP>
 __global__ __launch_bounds__(64) void sgbm_path_kernel(const int16_t* __restrict__ cost, int16_t* __restrict__ Lvol, int rows, int width1, int D, int P1, int P2)
 {
   constexpr int PF = SGBM_PF_VALUE, V = 2 * NP;
+  // dispatch order: the long chains (the rows, both ways) first, then the columns, then the diagonals
   int fam = 0, l = blockIdx.x;
-  for(; fam < 5; ++fam) {
-    const int nl = sgbm_family_lines(fam, rows, width1);
-    if(l < nl) break;
-    l -= nl;
+  {
+    const int order[5] = {0, 4, 2, 1, 3};
+    int k = 0;
+    for(; k < 5; ++k) {
+      const int nl = sgbm_family_lines(order[k], rows, width1);
+      if(l < nl) break;
+      l -= nl;
+    }
+    fam = order[min(k, 4)];
   }
   const SgbmLine ln = sgbm_line(fam, l, rows, width1);
+#if SGBM_PRIO_VALUE
+  // The launch lasts as long as its longest chains — the rows, `width1` dependent steps against at most `rows` for everything else — while
+  // every SIMD time-slices four or five lines: the rows get the issue priority, the short lines fill the gaps.
+  if(fam == 0 || fam == 4) __builtin_amdgcn_s_setprio(3);
+#endif
   const size_t vol = (size_t) rows * width1 * D;
   int16_t* __restrict__ L = Lvol + (size_t) fam * vol;
   const int lane = threadIdx.x;

@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void sgm_right_cost_tile_kernel(const uint16_t
 // are not).  What is sequential is a step's dependent chain — neighbours across lanes, the recurrence, the wave minimum that the next
 // step needs — so the chain is kept on the VALU: neighbours by DPP wave shifts, the minimum by the DPP row ladder + v_readlane (__shfl
 // compiles to ds_bpermute, an LDS round trip each, eight in a row per step).  Memory: batches of SGM_PF steps, see the loop.
+#ifndef SGM_PRIO_VALUE
+#define SGM_PRIO_VALUE 1
+#endif
 #ifndef SGM_PF_VALUE
 #define SGM_PF_VALUE 16
 #endif
@@ -251,15 +254,17 @@ __global__ __launch_bounds__(64) void sgm_path_packed_kernel(const uint16_t* __r
                                                              int rows, int cols, int D, int P1, int P2)
 {
   constexpr int PF = SGM_PF, V = 2 * NP;
-  const int per_side = 2 * rows + 2 * cols;
-  const int side = blockIdx.x / per_side;
-  int q = blockIdx.x - side * per_side;
-  int path, line;
-  if(q < rows) { path = 0; line = q; }
-  else if(q < 2 * rows) { path = 2; line = q - rows; }
-  else if(q < 2 * rows + cols) { path = 1; line = q - 2 * rows; }
-  else { path = 3; line = q - 2 * rows - cols; }
+  // dispatch order: the rows of both cost volumes first (with cols > rows the longest chains of the launch), then the columns
+  int side, path, line;
+  {
+    int q = blockIdx.x;
+    if(q < 4 * rows) { side = q / (2 * rows); q -= side * 2 * rows; path = q < rows ? 0 : 2; line = q < rows ? q : q - rows; }
+    else { q -= 4 * rows; side = q / (2 * cols); q -= side * 2 * cols; path = q < cols ? 1 : 3; line = q < cols ? q : q - cols; }
+  }
   const int vertical = path & 1, dir = path < 2 ? 1 : -1;
+#if SGM_PRIO_VALUE
+  if(!vertical && cols > rows) __builtin_amdgcn_s_setprio(3);      // the longest chains of the launch first (kernels_sgbm.hip, sgbm_path_kernel)
+#endif
   const uint16_t* __restrict__ cost = side ? cost_r : cost_l;
   const size_t vol = (size_t) rows * cols * D;
   int16_t* __restrict__ L = Lvol + (size_t) (side * 4 + path) * vol;
