@@ -82,6 +82,27 @@ def test_default_params_equal_reference_defaults():
     assert abs(p.minSaliency - 0.1) < 1e-7 and abs(p.minValidDisparity - 0.001) < 1e-9 and p.maxValidDisparity == 512.0
 
 
+def test_stereo_params_layout_and_the_references_sgbm_constructor_call():
+    """bpvo_hip_stereo_params: the header's fields are the ctypes mirror's, in order; and bpvo_hip_stereo_params_sgbm_from_config fills the
+    cv::StereoSGBM fields from the reference's config KEYS as its constructor call does — nine positional arguments into a constructor of
+    eleven, so the keys land one slot off (utils/stereo_algorithm.cc:30-39): uniquenessRatio -> disp12MaxDiff, speckleWindowSize ->
+    preFilterCap, speckleRange -> uniquenessRatio, (bool) fullDP -> speckleWindowSize; speckleRange and fullDP keep their defaults."""
+    src = open(HEADER).read()
+    body = re.search(r"typedef struct bpvo_hip_stereo_params \{(.*?)\} bpvo_hip_stereo_params;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int|double)\s+(\w+);", body)
+    assert fields == [f[0] for f in capi.StereoParams._fields_]
+    assert C.sizeof(capi.StereoParams) == 14 * 4 + 2 * 8 + 6 * 4
+    lib = bpvo_amd.load()
+    sp = capi.StereoParams()
+    lib.fn("stereo_params_sgbm_from_config", None)(C.byref(sp), 2, 96, 9, 11, 22, 33, 44, 55, 1)
+    assert (sp.algorithm, sp.minDisparity, sp.numberOfDisparities, sp.SADWindowSize, sp.P1, sp.P2) == (capi.STEREO_SGBM, 2, 96, 9, 11, 22)
+    assert (sp.disp12MaxDiff, sp.preFilterCap, sp.uniquenessRatio, sp.speckleWindowSize, sp.speckleRange, sp.fullDP) == (33, 44, 55, 1, 0, 0)
+    # conf/kitti_seq_0.cfg: minDisparity 0, numberOfDisparities 128, SADWindowSize 7, fullDP 0; the other keys at the defaults of their cf.get
+    lib.fn("stereo_params_sgbm_from_config", None)(C.byref(sp), 0, 128, 7, 0, 0, 0, 0, 0, 0)
+    assert (sp.P1, sp.P2, sp.disp12MaxDiff, sp.preFilterCap, sp.uniquenessRatio, sp.speckleWindowSize, sp.speckleRange, sp.fullDP) == (0,) * 8
+
+
 def _has_gpu():
     try:
         import torch
