@@ -273,6 +273,7 @@ const std::vector<OptionDef>& option_table()
               [](bpvo_hip_ctx* c, double) { c->team_joins.store(0); return BPVO_OK; }},
     OPT_INT("team_join_from_pairs", team_join_from_pairs, 0, 1 << 20),
     OPT_INT("team_spares", team_spares, 0, 1),
+    OPT_INT("normalization_side_stream", nrm_side_stream, 0, 1),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),

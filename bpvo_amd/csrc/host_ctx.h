@@ -198,6 +198,7 @@ struct bpvo_hip_ctx {
   int team_mode = 1, team_max_pairs = 128, team_full_pairs = 80, team_size_env = 0, num_cus = 0, device_cus = 0;   // (team_full_pairs: up to here whatever the fill)
   int team_join = 2;             // option "team_join": workgroups of a team that has run out of pairs join the teams still at work (kernels_gn_team.hip
                                  // pk_join_team): 0 never, 1 teams on the workgroup's own XCD, 2 any team
+  int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
   int team_spares = 1;           // option "team_spares": the team kernel's grid fills the chip, the workgroups beyond the teams join them (growing form only)
   int team_join_from_pairs = 48; // option "team_join_from_pairs": smaller batches run the fixed-size team kernel (A/B: profiles/r05_team_join.txt)
   int team_local_barriers = 1;   // option "team_local_barriers": kernels_gn_team.hip pk_team_barrier mode 2 for teams on one XCD (0: agent-scope fences always)

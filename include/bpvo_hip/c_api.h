@@ -379,6 +379,8 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_spares"            1         the growing form's grid fills the chip: workgroups beyond pairs x (CUs / pairs) start without a team and join one
  *                                      (96 pairs: 2 x 96 + 64 spares, + 4 %; 112: + 6 %) — with it every batch of up to team_max_pairs pairs takes the team kernel
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
+ *   "normalization_side_stream" 1      a frame stage that runs alone on the context's stream (single frames, batches on one lane) queues the
+ *                                      Hartley normalisation sums on the idle stream of lane 1, next to template_build, and joins them before it returns
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
  *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair
  *                                      inside the reduction launch — three kernels per iteration instead of four, same bits (0: never)
