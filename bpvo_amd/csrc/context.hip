@@ -274,6 +274,8 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_join_from_pairs", team_join_from_pairs, 0, 1 << 20),
     OPT_INT("team_spares", team_spares, 0, 1),
     OPT_INT("normalization_side_stream", nrm_side_stream, 0, 1),
+    OPT_INT("levels_in_one_launch_max_frames", merge_levels_max_frames, 0, 1 << 20),
+    OPT_INT("normalization_deferred", nrm_defer, 0, 1),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),
@@ -635,6 +637,8 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     for(auto e : ln.staging_ev) if(e) (void) hipEventDestroy(e);
     if(ln.owns_stream && ln.stream) (void) hipStreamDestroy(ln.stream);
   }
+  if(c->side_stream) { (void) hipStreamSynchronize(c->side_stream); (void) hipStreamDestroy(c->side_stream); }
+  for(auto e : c->side_ev) if(e) (void) hipEventDestroy(e);
   if(c->stream) (void) hipStreamDestroy(c->stream);
   delete c;
 }

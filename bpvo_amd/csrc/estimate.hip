@@ -73,7 +73,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   const int max_fun_evals = 6 * 200;
   // Small batches: the whole level loop in ONE launch, a team of workgroups per pair (gn_team_kernel)
   bool team_ran = false;
+  // the normalisation of the levels below the coarsest, of the template stage queued just before (frames.hip, ctx->nrm_pending), may still be
+  // running on the context's side stream: this lane waits for it where the second level starts — the team kernel, every level in one launch, at once
+  auto join_normalization = [&]() -> int {
+    if(!c->nrm_pending) return BPVO_OK;
+    LANE_CK(ln, hipStreamWaitEvent(ln->stream, c->nrm_pending, 0));
+    c->nrm_pending = nullptr;
+    return BPVO_OK;
+  };
   if(allow_persistent && ln == &c->lanes[0] && team_serves(c, n)) {
+    if(int rcj = join_normalization()) return rcj;
     GNTeamLaunch t;
     t.jobs_all = ln->d_pjobs; t.job_pitch = NP; t.n_pairs = n; t.level_hi = c->L - 1; t.level_lo = p.maxTestLevel;
     t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
@@ -117,6 +126,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
     // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
     const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+    if(l < c->L - 1)
+      if(int rcj = join_normalization()) return rcj;
     launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
     if(g.max_points <= 0) continue;
     if(persistent && gn_persistent_serves(g)) {
@@ -279,7 +290,10 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
   if(team_serves(c, n)) nl = 1;      // the team-persistent kernel takes the whole chip
   // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
-  if(nl > 1) HIP_CK(c, hipStreamSynchronize(c->stream));
+  if(nl > 1) {
+    if(c->nrm_pending) { HIP_CK(c, hipStreamWaitEvent(c->stream, c->nrm_pending, 0)); c->nrm_pending = nullptr; }
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+  }
   std::vector<int> rcs(nl, BPVO_OK);
   c->frac_valid = false;      // (on the API thread: the lane threads only read the context's settings)
   auto run = [&](int k) {

@@ -76,7 +76,13 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     double px = 0;
     for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) px += (double) c->geom[l].npix * count;
     ScopedTimer t(c, KC_DESCRIPTOR, px, fr.ln);
-    for(int l = c->L - 1; l >= c->params.maxTestLevel; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
+    // few frames, bit-planes with the census fused: every level in ONE launch (kernels_frame.hip level_job)
+    const bool fused_bp = c->C == 8 && c->params.descriptor == BPVO_DESC_BITPLANES && !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f;
+    const int l_lo = c->params.maxTestLevel;
+    const bool one_launch = fused_bp && count <= c->merge_levels_max_frames && c->L - l_lo > 1;
+    if(one_launch)
+      launch_bitplanes(s, tab + (size_t) l_lo * NF, c->geom[l_lo].cols, c->geom[l_lo].rows, count, c->params.sigmaBitPlanes, c->gauss_k, 1, c->L - l_lo, NF);
+    for(int l = c->L - 1; l >= c->params.maxTestLevel && !one_launch; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
       const FrameJob* jobs = tab + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];
       if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
@@ -139,7 +145,19 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   int* const d_ints = c->d_ints + (size_t) fr.tab * kMaxLevels;
   const bpvo_hip_params& p = c->params;
   const int border = std::max(p.nonMaxSuppRadius, 3);   // template_data.cc:51
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+  // few frames, every level on the tiled path (NMS radius <= 1): the levels in ONE launch of each of its three kernels (kernels_frame.hip level_job)
+  bool tiled = true;
+  for(int l = p.maxTestLevel; l < c->L; ++l) tiled = tiled && c->geom[l].nms_radius <= 1;
+  const bool one_launch = tiled && count <= c->merge_levels_max_frames && c->L - p.maxTestLevel > 1;
+  if(one_launch) {
+    const LevelGeom& g = c->geom[p.maxTestLevel];
+    double px = 0;
+    for(int l = p.maxTestLevel; l < c->L; ++l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_SALIENCY_SELECT, px, fr.ln);
+    launch_saliency_select(s, tab + (size_t) p.maxTestLevel * NF, c->C, g.cols, g.rows, count, 1, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border,
+                           c->L - p.maxTestLevel, NF);
+  }
+  for(int l = c->L - 1; l >= p.maxTestLevel && !one_launch; --l) {
     const FrameJob* jobs = tab + (size_t) l * NF;
     const LevelGeom& g = c->geom[l];
     ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count, fr.ln);
@@ -156,20 +174,39 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   if(fr.on_selected) fr.on_selected();
   // The normalisation — sequential sums in the reference's order, a latency chain of one workgroup per (frame, level): 0.2 ms whatever the
   // batch — is read by the Gauss-Newton kernels only (the Jacobian rows are rebuilt there; template_build stores pixels and gradients).
-  // A stage that runs alone on the context's stream (single frames, batches on one lane: the team kernel) puts it on the idle stream
-  // of lane 1, next to template_build, and joins the two before it returns; lanes of a fanned-out batch keep it in line.
+  // A stage that runs alone on the context's stream (single frames, batches on one lane) puts it on a stream of its own, next to
+  // template_build and the host's round trip for the point counts, and joins the two before it returns; lanes of a fanned-out batch keep it in line.
   hipStream_t side = nullptr;
-  if(c->nrm_side_stream && !fr.own_thread && fr.ln == &c->lanes[0] && c->lanes.size() > 1 && c->lanes[1].stream && counts_ev) side = c->lanes[1].stream;
+  if(c->nrm_side_stream && !fr.own_thread && fr.ln == &c->lanes[0] && counts_ev) {
+    if(!c->side_stream) {
+      FR_CK(c, fr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      for(auto& e : c->side_ev) FR_CK(c, fr, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    side = c->side_stream;
+  }
+  // ... and when the estimation follows on this stream within the same call (fr.defer_finest_nrm: a batch on one lane), only the COARSEST
+  // level's sums are joined here: the others — the longest is the first level without non-maximum suppression, 100 k points of a
+  // 1241x376 frame, 0.17 ms — are needed when the Gauss-Newton iterations leave the coarsest level: ctx->nrm_pending, waited for by the
+  // estimation just before its second level (estimate.hip).
+  const int with_nrm = c->dspace ? 0 : p.withNormalization;      // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
+  const bool defer = side && fr.defer_finest_nrm && c->nrm_defer && c->L - p.maxTestLevel > 1 && !c->nrm_pending;
   if(side) {
-    FR_CK(c, fr, hipEventRecord(fr.ln->round_ev[1], s));
-    FR_CK(c, fr, hipStreamWaitEvent(side, fr.ln->round_ev[1], 0));
-    // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
-    launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, c->dspace ? 0 : p.withNormalization);
-    FR_CK(c, fr, hipEventRecord(fr.ln->round_ev[2], side));
+    FR_CK(c, fr, hipEventRecord(c->side_ev[0], s));
+    FR_CK(c, fr, hipStreamWaitEvent(side, c->side_ev[0], 0));
+    if(defer) {
+      launch_normalization(side, tab, NF, count, c->L - 1, c->L, with_nrm);
+      FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
+      launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L - 1, with_nrm);
+      FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
+      c->nrm_pending = c->side_ev[2];
+    } else {
+      launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm);
+      FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
+    }
   } else {
     // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
     ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln);
-    launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, c->dspace ? 0 : p.withNormalization);
+    launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, with_nrm);
   }
   if(counts_ev) FR_CK(c, fr, hipEventSynchronize(counts_ev));
   else FR_CK(c, fr, hipStreamSynchronize(s));
@@ -188,12 +225,19 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
     c->kc_units[KC_TEMPLATE] += pts;
     c->kc_units[KC_NORMALIZATION] += pts;
   }
-  for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+  if(count <= c->merge_levels_max_frames && c->L - p.maxTestLevel > 1) {
     ScopedTimer t(c, KC_TEMPLATE, 0.0, fr.ln);
-    launch_template_build(s, tab + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5, c->gauss_k);
+    int most = 0;
+    for(int l = p.maxTestLevel; l < c->L; ++l) most = std::max(most, max_n[l]);
+    launch_template_build(s, tab + (size_t) p.maxTestLevel * NF, c->C, most, count, p.gradientEstimation == BPVO_GRAD_CD5, c->gauss_k, c->L - p.maxTestLevel, NF);
+  } else {
+    for(int l = c->L - 1; l >= p.maxTestLevel; --l) {
+      ScopedTimer t(c, KC_TEMPLATE, 0.0, fr.ln);
+      launch_template_build(s, tab + (size_t) l * NF, c->C, max_n[l], count, p.gradientEstimation == BPVO_GRAD_CD5, c->gauss_k);
+    }
   }
-  if(side) FR_CK(c, fr, hipStreamWaitEvent(s, fr.ln->round_ev[2], 0));      // the normalisation joins here: whatever follows on this stream sees it
-  if(!fr.own_thread) {      // (a lane thread goes straight on to its estimation on the same stream)
+  if(side) FR_CK(c, fr, hipStreamWaitEvent(s, c->side_ev[1], 0));      // the normalisation joins here: whatever follows on this stream sees it
+  if(!fr.own_thread && !fr.no_final_sync) {      // (a lane thread goes straight on to its estimation on the same stream)
     FR_CK(c, fr, hipStreamSynchronize(s));
     FR_CK(c, fr, hipGetLastError());
     resolve_events(c);

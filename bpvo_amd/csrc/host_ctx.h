@@ -198,7 +198,14 @@ struct bpvo_hip_ctx {
   int team_mode = 1, team_max_pairs = 128, team_full_pairs = 80, team_size_env = 0, num_cus = 0, device_cus = 0;   // (team_full_pairs: up to here whatever the fill)
   int team_join = 2;             // option "team_join": workgroups of a team that has run out of pairs join the teams still at work (kernels_gn_team.hip
                                  // pk_join_team): 0 never, 1 teams on the workgroup's own XCD, 2 any team
+  int merge_levels_max_frames = 8;   // option "levels_in_one_launch_max_frames": frame stages of at most this many frames run the levels of the
+                                 // bit-planes, selection and template-build kernels in one launch each (frames.hip)
   int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
+  int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
+  hipStream_t side_stream = nullptr;  // the normalisation's stream (created at its first use) and its events: [0] fork, [1] coarse levels done, [2] finest done
+  hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels below the coarsest of the template stage just queued; whoever
+                                 // reads those levels' (scale, centroid) next makes its stream wait for it (estimate.hip) and clears it
   int team_spares = 1;           // option "team_spares": the team kernel's grid fills the chip, the workgroups beyond the teams join them (growing form only)
   int team_join_from_pairs = 48; // option "team_join_from_pairs": smaller batches run the fixed-size team kernel (A/B: profiles/r05_team_join.txt)
   int team_local_barriers = 1;   // option "team_local_barriers": kernels_gn_team.hip pk_team_barrier mode 2 for teams on one XCD (0: agent-scope fences always)
@@ -334,6 +341,9 @@ struct FrameRun {
   bool own_thread;   // run by a lane thread next to others: no resolve_events, errors into ln->err
   hipEvent_t selected_ev;   // recorded once the selection of all levels has been queued (the next lane's frame stage starts behind it), or null
   std::function<void()> on_selected;   // ... and called right after that record (releases the next lane's host thread)
+  // a template stage whose estimation follows on the same stream inside the same call (bpvo_hip_batch_run on one lane):
+  bool defer_finest_nrm = false;       // the normalisation of every level but the coarsest stays on the side stream: ctx->nrm_pending, joined by the estimation
+  bool no_final_sync = false;          // no host synchronisation at the end of the stage
 };
 #define FR_CK(c_, fr_, expr)                                                                \
   do {                                                                                      \

@@ -47,16 +47,20 @@ void launch_latch(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
 void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
 // from_image: the census transform is computed inside the bit-planes kernel (no launch_census, sigma_bp > 0 and sigma_ct <= 0)
-void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image);
+// nlevels > 1 (bit-planes, tiled selection, template build): `jobs` is the FINEST level's row of the table [level][job_pitch], W / R / max_points that level's — the
+// levels in one launch (kernels_frame.hip level_job)
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image, int nlevels = 1,
+                      int job_pitch = 0);
 void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes, int nms_radius, float min_saliency,
-                            float min_disp, float max_disp, int border);
+                            float min_disp, float max_disp, int border, int nlevels = 1, int job_pitch = 0);
 void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, size_t pitch_bytes, size_t width_bytes, int rows);   // multiples of 8 bytes
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level, int num_levels,
                           int* out /*[nframes][kMaxLevels]*/);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
                           int num_levels, int with_normalization);
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
-void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3]);   // gauss_k: the bit-planes blur taps (lazy levels)
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3], int nlevels = 1,
+                           int job_pitch = 0);   // gauss_k: the bit-planes blur taps (lazy levels)
 
 // stereo front-end (kernels_stereo.hip): OpenCV 2.4 block matching with the reference's parameters, batched over frames
 struct StereoLaunch {

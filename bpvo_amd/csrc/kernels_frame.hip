@@ -15,6 +15,15 @@ namespace bpvo_hip {
 // buffer ([frame][rows*cols]) into the frame slots (VisualOdometryFrame::setData's image.copyTo / disparity.copyTo,
 // reference: bpvo/vo_frame.cc:50-51) instead of 2 memcpy calls per frame.
 // skip_odd_disp: pair batches (A0, B0, A1, B1, ...) — the current frame B of a pair never becomes a template, its disparity is not copied
+// Levels in one launch (few frames: every per-level launch is a 5 - 20 us latency floor, four levels of them in a row): the grid is sized for
+// the FINEST level of the group, z = level x nframes + frame, and the workgroups that fall outside a coarser level's own grid leave at
+// once.  `jobs` is the finest level's row of the table [level][job_pitch]; a per-level launch has z < nframes: its own row.
+__device__ __forceinline__ const FrameJob& level_job(const FrameJob* jobs, unsigned z, int nframes, int job_pitch)
+{
+  const unsigned lvl = z / (unsigned) nframes;
+  return jobs[(size_t) lvl * job_pitch + (z - lvl * (unsigned) nframes)];
+}
+
 __global__ __launch_bounds__(256) void ingest_kernel(const FrameJob* jobs, const uint8_t* images, const float* disps, size_t npix, int skip_odd_disp)
 {
   const FrameJob& j = jobs[blockIdx.z];
@@ -300,7 +309,7 @@ __device__ __forceinline__ uint2 spread_planes(unsigned c)
 }
 
 template <bool FROM_IMAGE>
-__global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2, int stack)
+__global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* jobs, float k0, float k1, float k2, int stack, int nframes, int job_pitch)
 {
   constexpr int CR = BP_TH + 2 * BP_HALO, CC = BP_TW + 2 * BP_HALO;   // staged census rows / columns
   constexpr int CW = CC + 4;                                             // padded LDS row pitch of the census tile
@@ -311,9 +320,10 @@ __global__ __launch_bounds__(256) void bitplanes_blur_kernel(const FrameJob* job
   __shared__ uint8_t s_img[FROM_IMAGE ? IR * IW : 4];
   __shared__ float s_row[(BP_PLANE + CR * BP_TW) * 4];
   __shared__ float s_lut[18];
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   const int W = j.cols, R = j.rows;
   const int x0 = blockIdx.x * BP_TW;
+  if(x0 >= W || (int) blockIdx.y * BP_TH * stack >= R) return;      // (a coarser level inside a launch sized for the finest)
   const int tid = threadIdx.x;
   const uint8_t* __restrict__ cen = FROM_IMAGE ? j.img : j.cen;
   // the job's pointers in registers: read through `j` inside the loop they are re-loaded after every store (the stores might alias the
@@ -771,13 +781,14 @@ __device__ __forceinline__ float saliency_generic(const FrameJob& j, int x, int 
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJob* jobs, float min_saliency, float min_disp, float max_disp, int border)
+__global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJob* jobs, float min_saliency, float min_disp, float max_disp, int border, int nframes, int job_pitch)
 {
   __shared__ float s_ch[ST_CH_ROWS][ST_CH_PITCH];
   __shared__ float s_sal[ST_S_ROWS][ST_S_PITCH];
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   const int W = j.cols, R = j.rows, n = W & ~3;
   const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
+  if(x0 >= W || y0 >= R) return;      // (a coarser level inside a launch sized for the finest)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // channel 0 with its halo (coordinates clamped into the image: such entries only feed saliencies that are defined as 0 or replaced)
   // (a frame whose descriptor was computed without the compact plane — the current frame of a pair batch made a template after all — reads
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
     if(lane == q) words = m;
   }
   const int y = y0 + ry0 + lane;
-  if(lane < ST_ROWS_PER_WAVE && y < R) j.words[(size_t) y * gridDim.x + blockIdx.x] = words;
+  if(lane < ST_ROWS_PER_WAVE && y < R) j.words[(size_t) y * ((W + 63) / 64) + blockIdx.x] = words;
   // the saliency map itself (bpvo_hip_get_saliency), LAST: stores issued before the gate's loads would be waited for with them (one in-order
   // counter for loads and stores), a memory round trip per tile
   if(x < W) {
@@ -855,9 +866,9 @@ __global__ __launch_bounds__(256) void saliency_select_tile_kernel(const FrameJo
 }
 
 // exclusive scan of the words' popcounts in (y, x / 64) order; N = total & ~15 (the reference drops the LAST N mod 16 points)
-__global__ __launch_bounds__(1024) void select_words_scan_kernel(const FrameJob* jobs)
+__global__ __launch_bounds__(1024) void select_words_scan_kernel(const FrameJob* jobs, int nframes, int job_pitch)
 {
-  const FrameJob& j = jobs[blockIdx.x];
+  const FrameJob& j = level_job(jobs, blockIdx.x, nframes, job_pitch);
   const int nw = j.rows * ((j.cols + 63) / 64);
   __shared__ int s_wave[16];
   __shared__ int s_carry;
@@ -904,9 +915,9 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n)      // 
   }
   return pos;
 }
-__global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob* jobs)
+__global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob* jobs, int nframes, int job_pitch)
 {
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   const int W = j.cols, WPR = (W + 63) / 64;
   const int nw = j.rows * WPR;
   const int lane = threadIdx.x & 63;
@@ -962,13 +973,54 @@ __global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob*
 }
 
 // ---- Hartley normalisation (reference: bpvo/warps.cc:27-48, bpvo/rigid_body_warp.h:62-71).
-// The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too (LDS-staged
-// chunks, one wave adding in point order).  It runs once per keyframe and level, all levels and frames side by side.
-// elements of the sequential sums per unrolled batch: the chain of dependent adds stops for an LDS round trip once per batch (setTemplate of one
-// 1241x376 frame: 470 / 387 / 350 / 336 / 358 / 384 us with 8 / 16 / 32 / 64 / 128 / 256; a register double buffer of the next batch: slower)
-#ifndef NRM_UNROLL
-#define NRM_UNROLL 64
+// The reference sums N points sequentially in f32; to reproduce its rounding the sums here are sequential too: chunks staged in LDS, one
+// wave adding in point order.  It runs once per keyframe and level, all levels and frames side by side.  The dependent adds are the whole
+// cost (26 k points at level 0 of a 1241x376 frame, two passes), and a wave issues one instruction every four cycles whatever it is: so
+// the adds take their operand from ANOTHER LANE of the row (DPP row_shl: no instruction of its own) — lane i of a row loads four
+// consecutive elements, lane 0 of the row adds the 64 of them in order, one `v_add_f32_dpp` per element and one LDS read per sixteen.
+// In the first pass the four rows of the wave keep the chains of x, y, z (and w) side by side.
+// (History: one `ds_read_b32` + one add per element, unrolled by 16 / 64: 387 / 336 us per setTemplate of one 1241x376 frame.)
+// Written as one asm block per batch: the compiler folds `update_dpp` + add into the same `v_add_f32_dpp`, but then separates every two
+// of them by `s_nop 1` — its hazard table asks for two wait states between a VALU write and a DPP instruction that reads the register,
+// whichever operand reads it; the hardware needs them for the operand that goes through the lane crossbar (src0: loaded from LDS here),
+// not for the accumulator on the ordinary port (the sums are compared bit for bit with the sequential sums of the CPU restatement at
+// every size the suite runs: tests/test_gpu_parity.py).  NRM_DPP_ASM=0 is the compiler's form.
+#ifndef NRM_DPP_ASM
+#define NRM_DPP_ASM 1
 #endif
+#define NRM_ROW_(I) \
+  "v_add_f32_dpp %0, %1, %0 row_shl:" #I " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+  "v_add_f32_dpp %0, %2, %0 row_shl:" #I " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+  "v_add_f32_dpp %0, %3, %0 row_shl:" #I " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
+  "v_add_f32_dpp %0, %4, %0 row_shl:" #I " row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+// value of lane (l + I) of l's row of 16 (0 where there is none: only lane 0 of a row is ever used)
+template <int I>
+__device__ __forceinline__ float nrm_row_lane(float v)
+{
+  if constexpr(I == 0) return v;
+  else return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + I /* row_shl:I */, 0xf, 0xf, true));
+}
+template <int I>
+__device__ __forceinline__ void nrm_add_row_c(float& acc, const float (&v)[4])
+{
+  if constexpr(I < 16) {
+#pragma unroll
+    for(int q = 0; q < 4; ++q) acc += nrm_row_lane<I>(v[q]);      // elements 4 I .. 4 I + 3 of the batch, in order
+    nrm_add_row_c<I + 1>(acc, v);
+  }
+}
+// acc (lane 0 of every row) += the 64 elements of the batch its row holds, in order
+__device__ __forceinline__ void nrm_add_batch(float& acc, const float (&v)[4])
+{
+#if NRM_DPP_ASM
+  asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4\n"
+               NRM_ROW_(1) NRM_ROW_(2) NRM_ROW_(3) NRM_ROW_(4) NRM_ROW_(5) NRM_ROW_(6) NRM_ROW_(7) NRM_ROW_(8)
+               NRM_ROW_(9) NRM_ROW_(10) NRM_ROW_(11) NRM_ROW_(12) NRM_ROW_(13) NRM_ROW_(14) NRM_ROW_(15)
+               : "+v"(acc) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
+  nrm_add_row_c<0>(acc, v);
+#endif
+}
 constexpr int NRM_THREADS = 256, NRM_CHUNK = 512;   // 20 KB of LDS: seven workgroups per CU (1024-point chunks: three; 0.93 -> 0.59 ms per 1024-pair step)
 __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
                                                                     int with_normalization)
@@ -980,17 +1032,16 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     if(tid == 0) { j.nrm[0] = 1.0f; j.nrm[1] = 0.0f; j.nrm[2] = 0.0f; j.nrm[3] = 0.0f; }
     return;
   }
-  // Chunks of 1024 points are staged in LDS with coalesced loads; wave 0 then adds them strictly in point order.  The
-  // dependent f32 adds are the whole cost (26 k points at level 0 of a 1241x376 frame), so (a) lane l of wave 0 keeps the
-  // chain of component l & 3 — one add per point instead of four, (b) the global loads of chunk i + 1 are in flight while
-  // chunk i is being added (registers -> the other LDS buffer afterwards), and (c) in the second pass every thread forms
-  // the distances of chunk i + 1 while wave 0 accumulates those of chunk i.  Same order, same roundings.
+  // Chunks of 512 points are staged in LDS with coalesced loads (zeros beyond N: x + 0 = x for every partial sum, which is never -0);
+  // wave 0 then adds them strictly in point order, in batches of 64.  (a) Row r of wave 0 keeps the chain of component r, (b) the
+  // global loads of chunk i + 1 are in flight while chunk i is being added (registers -> the other LDS buffer afterwards), and (c) in
+  // the second pass every thread forms the distances of chunk i + 1 while wave 0 accumulates those of chunk i.  Same order, same roundings.
   __shared__ float4 s_pts[2][NRM_CHUNK];
-  __shared__ float s_dist[2][NRM_CHUNK];
+  __shared__ __align__(16) float s_dist[2][NRM_CHUNK];
   __shared__ float s_c[4];
   constexpr int PER = NRM_CHUNK / NRM_THREADS;     // points per thread and chunk
   const int nchunks = (N + NRM_CHUNK - 1) / NRM_CHUNK;
-  const int comp = tid & 3;
+  const int row = (tid >> 4) & 3, li = tid & 15;
   float4 pre[PER];
   auto fetch = [&](int chunk) {
     const int base = chunk * NRM_CHUNK;
@@ -1010,9 +1061,20 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) fetch(ch + 1);
     if(tid < 64) {
-      const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + comp;
-#pragma unroll NRM_UNROLL
-      for(int k = 0; k < cnt; ++k) c += sp[4 * k];
+      const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + row + 16 * li;      // component `row` of point 4 li of a batch
+      float v[4], nx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for(int q = 0; q < 4; ++q) v[q] = sp[4 * q];
+      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0) here, so that the loop does not wait for the NEXT batch's reads before every batch
+      for(int b = 0; b < cnt; b += 64) {
+        if(b + 64 < cnt) {      // the next batch's LDS reads are in flight under this batch's adds
+#pragma unroll
+          for(int q = 0; q < 4; ++q) nx[q] = sp[4 * (b + 64 + q)];
+        }
+        nrm_add_batch(c, v);
+#pragma unroll
+        for(int q = 0; q < 4; ++q) v[q] = nx[q];
+      }
     }
     if(ch + 1 < nchunks) {
 #pragma unroll
@@ -1021,7 +1083,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     __syncthreads();
   }
   const float fN = (float) N;
-  if(tid < 4) s_c[tid] = c / fN;
+  if(tid < 64 && li == 0) s_c[row] = c / fN;
   __syncthreads();
   const float c0 = s_c[0], c1 = s_c[1], c2 = s_c[2], c3 = s_c[3];
   float dpre[PER];
@@ -1032,7 +1094,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
       const int k = base + q * NRM_THREADS + tid;
       const float4 p = (k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
-      dpre[q] = sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      dpre[q] = (k < N) ? sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) : 0.0f;
     }
   };
   dists(0);
@@ -1045,8 +1107,14 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) dists(ch + 1);
     if(tid < 64) {
-#pragma unroll NRM_UNROLL
-      for(int k = 0; k < cnt; ++k) m += s_dist[cur][k];
+      float4 d4 = *reinterpret_cast<const float4*>(&s_dist[cur][4 * li]), n4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      for(int b = 0; b < cnt; b += 64) {
+        if(b + 64 < cnt) n4 = *reinterpret_cast<const float4*>(&s_dist[cur][b + 64 + 4 * li]);
+        const float v[4] = {d4.x, d4.y, d4.z, d4.w};
+        nrm_add_batch(m, v);
+        d4 = n4;
+      }
     }
     if(ch + 1 < nchunks) {
 #pragma unroll
@@ -1095,9 +1163,9 @@ __device__ __forceinline__ void bp_col_pass(const float (&Tm2)[8], const float (
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5, float k0, float k1, float k2)
+__global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* jobs, int grad_cd5, float k0, float k1, float k2, int nframes, int job_pitch)
 {
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   __shared__ float s_lut[18];
   if(C == 8 && j.lazy) {      // (uniform over the workgroup: a frame's level is lazy or it is not)
     if(threadIdx.x < 18) {    // the row-pass table of bitplanes_blur_kernel: entry a + 3 b + 9 S0
@@ -1269,29 +1337,31 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
   else
     hipLaunchKernelGGL(census_kernel, dim3((W + 63) / 64, (R + 4 * CENSUS_ROWS - 1) / (4 * CENSUS_ROWS), nframes), dim3(256), 0, s, jobs);
 }
-void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image)
+void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image, int nlevels,
+                      int job_pitch)
 {
   const int stack = nframes >= 16 ? 8 : 4;
-  const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * stack - 1) / (BP_TH * stack), nframes);
+  const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * stack - 1) / (BP_TH * stack), nframes * nlevels);
   if(sigma > 0.0f && from_image)
-    hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack);
+    hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack, nframes, job_pitch);
   else if(sigma > 0.0f)
-    hipLaunchKernelGGL(bitplanes_blur_kernel<false>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack);
+    hipLaunchKernelGGL(bitplanes_blur_kernel<false>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack, nframes, job_pitch);
   else
     hipLaunchKernelGGL(bitplanes_noblur_kernel, dim3((W * R + 255) / 256, 1, nframes), dim3(256), 0, s, jobs);
 }
 void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, int R, int nframes, int nms_radius, float min_saliency,
-                            float min_disp, float max_disp, int border)
+                            float min_disp, float max_disp, int border, int nlevels, int job_pitch)
 {
   if(nms_radius <= 1) {
     // tiles: saliency + NMS + gate in one pass, candidate bits, word scan, lane-per-pixel compaction
     const int WPR = (W + 63) / 64, nw = R * WPR;
     dispatch_channels(C, [&](auto c) {
-      hipLaunchKernelGGL(saliency_select_tile_kernel<decltype(c)::value>, dim3(WPR, (R + ST_H - 1) / ST_H, nframes), dim3(256), 0, s, jobs,
-                         min_saliency, min_disp, max_disp, border);
+      hipLaunchKernelGGL(saliency_select_tile_kernel<decltype(c)::value>, dim3(WPR, (R + ST_H - 1) / ST_H, nframes * nlevels), dim3(256), 0, s, jobs,
+                         min_saliency, min_disp, max_disp, border, nframes, job_pitch);
     });
-    hipLaunchKernelGGL(select_words_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
-    hipLaunchKernelGGL(select_words_write_kernel, dim3((nw + 4 * SW_WORDS - 1) / (4 * SW_WORDS), 1, nframes), dim3(256), 0, s, jobs);
+    hipLaunchKernelGGL(select_words_scan_kernel, dim3(nframes * nlevels), dim3(1024), 0, s, jobs, nframes, job_pitch);
+    hipLaunchKernelGGL(select_words_write_kernel, dim3((nw + 4 * SW_WORDS - 1) / (4 * SW_WORDS), 1, nframes * nlevels), dim3(256), 0, s, jobs, nframes,
+                       job_pitch);
     return;
   }
   // larger NMS windows: the saliency map first, then flag bytes / chunk scan / compaction straight from it
@@ -1330,12 +1400,13 @@ void launch_gather_counts(hipStream_t s, const FrameJob* jobs, int job_pitch, in
   hipLaunchKernelGGL(gather_counts_kernel, dim3((nframes * kMaxLevels + 255) / 256), dim3(256), 0, s, jobs, job_pitch, nframes, first_level,
                      num_levels, out);
 }
-void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3])
+void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3], int nlevels,
+                           int job_pitch)
 {
   if(max_points <= 0) return;
-  const dim3 g((max_points + 255) / 256, 1, nframes);
+  const dim3 g((max_points + 255) / 256, 1, nframes * nlevels);
   dispatch_channels(C, [&](auto c) {
-    hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5, gauss_k[0], gauss_k[1], gauss_k[2]);
+    hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5, gauss_k[0], gauss_k[1], gauss_k[2], nframes, job_pitch);
   });
 }
 
