@@ -70,8 +70,15 @@ BPVO_HD M44 twist_to_matrix(const float p[6])
   M44 ret = m44_identity();
   const float theta = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
   if((double) theta > 1e-8) {
-    const float a = (float) sin((double) theta);
-    const float b = (float) (1.0 - cos((double) theta));
+    // (device: one argument reduction for both — the library's sin and cos are the two halves of its sincos, bit for bit)
+#ifdef __HIP_DEVICE_COMPILE__
+    double sn, cs;
+    sincos((double) theta, &sn, &cs);
+#else
+    const double sn = sin((double) theta), cs = cos((double) theta);
+#endif
+    const float a = (float) sn;
+    const float b = (float) (1.0 - cs);
     const float t_i = (float) (1.0 / (double) theta);
     const float S[9] = {t_i * 0.0f, t_i * -p[2], t_i * p[1], t_i * p[2], t_i * 0.0f, t_i * -p[0], t_i * -p[1], t_i * p[0], t_i * 0.0f};
     float S2[9];

@@ -54,19 +54,26 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       }
       max_pts[l] = std::max(max_pts[l], pj.n);
     }
-  if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, sizeof(PairJob) * (size_t) c->L * NP, 1);
-  else LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
-  const float* dT = nullptr;
-  if(T_init) {
-    std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
-    if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, sizeof(float) * 16 * n, 1);
-    else LANE_CK(ln, hipMemcpyAsync(ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, ln->stream));
-    dT = ln->d_Tinit;
-  }
-  launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n);
   const bool pk_group = allow_persistent && c->persistent && !c->persistent_failed.load() && n <= c->persist_max_ws && !c->profile_all;
   bool persistent = pk_group;
-  if(persistent) LANE_CK(ln, hipMemsetAsync(ln->d_pk_ctl, 0, sizeof(unsigned) * kPkCtlWords * kMaxLevels, ln->stream));
+  // a context of a few pairs (one pair per call): table, poses and control words in one launch, the states copied out by the last one
+  const bool small_ctx = (size_t) c->L * NP <= 64 && n <= 8 && c->small_batch_fused;
+  if(small_ctx) {
+    if(T_init) std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
+    launch_set_pose_upload(ln->stream, ln->d_pjobs, ln->h_pjobs, (size_t) c->L * NP, ln->h_pjobs + (size_t) (c->L - 1) * NP, T_init ? ln->h_T : nullptr, n,
+                           persistent ? ln->d_pk_ctl : nullptr, persistent ? kPkCtlWords * kMaxLevels : 0);
+  } else {
+    if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, sizeof(PairJob) * (size_t) c->L * NP, 1);
+    else LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
+    const float* dT = nullptr;
+    if(T_init) {
+      std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
+      if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, sizeof(float) * 16 * n, 1);
+      else LANE_CK(ln, hipMemcpyAsync(ln->d_Tinit, ln->h_T, sizeof(float) * 16 * n, hipMemcpyHostToDevice, ln->stream));
+      dT = ln->d_Tinit;
+    }
+    launch_set_pose(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, dT, n, persistent ? ln->d_pk_ctl : nullptr, persistent ? kPkCtlWords * kMaxLevels : 0);
+  }
 
   // PoseEstimatorParameters(AlgorithmParameters) (bpvo/pose_estimator_params.cc:27-33): maxFuncEvals stays 6*200 (Q4);
   // the low-res parameter set equals the full-res one (Q3).
@@ -112,7 +119,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       c->persistent_failed.store(true);      // degrade to the chain, now and for later calls
     }
   }
-  for(int l = c->L - 1; l >= p.maxTestLevel && !team_ran; --l) {
+  auto level_launch = [&](int l) {
     GNLaunch g;
     g.jobs = ln->d_pjobs + (size_t) l * NP;
     g.npairs = n;
@@ -124,24 +131,37 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fuse_frozen = c->fuse_frozen;
     g.step_in_reduce = n <= c->step_in_reduce_max ? 1 : 0;
     g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
-    // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
-    const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+    return g;
+  };
+  // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
+  const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+  bool begun = false;      // this level's start was left to its persistent kernel (its tap-cache keys invalidated by the kernel of the level before)
+  for(int l = c->L - 1; l >= p.maxTestLevel && !team_ran; --l) {
+    GNLaunch g = level_launch(l);
     if(l < c->L - 1)
       if(int rcj = join_normalization()) return rcj;
-    launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
+    const bool was_begun = begun;
+    begun = false;
+    if(!was_begun) launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
     if(g.max_points <= 0) continue;
     if(persistent && gn_persistent_serves(g)) {
-      // the whole level in one launch
+      // the whole level in one launch — and the start of the next level with it, when that one takes the kernel too
+      const bool next_too = l - 1 >= p.maxTestLevel && max_pts[l - 1] > 0 && gn_persistent_serves(level_launch(l - 1));
+      g.begin_level = was_begun ? l : -1;
+      g.begin_moot = l2_moot ? 1 : 0;
+      g.next_jobs = next_too ? ln->d_pjobs + (size_t) (l - 1) * NP : nullptr;
       const hipError_t pe = launch_gn_persistent(ln->stream, g, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance,
                                                  ln->d_pk_ctl + (size_t) l * kPkCtlWords, gn_persistent_grid(g, c->persist_grid), c->persist_timeout);
       if(pe == hipSuccess) {
         c->persistent_levels.fetch_add(1);
+        begun = next_too;
         continue;
       }
       // the device cannot grant the kernel its LDS / residency (or the launch failed): degrade to the four-kernel chain — this level,
       // the rest of the pyramid and every later call of the context — instead of failing the estimate
       (void) hipGetLastError();
       c->persistent_failed.store(true);
+      if(was_begun) launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);
     }
     persistent = false;     // (a level the kernel does not serve: the rest of the pyramid takes the chain as well)
     // At most maxIterations + 2 linearisations per level (pose_estimator_base.h:373-393); the state machine on the device
@@ -197,7 +217,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       g.active.list = lists[prev];
     }
   }
-  launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
+  if(small_ctx) launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out, c->d_states, ln->h_states, pk_group ? ln->d_pk_ctl : nullptr,
+                                    pk_group ? ln->h_pk_ctl : nullptr, kPkCtlWords * kMaxLevels);
+  else launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
   bool frac_queued = false;
   if(n == 1 && c->prefetch_frac_thr >= 0.0f && ln == &c->lanes[0]) {
     // fraction_good of this workspace at the level the estimate ended on, from the job already on the device
@@ -217,9 +239,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   // only this group's states: other lanes may still be writing theirs
   int ws_lo = wss[0], ws_hi = wss[0];
   for(int i = 1; i < n; ++i) { ws_lo = std::min(ws_lo, wss[i]); ws_hi = std::max(ws_hi, wss[i]); }
-  LANE_CK(ln, hipMemcpyAsync(ln->h_states + ws_lo, c->d_states + ws_lo, sizeof(GNState) * (size_t) (ws_hi - ws_lo + 1), hipMemcpyDeviceToHost, ln->stream));
-  if(pk_group)
-    LANE_CK(ln, hipMemcpyAsync(ln->h_pk_ctl, ln->d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels, hipMemcpyDeviceToHost, ln->stream));
+  if(!small_ctx) {
+    LANE_CK(ln, hipMemcpyAsync(ln->h_states + ws_lo, c->d_states + ws_lo, sizeof(GNState) * (size_t) (ws_hi - ws_lo + 1), hipMemcpyDeviceToHost, ln->stream));
+    if(pk_group)
+      LANE_CK(ln, hipMemcpyAsync(ln->h_pk_ctl, ln->d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels, hipMemcpyDeviceToHost, ln->stream));
+  }
   LANE_CK(ln, hipStreamSynchronize(ln->stream));
   LANE_CK(ln, hipGetLastError());
   if(frac_queued) { c->frac_valid = true; c->frac_ws = wss[0]; c->frac_thr = c->prefetch_frac_thr; c->frac_cnt = (unsigned) c->h_ints[0]; }

@@ -22,7 +22,8 @@ int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const F
   // rows [tab, tab + count) of every level in one copy
   const size_t pitch = sizeof(FrameJob) * (size_t) c->n_frames;
   static_assert(sizeof(FrameJob) % 8 == 0 && sizeof(PairJob) % 8 == 0, "copy_rows_kernel moves 8-byte words");
-  if(c->ctl_by_kernel.load())
+  // (small tables too: a 2-D copy of a few KB is a 20 us stop of the stream, the kernel 5 — what a stage of one or two frames notices)
+  if(c->ctl_by_kernel.load() || count <= 64)
     launch_copy_rows(fr.stream, c->d_fjobs + table + fr.tab, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, c->L);
   else
     FR_CK(c, fr, hipMemcpy2DAsync(c->d_fjobs + table + fr.tab, pitch, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, (size_t) c->L,
@@ -69,8 +70,19 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     double px = 0;
     for(int l = 1; l < c->L; ++l) px += (double) c->geom[l].npix * count;
     ScopedTimer t(c, KC_PYRAMID, px, fr.ln);
-    for(int l = 1; l < c->L; ++l)   // ImagePyramid::compute (bpvo/image_pyramid.cc:43-50)
-      launch_pyrdown(s, tab + (size_t) (l - 1) * NF, tab + (size_t) l * NF, c->geom[l].cols, c->geom[l].rows, count);
+    // ImagePyramid::compute (bpvo/image_pyramid.cc:43-50).  Few frames: up to three levels per launch (kernels_frame.hip pyramid_levels_kernel)
+    bool grouped = count <= c->merge_levels_max_frames;
+    for(int l = 0; l < c->L; ++l) grouped = grouped && c->geom[l].cols >= 8 && c->geom[l].rows >= 8;
+    for(int l = 1; l < c->L;) {
+      const int steps = grouped ? std::min(3, c->L - l) : 0;
+      if(steps >= 2) {
+        launch_pyramid_levels(s, tab + (size_t) (l - 1) * NF, NF, steps, c->geom[l + steps - 1].cols, c->geom[l + steps - 1].rows, count);
+        l += steps;
+      } else {
+        launch_pyrdown(s, tab + (size_t) (l - 1) * NF, tab + (size_t) l * NF, c->geom[l].cols, c->geom[l].rows, count);
+        l += 1;
+      }
+    }
   }
   {
     double px = 0;
@@ -149,33 +161,12 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   bool tiled = true;
   for(int l = p.maxTestLevel; l < c->L; ++l) tiled = tiled && c->geom[l].nms_radius <= 1;
   const bool one_launch = tiled && count <= c->merge_levels_max_frames && c->L - p.maxTestLevel > 1;
-  if(one_launch) {
-    const LevelGeom& g = c->geom[p.maxTestLevel];
-    double px = 0;
-    for(int l = p.maxTestLevel; l < c->L; ++l) px += (double) c->geom[l].npix * count;
-    ScopedTimer t(c, KC_SALIENCY_SELECT, px, fr.ln);
-    launch_saliency_select(s, tab + (size_t) p.maxTestLevel * NF, c->C, g.cols, g.rows, count, 1, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border,
-                           c->L - p.maxTestLevel, NF);
-  }
-  for(int l = c->L - 1; l >= p.maxTestLevel && !one_launch; --l) {
-    const FrameJob* jobs = tab + (size_t) l * NF;
-    const LevelGeom& g = c->geom[l];
-    ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count, fr.ln);
-    launch_saliency_select(s, jobs, c->C, g.cols, g.rows, count, g.nms_radius, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
-  }
-  // one read-back of the point counts: the host needs them to size the template-build and GN grids.  Queued AHEAD of the normalisation
-  // and waited for through an event of its own: the host's round trip (~30 us) then runs under the normalisation's sequential sums
-  // (0.24 ms for a 1241x376 frame) instead of behind them — what a single pair per call notices.
-  launch_gather_counts(s, tab, NF, count, p.maxTestLevel, c->L, d_ints);
-  FR_CK(c, fr, hipMemcpyAsync(h_ints, d_ints, sizeof(int) * kMaxLevels * (size_t) count, hipMemcpyDeviceToHost, s));
   hipEvent_t counts_ev = fr.ln ? fr.ln->round_ev[0] : nullptr;      // (the lane's round events are idle outside its estimation)
-  if(counts_ev) FR_CK(c, fr, hipEventRecord(counts_ev, s));
-  if(fr.selected_ev) FR_CK(c, fr, hipEventRecord(fr.selected_ev, s));
-  if(fr.on_selected) fr.on_selected();
   // The normalisation — sequential sums in the reference's order, a latency chain of one workgroup per (frame, level): 0.2 ms whatever the
   // batch — is read by the Gauss-Newton kernels only (the Jacobian rows are rebuilt there; template_build stores pixels and gradients).
-  // A stage that runs alone on the context's stream (single frames, batches on one lane) puts it on a stream of its own, next to
-  // template_build and the host's round trip for the point counts, and joins the two before it returns; lanes of a fanned-out batch keep it in line.
+  // A stage that runs alone on the context's stream (single frames, batches on one lane) puts it on a stream of its own — forked right
+  // behind the selection, next to the read-back of the point counts, the host's round trip for them and template_build — and joins
+  // the two before it returns; lanes of a fanned-out batch keep it in line.
   hipStream_t side = nullptr;
   if(c->nrm_side_stream && !fr.own_thread && fr.ln == &c->lanes[0] && counts_ev) {
     if(!c->side_stream) {
@@ -190,6 +181,20 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   // estimation just before its second level (estimate.hip).
   const int with_nrm = c->dspace ? 0 : p.withNormalization;      // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
   const bool defer = side && fr.defer_finest_nrm && c->nrm_defer && c->L - p.maxTestLevel > 1 && !c->nrm_pending;
+  if(one_launch) {
+    double px = 0;
+    for(int l = p.maxTestLevel; l < c->L; ++l) px += (double) c->geom[l].npix * count;
+    ScopedTimer t(c, KC_SALIENCY_SELECT, px, fr.ln);
+    const LevelGeom& g = c->geom[p.maxTestLevel];
+    launch_saliency_select(s, tab + (size_t) p.maxTestLevel * NF, c->C, g.cols, g.rows, count, 1, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border,
+                           c->L - p.maxTestLevel, NF);
+  }
+  for(int l = c->L - 1; l >= p.maxTestLevel && !one_launch; --l) {
+    const FrameJob* jobs = tab + (size_t) l * NF;
+    const LevelGeom& g = c->geom[l];
+    ScopedTimer t(c, KC_SALIENCY_SELECT, (double) g.npix * count, fr.ln);
+    launch_saliency_select(s, jobs, c->C, g.cols, g.rows, count, g.nms_radius, p.minSaliency, p.minValidDisparity, p.maxValidDisparity, border);
+  }
   if(side) {
     FR_CK(c, fr, hipEventRecord(c->side_ev[0], s));
     FR_CK(c, fr, hipStreamWaitEvent(side, c->side_ev[0], 0));
@@ -203,7 +208,16 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
       launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm);
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
     }
-  } else {
+  }
+  // one read-back of the point counts: the host needs them to size the template-build and GN grids.  Queued AHEAD of an in-line normalisation
+  // and waited for through an event of its own: the host's round trip (~30 us) then runs under the normalisation's sequential sums
+  // instead of behind them.
+  launch_gather_counts(s, tab, NF, count, p.maxTestLevel, c->L, d_ints);
+  FR_CK(c, fr, hipMemcpyAsync(h_ints, d_ints, sizeof(int) * kMaxLevels * (size_t) count, hipMemcpyDeviceToHost, s));
+  if(counts_ev) FR_CK(c, fr, hipEventRecord(counts_ev, s));
+  if(fr.selected_ev) FR_CK(c, fr, hipEventRecord(fr.selected_ev, s));
+  if(fr.on_selected) fr.on_selected();
+  if(!side) {
     // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
     ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln);
     launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, with_nrm);

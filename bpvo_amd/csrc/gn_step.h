@@ -41,6 +41,28 @@ __device__ void gn_finalize(GNState* st)
   st->active = 0;
 }
 
+// PoseEstimatorBase::reset + the head of run() (bpvo/pose_estimator_base.h:287-293,327-335): the state a pyramid level starts from —
+// level_begin_kernel on the state in HBM, the persistent single-pair kernel on its workgroups' copies (kernels_gn_team.hip).
+__device__ __forceinline__ void gn_level_reset(GNState* st, int level, int scale_is_moot, int n_points)
+{
+  st->scale = 1.0f;
+  st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
+  st->f_norm_prev = 0.0f;
+  st->g_tol = 0.0f;
+  st->g_norm = 0.0f;
+  st->num_fun_evals = 0;
+  st->num_iterations = 0;
+  st->status = BPVO_STATUS_MAX_ITERATIONS;
+  st->phase = PHASE_FIRST;
+  st->has_converged = 0;
+  st->level = level;
+  st->median_valid = 0;
+  st->last_median = 0.0f;
+  for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
+  for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
+  st->active = (n_points > 0) ? 1 : 0;
+}
+
 // the serial part of gn_step, executed by lane 0 on the LDS copy of the state; returns true if another linearisation
 // is requested (the workspace stays active)
 #ifdef BPVO_PK_TIMING

@@ -200,9 +200,10 @@ struct bpvo_hip_ctx {
                                  // pk_join_team): 0 never, 1 teams on the workgroup's own XCD, 2 any team
   int merge_levels_max_frames = 8;   // option "levels_in_one_launch_max_frames": frame stages of at most this many frames run the levels of the
                                  // bit-planes, selection and template-build kernels in one launch each (frames.hip)
+  int small_batch_fused = 1;     // option "small_batch_fused": contexts of a few pairs — job table + poses in one launch, states copied out by pack_records (estimate.hip)
   int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
   int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
-  hipStream_t side_stream = nullptr;  // the normalisation's stream (created at its first use) and its events: [0] fork, [1] coarse levels done, [2] finest done
+  hipStream_t side_stream = nullptr;  // the normalisation's stream (created at its first use) and its events: [0] fork, [1] coarsest level done (or all), [2] the levels below done
   hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
   hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels below the coarsest of the template stage just queued; whoever
                                  // reads those levels' (scale, centroid) next makes its stream wait for it (estimate.hip) and clears it

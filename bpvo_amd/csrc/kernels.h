@@ -36,6 +36,8 @@ struct GaussTaps { int n = 0; float k[kMaxGaussTaps] = {}; int ki[kMaxGaussTaps]
 // per-frame stage (batched over frames)
 void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_images, const float* d_disps, size_t npix, int nframes, int skip_odd_disp = 0);
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
+// few frames: `steps` (1..3) pyrDown steps in one launch — src_row is the source level's row of the table [level][job_pitch], dW x dR the COARSEST level of the group
+void launch_pyramid_levels(hipStream_t s, const FrameJob* src_row, int job_pitch, int steps, int dW, int dR, int nframes);
 void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
 void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre);   // (I, Ix, Iy), C = 3
 void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, const GaussTaps& g1,
@@ -127,9 +129,13 @@ struct GNLaunch {
   // gn_step_kernel does, with step_prm) — the chain is then three kernels per iteration and launch_gn_step is not called
   int step_in_reduce = 0;
   GNParams step_prm = {0, 0, 0.0f, 0.0f, 0.0f};
+  // gn_persistent_kernel only: begin_level >= 0 — the kernel takes the level's start itself (level_begin_kernel's state reset; the tap-cache
+  // keys were invalidated by the kernel of the level before, which was handed this level's jobs as next_jobs)
+  int begin_level = -1, begin_moot = 0;
+  const PairJob* next_jobs = nullptr;
 };
 int  gn_num_blocks(int max_points);
-void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init /*device [n][16] or null = Identity*/, int n);
+void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n, unsigned* clear = nullptr, int clear_words = 0);   // clear: words zeroed by the same launch
 // PoseEstimatorBase::reset of every workspace + invalidation of its tap-cache keys (max_points: the largest template of the launch)
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int max_points, int level, int scale_is_moot = 0);
 void launch_reset_tapkeys(hipStream_t s, const GNLaunch& g);
@@ -171,6 +177,10 @@ int  gn_pts_per_block(int C);
 int  gn_partials_entries(int cap, int C);   // kPartialStride-float entries of a workspace's (double-buffered) tile partials
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
-void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records);
+void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states = nullptr, GNState* h_states = nullptr,
+                         const unsigned* d_ctl = nullptr, unsigned* h_ctl = nullptr, int ctl_words = 0);   // h_states / h_ctl (pinned host): copied out by the same launch
+// a few pairs: job table upload (from the pinned host rows) + initial poses + cleared control words in one launch
+void launch_set_pose_upload(hipStream_t s, PairJob* d_table, const PairJob* h_table, size_t table_jobs, const PairJob* h_jobs_coarsest, const float* T_init,
+                            int n, unsigned* clear, int clear_words);
 
 }  // namespace bpvo_hip

@@ -165,6 +165,87 @@ __global__ __launch_bounds__(256) void pyrdown_u8_lds_kernel(const FrameJob* src
   }
 }
 
+// ---- K0 for a few frames: up to three pyrDown steps in ONE launch.  One level is a 15 - 20 us launch whatever the frame (a stage of one
+// or two frames fills a fraction of the chip), and the levels depend on each other: three of them are 53 us of a single pair's 220 us
+// frame stage.  Here a workgroup owns an 8 x 8 tile of the COARSEST level of the group and computes, in LDS, everything below it that
+// the tile depends on — 19 x 19 pixels of the level before, 41 x 41 of the one before that, from 85 x 85 source pixels — and stores
+// the part of every level that lies under its own tile (the halos are recomputed by the neighbours: integer arithmetic, same values).
+// Same definition as pyrdown_u8_lds_kernel: [1 4 6 4 1]^2, (s + 128) >> 8, BORDER_REFLECT_101 on every level's own coordinates.
+constexpr int PA_T = 8;
+constexpr int pa_edge(int steps) { return steps == 0 ? PA_T : 2 * pa_edge(steps - 1) + 3; }      // 8, 19, 41, 85
+template <int NL>
+__global__ __launch_bounds__(256) void pyramid_levels_kernel(const FrameJob* jobs /* the SOURCE level's row of the table */, int job_pitch)
+{
+  constexpr int E0 = pa_edge(NL), E1 = pa_edge(NL - 1);
+  __shared__ uint8_t s_a[E0 * E0];           // the level being read
+  __shared__ uint8_t s_b[E1 * E1];           // the level being written
+  __shared__ uint16_t s_h[E0 * E1];          // horizontal sums of the level being read (<= 16 * 255)
+  int W[NL + 1], H[NL + 1], xlo[NL + 1], xhi[NL + 1], ylo[NL + 1], yhi[NL + 1];      // (hi inclusive)
+#pragma unroll
+  for(int k = 0; k <= NL; ++k) { const FrameJob& j = jobs[(size_t) k * job_pitch + blockIdx.z]; W[k] = j.cols; H[k] = j.rows; }
+  xlo[NL] = blockIdx.x * PA_T; xhi[NL] = min(xlo[NL] + PA_T, W[NL]) - 1;
+  ylo[NL] = blockIdx.y * PA_T; yhi[NL] = min(ylo[NL] + PA_T, H[NL]) - 1;
+#pragma unroll
+  for(int k = NL - 1; k >= 0; --k) {
+    xlo[k] = max(0, 2 * xlo[k + 1] - 2); xhi[k] = min(W[k] - 1, 2 * xhi[k + 1] + 2);
+    ylo[k] = max(0, 2 * ylo[k + 1] - 2); yhi[k] = min(H[k] - 1, 2 * yhi[k + 1] + 2);
+  }
+  const int tid = threadIdx.x;
+  {   // the source region
+    const uint8_t* __restrict__ src = jobs[blockIdx.z].img;
+    const int nx = xhi[0] - xlo[0] + 1, ny = yhi[0] - ylo[0] + 1;
+    for(int i = tid; i < nx * ny; i += 256) {
+      const int r = i / nx, c = i - r * nx;
+      s_a[r * E0 + c] = src[(size_t) (ylo[0] + r) * W[0] + xlo[0] + c];
+    }
+  }
+  __syncthreads();
+  uint8_t* cur = s_a;
+  uint8_t* nxt = s_b;
+  int pc = E0, pn = E1;      // row pitches of the two buffers
+#pragma unroll
+  for(int k = 0; k < NL; ++k) {
+    const int snx = xhi[k] - xlo[k] + 1, sny = yhi[k] - ylo[k] + 1;          // region of level k in `cur`
+    const int dnx = xhi[k + 1] - xlo[k + 1] + 1, dny = yhi[k + 1] - ylo[k + 1] + 1;
+    (void) snx;
+    for(int i = tid; i < sny * dnx; i += 256) {      // horizontal sums: (source row, destination column)
+      const int r = i / dnx, c = i - r * dnx;
+      const int x2 = 2 * (xlo[k + 1] + c);
+      const uint8_t* row = cur + r * pc - xlo[k];
+      const unsigned a0 = row[reflect101(x2 - 2, W[k])], a1 = row[reflect101(x2 - 1, W[k])], a2 = row[x2], a3 = row[reflect101(x2 + 1, W[k])],
+                     a4 = row[reflect101(x2 + 2, W[k])];
+      s_h[r * E1 + c] = (uint16_t) (a0 + 4u * a1 + 6u * a2 + 4u * a3 + a4);
+    }
+    __syncthreads();
+    // the level's owned part: under this workgroup's tile of the coarsest level
+    const int sh = NL - (k + 1);
+    const int ox0 = (blockIdx.x * PA_T) << sh, ox1 = min(((blockIdx.x + 1) * PA_T) << sh, W[k + 1]);
+    const int oy0 = (blockIdx.y * PA_T) << sh, oy1 = min(((blockIdx.y + 1) * PA_T) << sh, H[k + 1]);
+    uint8_t* __restrict__ dst = const_cast<uint8_t*>(jobs[(size_t) (k + 1) * job_pitch + blockIdx.z].img.get());
+    for(int i = tid; i < dny * dnx; i += 256) {
+      const int r = i / dnx, c = i - r * dnx;
+      const int y = ylo[k + 1] + r, x = xlo[k + 1] + c, y2 = 2 * y;
+      const uint16_t* col = s_h + c - ylo[k] * E1;
+      const unsigned b0 = col[reflect101(y2 - 2, H[k]) * E1], b1 = col[reflect101(y2 - 1, H[k]) * E1], b2 = col[y2 * E1],
+                     b3 = col[reflect101(y2 + 1, H[k]) * E1], b4 = col[reflect101(y2 + 2, H[k]) * E1];
+      const uint8_t v = (uint8_t) ((b0 + 4u * b1 + 6u * b2 + 4u * b3 + b4 + 128u) >> 8);
+      nxt[r * pn + c] = v;
+      if(x >= ox0 && x < ox1 && y >= oy0 && y < oy1) dst[(size_t) y * W[k + 1] + x] = v;
+    }
+    __syncthreads();
+    { uint8_t* t = cur; cur = nxt; nxt = t; }
+    { const int t = pc; pc = pn; pn = t; }
+  }
+}
+// is the group [first, first + steps] servable?  (every level at least 8 pixels either way: the reflections then stay inside a workgroup's regions)
+void launch_pyramid_levels(hipStream_t s, const FrameJob* src_row, int job_pitch, int steps, int dW, int dR, int nframes)
+{
+  const dim3 grid((dW + PA_T - 1) / PA_T, (dR + PA_T - 1) / PA_T, nframes);
+  if(steps == 3) hipLaunchKernelGGL(pyramid_levels_kernel<3>, grid, dim3(256), 0, s, src_row, job_pitch);
+  else if(steps == 2) hipLaunchKernelGGL(pyramid_levels_kernel<2>, grid, dim3(256), 0, s, src_row, job_pitch);
+  else hipLaunchKernelGGL(pyramid_levels_kernel<1>, grid, dim3(256), 0, s, src_row, job_pitch);
+}
+
 // ---- IntensityDescriptor::compute: u8 -> f32 (reference: bpvo/intensity_descriptor.cc:31-43)
 __global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
 {
@@ -1340,7 +1421,8 @@ void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframe
 void launch_bitplanes(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, float sigma, const float k[3], int from_image, int nlevels,
                       int job_pitch)
 {
-  const int stack = nframes >= 16 ? 8 : 4;
+  // tiles a workgroup walks: few frames do not fill the chip with stacks of four (1241x376 x 2 frames: 480 workgroups of 32 rows)
+  const int stack = nframes >= 16 ? 8 : (nframes > 4 ? 4 : 1);
   const dim3 grid((W + BP_TW - 1) / BP_TW, (R + BP_TH * stack - 1) / (BP_TH * stack), nframes * nlevels);
   if(sigma > 0.0f && from_image)
     hipLaunchKernelGGL(bitplanes_blur_kernel<true>, grid, dim3(256), 0, s, jobs, k[0], k[1], k[2], stack, nframes, job_pitch);

@@ -306,11 +306,34 @@ __global__ __launch_bounds__(1024) void compact_active_kernel(const PairJob* __r
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n)
+__global__ void set_pose_kernel(const PairJob* jobs, const float* T_init, int n, unsigned* clear, int clear_words)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  for(int i = p; i < clear_words; i += gridDim.x * blockDim.x) clear[i] = 0u;      // (the persistent kernel's control words: no memset launch of their own)
   if(p >= n) return;
   GNState* st = jobs[p].st;
+  for(int i = 0; i < 16; ++i) st->T_out[i] = T_init ? T_init[p * 16 + i] : ((i % 5 == 0) ? 1.0f : 0.0f);
+  st->trace_n = 0;
+  for(int l = 0; l < kMaxLevels; ++l) {                 // OptimizerStatistics() defaults (bpvo/types.cc:306-310)
+    st->stats[l].numIterations = 0;
+    st->stats[l].finalError = -1.0f;
+    st->stats[l].firstOrderOptimality = -1.0f;
+    st->stats[l].status = BPVO_STATUS_SOLVER_ERROR;
+  }
+}
+
+// A few pairs: the job table's upload, the initial poses and the cleared control words in ONE launch of one workgroup — the table is read
+// straight from the pinned host rows (8-byte words), the poses are set through the HOST copy of the coarsest level's jobs (the device
+// copy is being written by the neighbours).  A copy + a kernel otherwise: two 5 us stops of the stream in front of the first iteration.
+__global__ __launch_bounds__(256) void set_pose_upload_kernel(unsigned long long* __restrict__ d_table, const unsigned long long* __restrict__ h_table,
+                                                              size_t words, const PairJob* h_jobs_coarsest, const float* T_init, int n, unsigned* clear,
+                                                              int clear_words)
+{
+  for(size_t i = threadIdx.x; i < words; i += 256) d_table[i] = h_table[i];
+  for(int i = threadIdx.x; i < clear_words; i += 256) clear[i] = 0u;
+  const int p = threadIdx.x;
+  if(p >= n) return;
+  GNState* st = h_jobs_coarsest[p].st;
   for(int i = 0; i < 16; ++i) st->T_out[i] = T_init ? T_init[p * 16 + i] : ((i % 5 == 0) ? 1.0f : 0.0f);
   st->trace_n = 0;
   for(int l = 0; l < kMaxLevels; ++l) {                 // OptimizerStatistics() defaults (bpvo/types.cc:306-310)
@@ -338,23 +361,7 @@ __global__ __launch_bounds__(GN_BLOCK) void level_begin_kernel(const PairJob* jo
     if(i < j.n && j.tapkey) j.tapkey[i] = 0xffffffffu;
   }
   if(blockIdx.x != 0 || threadIdx.x != 0) return;
-  GNState* st = j.st;
-  st->scale = 1.0f;
-  st->delta_scale = scale_is_moot ? 0.0f : 1e10f;
-  st->f_norm_prev = 0.0f;
-  st->g_tol = 0.0f;
-  st->g_norm = 0.0f;
-  st->num_fun_evals = 0;
-  st->num_iterations = 0;
-  st->status = BPVO_STATUS_MAX_ITERATIONS;
-  st->phase = PHASE_FIRST;
-  st->has_converged = 0;
-  st->level = level;
-  st->median_valid = 0;
-  st->last_median = 0.0f;
-  for(int i = 0; i < 16; ++i) st->T[i] = st->T_out[i];
-  for(int i = 0; i < 6; ++i) st->dp[i] = 0.0f;
-  st->active = (j.n > 0) ? 1 : 0;
+  gn_level_reset(j.st, level, scale_is_moot, j.n);
 }
 
 // invalidates the tap cache keys of every workspace of a launch (start of a level / of a linearize call)
@@ -428,8 +435,21 @@ __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, flo
 
 // 32-float result record per pair for the RCCL gather: pose 3x4 (12), numIterations per level (8), status per level (8),
 // total function evaluations are not kept per level so [28..31] = {finalError of the finest level, n_valid, 0, 0}
-__global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* records)
+// h_states (pinned host, or null): the states — and h_ctl: the persistent kernel's control words — written to the host by this launch as well
+// (a few pairs: two copies of a few hundred bytes are two more stops of the stream behind the last iteration)
+__global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,
+                                    unsigned* h_ctl, int ctl_words)
 {
+  if(h_states) {
+    constexpr int kWords = (int) (sizeof(GNState) / 4);
+    for(int q = 0; q < n; ++q) {
+      const GNState* st = jobs[q].st;
+      const unsigned* src = reinterpret_cast<const unsigned*>(st);
+      unsigned* dst = reinterpret_cast<unsigned*>(h_states + (st - d_states));
+      for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < kWords; i += gridDim.x * blockDim.x) dst[i] = src[i];
+    }
+    for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < ctl_words; i += gridDim.x * blockDim.x) h_ctl[i] = d_ctl[i];
+  }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if(p >= n) return;
   const GNState* st = jobs[p].st;
@@ -463,9 +483,9 @@ int gn_partials_entries(int cap, int C)
   return 2 * std::max(1, (cap + ppb - 1) / ppb);
 }
 
-void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n)
+void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n, unsigned* clear, int clear_words)
 {
-  hipLaunchKernelGGL(set_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, T_init, n);
+  hipLaunchKernelGGL(set_pose_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, T_init, n, clear, clear_words);
 }
 void launch_level_begin(hipStream_t s, const PairJob* jobs, int npairs, int max_points, int level, int scale_is_moot)
 {
@@ -606,8 +626,18 @@ void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss
   if(n <= 0) return;
   dispatch_channels(C, [&](auto c) { launch_count_good_c<decltype(c)::value>(s, job, n, loss, thr, count); });
 }
-void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records)
+void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,
+                         unsigned* h_ctl, int ctl_words)
 {
-  hipLaunchKernelGGL(pack_records_kernel, dim3((n + 63) / 64), dim3(64), 0, s, jobs, n, L, records);
+  static_assert(sizeof(GNState) % 4 == 0, "pack_records_kernel moves 4-byte words");
+  hipLaunchKernelGGL(pack_records_kernel, dim3((n + 63) / 64), dim3(h_states ? 256 : 64), 0, s, jobs, n, L, records, d_states, h_states, d_ctl, h_ctl,
+                     h_ctl ? ctl_words : 0);
+}
+void launch_set_pose_upload(hipStream_t s, PairJob* d_table, const PairJob* h_table, size_t table_jobs, const PairJob* h_jobs_coarsest, const float* T_init,
+                            int n, unsigned* clear, int clear_words)
+{
+  static_assert(sizeof(PairJob) % 8 == 0, "set_pose_upload_kernel moves 8-byte words");
+  hipLaunchKernelGGL(set_pose_upload_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<unsigned long long*>(d_table),
+                     reinterpret_cast<const unsigned long long*>(h_table), table_jobs * (sizeof(PairJob) / 8), h_jobs_coarsest, T_init, n, clear, clear_words);
 }
 }  // namespace bpvo_hip

@@ -325,7 +325,8 @@ __device__ __attribute__((noinline)) bool pk_grid_barrier(unsigned* ctl, unsigne
 
 template <int C, int LOSS>
 __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob* __restrict__ jobs, int nws, int pts_per_block, GNParams prm,
-                                                                   int fuse_frozen, unsigned* ctl, long long timeout)
+                                                                   int fuse_frozen, unsigned* ctl, long long timeout, int begin_level, int begin_moot,
+                                                                   const PairJob* __restrict__ next_jobs)
 {
   constexpr bool kCanFuse = (C == 8);
   const int tid = threadIdx.x;
@@ -340,6 +341,12 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
     if(tid == 4) pk_nrm[ws][4] = jobs[ws].dspace ? 1.0f : 0.0f;
   }
   __syncthreads();
+  // begin_level >= 0: the level's start (level_begin_kernel's reset of the state) is taken here, by every workgroup on its own copy — the
+  // tap-cache keys of this level were invalidated by the epilogue of the kernel of the level before (next_jobs there): no launch between two levels
+  if(begin_level >= 0) {
+    if(tid < nws) gn_level_reset(pk_st(tid), begin_level, begin_moot, jobs[tid].n);
+    __syncthreads();
+  }
 
   unsigned epoch = 0, epoch_it = 0;     // grid barriers passed; iterations done (parity of the partials buffer)
   bool ok = true;
@@ -415,6 +422,15 @@ __global__ __launch_bounds__(PK_THREADS) void gn_persistent_kernel(const PairJob
     for(int ws = 0; ws < nws; ++ws) {
       uint32_t* g = reinterpret_cast<uint32_t*>(jobs[ws].st.get());
       for(int i = tid; i < kStateWords; i += PK_THREADS) g[i] = pk_state[ws][i];
+    }
+  }
+  // the tap-cache keys of the NEXT level's points (one key array per workspace, shared by the levels): nobody reads a key after the last
+  // barrier of the last iteration, the next level's kernel starts behind this one
+  if(ok && next_jobs) {
+    for(int ws = 0; ws < nws; ++ws) {
+      const PairJob& nj = next_jobs[ws];
+      if(!nj.tapkey) continue;
+      for(int i = (int) blockIdx.x * PK_THREADS + tid; i < nj.n; i += (int) gridDim.x * PK_THREADS) nj.tapkey[i] = 0xffffffffu;
     }
   }
 }
@@ -1081,7 +1097,7 @@ static hipError_t launch_gn_persistent_c(hipStream_t s, const GNLaunch& g, const
       if(status[dev] == hipSuccess && per_cu < 1) status[dev] = hipErrorLaunchOutOfResources;
     });
     if(status[dev] != hipSuccess) return status[dev];
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PK_THREADS), kMedianLds, s, g.jobs, g.npairs, ppb, prm, fuse, ctl, timeout);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PK_THREADS), kMedianLds, s, g.jobs, g.npairs, ppb, prm, fuse, ctl, timeout, g.begin_level, g.begin_moot, g.next_jobs);
     return hipGetLastError();
   };
   switch(g.loss) {
