@@ -71,7 +71,7 @@ BPVO_HD M44 twist_to_matrix(const float p[6])
   const float theta = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
   if((double) theta > 1e-8) {
     // (device: one argument reduction for both — the library's sin and cos are the two halves of its sincos, bit for bit)
-#ifdef __HIP_DEVICE_COMPILE__
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(BPVO_TWIST_SEPARATE_SIN_COS)
     double sn, cs;
     sincos((double) theta, &sn, &cs);
 #else

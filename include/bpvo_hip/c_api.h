@@ -370,6 +370,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team"                   1         batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in one team-persistent launch
  *   "team_max_pairs"         128       ... up to this many pairs; above "team_full_pairs" (80) only when CUs / pairs workgroups per pair fill at least
  *                                      95 % of the CUs (128 pairs on 256 CUs do, 96 do not: the chain is faster there)
+ *   "team_full_pairs"        80        batches of up to this many pairs take the team kernel whatever the fill of the chip (see "team_max_pairs", "team_spares")
  *   "team_size"              0         workgroups per team; 0 = CUs / pairs
  *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
  *   "team_local_barriers"    1         teams whose workgroups all run on one XCD (checked on the device) skip the L2 write-back of their barriers
@@ -380,7 +381,12 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *                                      (96 pairs: 2 x 96 + 64 spares, + 4 %; 112: + 6 %) — with it every batch of up to team_max_pairs pairs takes the team kernel
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
  *   "normalization_side_stream" 1      a frame stage that runs alone on the context's stream (single frames, batches on one lane) queues the
- *                                      Hartley normalisation sums on the idle stream of lane 1, next to template_build, and joins them before it returns
+ *                                      Hartley normalisation sums on a stream of its own, next to template_build, and joins them before it returns
+ *   "normalization_deferred" 1         ... and inside bpvo_hip_batch_run on one lane (not the team kernel) only the coarsest level's sums are joined:
+ *                                      the others run on under that level's Gauss-Newton iterations, the estimation waits for them before its second level
+ *   "levels_in_one_launch_max_frames" 8  frame stages of at most this many frames run ALL levels of the pyramid (three pyrDown steps per launch), of
+ *                                      the bit-planes, of the tiled selection and of the template build in one launch each (a single pair: 33 -> 14 launches)
+ *   "small_batch_fused"      1         contexts of a few pairs: job table + initial poses in one launch, states copied out by the record-packing launch
  *   "fuse_frozen"            1         residuals recomputed inside the reduction once a workspace's robust scale is frozen (C = 8)
  *   "step_in_reduce_max_pairs" 128     groups (the pairs of one lane) of up to this many pairs: the Gauss-Newton step is taken by the last tile of a pair
  *                                      inside the reduction launch — three kernels per iteration instead of four, same bits (0: never)

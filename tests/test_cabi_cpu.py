@@ -266,3 +266,17 @@ def test_io_formats_and_kitti_metric(tmp_path):
     # metric is restated, not repaired)
     assert tl.shape[1] == 2 and tl[0, 0] == 100 and abs(tl[0, 1] - want[want[:, 3] == 100][:, 2].mean()) <= 2e-3 * tl[0, 1]
     assert (tmp_path / "plot_rs.txt").exists() and (tmp_path / "plot_ts.txt").stat().st_size > 0
+
+
+def test_every_option_of_the_library_is_in_the_headers_table():
+    """bpvo_hip_set_option's keys (context.hip option_table) against the table of include/bpvo_hip/c_api.h: a key without its line of
+    default and meaning there is an undocumented switch."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bpvo_amd", "csrc", "context.hip")).read()
+    table = src[src.index("const std::vector<OptionDef>& option_table()"):src.index("int set_option(")]
+    keys = set(re.findall(r'OPT_INT\("([a-z_0-9]+)"', table)) | set(re.findall(r'OptionDef\{"([a-z_0-9]+)"', table))
+    assert len(keys) >= 25, keys
+    header = open(os.path.join(root, "include", "bpvo_hip", "c_api.h")).read()
+    missing = sorted(k for k in keys if ' *   "%s"' % k not in header)
+    assert not missing, missing

@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 # finding, not an explanation.
 AGREED = {"template-error", "estimate-error", "non-finite"}
 EXPLAINED = {"unstable-problem", "iteration-limit", "stops-where-the-oracle-would", "function-tol-at-the-noise-floor", "genuine-function-tol-stop",
-             "genuine-scale-freeze", "noise-floor-minimum", "solver-fallback-edge"}
+             "genuine-scale-freeze", "noise-floor-minimum", "solver-fallback-edge", "solver-acceptance-flip"}
 ACCEPTED = {"ok"} | AGREED | EXPLAINED
 RULE_CAP, EXPLAINED_CAP, AGREED_CAP = 0.03, 0.08, 0.05      # fractions of the cases of a run
 UNNORMALISED_SHARE = 1.0 / 3.0                              # of the cases of a run

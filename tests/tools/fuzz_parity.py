@@ -138,6 +138,39 @@ def exact_f_norm(orc, co, level, T, sigma, loss):
     return float(np.sqrt(np.sum(terms.astype(np.float64))))
 
 
+def solver_acceptance_flip(orc, ch, co, K, slack):
+    """True if the two Gauss-Newton traces part at ONE linearisation whose steps differ by a factor although the iterates agreed until
+    then, and the oracle's solver (PoseEstimatorData_::solve restated, bpvo_orc_solve) reproduces the GPU's step from the GPU's (H, G)."""
+    import ctypes as C
+    _, _, trh = ch.estimate_pose_trace(0, 0, 1)
+    _, _, tro = co.estimate_pose_trace(0, 0, 1)
+
+    def orc_solve(rec):
+        H, G = np.ascontiguousarray(rec[16:52], np.float32), np.ascontiguousarray(rec[52:58], np.float32)
+        dp = np.zeros(6, np.float32)
+        ok = orc.fn("solve")(H.ctypes.data_as(C.c_void_p), G.ctypes.data_as(C.c_void_p), dp.ctypes.data_as(C.c_void_p))
+        return ok, dp
+
+    for lvl in sorted(set(trh[:, 67].astype(int)) & set(tro[:, 67].astype(int)), reverse=True):
+        h, o = trh[trh[:, 67] == lvl], tro[tro[:, 67] == lvl]
+        for k in range(min(len(h), len(o))):
+            r_, t_ = pose_error(h[k, :16].reshape(4, 4), o[k, :16].reshape(4, 4))
+            if r_ > slack * ROT_TOL or t_ > slack * trans_tol(K):
+                return False                      # the runs had left the bar before any step differed by a factor: not this rule's case
+            dh, do = h[k, 61:67].astype(np.float64), o[k, 61:67].astype(np.float64)
+            nh, no = np.linalg.norm(dh), np.linalg.norm(do)
+            if max(nh, no) < 5.0 * min(nh, no) or max(nh, no) < 1e-5:
+                continue                          # the same step, to rounding (or both at the noise floor): go on
+            ok_h, dp_h = orc_solve(h[k])
+            ok_o, dp_o = orc_solve(o[k])
+            same_h = ok_h and np.linalg.norm(dp_h - dh) <= 1e-4 * nh
+            same_o = ok_o and np.linalg.norm(dp_o - do) <= 1e-4 * no
+            return bool(same_h and same_o)
+        # (a level may end at different iterations on the two sides — a repeated f_norm at the noise floor — with the iterates still
+        # together: the first record of the next level says whether they were)
+    return False
+
+
 def check(hip, orc, rows, cols, kw, scene, seed):
     """One case; the two contexts are closed whatever happens (a context left alive by a failed assertion keeps later batches of the
     same process off the estimation lanes and the team kernel)."""
@@ -272,6 +305,19 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
         fixed = rot_r <= slack * ROT_TOL and trans_r <= slack * trans_tol(K)
         if leaves and (within or fixed):
             return "solver-fallback-edge"
+        # ... or the flip itself, caught in the act.  The perturbed replays above find it when it is likely; a flip that only the GPU's
+        # rounding draws (1 case in 3 157: profiles/r05_fuzz_soak.txt) leaves them inside the bar.  Then the two traces show it: up to
+        # one linearisation k the iterates are the oracle's (inside the bar, every one of them), there the two steps differ by a factor
+        # (the f32 LDLT solution accepted on one side, the damped f64 solve — 5 - 100x shorter — taken on the other), and the ORACLE'S
+        # OWN SOLVER, handed the GPU's (H, G) of that linearisation, returns the GPU's step: the GPU's solve is the reference's, on
+        # sums that differ from the oracle's by rounding.  From there on the two runs are different trajectories of the same algorithm;
+        # the GPU's end point must still be one the oracle stays near when restarted there.
+        out = solver_acceptance_flip(orc, ch, co, K, slack)
+        if out:
+            To_r2, _ = co.estimate_pose(0, 0, 1, Th)
+            rot_n, trans_n = pose_error(Th, To_r2)
+            if rot_n <= 4.0 * slack * ROT_TOL and trans_n <= 4.0 * slack * trans_tol(K):
+                return "solver-acceptance-flip"
     # Last resort: both sides wander at the f32 noise floor of G (iteration limit or a repeated f_norm ends the level), on a
     # flat minimum.  Then the GPU's pose must be as good a minimum for the oracle as its own: restarted there, the oracle
     # stays within the bar of it and ends with the same weighted error.
