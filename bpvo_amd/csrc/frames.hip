@@ -22,8 +22,8 @@ int upload_frame_jobs(bpvo_hip_ctx* c, int first, int stride, int count, const F
   // rows [tab, tab + count) of every level in one copy
   const size_t pitch = sizeof(FrameJob) * (size_t) c->n_frames;
   static_assert(sizeof(FrameJob) % 8 == 0 && sizeof(PairJob) % 8 == 0, "copy_rows_kernel moves 8-byte words");
-  // (small tables too: a 2-D copy of a few KB is a 20 us stop of the stream, the kernel 5 — what a stage of one or two frames notices)
-  if(c->ctl_by_kernel.load() || count <= 64)
+  // (small tables too — up to 512 frames, 0.4 MB: a 2-D copy of a few KB is a 20 us stop of the stream, the kernel 5 — what a stage of one or two frames notices)
+  if(c->ctl_by_kernel.load() || count <= 512)
     launch_copy_rows(fr.stream, c->d_fjobs + table + fr.tab, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, c->L);
   else
     FR_CK(c, fr, hipMemcpy2DAsync(c->d_fjobs + table + fr.tab, pitch, c->h_fjobs + table + fr.tab, pitch, sizeof(FrameJob) * (size_t) count, (size_t) c->L,
