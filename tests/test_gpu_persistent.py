@@ -271,3 +271,39 @@ def test_which_batches_take_the_team_kernel(hip):
             if spares and n == 96 and cus == 256:
                 assert ctx.get_option("team_joins_seen") >= 64      # the 64 spare workgroups found a team
             ctx.close()
+
+
+@pytest.mark.parametrize("rows,cols,levels,descriptor,loss", [pytest.param(376, 1241, 4, "bitplanes", "tukey", id="kitti-bitplanes"),
+                                                              pytest.param(480, 640, 5, "bitplanes", "huber", id="vga-L5"),
+                                                              pytest.param(120, 160, 3, "intensity", "huber", id="160x120-intensity"),
+                                                              pytest.param(97, 133, 2, "bitplanes", "tukey", id="97x133-L2")])
+def test_one_pair_per_call_is_bit_identical_whatever_ran_before(hip, rows, cols, levels, descriptor, loss, monkeypatch):
+    """bpvo_hip_batch_run with ONE pair per call — the path with the frame stage's levels in merged launches, the one-kernel pyramid, the
+    normalisation of every level but the coarsest still running on the side stream when the first iterations start, the level starts folded
+    into the persistent kernel, table + poses in one launch — on ONE context fed six DIFFERENT pairs in a row, against each pair
+    estimated through setData / setTemplate / estimatePose on a fresh context: poses and statistics bit for bit.  A normalisation (or a
+    tap-cache key, or a state word) left over from the pair before would show here; with the options off the same must hold."""
+    n = 6
+    b = synth.make_batch(rows, cols, n, first_index=40)
+    p = make_params(hip, levels=levels, descriptor=descriptor, loss=loss)
+    want = []
+    for k in range(n):
+        sc = hip.create(b["K"], b["b"], rows, cols, p, n_frames=2, n_pairs=1)
+        sc.frame_set_data(0, b["images"][2 * k], b["disparities"][2 * k])
+        sc.frame_set_template(0)
+        sc.frame_set_data(1, b["images"][2 * k + 1], b["disparities"][2 * k + 1])
+        want.append(sc.estimate_pose(0, 0, 1))
+        sc.close()
+    for opts in (dict(), dict(normalization_deferred=0), dict(levels_in_one_launch_max_frames=0, small_batch_fused=0, normalization_side_stream=0)):
+        set_options(monkeypatch, **opts)
+        ctx = hip.create(b["K"], b["b"], rows, cols, p, n_frames=2, n_pairs=1)
+        for rep in range(2):
+            for k in range(n):
+                poses, stats = ctx.batch_run(b["images"][2 * k: 2 * k + 2], b["disparities"][2 * k: 2 * k + 2])
+                T, st = want[k]
+                assert bits_equal(T, poses[0]), (opts, rep, k)
+                for l in range(levels):
+                    assert st[l]["numIterations"] == int(stats["numIterations"][0, l]) and st[l]["status"] == int(stats["status"][0, l]), (opts, rep, k, l)
+        if not opts:
+            assert ctx.persistent_counts()[0] >= 2 * n and ctx.persistent_counts()[1] == 0, ctx.persistent_counts()      # the persistent kernel ran, never gave up
+        ctx.close()
