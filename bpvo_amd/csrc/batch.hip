@@ -291,11 +291,12 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   }
   if(rc) return rc;
   // The estimation follows on the same stream (one lane) or behind a synchronisation of it (several): the template stage ends without a
-  // host round trip of its own, and — unless the team kernel, every level in one launch, runs next — leaves the normalisation sums of the
-  // levels below the coarsest on the side stream, under the Gauss-Newton iterations of the coarsest (a single pair per call: 0.15 of 3.2 ms)
+  // host round trip of its own, and — unless the team kernel runs next with every level in one launch (more than team_split_max_pairs
+  // pairs) — leaves the normalisation sums of the levels below the coarsest on the side stream, under the Gauss-Newton iterations of the
+  // coarsest (a single pair per call: 0.15 of 3.2 ms)
   FrameRun fr = ctx_run(c);
   fr.no_final_sync = !c->profiling;
-  fr.defer_finest_nrm = !team_serves(c, n_pairs);
+  fr.defer_finest_nrm = !team_serves(c, n_pairs) || n_pairs <= c->team_split_max_pairs;      // (the team kernel: in two launches then, estimate.hip)
   rc = frames_set_template(c, 0, 2, n_pairs, fr);
   if(rc == BPVO_OK) rc = bpvo_hip_batch_estimate(c, n_pairs, nullptr, poses, stats);
   if(c->nrm_pending) {      // (an error on the way: nothing of this call stays in flight)

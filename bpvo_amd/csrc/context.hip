@@ -228,8 +228,8 @@ int ensure_lanes(bpvo_hip_ctx* c, int n)
     HIP_CK(c, hipHostMalloc((void**) &ln.h_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
     if(first) {
       HIP_CK(c, hipMalloc((void**) &ln.d_team_ctl, sizeof(unsigned) * (size_t) gn_team_ctl_words(kMaxTeams)));
-      HIP_CK(c, hipHostMalloc((void**) &ln.h_team_ctl, sizeof(unsigned) * 32));
-      std::memset(ln.h_team_ctl, 0, sizeof(unsigned) * 32);
+      HIP_CK(c, hipHostMalloc((void**) &ln.h_team_ctl, sizeof(unsigned) * 64));      // (two launches' first lines: estimate.hip)
+      std::memset(ln.h_team_ctl, 0, sizeof(unsigned) * 64);
     }
     HIP_CK(c, hipHostMalloc((void**) &ln.h_states, sizeof(GNState) * n_pairs));
   }
@@ -277,6 +277,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("small_batch_fused", small_batch_fused, 0, 1),
     OPT_INT("levels_in_one_launch_max_frames", merge_levels_max_frames, 0, 1 << 20),
     OPT_INT("normalization_deferred", nrm_defer, 0, 1),
+    OPT_INT("team_split_max_pairs", team_split_max_pairs, 0, 1 << 20),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),

@@ -88,8 +88,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     c->nrm_pending = nullptr;
     return BPVO_OK;
   };
+  bool team_split = false;
   if(allow_persistent && ln == &c->lanes[0] && team_serves(c, n)) {
-    if(int rcj = join_normalization()) return rcj;
+    // Small batches whose template stage left the normalisation of the levels below the coarsest on the side stream (frames.hip): the
+    // team kernel in TWO launches — the coarsest level of every pair, then (behind that normalisation) the others.  The sums (0.17 - 0.19 ms
+    // for a 1241x376 frame, whatever the batch) then run under the coarsest level's iterations instead of in front of the first one;
+    // larger batches join them here, at once: a launch boundary makes every pair wait for the slowest (measured: 2 / 4 pairs + 1.2 / + 1.5 %,
+    // 8 / 16 / 32 / 64 pairs - 5 / - 7 / - 4 / - 6 %: option "team_split_max_pairs", 4).
+    team_split = c->nrm_pending != nullptr && n <= c->team_split_max_pairs && c->L - 1 > p.maxTestLevel;
+    if(!team_split)
+      if(int rcj = join_normalization()) return rcj;
     GNTeamLaunch t;
     t.jobs_all = ln->d_pjobs; t.job_pitch = NP; t.n_pairs = n; t.level_hi = c->L - 1; t.level_lo = p.maxTestLevel;
     t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
@@ -109,7 +117,21 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // what the division CUs / pairs leaves over starts as spare workgroups that join the teams at their first admission
     t.spare_workgroups = (t.join_mode && c->team_spares) ? std::max(0, slots - t.team_size * t.n_teams) : 0;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
-    const hipError_t te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+    hipError_t te;
+    if(team_split) {
+      t.level_lo = c->L - 1;
+      te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+      if(te == hipSuccess) {
+        // (the first launch's control words: its abort word and join count are looked at with the second's)
+        LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl + 32, ln->d_team_ctl, sizeof(unsigned) * 32, hipMemcpyDeviceToHost, ln->stream));
+        LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
+      }
+      if(int rcj = join_normalization()) return rcj;
+      t.level_hi = c->L - 2; t.level_lo = p.maxTestLevel;
+      if(te == hipSuccess) te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+    } else {
+      te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
+    }
     if(te == hipSuccess) {
       team_ran = true;
       c->team_launches.fetch_add(1);
@@ -271,8 +293,8 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     }
   }
 #endif
-  if(team_ran) c->team_joins.fetch_add(ln->h_team_ctl[3]);      // workgroups that joined another team in this launch (measurement)
-  if(team_ran && ln->h_team_ctl[1] != 0) {
+  if(team_ran) c->team_joins.fetch_add(ln->h_team_ctl[3] + (team_split ? ln->h_team_ctl[32 + 3] : 0u));      // workgroups that joined another team (measurement)
+  if(team_ran && (ln->h_team_ctl[1] != 0 || (team_split && ln->h_team_ctl[32 + 1] != 0))) {
     // a team barrier timed out (teams not co-resident): rerun the group through the four-kernel chain and stay on it
     c->persistent_failed.store(true);
     return estimate_group(c, ln, n, wss, refs, curs, T_init, poses, stats, d_records_out, false);

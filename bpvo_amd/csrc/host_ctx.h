@@ -203,6 +203,8 @@ struct bpvo_hip_ctx {
   int small_batch_fused = 1;     // option "small_batch_fused": contexts of a few pairs — job table + poses in one launch, states copied out by pack_records (estimate.hip)
   int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
   int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
+  int team_split_max_pairs = 4;  // option "team_split_max_pairs": team batches of up to this many pairs run the coarsest level in a launch of its own, the deferred
+                                 // normalisation under it (estimate.hip)
   hipStream_t side_stream = nullptr;  // the normalisation's stream (created at its first use) and its events: [0] fork, [1] coarsest level done (or all), [2] the levels below done
   hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
   hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels below the coarsest of the template stage just queued; whoever

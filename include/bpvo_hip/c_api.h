@@ -384,6 +384,9 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *                                      Hartley normalisation sums on a stream of its own, next to template_build, and joins them before it returns
  *   "normalization_deferred" 1         ... and inside bpvo_hip_batch_run on one lane (not the team kernel) only the coarsest level's sums are joined:
  *                                      the others run on under that level's Gauss-Newton iterations, the estimation waits for them before its second level
+ *   "team_split_max_pairs"   4         ... and team batches of up to this many pairs run the coarsest level of every pair in a launch of its own, the
+ *                                      deferred sums under it, the other levels in a second launch behind them (2 / 4 pairs + 1.2 / + 1.5 %; from 8 pairs on the
+ *                                      launch boundary — every pair waits for the slowest — costs 4 - 7 %: DESIGN.md 7; 0: one launch, sums joined first)
  *   "levels_in_one_launch_max_frames" 8  frame stages of at most this many frames run ALL levels of the pyramid (three pyrDown steps per launch), of
  *                                      the bit-planes, of the tiled selection and of the template build in one launch each (a single pair: 33 -> 14 launches)
  *   "small_batch_fused"      1         contexts of a few pairs: job table + initial poses in one launch, states copied out by the record-packing launch
