@@ -91,9 +91,18 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     // few frames, bit-planes with the census fused: every level in ONE launch (kernels_frame.hip level_job)
     const bool fused_bp = c->C == 8 && c->params.descriptor == BPVO_DESC_BITPLANES && !(c->params.sigmaPriorToCensusTransform > 0.0f) && c->params.sigmaBitPlanes > 0.0f;
     const int l_lo = c->params.maxTestLevel;
-    const bool one_launch = fused_bp && count <= c->merge_levels_max_frames && c->L - l_lo > 1;
-    if(one_launch)
+    // ... and the same for the census of the smoothed image + the bit-planes blur (conf/perf_bitplanes.cfg: two launches) and the intensity descriptor
+    const bool smoothed_bp = c->C == 8 && c->params.descriptor == BPVO_DESC_BITPLANES && c->params.sigmaPriorToCensusTransform > 0.0f && c->params.sigmaBitPlanes > 0.0f;
+    const bool plain_intensity = c->C == 1 && c->params.descriptor != BPVO_DESC_LAPLACIAN;
+    const bool one_launch = (fused_bp || smoothed_bp || plain_intensity) && count <= c->merge_levels_max_frames && c->L - l_lo > 1;
+    if(one_launch && fused_bp) {
       launch_bitplanes(s, tab + (size_t) l_lo * NF, c->geom[l_lo].cols, c->geom[l_lo].rows, count, c->params.sigmaBitPlanes, c->gauss_k, 1, c->L - l_lo, NF);
+    } else if(one_launch && smoothed_bp) {
+      launch_census(s, tab + (size_t) l_lo * NF, c->geom[l_lo].cols, c->geom[l_lo].rows, count, c->census_taps, c->L - l_lo, NF);
+      launch_bitplanes(s, tab + (size_t) l_lo * NF, c->geom[l_lo].cols, c->geom[l_lo].rows, count, c->params.sigmaBitPlanes, c->gauss_k, 0, c->L - l_lo, NF);
+    } else if(one_launch) {
+      launch_intensity(s, tab + (size_t) l_lo * NF, c->geom[l_lo].cols, c->geom[l_lo].rows, count, c->L - l_lo, NF);
+    }
     for(int l = c->L - 1; l >= c->params.maxTestLevel && !one_launch; --l) {   // DenseDescriptorPyramid::init (dense_descriptor_pyramid.cc:67-71)
       const FrameJob* jobs = tab + (size_t) l * NF;
       const LevelGeom& g = c->geom[l];

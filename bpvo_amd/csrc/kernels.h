@@ -38,7 +38,7 @@ void launch_ingest(hipStream_t s, const FrameJob* jobs_level0, const uint8_t* d_
 void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int dW, int dR, int nframes);
 // few frames: `steps` (1..3) pyrDown steps in one launch — src_row is the source level's row of the table [level][job_pitch], dW x dR the COARSEST level of the group
 void launch_pyramid_levels(hipStream_t s, const FrameJob* src_row, int job_pitch, int steps, int dW, int dR, int nframes);
-void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes);
+void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int nlevels = 1, int job_pitch = 0);
 void launch_gradient_descriptor(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const GaussTaps& pre);   // (I, Ix, Iy), C = 3
 void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int second_order, const GaussTaps& g1,
                               const GaussTaps& g2);   // C = 5 / 10
@@ -47,7 +47,7 @@ void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R
 void launch_latch(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int bytes, int half_ssd, const signed char* d_offsets, int kc, int ks,
                   const GaussTaps& after);   // C = 8 * bytes, bytes = 1 / 2 / 4
 void launch_laplacian(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int ksize /*1 or 3*/);
-void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /* {centre, side} or null */);
+void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps /*null: no smoothing*/, int nlevels = 1, int job_pitch = 0);
 // from_image: the census transform is computed inside the bit-planes kernel (no launch_census, sigma_bp > 0 and sigma_ct <= 0)
 // nlevels > 1 (bit-planes, tiled selection, template build): `jobs` is the FINEST level's row of the table [level][job_pitch], W / R / max_points that level's — the
 // levels in one launch (kernels_frame.hip level_job)

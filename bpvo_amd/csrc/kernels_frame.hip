@@ -247,9 +247,9 @@ void launch_pyramid_levels(hipStream_t s, const FrameJob* src_row, int job_pitch
 }
 
 // ---- IntensityDescriptor::compute: u8 -> f32 (reference: bpvo/intensity_descriptor.cc:31-43)
-__global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs)
+__global__ __launch_bounds__(256) void intensity_kernel(const FrameJob* jobs, int nframes, int job_pitch)
 {
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   const int n = j.rows * j.cols;
   const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
   if(i >= n) return;
@@ -305,14 +305,15 @@ __global__ __launch_bounds__(256) void census_kernel(const FrameJob* jobs)
 // written out: a 64 x 4 output tile stages its source pixels + 2-px halo (reflected coordinates) in LDS, the row and
 // column passes run in LDS, and the census reads the 66 x 6 smoothed tile.
 constexpr int CB_TW = 64, CB_TH = 4;
-__global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, int kc, int ks)
+__global__ __launch_bounds__(256) void census_blur_kernel(const FrameJob* jobs, int kc, int ks, int nframes, int job_pitch)
 {
   __shared__ uint8_t s_src[(CB_TH + 4) * (CB_TW + 4)];
   __shared__ int s_tmp[(CB_TH + 4) * (CB_TW + 2)];
   __shared__ uint8_t s_b[(CB_TH + 2) * (CB_TW + 2)];
-  const FrameJob& j = jobs[blockIdx.z];
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
   const int W = j.cols, R = j.rows;
   const int x0 = blockIdx.x * CB_TW, y0 = blockIdx.y * CB_TH;
+  if(x0 >= W || y0 >= R) return;      // (a coarser level inside a launch sized for the finest)
   const int tid = threadIdx.x;
   // source tile: rows y0-2 .. y0+CB_TH+1, columns x0-2 .. x0+CB_TW+1
   for(int i = tid; i < (CB_TH + 4) * (CB_TW + 4); i += 256) {
@@ -1406,15 +1407,16 @@ void launch_pyrdown(hipStream_t s, const FrameJob* src, const FrameJob* dst, int
 {
   hipLaunchKernelGGL(pyrdown_u8_lds_kernel, dim3((dW + PDT_W - 1) / PDT_W, (dR + PDT_H * PD_STACK - 1) / (PDT_H * PD_STACK), nframes), dim3(256), 0, s, src, dst);
 }
-void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes)
+void launch_intensity(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, int nlevels, int job_pitch)
 {
-  hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes), dim3(256), 0, s, jobs);
+  hipLaunchKernelGGL(intensity_kernel, dim3((W * R + 1023) / 1024, 1, nframes * nlevels), dim3(256), 0, s, jobs, nframes, job_pitch);
 }
-void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps)
+// (nlevels > 1: the smoothed-census form only)
+void launch_census(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes, const int* blur_taps, int nlevels, int job_pitch)
 {
   if(blur_taps)
-    hipLaunchKernelGGL(census_blur_kernel, dim3((W + CB_TW - 1) / CB_TW, (R + CB_TH - 1) / CB_TH, nframes), dim3(256), 0, s,
-                       jobs, blur_taps[0], blur_taps[1]);
+    hipLaunchKernelGGL(census_blur_kernel, dim3((W + CB_TW - 1) / CB_TW, (R + CB_TH - 1) / CB_TH, nframes * nlevels), dim3(256), 0, s,
+                       jobs, blur_taps[0], blur_taps[1], nframes, job_pitch);
   else
     hipLaunchKernelGGL(census_kernel, dim3((W + 63) / 64, (R + 4 * CENSUS_ROWS - 1) / (4 * CENSUS_ROWS), nframes), dim3(256), 0, s, jobs);
 }
