@@ -25,7 +25,10 @@ OPTION_SETS = ["", "team=0", "team=0,step_in_reduce_max_pairs=0", "lazy_template
                # teams that grow (round 5): forced on for every batch size, teams of 2 - 4 so that workgroups do run out of pairs and join others;
                # joins on the workgroup's own XCD only, and a grid smaller than the chip
                "team_join_from_pairs=0,team_size=2", "team_join_from_pairs=0,team_size=3,team_join=1", "team_join_from_pairs=0,team_size=4,team_cus=64",
-               "team_join_from_pairs=0,team_size=2,team_cus=24"]
+               "team_join_from_pairs=0,team_size=2,team_cus=24",
+               # one pair per call and the smallest team batches (round 5): each piece of the rebuilt frame stage / launch sequence switched off
+               "normalization_deferred=0", "levels_in_one_launch_max_frames=0", "team_split_max_pairs=0", "small_batch_fused=0,normalization_side_stream=0",
+               "team_split_max_pairs=8"]
 
 
 def main():
@@ -46,9 +49,9 @@ def main():
             continue
         n += 1
         opts = OPTION_SETS[int(rng.integers(len(OPTION_SETS)))]
-        npairs = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 24, 32, 40]))      # (multiples of 8: teams that sit on one XCD each)
+        npairs = int(rng.choice([1, 1, 1, 2, 3, 4, 5, 8, 9, 16, 17, 24, 32, 40]))      # (1: the single-pair path inside batch_run; multiples of 8: teams that sit on one XCD each)
         if npairs * rows * cols > 40 * 120 * 160:
-            npairs = max(2, (40 * 120 * 160) // (rows * cols))
+            npairs = max(1 if npairs == 1 else 2, (40 * 120 * 160) // (rows * cols))
         try:
             out = fz.check_batch(hip, rows, cols, kw, seed, options=opts, dirty=True, n=npairs)
         except AssertionError as e:
