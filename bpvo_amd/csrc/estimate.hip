@@ -239,11 +239,12 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       g.active.list = lists[prev];
     }
   }
+  const bool want_frac = n == 1 && c->prefetch_frac_thr >= 0.0f && ln == &c->lanes[0];
   if(small_ctx) launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out, c->d_states, ln->h_states, pk_group ? ln->d_pk_ctl : nullptr,
-                                    pk_group ? ln->h_pk_ctl : nullptr, kPkCtlWords * kMaxLevels);
+                                    pk_group ? ln->h_pk_ctl : nullptr, kPkCtlWords * kMaxLevels, want_frac ? c->d_count : nullptr);
   else launch_pack_records(ln->stream, ln->d_pjobs + (size_t) (c->L - 1) * NP, n, c->L, d_records_out);
   bool frac_queued = false;
-  if(n == 1 && c->prefetch_frac_thr >= 0.0f && ln == &c->lanes[0]) {
+  if(want_frac) {
     // fraction_good of this workspace at the level the estimate ended on, from the job already on the device
     const PairJob* job = ln->d_pjobs + (size_t) p.maxTestLevel * NP;
     const int npts = ln->h_pjobs[(size_t) p.maxTestLevel * NP].n;
@@ -251,7 +252,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       GNLaunch gr;
       gr.jobs = job; gr.npairs = 1; gr.max_points = npts; gr.C = c->C;
       launch_refresh_residuals(ln->stream, gr);
-      LANE_CK(ln, hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), ln->stream));
+      if(!small_ctx) LANE_CK(ln, hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), ln->stream));      // (small contexts: cleared by pack_records)
       launch_count_good(ln->stream, job, npts, c->C, p.lossFunction, c->prefetch_frac_thr, c->d_count);
       LANE_CK(ln, hipMemcpyAsync(c->h_ints, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, ln->stream));
       frac_queued = true;

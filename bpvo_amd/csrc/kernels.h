@@ -178,7 +178,7 @@ int  gn_partials_entries(int cap, int C);   // kPartialStride-float entries of a
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states = nullptr, GNState* h_states = nullptr,
-                         const unsigned* d_ctl = nullptr, unsigned* h_ctl = nullptr, int ctl_words = 0);   // h_states / h_ctl (pinned host): copied out by the same launch
+                         const unsigned* d_ctl = nullptr, unsigned* h_ctl = nullptr, int ctl_words = 0, unsigned* zero = nullptr);   // h_states / h_ctl (pinned host): copied out by the same launch; zero: a word cleared by it
 // a few pairs: job table upload (from the pinned host rows) + initial poses + cleared control words in one launch
 void launch_set_pose_upload(hipStream_t s, PairJob* d_table, const PairJob* h_table, size_t table_jobs, const PairJob* h_jobs_coarsest, const float* T_init,
                             int n, unsigned* clear, int clear_words);

@@ -237,7 +237,8 @@ __global__ __launch_bounds__(256) void pyramid_levels_kernel(const FrameJob* job
     { const int t = pc; pc = pn; pn = t; }
   }
 }
-// is the group [first, first + steps] servable?  (every level at least 8 pixels either way: the reflections then stay inside a workgroup's regions)
+// `steps` (1 .. 3) levels below src_row in one launch; dW x dR = the coarsest of them.  The caller (frames.hip) takes this form only when every
+// level is at least 8 pixels either way: the reflections then stay inside a workgroup's regions.
 void launch_pyramid_levels(hipStream_t s, const FrameJob* src_row, int job_pitch, int steps, int dW, int dR, int nframes)
 {
   const dim3 grid((dW + PA_T - 1) / PA_T, (dR + PA_T - 1) / PA_T, nframes);

@@ -438,8 +438,9 @@ __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, flo
 // h_states (pinned host, or null): the states — and h_ctl: the persistent kernel's control words — written to the host by this launch as well
 // (a few pairs: two copies of a few hundred bytes are two more stops of the stream behind the last iteration)
 __global__ void pack_records_kernel(const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,
-                                    unsigned* h_ctl, int ctl_words)
+                                    unsigned* h_ctl, int ctl_words, unsigned* zero)
 {
+  if(zero && blockIdx.x == 0 && threadIdx.x == 0) *zero = 0u;      // (the counter of the count_good launch that follows: no memset launch of its own)
   if(h_states) {
     constexpr int kWords = (int) (sizeof(GNState) / 4);
     for(int q = 0; q < n; ++q) {
@@ -627,11 +628,11 @@ void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss
   dispatch_channels(C, [&](auto c) { launch_count_good_c<decltype(c)::value>(s, job, n, loss, thr, count); });
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,
-                         unsigned* h_ctl, int ctl_words)
+                         unsigned* h_ctl, int ctl_words, unsigned* zero)
 {
   static_assert(sizeof(GNState) % 4 == 0, "pack_records_kernel moves 4-byte words");
   hipLaunchKernelGGL(pack_records_kernel, dim3((n + 63) / 64), dim3(h_states ? 256 : 64), 0, s, jobs, n, L, records, d_states, h_states, d_ctl, h_ctl,
-                     h_ctl ? ctl_words : 0);
+                     h_ctl ? ctl_words : 0, zero);
 }
 void launch_set_pose_upload(hipStream_t s, PairJob* d_table, const PairJob* h_table, size_t table_jobs, const PairJob* h_jobs_coarsest, const float* T_init,
                             int n, unsigned* clear, int clear_words)
