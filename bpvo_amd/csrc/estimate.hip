@@ -104,7 +104,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     t.scale_is_moot = (p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen) ? 1 : 0;
     // one workgroup per CU: teams of CUs / pairs workgroups (at most 64: the single-pair kernel's size), as many teams as fit
     const int slots = c->num_cus;
-    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(64, slots / n));
+    // (at most 32 of 256 CUs per team: teams of 64 were 8 - 12 % slower at 2 - 5 pairs, 4 % at 6 - 7; a team's workgroups stay dealt over ALL XCDs —
+    // pinned to one XCD each, 2 - 4 teams were 3 - 8 % slower: one L2 and its memory channels for a whole pair)
+    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(std::max(1, c->device_cus > 0 ? c->device_cus / 8 : 32), slots / n));
     ts = std::max(1, std::min(ts, slots));
     t.team_size = ts;
     t.n_teams = std::max(1, std::min(std::min(n, slots / ts), kMaxTeams));

@@ -371,7 +371,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_max_pairs"         128       ... up to this many pairs; above "team_full_pairs" (80) only when CUs / pairs workgroups per pair fill at least
  *                                      95 % of the CUs (128 pairs on 256 CUs do, 96 do not: the chain is faster there)
  *   "team_full_pairs"        80        batches of up to this many pairs take the team kernel whatever the fill of the chip (see "team_max_pairs", "team_spares")
- *   "team_size"              0         workgroups per team; 0 = CUs / pairs
+ *   "team_size"              0         workgroups per team; 0 = CUs / pairs, at most an eighth of the CUs (32 of 256: larger teams were slower at 2 - 7 pairs)
  *   "team_cus"               (device)  CUs the team kernel may claim (tests: fewer teams than pairs)
  *   "team_local_barriers"    1         teams whose workgroups all run on one XCD (checked on the device) skip the L2 write-back of their barriers
  *   "team_join"              2         workgroups of a team that has run out of pairs join the teams still at work (a batch ends with its slowest
