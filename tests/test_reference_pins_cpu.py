@@ -167,3 +167,52 @@ def test_weight_functions_agree_with_robust_loss_h(ref, orc):
             edge = np.abs(np.abs(r / np.float32(sigma)) - (4.685 if loss == 0x11 else 1.345)) < 1e-4
             assert np.all(np.abs(w - want)[~edge] <= 1e-6), (sigma, loss, np.abs(w - want)[~edge].max())
             assert np.all((w >= 0) & (w <= 1))
+
+
+def test_the_fuzz_rule_solver_acceptance_flip_on_synthetic_traces():
+    """tests/tools/fuzz_parity.py acceptance_flip_in_traces: the rule fires only when (a) the iterates agree up to one linearisation, (b) the two
+    steps there differ by a factor and (c) the ORACLE'S solver returns each side's step from that side's (H, G).  Synthetic traces around a
+    well-conditioned system: identical runs -> no; a step that differs by a factor but is NOT what the solver gives -> no; the oracle's side
+    solved from a damped system, the other from the plain one, each consistent with its own (H, G) -> yes; the same after the poses parted -> no."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import ctypes as C
+    import fuzz_parity as fz
+    import __graft_entry__ as ge
+    from bpvo_amd import capi
+    orc = capi.Binding(ge.ORACLE_LIB, "bpvo_orc_")
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(6, 6))
+    H = (A @ A.T + 6.0 * np.eye(6)).astype(np.float32)
+    G = rng.normal(size=6).astype(np.float32)
+
+    def solve(Hm, Gv):
+        dp = np.zeros(6, np.float32)
+        Hc, Gc = np.ascontiguousarray(Hm.reshape(-1), np.float32), np.ascontiguousarray(Gv, np.float32)
+        assert orc.fn("solve")(Hc.ctypes.data_as(C.c_void_p), Gc.ctypes.data_as(C.c_void_p), dp.ctypes.data_as(C.c_void_p))
+        return dp
+
+    def record(Hm, Gv, dp, level=0, T=None):
+        r = np.zeros(68, np.float32)
+        r[:16] = (np.eye(4, dtype=np.float32) if T is None else T).reshape(-1)
+        r[16:52] = Hm.reshape(-1); r[52:58] = Gv; r[58] = 1.0; r[59] = 1.0; r[60] = 100.0; r[61:67] = dp; r[67] = level
+        return r
+
+    K = np.array([[500.0, 0, 80], [0, 500.0, 60], [0, 0, 1]], np.float32)
+    dp = solve(H, G)
+    same = np.stack([record(H, G, dp), record(H, G, dp)])
+    assert not fz.acceptance_flip_in_traces(orc, same, same.copy(), K, 1.0)
+    # a step ten times shorter that the solver does NOT give for that system
+    short = np.stack([record(H, G, dp), record(H, G, 0.1 * dp)])
+    assert not fz.acceptance_flip_in_traces(orc, short, same, K, 1.0)
+    # a damped system on one side (what the f64 fallback amounts to: a much shorter step), each side consistent with its own (H, G)
+    Hd = (H + 60.0 * np.eye(6, dtype=np.float32)).astype(np.float32)
+    dpd = solve(Hd, G)
+    assert np.linalg.norm(dp) > 5.0 * np.linalg.norm(dpd)
+    gpu = np.stack([record(H, G, dp), record(H, G, dp)])
+    cpu = np.stack([record(H, G, dp), record(Hd, G, dpd)])
+    assert fz.acceptance_flip_in_traces(orc, gpu, cpu, K, 1.0)
+    # ... but not when the iterates had already left the bar before that linearisation
+    T_far = np.eye(4, dtype=np.float32); T_far[0, 3] = 0.05
+    cpu_far = np.stack([record(H, G, dp, T=T_far), record(Hd, G, dpd, T=T_far)])
+    assert not fz.acceptance_flip_in_traces(orc, gpu, cpu_far, K, 1.0)

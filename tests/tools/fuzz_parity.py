@@ -141,9 +141,14 @@ def exact_f_norm(orc, co, level, T, sigma, loss):
 def solver_acceptance_flip(orc, ch, co, K, slack):
     """True if the two Gauss-Newton traces part at ONE linearisation whose steps differ by a factor although the iterates agreed until
     then, and the oracle's solver (PoseEstimatorData_::solve restated, bpvo_orc_solve) reproduces the GPU's step from the GPU's (H, G)."""
-    import ctypes as C
     _, _, trh = ch.estimate_pose_trace(0, 0, 1)
     _, _, tro = co.estimate_pose_trace(0, 0, 1)
+    return acceptance_flip_in_traces(orc, trh, tro, K, slack)
+
+
+def acceptance_flip_in_traces(orc, trh, tro, K, slack):
+    """The rule on two traces (records of BPVO_HIP_TRACE_FLOATS floats: pose, H, G, f, sigma, valid, dp, level) — the GPU's and the oracle's."""
+    import ctypes as C
 
     def orc_solve(rec):
         H, G = np.ascontiguousarray(rec[16:52], np.float32), np.ascontiguousarray(rec[52:58], np.float32)
