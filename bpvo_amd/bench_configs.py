@@ -52,6 +52,7 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
     dT = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - batch["T_gt"][:n, :3, 3], axis=1)
     ctx.close()
     return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "frames_per_s": 2.0 * n * steps / dt, "ms_per_step": 1e3 * dt / steps,
+            "us_per_linearisation_per_pair": 1e6 * dt * n / max(1, gn),      # (a pair's step time over its linearisations: the B = 1 latency figure)
             "frame_stage_ms_per_step": frame_ms,
             "gn_iterations_per_pair": gn / (steps * n), "numIterations_per_pair": float(stats["numIterations"].sum()) / n,
             "median_trans_err_vs_gt_m": float(np.median(dT))}
