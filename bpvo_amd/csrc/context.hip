@@ -279,6 +279,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("normalization_deferred", nrm_defer, 0, 1),
     OPT_INT("team_split_max_pairs", team_split_max_pairs, 0, 1 << 20),
     OPT_INT("fuse_frozen", fuse_frozen, 0, 1),
+    OPT_INT("reference_reduction", reference_reduction, 0, 1),
     OPT_INT("step_in_reduce_max_pairs", step_in_reduce_max, 0, 1 << 20),
     OPT_INT("stagger", stagger, 0, 1),
     OPT_INT("stagger_min_pairs", stagger_min_pairs, 0, 1 << 20),

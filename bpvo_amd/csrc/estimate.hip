@@ -24,7 +24,7 @@ bool team_serves(const bpvo_hip_ctx* c, int n)
     const int ts = std::max(1, std::min(64, c->num_cus / n));
     size_ok = 20 * ts * std::min(n, c->num_cus / ts) >= 19 * c->num_cus;
   }
-  return c->team_mode && c->persistent && !c->persistent_failed.load() && size_ok &&
+  return c->team_mode && c->persistent && !c->persistent_failed.load() && size_ok && !c->reference_reduction &&
          (c->C == 8 || c->C == 1) && c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !c->profile_all && !c->profile_k6_all &&
          c->num_cus >= 2 && g_live_ctx[c->device & 63].load() <= 1;
 }
@@ -54,7 +54,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       }
       max_pts[l] = std::max(max_pts[l], pj.n);
     }
-  const bool pk_group = allow_persistent && c->persistent && !c->persistent_failed.load() && n <= c->persist_max_ws && !c->profile_all;
+  // validation mode "reference_reduction": the four-kernel chain with the index-order reduction in irls_reduce's place — residuals always written
+  // (no fused path), the step in its own launch, no persistent / team kernel
+  const bool ref_mode = c->reference_reduction != 0;
+  const int fuse_frozen = ref_mode ? 0 : c->fuse_frozen;
+  const bool pk_group = allow_persistent && c->persistent && !c->persistent_failed.load() && n <= c->persist_max_ws && !c->profile_all && !ref_mode;
   bool persistent = pk_group;
   // a context of a few pairs (one pair per call): table, poses and control words in one launch, the states copied out by the last one
   const bool small_ctx = (size_t) c->L * NP <= 64 && n <= 8 && c->small_batch_fused;
@@ -152,13 +156,14 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.loss = p.lossFunction;
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
-    g.fuse_frozen = c->fuse_frozen;
-    g.step_in_reduce = n <= c->step_in_reduce_max ? 1 : 0;
+    g.fuse_frozen = fuse_frozen;
+    g.step_in_reduce = (n <= c->step_in_reduce_max && !ref_mode) ? 1 : 0;
+    g.reference_reduction = ref_mode ? 1 : 0;
     g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
     return g;
   };
   // kL2: the weights are 1 whatever the robust scale — with the fused path every linearisation is irls_reduce + gn_step only
-  const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+  const bool l2_moot = p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
   bool begun = false;      // this level's start was left to its persistent kernel (its tap-cache keys invalidated by the kernel of the level before)
   for(int l = c->L - 1; l >= p.maxTestLevel && !team_ran; --l) {
     GNLaunch g = level_launch(l);
@@ -206,7 +211,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // list only shrinks), the median has nothing to do and — with the fused path, where irls_reduce recomputes the residuals of
     // frozen workspaces itself — neither has warp_residual: their launches are dropped for the rest of the level.  (Each would
     // still cost its floor of ~5 us per iteration in the tail of a level.)  l2_moot: true from the first linearisation.
-    const bool fused_path = c->C == 8 && c->fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
+    const bool fused_path = c->C == 8 && fuse_frozen && !c->fast_warp && p.interp == BPVO_INTERP_LINEAR;
     bool none_moving = l2_moot;
     for(int round = 0; round < max_rounds; ++round) {
       g.npairs = n_cur;
@@ -527,6 +532,7 @@ static int linearize_impl(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, i
   g.jobs = c->d_job1; g.npairs = 1; g.max_points = c->frames[ref_slot].n_host[level]; g.C = c->C; g.loss = c->params.lossFunction;
   g.fast_warp = c->fast_warp;
   g.interp = c->params.interp;
+  g.reference_reduction = c->reference_reduction ? 1 : 0;
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }

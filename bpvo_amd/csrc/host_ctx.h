@@ -182,6 +182,8 @@ struct bpvo_hip_ctx {
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  Option "fuse_frozen".  (C = 8: ONE irls_reduce launch serves the plain and
                                // the fused workspaces with a per-workspace branch; the two-launch form measured slower at every batch size, round 2)
+  int reference_reduction = 0; // option "reference_reduction" (validation mode): H, G and the squared norm summed in the reference's index order in f32
+                               // (kernels_gn_ref.hip) — the four-kernel chain only, no fused path, no step inside the reduction, no persistent / team kernel
   int step_in_reduce_max = 128; // groups of up to this many pairs run the four-kernel chain as three: the last tile of a workspace in irls_reduce takes
                                // the Gauss-Newton step (gn_step.h gn_last_tile; same sums in the same order).  Worth +2 % at 64 pairs per lane (the
                                // 128-pair shard), nothing at 128, -3 % at 512: the first wave of every tile waits for its write-through store and its

@@ -133,6 +133,9 @@ struct GNLaunch {
   // keys were invalidated by the kernel of the level before, which was handed this level's jobs as next_jobs)
   int begin_level = -1, begin_moot = 0;
   const PairJob* next_jobs = nullptr;
+  // 1: validation mode "reference_reduction" (kernels_gn_ref.hip) — launch_irls_reduce sums H, G and the squared norm in the reference's
+  // index order (one partial per workspace), launch_gn_step reads that one partial; the fused path and step_in_reduce are ignored
+  int reference_reduction = 0;
 };
 int  gn_num_blocks(int max_points);
 void launch_set_pose(hipStream_t s, const PairJob* jobs, const float* T_init, int n, unsigned* clear = nullptr, int clear_words = 0);   // clear: words zeroed by the same launch
@@ -145,6 +148,7 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g);
 void launch_refresh_residuals(hipStream_t s, const GNLaunch& g);   // fused path: rebuild r / valid of stale workspaces from T_lin
 void launch_median(hipStream_t s, const GNLaunch& g);
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g);
+void launch_reference_reduce(hipStream_t s, const GNLaunch& g);   // what launch_irls_reduce does with g.reference_reduction (kernels_gn_ref.hip)
 // mode 0: full PoseEstimatorBase::run step (solve, update, convergence); mode 1: linearize only (H, G, f_norm)
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol);

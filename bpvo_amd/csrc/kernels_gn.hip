@@ -578,6 +578,7 @@ static void launch_irls_c(hipStream_t s, const GNLaunch& g, int ppb)
 void launch_irls_reduce(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0) return;
+  if(g.reference_reduction) { launch_reference_reduce(s, g); return; }
   const int ppb = gn_pts_per_block(g.C);
   dispatch_channels(g.C, [&](auto c) { launch_irls_c<decltype(c)::value>(s, g, ppb); });
 }
@@ -588,8 +589,9 @@ void launch_compact_active(hipStream_t s, const PairJob* jobs, ActiveSet in, int
 void launch_gn_step(hipStream_t s, const GNLaunch& g, int mode, int max_iterations, int max_fun_evals, float p_tol,
                     float f_tol, float g_tol)
 {
-  const int ppb = gn_pts_per_block(g.C);
-  const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR) ? 1 : 0;
+  // (reference_reduction: ONE partial per workspace whatever its size — a tile that holds every point)
+  const int ppb = g.reference_reduction ? (1 << 30) : gn_pts_per_block(g.C);
+  const int fuse = (g.C == 8 && g.fuse_frozen && !g.fast_warp && g.interp == BPVO_INTERP_LINEAR && !g.reference_reduction) ? 1 : 0;
   hipLaunchKernelGGL(gn_step_kernel, dim3(g.npairs), dim3(64), 0, s, g.jobs, ppb, mode, max_iterations, max_fun_evals, p_tol,
                      f_tol, g_tol, g.active, fuse);
 }
