@@ -93,10 +93,17 @@ __global__ __launch_bounds__(256) void reference_reduce_kernel(const PairJob* __
     }
     __syncthreads();
     if(tid < 28) {
-      for(int e = 0; e < m; ++e) {
-        const float x = rec[e][7] * rec[e][ia];      // w' * J[a]   |   w' * r
-        acc = acc + x * rec[e][ib];                  // ... * J[b]  |   ... * J[a]   |   ... * r        (no contraction: -ffp-contract=off)
+      // (w' * J[a]) * J[b]   |   (w' * r) * J[a]   |   (w' * r) * r — the products of eight entries first (independent), then their adds in index order
+      // (no contraction, no reassociation: -ffp-contract=off, no fast-math)
+      int e = 0;
+      for(; e + 8 <= m; e += 8) {
+        float p[8];
+#pragma unroll
+        for(int q = 0; q < 8; ++q) p[q] = (rec[e + q][7] * rec[e + q][ia]) * rec[e + q][ib];
+#pragma unroll
+        for(int q = 0; q < 8; ++q) acc = acc + p[q];
       }
+      for(; e < m; ++e) acc = acc + (rec[e][7] * rec[e][ia]) * rec[e][ib];
     }
     __syncthreads();
   }

@@ -86,6 +86,21 @@ def test_hip_matches_golden(hip, path):
     assert rot <= ROT_TOL and trans <= trans_tol(g["K"]), (rot, trans)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_hip_in_reference_order_matches_golden_bit_for_bit(hip, path):
+    """... and with the option "reference_reduction" (the reference's f32 index-order sums, kernels_gn_ref.hip) the committed vectors are
+    reproduced exactly: H, G, f_norm of the linearisation, the estimated pose, numIterations and status of every level."""
+    g = np.load(path)
+    ctx, levels = run_case(hip, g)
+    ctx.set_option("reference_reduction", 1)
+    check_against_golden(ctx, levels, g, exact_reduction=True)
+    T, stats = ctx.estimate_pose(0, 0, 1)
+    assert bits_equal(T, g["T_est"])
+    assert [s["numIterations"] for s in stats] == list(g["iters"])
+    assert [s["status"] for s in stats] == list(g["status"])
+
+
 def test_golden_fixtures_present():
     assert len(GOLDEN) >= 4
 

@@ -411,10 +411,78 @@ def check_case(hip, orc, rows, cols, kw, scene, seed, ctxs):
     return "noise-floor-minimum"
 
 
-def iteration_cells(hip, orc, rows, cols, kw, scene, seed):
+REFERENCE_ORDER_OUTCOMES = {"ok-bit-exact", "template-error", "estimate-error"}
+
+
+def check_reference_order(hip, orc, rows, cols, kw, scene, seed):
+    """One case with the library's validation mode "reference_reduction" (H, G, f summed in the reference's f32 index order,
+    bpvo_amd/csrc/kernels_gn_ref.hip): NO rule, NO tolerance — every linearisation's record (pose, H, G, f_norm, robust scale, valid count,
+    step), the final pose and every level's numIterations / status / finalError / firstOrderOptimality must be the oracle's bit for bit
+    (NaNs compared as bits too), or both sides must raise.  Returns one of REFERENCE_ORDER_OUTCOMES; raises AssertionError naming the
+    first linearisation and field that differs."""
+    ctxs = []
+    try:
+        K, b, imgA, dispA, imgB, dispB, _ = make_inputs(rows, cols, scene, seed)
+        kw = dict(kw)
+        fast_warp = kw.pop("_fast_warp", False)
+        kw.pop("_fuse_frozen", None)
+        formulation = 2 if kw.pop("_dspace", False) else (1 if fast_warp else 0)
+        os.environ.pop("BPVO_HIP_OPTIONS", None)
+        for bind in (hip, orc):
+            ctx = bind.create(K, b, rows, cols, make_params(bind, **kw), n_frames=2, n_pairs=1)
+            ctxs.append(ctx)
+            if formulation:
+                ctx.set_warp_formulation(formulation)
+            ctx.frame_set_data(0, imgA, dispA)
+            ctx.frame_set_data(1, imgB, dispB)
+        ch, co = ctxs
+        ch.set_option("reference_reduction", 1)
+        errs = []
+        for ctx in (ch, co):
+            try:
+                ctx.frame_set_template(0)
+                errs.append(None)
+            except capi.BpvoError as e:
+                errs.append(str(e))
+        assert (errs[0] is None) == (errs[1] is None), ("set_template error behaviour", errs)
+        if errs[0] is not None:
+            return "template-error"
+        runs = []
+        for ctx in (ch, co):
+            try:
+                runs.append(ctx.estimate_pose_trace(0, 0, 1, max_records=8192))
+            except capi.BpvoError as e:
+                runs.append(str(e))
+        assert isinstance(runs[0], str) == isinstance(runs[1], str), ("estimate_pose error behaviour", runs[0] if isinstance(runs[0], str) else None,
+                                                                         runs[1] if isinstance(runs[1], str) else None)
+        if isinstance(runs[0], str):
+            return "estimate-error"
+        (Th, sh, rh), (To, so, ro) = runs
+        fields = [("T", 0, 16), ("H", 16, 52), ("G", 52, 58), ("f_norm", 58, 59), ("sigma", 59, 60), ("num_valid", 60, 61), ("dp", 61, 67), ("level", 67, 68)]
+        for i in range(min(len(rh), len(ro))):
+            if not bits_equal(rh[i], ro[i]):
+                bad = [n for n, lo, hi in fields if not bits_equal(rh[i][lo:hi], ro[i][lo:hi])]
+                raise AssertionError(("linearisation", i, "level", int(ro[i][67]), "first differing fields", bad, "hip f / sigma / valid", rh[i][58:61].tolist(),
+                                      "oracle", ro[i][58:61].tolist()))
+        assert len(rh) == len(ro), ("number of linearisations", len(rh), len(ro), [s_["numIterations"] for s_ in sh], [s_["numIterations"] for s_ in so])
+        for l, (a, o) in enumerate(zip(sh, so)):
+            assert a["numIterations"] == o["numIterations"] and a["status"] == o["status"], ("statistics", l, a, o)
+            assert np.float32(a["finalError"]).tobytes() == np.float32(o["finalError"]).tobytes(), ("finalError", l, a, o)
+            assert np.float32(a["firstOrderOptimality"]).tobytes() == np.float32(o["firstOrderOptimality"]).tobytes(), ("firstOrderOptimality", l, a, o)
+        assert bits_equal(Th, To), ("pose", Th.tolist(), To.tolist())
+        return "ok-bit-exact"
+    finally:
+        for ctx in ctxs:
+            ctx.close()
+
+
+def iteration_cells(hip, orc, rows, cols, kw, scene, seed, calibrate=False):
     """(equal, within one, total) over the levels of one case: OptimizerStatistics::numIterations AND status of the GPU run against the oracle's
     under the reference's timing tolerances (conf/perf_*.cfg: 1e-6 / 1e-4 / 1e-6), where a level ends on a tolerance test well above
-    the f32 noise floor — the count is then a property of the path, not of the last bits of a sum."""
+    the f32 noise floor — the count is then a property of the path, not of the last bits of a sum.
+    calibrate: four more numbers — (equal, within one) of the ORACLE's 8-chunk reduction (the reference's TBB build: tbb::parallel_reduce,
+    bpvo/linear_system_builder.cc:91-131,233-237, restated as eight contiguous chunks summed in order) and of its f64 accumulation against the
+    oracle's serial f32 run, over the same cells: the reference's OWN spread of numIterations under its own summation orders."""
     K, b, imgA, dispA, imgB, dispB, _ = make_inputs(rows, cols, scene, seed)
     kw = dict(kw, parameterTolerance=1e-6, functionTolerance=1e-4, gradientTolerance=1e-6)
     fast_warp, fuse = kw.pop("_fast_warp", False), kw.pop("_fuse_frozen", False)
@@ -430,16 +498,31 @@ def iteration_cells(hip, orc, rows, cols, kw, scene, seed):
             ctx.frame_set_data(1, imgB, dispB)
             ctx.frame_set_template(0)
             stats.append(ctx.estimate_pose(0, 0, 1)[1])
+            if calibrate and bind is orc:
+                ctx.call("set_num_threads", 8)
+                stats.append(ctx.estimate_pose(0, 0, 1)[1])
+                ctx.call("set_num_threads", 1)
+                ctx.call("set_reduction", 1)
+                stats.append(ctx.estimate_pose(0, 0, 1)[1])
         except capi.BpvoError:
             stats.append(None)
         finally:
             ctx.close()
-    if stats[0] is None or stats[1] is None:
-        return 0, 0, 0
-    pairs = list(zip(stats[0], stats[1]))[kw.get("maxTestLevel", 0):]
-    equal = sum(1 for a, o in pairs if a["numIterations"] == o["numIterations"] and a["status"] == o["status"])
-    close = sum(1 for a, o in pairs if abs(a["numIterations"] - o["numIterations"]) <= 1)
-    return equal, close, len(pairs)
+    if any(st is None for st in stats) or len(stats) != (4 if calibrate else 2):
+        return (0, 0, 0, 0, 0, 0, 0) if calibrate else (0, 0, 0)
+    first = kw.get("maxTestLevel", 0)
+
+    def agree(x, y):
+        pairs = list(zip(x, y))[first:]
+        return (sum(1 for a, o in pairs if a["numIterations"] == o["numIterations"] and a["status"] == o["status"]),
+                sum(1 for a, o in pairs if abs(a["numIterations"] - o["numIterations"]) <= 1), len(pairs))
+
+    equal, close, total = agree(stats[0], stats[1])
+    if not calibrate:
+        return equal, close, total
+    e8, c8, _ = agree(stats[2], stats[1])
+    e64, c64, _ = agree(stats[3], stats[1])
+    return equal, close, total, e8, c8, e64, c64
 
 
 def check_batch(hip, rows, cols, kw, seed, options="", dirty=False, n=None):
@@ -505,6 +588,7 @@ def main():
     ap.add_argument("--max-cols", type=int, default=300)
     ap.add_argument("--batch-every", type=int, default=0)
     ap.add_argument("--cells-every", type=int, default=0, help="every n-th ok case also compares the iteration counts under the timing tolerances")
+    ap.add_argument("--reference-order", action="store_true", help="every case through check_reference_order: the library's reference_reduction mode, bit for bit, no rule")
     ap.add_argument("--latch", action="store_true", help="LATCH among the descriptors drawn (levels too small for a key point give an empty template on both sides)")
     args = ap.parse_args()
     global MAX_ROWS, MAX_COLS
@@ -520,17 +604,20 @@ def main():
     outcomes = {}
     by_class = {"normalised": {}, "un-normalised": {}}
     by_desc = {}
-    cells = [0, 0, 0]
+    cells = [0, 0, 0, 0, 0, 0, 0]
     fails = 0
     n = 0
     while time.time() - t0 < args.seconds and n < args.max_cases:
         rows, cols, kw, scene, seed = draw(rng)
         n += 1
         try:
-            out = check(hip, orc, rows, cols, kw, scene, seed)
+            if args.reference_order:
+                out = check_reference_order(hip, orc, rows, cols, kw, scene, seed)
+            else:
+                out = check(hip, orc, rows, cols, kw, scene, seed)
             if args.cells_every > 0 and n % args.cells_every == 0 and out == "ok":
-                e, c1, t = iteration_cells(hip, orc, rows, cols, kw, scene, seed)
-                cells[0] += e; cells[1] += t; cells[2] += c1
+                e, c1, t, e8, c8, e64, c64 = iteration_cells(hip, orc, rows, cols, kw, scene, seed, calibrate=True)
+                cells[0] += e; cells[1] += t; cells[2] += c1; cells[3] += e8; cells[4] += c8; cells[5] += e64; cells[6] += c64
             if args.batch_every > 0 and n % args.batch_every == 0 and out == "ok":
                 outb = check_batch(hip, rows, cols, kw, seed)
                 outcomes["batch-" + outb] = outcomes.get("batch-" + outb, 0) + 1
@@ -550,6 +637,8 @@ def main():
     print("by class", by_class, flush=True)
     if cells[1]:
         print("(case, level) cells with numIterations and status equal to the oracle's under the timing tolerances: %d of %d = %.4f; numIterations within one: %d = %.4f" % (cells[0], cells[1], cells[0] / cells[1], cells[2], cells[2] / cells[1]), flush=True)
+        print("  the oracle's own spread over the same cells (against its serial f32 run): 8-chunk reduction equal %d = %.4f, within one %d = %.4f; f64 accumulation equal %d = %.4f, within one %d = %.4f"
+              % (cells[3], cells[3] / cells[1], cells[4], cells[4] / cells[1], cells[5], cells[5] / cells[1], cells[6], cells[6] / cells[1]), flush=True)
     return 1 if fails else 0
 
 
