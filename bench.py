@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--descriptor", default="bitplanes", choices=["bitplanes", "intensity"])
     ap.add_argument("--loss", default="tukey", choices=["tukey", "huber", "l2"])
     ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--interp", default="linear", choices=["linear", "cosine", "cubic", "cubic_hermite"],
+                    help="PhotoError interpolation (AlgorithmParameters::interp); the non-linear ones run warp_residual_interp_kernel (profiling runs)")
     ap.add_argument("--strong", action="store_true", help="(the default; kept so that older command lines still parse)")
     ap.add_argument("--tolerances", default="default", choices=["default", "timing"],
                     help="default = AlgorithmParameters() (1e-7 / 1e-6 / 1e-8); timing = the reference's conf/perf_*.cfg (1e-6 / 1e-4 / 1e-6)")
@@ -68,7 +70,10 @@ def parse_args():
                     help="functional test only: every rank uses GPU 0 (needs --dist-backend gloo)")
     ap.add_argument("--dump-records", default="", help="rank 0 saves the gathered [world * pairs, 32] result records of the last "
                     "step here (.npy); slots [30], [31] of every record carry the rank and the device ordinal that produced it")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.interp != "linear":
+        a.over = {"interp": {"cosine": 1, "cubic": 2, "cubic_hermite": 3}[a.interp]}
+    return a
 
 
 from bpvo_amd.bench_configs import make_params, other_configs, stereo_lines  # noqa: E402,F401  (stereo_lines: scripts/stereo_bench.py)
@@ -213,6 +218,8 @@ def main():
     d_records = torch.zeros((P, RECORD_FLOATS), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
+    gather_s = [0.0, 0]      # seconds this rank spent in the gather (its own clock: includes waiting for the slowest rank), calls
+
     def step():
         poses, stats = ctx.batch_run_device(P, d_images.data_ptr(), d_disps.data_ptr())
         gathered = None
@@ -220,7 +227,12 @@ def main():
             ctx.batch_copy_records_device(d_records.data_ptr(), P)
             d_records[:, 30] = float(rank)         # who produced the record (slots the library leaves at 0)
             d_records[:, 31] = float(dev_index)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
             gathered = gather_records(d_records if coll_dev.type == "cuda" else d_records.cpu(), dst=0)
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - tg
+            gather_s[1] += 1
         return poses, stats, gathered
 
     def sync_all():
@@ -231,6 +243,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    gather_s[0], gather_s[1] = 0.0, 0
     ctx.profiling(0 if args.no_profile else (2 if args.profile_all else 1))   # resets counters; events on the library's streams
     sync_all()
     t0 = time.perf_counter()
@@ -275,6 +288,27 @@ def main():
         elapsed_max, gn_total, numit_total, ranks_seen = elapsed, float(gn_local), numit_last_step, 1
     if ranks_seen != args.gpus:
         raise SystemExit(f"bench.py: {ranks_seen} rank(s) took part in the all-reduce, --gpus {args.gpus}")
+    # What every rank did, so that the first multi-GPU run can be read: its own step time, the time it spent in the gather (its own clock: a rank
+    # that finishes early waits there for the slowest), which Gauss-Newton driver its batch took (team launches / chain), whether a persistent or
+    # team launch of its context ever gave up at a barrier and fell back to the chain, and which device it ran on.
+    levels_pk, gave_up = ctx.persistent_counts()
+    team_launches = ctx.team_counts()
+    expect_team = bool(ctx.get_option("team") and ctx.get_option("persistent") and 2 <= P <= ctx.get_option("team_max_pairs") and not args.profile_all)
+    my_diag = {"rank": rank, "local_rank": local_rank, "device": dev_index, "device_name": torch.cuda.get_device_name(dev_index),
+               "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES"),
+               "pairs": P, "ms_per_step": 1e3 * elapsed / args.steps, "gather_ms_per_step": (1e3 * gather_s[0] / gather_s[1]) if gather_s[1] else None,
+               "team_launches": int(team_launches), "team_expected": expect_team, "persistent_levels": int(levels_pk), "gave_up": int(gave_up),
+               "gn_iterations": int(gn_local)}
+    if world > 1:
+        diags = [None] * world
+        dist.all_gather_object(diags, my_diag)
+    else:
+        diags = [my_diag]
+    silent_fallback = [d["rank"] for d in diags if d["gave_up"] or (d["team_expected"] and d["team_launches"] == 0)]
+    if silent_fallback:
+        raise SystemExit("bench.py: rank(s) %s fell back from the team / persistent kernel to the four-kernel chain (a device-side barrier timed out, "
+                         "or the team kernel never ran where the batch size asks for it) — no line is printed for a run whose ranks did different work: %s"
+                         % (silent_fallback, json.dumps(diags)))
     rccl_version = None
     if world > 1 and args.dist_backend == "nccl":
         try:
@@ -326,10 +360,17 @@ def main():
                     traffic = json.load(open(tpath))["warp_residual_hbm_bytes_per_point"] * k["units_per_launch"]
                 except Exception:
                     traffic = None
-            roofline = {"bound": "hbm", "kernel": "warp_residual_kernel<8>" if args.descriptor == "bitplanes" else "warp_residual_kernel<1>",
-                        "achieved": k["algorithmic_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": k["algorithmic_GBps"] / HBM_PEAK_GBS, "traffic": traffic,
-                        "bytes_per_point": 18 + 24 * (8 if args.descriptor == "bitplanes" else 1),
+            C_k6 = 8 if args.descriptor == "bitplanes" else 1
+            kname, bpp = "warp_residual_kernel<%d>" % C_k6, 18 + 24 * C_k6
+            gbps_k6 = k["algorithmic_GBps"]
+            if args.interp != "linear":      # the other interpolation types: 4 (kCosine) or 16 taps per point and channel, no tap cache
+                kname, bpp = "warp_residual_interp_kernel<%d, %s>" % (C_k6, args.interp), 18 + C_k6 * (4 * (4 if args.interp == "cosine" else 16) + 8)
+                gbps_k6 = bpp * k["units_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
+                traffic = None
+            roofline = {"bound": "hbm", "kernel": kname,
+                        "achieved": gbps_k6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbps_k6 / HBM_PEAK_GBS, "traffic": traffic,
+                        "bytes_per_point": bpp,
                         "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"],
                         "measured": "one untimed step of the same workload on a single estimation lane, HIP events around EVERY launch on the "
                                     "library's stream (the timed steps overlap the lanes: roofline_timed_region)"}
@@ -362,6 +403,17 @@ def main():
                              "fused_fraction_of_points": frac_fused, "points_per_launch": k["units_per_launch"], "avg_launch_ms": k["avg_ms"],
                              "launches": k["launches"], "accounting": "moved (requested) bytes, not SURVEY 8d's algorithmic 226 B: Jacobians are recomputed, a third of the points recompute their residuals",
                              "measured": "the same single-lane pass, HIP events around EVERY launch"}
+
+        if roofline is not None and roofline_irls is not None:
+            # north_star names warp + residual, so `roofline` is that kernel; the DOMINANT kernel of the step is the reduction, and its figures ride along
+            k6t, k8t = kernels_1lane["warp_residual"]["total_ms"], kernels_1lane["irls_reduce"]["total_ms"]
+            all_t = sum(v["total_ms"] for v in kernels_1lane.values())
+            t_pp = tjson.get("irls_reduce_hbm_bytes_per_point")
+            cnt_gbps = (t_pp * roofline_irls["points_per_launch"] / (roofline_irls["avg_launch_ms"] * 1e-3) / 1e9) if t_pp else None
+            roofline["dominant"] = {"kernel": "irls_reduce_both_kernel", "avg_launch_ms": roofline_irls["avg_launch_ms"], "launches": roofline_irls["launches"],
+                                    "share_of_timed_kernel_ms": k8t / all_t if all_t else None, "warp_residual_share": k6t / all_t if all_t else None,
+                                    "frac_counter_bytes": (cnt_gbps / HBM_PEAK_GBS) if cnt_gbps else None, "counter_bytes_per_point": t_pp,
+                                    "frac_moved_bytes": roofline_irls["frac"], "moved_bytes_per_point": roofline_irls["bytes_per_point"]}
 
         # Both chip-filling kernels of the Gauss-Newton loop together, in HBM bytes the counters saw (PMC passes on this workload, bytes per
         # point from profiles/traffic.json) over the sum of their launch durations in the single-lane pass
@@ -459,8 +511,79 @@ def main():
             "other_configs": others,
             "projected_strong_scaling": projected,
             "setup": {"synth_seconds": t_gen, "gen_workers": workers},
+            "ranks": diags,
         }
-        print(json.dumps(out))
+        # ONE JSON line on stdout (the contract), short enough (< 7 KB) that a tail of the output holds all of it: the contract's keys, `roofline`
+        # (warp + residual, the kernel north_star names, with the dominant kernel's figures inside), `cpu_baseline`, what every rank did, the
+        # config-5 shards, the single pair, the other configurations as one number each.  The full record (kernel tables, notes, every
+        # other_configs line) goes to stderr as a second JSON line and to gpurun_out/bench_details.json.
+        def rnd(x, nd=4):
+            if isinstance(x, float):
+                return float(("%." + str(nd) + "g") % x)
+            if isinstance(x, dict):
+                return {k: rnd(v, nd) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return [rnd(v, nd) for v in x]
+            return x
+        head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")}
+        head["metric"] = "GN iterations/s (1241x376 bit-planes 8ch, 4 levels, Tukey; linearise + solve + update = 1, the reference's _num_fun_evals)" \
+            if (args.rows, args.cols, args.descriptor) == (376, 1241, "bitplanes") else "GN iterations/s"
+        for k in ("frames_per_s", "gn_iterations_per_step", "ranks_seen", "dist_backend", "rccl_version", "points_linearized_rank0"):
+            head[k] = out[k]
+        head["fused_path"] = {k: out["fused_path"][k] for k in ("points", "of")}
+        if roofline_timed is not None:
+            head["roofline_timed_region"] = {k: roofline_timed[k] for k in ("achieved", "frac", "avg_launch_ms")}
+        head["kernels"] = {n_: {"launches": v["launches"], "avg_ms": v["avg_ms"], "algorithmic_GBps": v["algorithmic_GBps"]} for n_, v in kernels_1lane.items()}
+        if roofline is not None:
+            rl = dict(roofline)
+            rl["measured"] = "HIP events around every launch, one untimed single-lane step"
+            head["roofline"] = rl
+        else:
+            head["roofline"] = None
+        if cpu is not None:
+            head["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                    "sample": f"{min(args.cpu_pairs, P)} pairs of the same workload, oracle/ restatement, 1 thread",
+                                    "all_cores": {"value": cpu["all_cores"]["value"], "cores": cpu["all_cores"]["cores"]}}
+        else:
+            head["cpu_baseline"] = None
+        if pose_vs_cpu is not None:
+            head["pose_vs_cpu"] = {k: pose_vs_cpu[k] for k in ("pairs", "rot_max_rad", "trans_max_m")}
+        ms = [d["ms_per_step"] for d in diags]
+        head["ranks"] = {"ms_per_step_min": min(ms), "ms_per_step_max": max(ms), "slowest_rank": int(np.argmax(ms)), "dist_backend": out["dist_backend"],
+                         "ranks_seen": ranks_seen, "rccl_version": rccl_version,
+                         "per_rank": [{k: d[k] for k in ("rank", "device", "HIP_VISIBLE_DEVICES", "pairs", "ms_per_step", "gather_ms_per_step", "team_launches", "gave_up")} for d in diags]}
+        if others is not None:
+            shards, brief = {}, {}
+            for k, v in others.items():
+                if k.startswith("config-5 shard:"):
+                    shards[str(v["pairs"])] = {"value": v["value"], "of_headline": v["value"] / out["value"], "ms_per_step": v["ms_per_step"]}
+                elif "one pair per call" in k:
+                    head["single_pair"] = {"value": v["value"], "ms_per_pair": v["ms_per_step"], "us_per_linearisation": v["us_per_linearisation_per_pair"]}
+                elif k == "stereo front-end":
+                    brief["stereo ms/frame"] = {kk.split(",")[0]: vv.get("ms_per_frame") for kk, vv in v.items()}
+                elif "addFrame" in k:
+                    brief[k.replace("parameters of ", "")] = {"ms_per_frame": v["ms_per_frame"]}
+                elif "HOST buffers" in k:
+                    brief["1024 pairs from host buffers"] = {"value": v["value"], "vs_resident_inputs": v["vs_resident_inputs"], "upload_GBps": v["upload"]["GBps"]}
+                else:
+                    e = {"value": v["value"], "pairs": v["pairs"], "us_per_linearisation_per_pair": v["us_per_linearisation_per_pair"]}
+                    if v.get("residual_kernel"):
+                        rk = v["residual_kernel"]
+                        e["residual_kernel"] = {"kernel": rk["kernel"], "avg_launch_ms": rk["avg_launch_ms"], "bytes_per_point": rk["bytes_per_point"],
+                                                "achieved_GBps": rk["achieved_GBps"], "frac_of_hbm_peak": rk["frac_of_hbm_peak"]}
+                    brief[k.replace("the parameters of ", "")] = e
+            head["config5_shards"] = shards
+            head["other_configs"] = brief
+        head["details"] = "second JSON line on stderr; gpurun_out/bench_details.json"
+        line = json.dumps(rnd(head))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_details.json"), "w") as f:
+                f.write(json.dumps(out) + "\n")
+        except OSError:
+            pass
+        print(json.dumps({"details": out}), file=sys.stderr, flush=True)
+        print(line, flush=True)
 
     if ctx.h:
         ctx.close()

@@ -24,14 +24,23 @@ def make_params(binding, args):
         p.parameterTolerance = 0.0
         p.functionTolerance = 0.0
         p.gradientTolerance = 0.0
+    for k, v in (getattr(args, "over", None) or {}).items():      # further AlgorithmParameters fields (the conf/*.cfg lines)
+        setattr(p, k, v)
     return p
 
 
 
-def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, levels, loss, steps=3, warmup=1, tolerances="default", want_stages=False):
-    """GN iterations/s of one more configuration (same step definition as the headline, inputs resident in HBM)."""
+HBM_PEAK_GBS = 8000.0
+
+
+def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, levels, loss, steps=3, warmup=1, tolerances="default", want_stages=False,
+                over=None, residual_kernel_taps=0):
+    """GN iterations/s of one more configuration (same step definition as the headline, inputs resident in HBM).
+    over: more AlgorithmParameters fields.  residual_kernel_taps (4 = kCosine, 16 = kCubic / kCubicHermite): one more, untimed step on a single
+    lane with HIP events around every warp + residual launch -> the kernel's average launch and its algorithmic bytes / s (18 + C (4 taps + 8)
+    B per point: point 16, valid 1 (+1), per channel the taps, the template pixel and the residual) against the HBM peak."""
     from types import SimpleNamespace
-    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0, tolerances=tolerances))
+    p = make_params(hip, SimpleNamespace(levels=levels, descriptor=descriptor, loss=loss, fixed_iters=0, tolerances=tolerances, over=over))
     ctx = hip.create(batch["K"], batch["b"], rows, cols, p, device=dev_index, n_frames=2 * n, n_pairs=n)
     d_i = torch.from_numpy(batch["images"][: 2 * n]).to(dev)
     d_d = torch.from_numpy(batch["disparities"][: 2 * n]).to(dev)
@@ -50,12 +59,28 @@ def timed_batch(hip, torch, dev, dev_index, batch, rows, cols, n, descriptor, le
         ks = {k["name"]: k for k in ctx.kernel_stats()}
         frame_ms = sum(ks[k]["total_ms"] for k in ("pyramid", "descriptor", "saliency_select", "normalization", "template_build")) / steps
     dT = np.linalg.norm(poses[:, :3, 3].astype(np.float64) - batch["T_gt"][:n, :3, 3], axis=1)
+    kernel = None
+    if residual_kernel_taps:
+        C = 8 if descriptor == "bitplanes" else 1
+        ctx.set_max_lanes(1)
+        ctx.profiling(3)
+        ctx.batch_run_device(n, d_i.data_ptr(), d_d.data_ptr())
+        torch.cuda.synchronize()
+        k = {q["name"]: q for q in ctx.kernel_stats()}["warp_residual"]
+        bpp = 18 + C * (4 * residual_kernel_taps + 8)
+        if k["launches"]:
+            avg_ms = k["total_ms"] / k["launches"]
+            gbps = bpp * (k["units"] / k["launches"]) / (avg_ms * 1e-3) / 1e9
+            kernel = {"kernel": "warp_residual_interp_kernel<%d>" % C, "launches": int(k["launches"]), "avg_launch_ms": avg_ms, "points_per_launch": k["units"] / k["launches"],
+                      "bytes_per_point": bpp, "achieved_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS,
+                      "note": "algorithmic bytes (every tap counted once per point; neighbouring points share most of their 4 x 4 footprints in L2) over "
+                              "HIP events around every launch of one untimed single-lane step"}
     ctx.close()
     return {"pairs": n, "value": gn / dt, "unit": "GN iterations/s", "frames_per_s": 2.0 * n * steps / dt, "ms_per_step": 1e3 * dt / steps,
             "us_per_linearisation_per_pair": 1e6 * dt * n / max(1, gn),      # (a pair's step time over its linearisations: the B = 1 latency figure)
             "frame_stage_ms_per_step": frame_ms,
             "gn_iterations_per_pair": gn / (steps * n), "numIterations_per_pair": float(stats["numIterations"].sum()) / n,
-            "median_trans_err_vs_gt_m": float(np.median(dT))}
+            "median_trans_err_vs_gt_m": float(np.median(dT)), "residual_kernel": kernel}
 
 
 def timed_batch_host(hip, torch, dev_index, batch, rows, cols, n, descriptor, levels, loss, resident_ms, steps=3, warmup=1):
@@ -203,6 +228,20 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
         "1241x376 bitplanes, 4 levels, tukey, one pair per call (B = 1)":
             timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, 1, args.descriptor, args.levels, args.loss, steps=40, warmup=5),   # (3 ms steps: 40 of them)
     }
+    # The other interpolation types of PhotoError (bpvo/photo_error.cc:391-444; warp_residual_interp_kernel): conf/tsukuba.cfg:45 selects
+    # CubicHermite — its parameter set (Intensity as the file is read, 3 levels, 55 iterations, 1e-6 / 1e-4 / 1e-6, Huber, CD5, minSaliency
+    # 0.001, NMS radius 0 -> off, sigma_ct 0.75, sigma_bp 1.75; types.cc:68-107 for the file constructor's other defaults) — and the
+    # headline shape (bit-planes, Tukey, 4 levels) with kCubic
+    from bpvo_amd import capi as _capi
+    tsukuba = dict(interp=_capi.INTERP_CUBIC_HERMITE, maxIterations=55, parameterTolerance=1e-6, functionTolerance=1e-4, gradientTolerance=1e-6,
+                   gradientEstimation=_capi.GRAD_CD5, minSaliency=0.001, nonMaxSuppRadius=0, minNumPixelsForNonMaximaSuppression=76800,
+                   relaxTolerancesForCoarseLevels=0, sigmaPriorToCensusTransform=0.75, sigmaBitPlanes=1.75, minValidDisparity=1.0, goodPointThreshold=0.75,
+                   minTranslationMagToKeyFrame=0.05, minRotationMagToKeyFrame=2.5, maxFractionOfGoodPointsToKeyFrame=0.5)
+    out["640x480 intensity, 3 levels, huber, CubicHermite: the parameters of conf/tsukuba.cfg"] = \
+        timed_batch(hip, torch, dev, dev_index, other_batch, 480, 640, n, "intensity", 3, "huber", steps=6, warmup=2, over=tsukuba, residual_kernel_taps=16)
+    out["1241x376 bitplanes, 4 levels, tukey, kCubic interpolation"] = \
+        timed_batch(hip, torch, dev, dev_index, batch, args.rows, args.cols, min(n, batch["images"].shape[0] // 2), args.descriptor, args.levels, args.loss, steps=3, warmup=1,
+                    over=dict(interp=_capi.INTERP_CUBIC), residual_kernel_taps=16)
     npairs = batch["images"].shape[0] // 2
     if npairs >= 128:
         # BASELINE config 5 as it is really sharded: 1024 pairs over 8 GPUs = 128 pairs per GPU (strong scaling; `--gpus 8` runs

@@ -81,33 +81,46 @@ __device__ __forceinline__ float dot4(float a0, float a1, float a2, float a3, co
   return (a0 * b[0] + a1 * b[1]) + (a2 * b[2] + a3 * b[3]);
 }
 
-template <int C>
-__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int interp)
+// Channels are handled in GROUPS of G (8 where C is a multiple of 8: the 32 bytes of a bit-planes pixel in one go; else 4, 2 (C = 10) or 1), and a
+// group's 4 x 4 footprint ROW PAIR by row pair: the taps of two rows — 2 x 4 x G floats, every row one contiguous run of 4 x C floats that is requested
+// once — are loaded, reduced along x to d[row][channel] (kCubic: dot4 with the x coefficients; kCubicHermite: interp_hermite at xf), and only then
+// (sched_barrier) the next two rows are requested; the y pass runs on the four d's.  All channels and rows at once (the first form of this kernel)
+// kept 16 x C tap registers live: 198 VGPRs / 2 waves per SIMD for C = 8, spills from C = 24 on.  Groups of FOUR channels over all four rows (tried
+// first this round) fit the registers but requested every 128-byte row segment twice, half a record at a time: kCubic 113 -> 149 us per launch
+// (profiles/r06_interp_kernel.txt).  Per channel the arithmetic and its order are unchanged.
+template <int C> struct InterpGroup { static constexpr int G = (C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : (C % 2 == 0) ? 2 : 1; };
+template <int G>
+__device__ __forceinline__ void load_group(const float* __restrict__ p, float (&v)[G])
 {
+  if constexpr(G == 8) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else if constexpr(G == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  else if constexpr(G == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+  else v[0] = p[0];
+}
+
+template <int C, int INTERP>
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+{
+  constexpr int interp = INTERP;
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
   const GNState* __restrict__ st = j.st;
   if(!st->active) return;
   const int n = j.n;
   if((int) (blockIdx.x * K6_BLOCK) >= n) return;
+  if(blockIdx.x == 0 && threadIdx.x == 0) j.cnt[4] += (unsigned long long) n;   // points this kernel processes (measurement)
 
   float P[12];
-#pragma unroll
-  for(int r = 0; r < 3; ++r)
-#pragma unroll
-    for(int c = 0; c < 4; ++c) {
-      float s = j.K[r * 3 + 0] * st->T[0 * 4 + c];
-      s += j.K[r * 3 + 1] * st->T[1 * 4 + c];
-      s += j.K[r * 3 + 2] * st->T[2 * 4 + c];
-      P[r * 4 + c] = s;
-    }
+  projection_matrix(j, st->T, P);
 
   const int i_raw = blockIdx.x * K6_BLOCK + threadIdx.x;
   const bool in_block = i_raw < n;
   const int i = in_block ? i_raw : n - 1;
   const int W = j.cols, R = j.rows;
   const float4 X = j.pts[i];
-  const bool two_tap = interp == BPVO_INTERP_COSINE;
-  const int border_lo = two_tap ? 0 : 1, border_hi = two_tap ? 1 : 3;
+  constexpr bool two_tap = interp == BPVO_INTERP_COSINE;
+  constexpr int border_lo = two_tap ? 0 : 1, border_hi = two_tap ? 1 : 3;
   int xi = 0, yi = 0;
   const double X0 = (double) X.x, X1 = (double) X.y, X2 = (double) X.z, X3 = (double) X.w;
   double u[3];
@@ -130,55 +143,77 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
   const float xf = (float) (x - (double) xi), yf = (float) (y - (double) yi);
   if(in_block) j.valid[i] = valid ? 1 : 0;
 
+  constexpr int G = InterpGroup<C>::G;
   float res[C];
 #pragma unroll
   for(int c = 0; c < C; ++c) res[c] = 0.0f;
   if(valid) {
-    float I0[C];
-    if constexpr(C == 8) {
-      const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
-      const float4 t0 = p0[tile_index<2>(i, 0)], t1 = p0[tile_index<2>(i, 1)];
-      I0[0] = t0.x; I0[1] = t0.y; I0[2] = t0.z; I0[3] = t0.w; I0[4] = t1.x; I0[5] = t1.y; I0[6] = t1.z; I0[7] = t1.w;
-    } else {
-#pragma unroll
-      for(int c = 0; c < C; ++c) I0[c] = j.pix[(size_t) i * C + c];
+    // coefficients of the point (f32; the cosine's from a double cosine) — once, not per channel
+    float Cx[4] = {0, 0, 0, 0}, Cy[4] = {0, 0, 0, 0};
+    if constexpr(two_tap) {
+      float c2[2];
+      interp_cosine(xf, c2); Cx[0] = c2[0]; Cx[1] = c2[1];
+      interp_cosine(yf, c2); Cy[0] = c2[0]; Cy[1] = c2[1];
+    } else if constexpr(interp == BPVO_INTERP_CUBIC) {
+      interp_cubic(xf, Cx);
+      interp_cubic(yf, Cy);
     }
-    if(two_tap) {
-      float Cx[2], Cy[2];
-      interp_cosine(xf, Cx);
-      interp_cosine(yf, Cy);
-      const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
-      const float* __restrict__ d1 = d0 + (size_t) W * C;
+    size_t row_off[4];      // float offset of (row, xi) for the 4 x 4 forms: rows yi-1 .. yi+2, the last clamped (Q21)
 #pragma unroll
-      for(int c = 0; c < C; ++c) {
-        const float e1 = d0[c] * Cx[0] + d0[C + c] * Cx[1];
-        const float e2 = d1[c] * Cx[0] + d1[C + c] * Cx[1];
-        res[c] = (Cy[0] * e1 + Cy[1] * e2) - I0[c];
-      }
-    } else {
-      const float* __restrict__ rowp[4];
+    for(int k = 0; k < 4; ++k) row_off[k] = ((size_t) min(yi - 1 + k, R - 1) * W + xi) * C;
+    const size_t off00 = ((size_t) yi * W + xi) * C;
 #pragma unroll
-      for(int k = 0; k < 4; ++k) rowp[k] = j.desc + ((size_t) min(yi - 1 + k, R - 1) * W + xi) * C;
-      if(interp == BPVO_INTERP_CUBIC) {
-        float Cx[4], Cy[4];
-        interp_cubic(xf, Cx);
-        interp_cubic(yf, Cy);
-#pragma unroll
-        for(int c = 0; c < C; ++c) {
-          float d[4];
-#pragma unroll
-          for(int k = 0; k < 4; ++k) d[k] = dot4(rowp[k][c], rowp[k][C + c], rowp[k][2 * C + c], rowp[k][3 * C + c], Cx);
-          res[c] = dot4(Cy[0], Cy[1], Cy[2], Cy[3], d) - I0[c];
-        }
+    for(int g = 0; g < C / G; ++g) {
+      const int c0 = g * G;
+      float I0[G];
+      if constexpr(C == 8) {
+        const float4* p0 = reinterpret_cast<const float4*>(j.pix.get());
+        const float4 ta = p0[tile_index<2>(i, 0)], tb = p0[tile_index<2>(i, 1)];
+        I0[0] = ta.x; I0[1] = ta.y; I0[2] = ta.z; I0[3] = ta.w; I0[4] = tb.x; I0[5] = tb.y; I0[6] = tb.z; I0[7] = tb.w;
       } else {
 #pragma unroll
-        for(int c = 0; c < C; ++c) {
-          float V[4];
+        for(int q = 0; q < G; ++q) I0[q] = j.pix[(size_t) i * C + c0 + q];
+      }
+      if constexpr(two_tap) {
+        float a[G], b[G], c[G], d[G];      // (yi, xi), (yi, xi+1), (yi+1, xi), (yi+1, xi+1)
+        const float* __restrict__ d0 = j.desc + off00 + c0;
+        load_group<G>(d0, a); load_group<G>(d0 + C, b);
+        load_group<G>(d0 + (size_t) W * C, c); load_group<G>(d0 + (size_t) W * C + C, d);
 #pragma unroll
-          for(int k = 0; k < 4; ++k) V[k] = interp_hermite(rowp[k][c], rowp[k][C + c], rowp[k][2 * C + c], rowp[k][3 * C + c], xf);
-          res[c] = interp_hermite(V[0], V[1], V[2], V[3], yf) - I0[c];
+        for(int q = 0; q < G; ++q) {
+          const float e1 = a[q] * Cx[0] + b[q] * Cx[1];
+          const float e2 = c[q] * Cx[0] + d[q] * Cx[1];
+          res[c0 + q] = (Cy[0] * e1 + Cy[1] * e2) - I0[q];
+        }
+      } else {
+        float d[4][G];      // the x pass of row k: kCubic dot4(taps, Cx), kCubicHermite interp_hermite(taps, xf)
+#pragma unroll
+        for(int rp = 0; rp < 2; ++rp) {
+          float t[2][4][G];      // [row of the pair][tap][channel of the group]
+#pragma unroll
+          for(int k = 0; k < 2; ++k)
+#pragma unroll
+            for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * C + c0, t[k][m]);
+#pragma unroll
+          for(int k = 0; k < 2; ++k)
+#pragma unroll
+            for(int q = 0; q < G; ++q) {
+              if constexpr(interp == BPVO_INTERP_CUBIC) d[2 * rp + k][q] = dot4(t[k][0][q], t[k][1][q], t[k][2][q], t[k][3][q], Cx);
+              else d[2 * rp + k][q] = interp_hermite(t[k][0][q], t[k][1][q], t[k][2][q], t[k][3][q], xf);
+            }
+          if(rp == 0) __builtin_amdgcn_sched_barrier(0);      // rows 2, 3 are requested behind the x pass of rows 0, 1
+        }
+#pragma unroll
+        for(int q = 0; q < G; ++q) {
+          if constexpr(interp == BPVO_INTERP_CUBIC) {
+            const float dd[4] = {d[0][q], d[1][q], d[2][q], d[3][q]};
+            res[c0 + q] = dot4(Cy[0], Cy[1], Cy[2], Cy[3], dd) - I0[q];
+          } else {
+            res[c0 + q] = interp_hermite(d[0][q], d[1][q], d[2][q], d[3][q], yf) - I0[q];
+          }
         }
       }
+      if(g + 1 < C / G) __builtin_amdgcn_sched_barrier(0);      // the next group's loads stay behind this group's arithmetic
     }
   }
   if(in_block) {
@@ -503,7 +538,12 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
   if(g.interp != BPVO_INTERP_LINEAR) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL(warp_residual_interp_kernel<decltype(c)::value>, grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.interp);
+      constexpr int CC = decltype(c)::value;
+      switch(g.interp) {
+        case BPVO_INTERP_COSINE: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_COSINE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
+        case BPVO_INTERP_CUBIC: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
+        default: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC_HERMITE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
+      }
     });
     return;
   }

@@ -353,7 +353,8 @@ int bpvo_hip_fused_point_counts(bpvo_hip_ctx* ctx, uint64_t* fused, uint64_t* to
  * the first 8 linearisations of every level (the moving-pose regime) */
 int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
 /* ---- per-context options: how the library schedules its work.  None of them changes a result (every setting is covered by a
- * bit-identity test); they exist so that a caller — not the process environment — decides, per context.  Call between API calls, from the
+ * bit-identity test) — with ONE exception, the validation mode "reference_reduction" at the end of the table, which changes the summation
+ * order of the normal equations to the reference's own; they exist so that a caller — not the process environment — decides, per context.  Call between API calls, from the
  * thread that drives the context.  Unknown key or value out of range: BPVO_ERR_INVALID_ARG (bpvo_hip_last_error names the key).
  *
  *   key                      default   meaning
@@ -404,6 +405,17 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *                                      one pixel in ~18 is a template point there, template_build forms the records of its stencils from the census
  *                                      bytes (same operations, same bits).  The accessors and a later estimate with such a slot as the CURRENT frame
  *                                      rebuild the records on demand.
+ *   "reference_reduction"    0         VALIDATION MODE (the one option that changes numbers).  1: H, G and the squared residual norm of every
+ *                                      linearisation are accumulated exactly as the reference's default (serial, WITH_TBB OFF) build does —
+ *                                      f32, in index order over the channel-major arrays, w' = w * float(valid), (w' J_a) J_b, (w' r) J, (w' r) r,
+ *                                      one multiply and one add per slot (bpvo/linear_system_builder.cc:140-205,239-266) — by one wavefront per
+ *                                      pair (kernels_gn_ref.hip), ~100 x slower than the default reduction.  Every iterate, the final pose,
+ *                                      numIterations and status of every level then equal the reference path's BIT FOR BIT
+ *                                      (tests/test_gpu_reference_order.py, the conf/ sequences, the goldens, a 330-case randomised run).  The
+ *                                      default (0) regroups the same sums (rank-2 form, FMA, wave tree, f64 block combine): H, G, f within
+ *                                      4e-6 of an f64 evaluation, poses within 1e-4 rad / 1e-3 m, iteration counts inside the reference's own
+ *                                      spread between its serial and its TBB build.  In this mode every estimate takes the four-kernel chain
+ *                                      (no persistent / team kernel, no fused path, no step inside the reduction).
  *   "keep_current_disparity" 0         bpvo_hip_batch_run stores the disparity of the CURRENT frame (B) of every pair too.  By default it is
  *                                      neither uploaded nor stored — nothing on the path reads it — and bpvo_hip_frame(s)_set_template on
  *                                      such a slot returns BPVO_ERR_NO_DATA; set 1 before batches whose B frames become templates later.

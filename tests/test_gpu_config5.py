@@ -253,6 +253,10 @@ def test_bench_multi_rank_gather_equals_single_context(hip, tmp_path, pairs_per_
     assert np.array_equal(it[:, :LEVELS], stats["numIterations"]) and np.array_equal(st[:, :LEVELS], stats["status"])
 
 
+def line_of(stdout):
+    return [ln for ln in stdout.splitlines() if ln.startswith("{")][-1]
+
+
 def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
     """`python bench.py --gpus N` with no launcher around it — the shape of the driver's command — starts N ranks as children
     (before it touches the GPU) and passes rank 0's line through: n_gpus = ranks_seen = N, the batch split over the ranks.  With one
@@ -267,8 +271,19 @@ def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    out = json.loads(line_of(r.stdout))
     assert out["n_gpus"] == world and out["ranks_seen"] == world and out["config"]["pairs_per_gpu"] == 3
+    # what every rank did (read before the first run on a multi-GPU node): its device, its own step time, its time in the gather, the
+    # Gauss-Newton driver its 3-pair batch took (the team kernel) and that no launch gave up at a barrier — a rank that fell back to the
+    # chain makes bench.py refuse the line
+    rk = out["ranks"]
+    assert [d["rank"] for d in rk["per_rank"]] == list(range(world)) and all(d["pairs"] == 3 for d in rk["per_rank"])
+    assert all(d["ms_per_step"] > 0 and d["gather_ms_per_step"] is not None and d["gather_ms_per_step"] >= 0 for d in rk["per_rank"])
+    assert all(d["team_launches"] >= 1 and d["gave_up"] == 0 for d in rk["per_rank"])
+    assert [d["device"] for d in rk["per_rank"]] == ([0] * world if ndev <= 1 else list(range(world)))
+    assert rk["ms_per_step_min"] <= rk["ms_per_step_max"] and 0 <= rk["slowest_rank"] < world
+    assert abs(out["ms_per_step"] - rk["ms_per_step_max"]) <= 0.25 * out["ms_per_step"] + 5.0      # (the line's time is the max over ranks, bracketed by barriers)
+    assert len(line_of(r.stdout)) < 7500      # the whole line fits a tail of the output
     rec = np.load(dump)
     assert np.array_equal(rec[:, 30], np.repeat(np.arange(world), 3).astype(np.float32))
     if ndev > 1:
