@@ -66,7 +66,7 @@ void carve_frame_data(bpvo_hip_ctx* c, FrameSlot& f, unsigned char* base, size_t
   for(int l = 0; l < c->L; ++l) f.desc[l] = cv.take<float>(c->geom[l].npix * c->C);
   for(int l = 0; l < c->L; ++l) f.cen[l] = (c->C == 8) ? cv.take<uint8_t>(c->geom[l].npix) : nullptr;
   for(int l = 0; l < c->L; ++l) f.ch0[l] = (c->C == 8) ? cv.take<float>(c->geom[l].npix) : nullptr;
-  f.scratch = c->plane_scratch ? cv.take<float>((size_t) kDfPlanes * c->geom[0].npix) : nullptr;
+  f.scratch = c->plane_scratch ? cv.take<float>((size_t) c->scratch_planes * c->geom[0].npix) : nullptr;
   if(total) *total = cv.off;
 }
 
@@ -161,6 +161,27 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   j.cnt = c->d_counters + kWsCounters * (size_t) ws;
   j.ticket = c->d_tickets + ws;
   if(ws == c->trace_ws) { j.trace = c->d_trace; j.trace_cap = c->trace_cap; }
+  j.pitch = c->C;
+  j.n_groups = c->G;
+  return j;
+}
+
+// channel group k (0 .. G-1) of a whole job: the same point set, the descriptor / template / residual records entered at the group's first
+// channel, its own run of bracket segments and tile partials behind those of the groups before it
+PairJob group_pair_job(const bpvo_hip_ctx* c, const PairJob& whole, int k)
+{
+  PairJob j = whole;
+  const size_t off = (size_t) k * c->Cg;
+  const size_t nblk = (size_t) ((whole.n + kChunkPoints - 1) / kChunkPoints);
+  const size_t ntiles = (size_t) std::max(1, (whole.n + gn_pts_per_block(c->Cg) - 1) / gn_pts_per_block(c->Cg));
+  j.desc = whole.desc.get() + off;
+  j.pix = whole.pix.get() + off;
+  j.grad = whole.grad.get() + off;
+  j.r = whole.r.get() + off;
+  j.cand = whole.cand.get() + (size_t) k * nblk * kChunkPoints * c->Cg;
+  j.med_blk = whole.med_blk.get() + (size_t) k * nblk * 4;
+  j.partials = whole.partials.get() + (size_t) k * ntiles * kPartialStride;
+  j.n_groups = 1;
   return j;
 }
 
@@ -214,14 +235,15 @@ int ensure_lanes(bpvo_hip_ctx* c, int n)
     const bool first = c->lanes.size() == 1;
     if(first) { ln.stream = c->stream; ln.owns_stream = false; }
     else { HIP_CK(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)); ln.owns_stream = true; }
-    HIP_CK(c, hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) c->L * n_pairs));
+    // (wide descriptors: the table of the whole jobs, then one table per channel group)
+    HIP_CK(c, hipMalloc((void**) &ln.d_pjobs, sizeof(PairJob) * (size_t) c->L * n_pairs * job_tables(c)));
     HIP_CK(c, hipMalloc((void**) &ln.d_Tinit, sizeof(float) * 16 * n_pairs));
     HIP_CK(c, hipMalloc((void**) &ln.d_active, 8 * sizeof(int)));
     HIP_CK(c, hipMalloc((void**) &ln.d_list, 3 * sizeof(int) * (size_t) n_pairs));
     for(auto& e : ln.round_ev) HIP_CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_CK(c, hipEventCreateWithFlags(&ln.selected_ev, hipEventDisableTiming));
     for(auto& e : ln.staging_ev) HIP_CK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_CK(c, hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * (size_t) c->L * n_pairs));
+    HIP_CK(c, hipHostMalloc((void**) &ln.h_pjobs, sizeof(PairJob) * std::max((size_t) c->L * n_pairs * job_tables(c), (size_t) (1 + kMaxGroups))));
     HIP_CK(c, hipHostMalloc((void**) &ln.h_T, sizeof(float) * 16 * n_pairs));
     HIP_CK(c, hipHostMalloc((void**) &ln.h_active, 8 * sizeof(int)));
     HIP_CK(c, hipMalloc((void**) &ln.d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels));
@@ -274,6 +296,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_join_from_pairs", team_join_from_pairs, 0, 1 << 20),
     OPT_INT("team_spares", team_spares, 0, 1),
     OPT_INT("normalization_side_stream", nrm_side_stream, 0, 1),
+    OPT_INT("normalization_dpp_asm", nrm_dpp_asm, 0, 1),
     OPT_INT("small_batch_fused", small_batch_fused, 0, 1),
     OPT_INT("levels_in_one_launch_max_frames", merge_levels_max_frames, 0, 1 << 20),
     OPT_INT("normalization_deferred", nrm_defer, 0, 1),
@@ -419,12 +442,14 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       g_create_error = "descriptorSize must be 1, 2, 4, 8, 16, 32, or 64";
       return BPVO_ERR_INVALID_ARG;
     }
-    if(nb > 4) return unsupported("latchNumBytes: 1, 2 and 4 (8, 16 and 32 channels) are on the device path");
+    // (8 - 64 bytes: 64 - 512 channels, in channel groups of 32 through the per-point kernels — types.h PairJob::pitch)
     if(c->params.latchHalfSsdSize < 0 || c->params.latchHalfSsdSize > 8) return unsupported("latchHalfSsdSize: 0 .. 8 are on the device path");
   }
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
     if(c->params.centralDifferenceRadius <= 0) { g_create_error = "invalid radius"; return BPVO_ERR_INVALID_ARG; }   // central_difference_descriptor.cc:19
-    if(c->params.centralDifferenceRadius > 3) return unsupported("centralDifferenceRadius: 1, 2 and 3 (8, 24 and 48 channels) are on the device path");
+    // radius > 3: (2r + 1)^2 - 1 > 48 channels, in channel groups (types.h PairJob::pitch) where the count splits into at most kMaxGroups groups of a
+    // channel count the per-point kernels are built for: r = 4 (80 = 5 x 16), 5 (120 = 5 x 24), 6 (168 = 7 x 24), 7 (224 = 7 x 32), 8 (288 = 6 x 48), 9 (360 = 15 x 24)
+    if(c->params.centralDifferenceRadius > 9) return unsupported("centralDifferenceRadius: 1 .. 9 (8 .. 360 channels) are on the device path");
     if((c->params.centralDifferenceSigmaBefore > 0.0f && imsmooth_taps(c->params.centralDifferenceSigmaBefore) > kMaxGaussTaps) ||
        (c->params.centralDifferenceSigmaAfter > 0.0f && imsmooth_taps(c->params.centralDifferenceSigmaAfter) > kMaxGaussTaps))
       return unsupported("centralDifferenceSigmaBefore / After: imsmooth kernels of up to 31 taps (sigma < 15.5) are on the device path");
@@ -455,7 +480,17 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     case BPVO_DESC_LATCH: c->C = 8 * c->params.latchNumBytes; break;
     default: c->C = 1; break;
   }
+  c->G = 1; c->Cg = 0;
+  if(c->C > 48) {
+    // a wide descriptor: the largest group size the per-point kernels are instantiated for that divides C into at most kMaxGroups groups
+    for(int cg : {48, 32, 24, 16}) {
+      if(c->C % cg == 0 && c->C / cg <= kMaxGroups) { c->Cg = cg; c->G = c->C / cg; break; }
+    }
+    if(c->G == 1) return unsupported("descriptor channel count does not split into channel groups of 16 / 24 / 32 / 48");
+  }
   const bool grad_smoothed = c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f;
+  // (LATCH keeps its [key points][bytes] buffer behind three work planes: kernels_planes.hip)
+  c->scratch_planes = c->params.descriptor == BPVO_DESC_LATCH ? std::max(kDfPlanes, 3 + (c->params.latchNumBytes + 3) / 4) : kDfPlanes;
   c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE || c->params.descriptor == BPVO_DESC_LATCH || grad_smoothed;
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
     gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaBefore), c->params.centralDifferenceSigmaBefore, &c->cd_before);
@@ -537,19 +572,20 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   for(auto& w : cp->ws) {
     CREATE_CK(hipMalloc((void**) &w.r, sizeof(float) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
-    CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * (size_t) cp->cap_max * cp->C));
-    CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max));
+    // (channel groups: a group's candidate segments and bracket counters follow those of the group before it, whole 256-point chunks each)
+    CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * nblk_max * kChunkPoints * (size_t) cp->C));
+    CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max * (size_t) cp->G));
     if(cp->C == 8 || cp->C == 1) {      // tap cache of warp_residual: 4 taps x C floats per point
       CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
       CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
     }
     // two buffers of tile partials (the persistent kernels double-buffer them by iteration parity, kernels_gn.hip pk_partials)
-    CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * (size_t) gn_partials_entries(cp->cap_max, cp->C) * kPartialStride));
+    CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * (size_t) gn_partials_entries(cp->cap_max, cp->G > 1 ? cp->Cg : cp->C) * std::max(1, (cp->G + 1) / 2) * kPartialStride));
   }
   CREATE_CK(hipMalloc((void**) &cp->d_states, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMemset(cp->d_states, 0, sizeof(GNState) * n_pairs));
   CREATE_CK(hipMalloc((void**) &cp->d_fjobs, 2 * sizeof(FrameJob) * (size_t) cp->L * n_frames));
-  CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob)));
+  CREATE_CK(hipMalloc((void**) &cp->d_job1, sizeof(PairJob) * (1 + kMaxGroups)));      // the whole job + its channel groups (wide descriptors)
   if(cp->params.descriptor == BPVO_DESC_LATCH) {
     // The triplet coordinates as CalcuateSums uses them (bpvo/latch_descriptor.cc:170-236): the table's, or — latchRotationInvariance —
     // rotated by the key point's angle and clamped to the patch.  The dense evaluation builds its key points with cv::KeyPoint() (:135-141),

@@ -13,16 +13,37 @@ namespace bpvo_hip_host {
 // lane.  wss[i]: workspace, refs[i] / curs[i]: frame slots.  T_init host [n][16] or null (Identity).
 // Does a group of n pairs take the team-persistent kernel?  (kLinear, the f64 formulation, C = 8 or 1 like gn_persistent_kernel; not
 // while per-kernel timings are being collected: there are no kernels to time)
+// The shape of the team launch for a group of n pairs — ONE place decides it, for the launcher below and for team_serves: one workgroup per CU,
+// teams of CUs / pairs workgroups (at most an eighth of the device's CUs, 32 of 256: teams of 64 were 8 - 12 % slower at 2 - 5 pairs, 4 % at 6 - 7; a
+// team's workgroups stay dealt over ALL XCDs — pinned to one XCD each, 2 - 4 teams were 3 - 8 % slower), as many teams as fit; whether idle
+// workgroups may join other teams (the growing form), and how many spare workgroups the division leaves for that.
+struct TeamPlan { int team_size, n_teams, join_mode, spare_workgroups; };
+static TeamPlan team_plan(const bpvo_hip_ctx* c, int n)
+{
+  TeamPlan t;
+  const int slots = std::max(1, c->num_cus);
+  int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(std::max(1, c->device_cus > 0 ? c->device_cus / 8 : 32), slots / std::max(1, n)));
+  ts = std::max(1, std::min(ts, slots));
+  t.team_size = ts;
+  t.n_teams = std::max(1, std::min(std::min(n, slots / ts), kMaxTeams));
+  // (nobody can join where the teams start at the admission cap or there is one team only: the leaders' looks at the tickets are then
+  // skipped altogether — a 16-pair batch, teams of 16, lost 1.5 % to them)
+  t.join_mode = (t.team_size < gn_team_max_size() && t.n_teams > 1 && n >= c->team_join_from_pairs) ? c->team_join : 0;
+  // what the division CUs / pairs leaves over starts as spare workgroups that join the teams at their first admission
+  t.spare_workgroups = (t.join_mode && c->team_spares) ? std::max(0, slots - t.team_size * t.n_teams) : 0;
+  return t;
+}
+
 bool team_serves(const bpvo_hip_ctx* c, int n)
 {
   bool size_ok = n >= 2 && n > c->persist_max_ws && n <= c->team_max_pairs;
-  // above team_full_pairs only when the teams fill the chip: the kernel runs CUs / n workgroups per pair, and what that division leaves over
-  // idles for the whole launch (96 pairs: 2 x 96 of 256 CUs, 770 k GN it/s against the chain's 840 k; 128 pairs: 2 x 128, 935 k against 890 k)
-  // (with spare workgroups the chip is full whatever the division leaves: any batch of up to team_max_pairs pairs that is large enough to grow)
-  const bool spares_fill = c->team_join && c->team_spares && n >= c->team_join_from_pairs;
-  if(size_ok && n > c->team_full_pairs && c->team_size_env <= 0 && c->num_cus > 0 && !spares_fill) {
-    const int ts = std::max(1, std::min(64, c->num_cus / n));
-    size_ok = 20 * ts * std::min(n, c->num_cus / ts) >= 19 * c->num_cus;
+  // above team_full_pairs only when the launch fills the chip: the kernel runs CUs / n workgroups per pair, and what that division leaves over
+  // idles for the whole launch (96 pairs: 2 x 96 of 256 CUs, 770 k GN it/s against the chain's 840 k; 128 pairs: 2 x 128, 935 k against 890 k) —
+  // unless the PLAN of this very launch turns the remainder into spare workgroups that join the teams (the growing form)
+  if(size_ok && n > c->team_full_pairs && c->team_size_env <= 0 && c->num_cus > 0) {
+    const TeamPlan t = team_plan(c, n);
+    const int busy = t.team_size * t.n_teams + t.spare_workgroups;
+    size_ok = 20 * busy >= 19 * c->num_cus;
   }
   return c->team_mode && c->persistent && !c->persistent_failed.load() && size_ok && !c->reference_reduction &&
          (c->C == 8 || c->C == 1) && c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !c->profile_all && !c->profile_k6_all &&
@@ -40,10 +61,12 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   const int NP = c->n_pairs;
   // (the pinned staging of a lane is free here: every call that uses it ends with a synchronisation of the lane's stream)
   std::vector<int> max_pts(c->L, 0);
+  const size_t table = (size_t) c->L * NP;      // jobs of one table [L][NP]; wide descriptors: table 0 the whole jobs, tables 1 .. G their channel groups
   for(int l = 0; l < c->L; ++l)
     for(int i = 0; i < n; ++i) {
       PairJob& pj = ln->h_pjobs[(size_t) l * NP + i];
       pj = make_pair_job(c, wss[i], refs[i], curs[i], l);
+      for(int k = 0; k < c->G && c->G > 1; ++k) ln->h_pjobs[(size_t) (1 + k) * table + (size_t) l * NP + i] = group_pair_job(c, pj, k);
       // Dense levels (no non-maximum suppression: most pixels are template points) gather their taps straight from the descriptor:
       // neighbouring points share three quarters of their footprints, so the 32-byte records are fetched about once per pixel
       // from HBM, where the per-point tap cache reads 128 bytes per point whatever the neighbours do.  The cache pays at the
@@ -61,14 +84,15 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   const bool pk_group = allow_persistent && c->persistent && !c->persistent_failed.load() && n <= c->persist_max_ws && !c->profile_all && !ref_mode;
   bool persistent = pk_group;
   // a context of a few pairs (one pair per call): table, poses and control words in one launch, the states copied out by the last one
-  const bool small_ctx = (size_t) c->L * NP <= 64 && n <= 8 && c->small_batch_fused;
+  const bool small_ctx = (size_t) c->L * NP <= 64 && n <= 8 && c->small_batch_fused && c->G == 1;
   if(small_ctx) {
     if(T_init) std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
     launch_set_pose_upload(ln->stream, ln->d_pjobs, ln->h_pjobs, (size_t) c->L * NP, ln->h_pjobs + (size_t) (c->L - 1) * NP, T_init ? ln->h_T : nullptr, n,
                            persistent ? ln->d_pk_ctl : nullptr, persistent ? kPkCtlWords * kMaxLevels : 0);
   } else {
-    if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, sizeof(PairJob) * (size_t) c->L * NP, 1);
-    else LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, sizeof(PairJob) * (size_t) c->L * NP, hipMemcpyHostToDevice, ln->stream));
+    const size_t table_bytes = sizeof(PairJob) * table * (size_t) job_tables(c);
+    if(c->ctl_by_kernel.load()) launch_copy_rows(ln->stream, ln->d_pjobs, ln->h_pjobs, table_bytes, table_bytes, 1);
+    else LANE_CK(ln, hipMemcpyAsync(ln->d_pjobs, ln->h_pjobs, table_bytes, hipMemcpyHostToDevice, ln->stream));
     const float* dT = nullptr;
     if(T_init) {
       std::memcpy(ln->h_T, T_init, sizeof(float) * 16 * n);
@@ -106,22 +130,14 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     t.jobs_all = ln->d_pjobs; t.job_pitch = NP; t.n_pairs = n; t.level_hi = c->L - 1; t.level_lo = p.maxTestLevel;
     t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
     t.scale_is_moot = (p.lossFunction == BPVO_LOSS_L2 && c->C == 8 && c->fuse_frozen) ? 1 : 0;
-    // one workgroup per CU: teams of CUs / pairs workgroups (at most 64: the single-pair kernel's size), as many teams as fit
-    const int slots = c->num_cus;
-    // (at most 32 of 256 CUs per team: teams of 64 were 8 - 12 % slower at 2 - 5 pairs, 4 % at 6 - 7; a team's workgroups stay dealt over ALL XCDs —
-    // pinned to one XCD each, 2 - 4 teams were 3 - 8 % slower: one L2 and its memory channels for a whole pair)
-    int ts = c->team_size_env > 0 ? c->team_size_env : std::max(1, std::min(std::max(1, c->device_cus > 0 ? c->device_cus / 8 : 32), slots / n));
-    ts = std::max(1, std::min(ts, slots));
-    t.team_size = ts;
-    t.n_teams = std::max(1, std::min(std::min(n, slots / ts), kMaxTeams));
+    const TeamPlan plan = team_plan(c, n);      // (the same plan team_serves judged)
+    t.team_size = plan.team_size;
+    t.n_teams = plan.n_teams;
     t.ctl = ln->d_team_ctl;
     t.timeout_ticks = c->persist_timeout;
     t.local_barriers = c->team_local_barriers;
-    // (nobody can join where the teams start at the admission cap or there is one team only: the leaders' looks at the tickets are then
-    // skipped altogether — a 16-pair batch, teams of 16, lost 1.5 % to them)
-    t.join_mode = (t.team_size < gn_team_max_size() && t.n_teams > 1 && n >= c->team_join_from_pairs) ? c->team_join : 0;
-    // what the division CUs / pairs leaves over starts as spare workgroups that join the teams at their first admission
-    t.spare_workgroups = (t.join_mode && c->team_spares) ? std::max(0, slots - t.team_size * t.n_teams) : 0;
+    t.join_mode = plan.join_mode;
+    t.spare_workgroups = plan.spare_workgroups;
     LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
     hipError_t te;
     if(team_split) {
@@ -157,7 +173,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fast_warp = c->fast_warp;
     g.interp = p.interp;
     g.fuse_frozen = fuse_frozen;
-    g.step_in_reduce = (n <= c->step_in_reduce_max && !ref_mode) ? 1 : 0;
+    g.step_in_reduce = (n <= c->step_in_reduce_max && !ref_mode && c->G == 1) ? 1 : 0;
     g.reference_reduction = ref_mode ? 1 : 0;
     g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
     return g;
@@ -222,11 +238,15 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         if(launch_warp_k) {
           const bool sampled = c->profile_all || c->profile_k6_all || (ln->k6_seq++ % kProfileEvery) == 0;
           ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0, ln, sampled);
-          launch_warp_residual(ln->stream, g);
+          for_each_group(c, g, table, [&](const GNLaunch& gg) { launch_warp_residual(ln->stream, gg); });
         }
         // level 2 times every kernel; level 3 (bench.py's single-lane roofline pass) every warp_residual AND every irls_reduce launch
-        { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all && launch_median_k); if(launch_median_k) launch_median(ln->stream, g); }
-        { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all || c->profile_k6_all); launch_irls_reduce(ln->stream, g); }
+        { ScopedTimer t(c, KC_MEDIAN, 0.0, ln, c->profile_all && launch_median_k); if(launch_median_k) launch_median(ln->stream, median_launch(c, g)); }
+        {
+          ScopedTimer t(c, KC_IRLS_REDUCE, 0.0, ln, c->profile_all || c->profile_k6_all);
+          if(ref_mode) launch_irls_reduce(ln->stream, g);      // (reference order: one wave per pair walks every channel of the whole job)
+          else for_each_group(c, g, table, [&](const GNLaunch& gg) { launch_irls_reduce(ln->stream, gg); });
+        }
         if(!g.step_in_reduce) {
           ScopedTimer t(c, KC_GN_STEP, 0.0, ln, c->profile_all);
           launch_gn_step(ln->stream, g, 0, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
@@ -420,8 +440,10 @@ int refresh_counters(bpvo_hip_ctx* c)
 
 int upload_single_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int level)
 {
-  c->lanes[0].h_pjobs[0] = make_pair_job(c, ws, ref, cur, level);
-  HIP_CK(c, hipMemcpyAsync(c->d_job1, c->lanes[0].h_pjobs, sizeof(PairJob), hipMemcpyHostToDevice, c->stream));
+  PairJob* h = c->lanes[0].h_pjobs;
+  h[0] = make_pair_job(c, ws, ref, cur, level);
+  for(int k = 0; k < c->G && c->G > 1; ++k) h[1 + k] = group_pair_job(c, h[0], k);      // (wide descriptors: d_job1[1 + k] = channel group k)
+  HIP_CK(c, hipMemcpyAsync(c->d_job1, h, sizeof(PairJob) * (size_t) job_tables(c), hipMemcpyHostToDevice, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));   // h_pjobs is reused by the next call
   return BPVO_OK;
 }
@@ -534,9 +556,13 @@ static int linearize_impl(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, i
   g.interp = c->params.interp;
   g.reference_reduction = c->reference_reduction ? 1 : 0;
   launch_reset_tapkeys(c->stream, g);
-  { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); launch_warp_residual(c->stream, g); }
-  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, g); }
-  { ScopedTimer t(c, KC_IRLS_REDUCE, 0.0); launch_irls_reduce(c->stream, g); }
+  { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); for_each_group(c, g, 1, [&](const GNLaunch& gg) { launch_warp_residual(c->stream, gg); }); }
+  { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, median_launch(c, g)); }
+  {
+    ScopedTimer t(c, KC_IRLS_REDUCE, 0.0);
+    if(g.reference_reduction) launch_irls_reduce(c->stream, g);
+    else for_each_group(c, g, 1, [&](const GNLaunch& gg) { launch_irls_reduce(c->stream, gg); });
+  }
   { ScopedTimer t(c, KC_GN_STEP, 0.0); launch_gn_step(c->stream, g, 1, 0, 0, 0, 0, 0); }
   HIP_CK(c, hipMemcpyAsync(l0.h_states, c->d_states + ws, sizeof(GNState), hipMemcpyDeviceToHost, c->stream));
   HIP_CK(c, hipStreamSynchronize(c->stream));

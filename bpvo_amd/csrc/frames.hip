@@ -207,14 +207,15 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   if(side) {
     FR_CK(c, fr, hipEventRecord(c->side_ev[0], s));
     FR_CK(c, fr, hipStreamWaitEvent(side, c->side_ev[0], 0));
+    // (timed like the in-line form, with events on the side stream: they are resolved once this stream — which the side stream joins — is synchronised)
     if(defer) {
-      launch_normalization(side, tab, NF, count, c->L - 1, c->L, with_nrm);
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, c->L - 1, c->L, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
-      launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L - 1, with_nrm);
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L - 1, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
       c->nrm_pending = c->side_ev[2];
     } else {
-      launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm);
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
     }
   }
@@ -229,7 +230,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   if(!side) {
     // the sequential (reference-order) normalisation sums of all levels and frames run side by side in one launch
     ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln);
-    launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, with_nrm);
+    launch_normalization(s, tab, NF, count, p.maxTestLevel, c->L, with_nrm, c->nrm_dpp_asm);
   }
   if(counts_ev) FR_CK(c, fr, hipEventSynchronize(counts_ev));
   else FR_CK(c, fr, hipStreamSynchronize(s));

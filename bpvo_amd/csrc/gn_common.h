@@ -19,6 +19,7 @@ constexpr int GN_BLOCK = 256;
 #define K6_BLOCK_VALUE 256
 #endif
 constexpr int K6_BLOCK = K6_BLOCK_VALUE;
+static_assert(K6_BLOCK == kChunkPoints, "the host sizes bracket segments and group offsets with kChunkPoints");
 constexpr int K6_WAVES = K6_BLOCK / 64;
 
 // Sums of N <= 32 per-lane accumulators over the 64 lanes of a wavefront, every one with the pairing of

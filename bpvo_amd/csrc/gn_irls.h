@@ -117,12 +117,13 @@ __device__ __forceinline__ void irls_tile(const PairJob& j, const GNState* __res
       rr[0] = j.r[i];
       const float2 g2 = reinterpret_cast<const float2*>(j.grad.get())[i];
       Ix[0] = g2.x; Iy[0] = g2.y;
-    } else {      // generic C: point-major r[N][C], grad[N][2][C]
+    } else {      // generic C: point-major r[N][pitch], grad[N][2][pitch] (pitch = C, or the whole channel count for a channel group)
+      const size_t PT = (size_t) j.pitch;
 #pragma unroll
       for(int c = 0; c < C; ++c) {
-        rr[c] = j.r[(size_t) i * C + c];
-        Ix[c] = j.grad[((size_t) i * 2 + 0) * C + c];
-        Iy[c] = j.grad[((size_t) i * 2 + 1) * C + c];
+        rr[c] = j.r[(size_t) i * PT + c];
+        Ix[c] = j.grad[((size_t) i * 2 + 0) * PT + c];
+        Iy[c] = j.grad[((size_t) i * 2 + 1) * PT + c];
       }
     }
     float Sxx = 0.0f, Sxy = 0.0f, Syy = 0.0f, Gx = 0.0f, Gy = 0.0f;

@@ -89,11 +89,15 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
         f(__float_as_uint(b[u].z) & 0x7fffffffu, pt); f(__float_as_uint(b[u].w) & 0x7fffffffu, pt);
       }
     }
-  } else if constexpr(C != 1) {   // generic C: point-major records
+  } else if constexpr(C != 1) {   // generic C: point-major records; every channel of the record (C x the groups of a wide descriptor)
+    const int CT = C * j.n_groups;
+    const size_t PT = (size_t) j.pitch;
     for(int pt = threadIdx.x; pt < n; pt += NT) {
       if(!j.valid[pt]) continue;
+      for(int c0 = 0; c0 < CT; c0 += C) {
 #pragma unroll
-      for(int c = 0; c < C; ++c) f(__float_as_uint(j.r[(size_t) pt * C + c]) & 0x7fffffffu, pt);
+        for(int c = 0; c < C; ++c) f(__float_as_uint(j.r[(size_t) pt * PT + c0 + c]) & 0x7fffffffu, pt);
+      }
     }
   } else {
     for(int p4 = threadIdx.x * 4; p4 < n; p4 += NT * 4) {   // n is a multiple of 16
@@ -182,7 +186,9 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
   // ---- bracketed path
   if(st->median_valid) {
     // totals of the per-block counters written by the bracket step of warp_residual (bracket_block)
-    const int nblk = (j.n + K6_BLOCK - 1) / K6_BLOCK;
+    // (wide descriptors: the chunks of every channel group, one run of segments after the other; the valid-point counters then add up to
+    // groups x valid points, and C x that is every valid entry, as below)
+    const int nblk = ((j.n + K6_BLOCK - 1) / K6_BLOCK) * j.n_groups;
     unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0, cnt_first = 0;    // cnt_first: candidates of segment `tid`
     for(int b = tid; b < nblk; b += NT) {
       const uint4 o = reinterpret_cast<const uint4*>(j.med_blk.get())[b];

@@ -175,7 +175,10 @@ template <bool COHERENT = false>
 __device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_block, int lane, float* s_sum /*[kPartialStride]*/,
                                                 const float* __restrict__ partials)
 {
-  const int nblk = (j.n + pts_per_block - 1) / pts_per_block;
+  // (wide descriptors: the tiles of every channel group, one run after the other — except in reference order, pts_per_block = 2^30, where one
+  // partial holds the sums over all channels)
+  const int groups = (pts_per_block >= (1 << 30)) ? 1 : j.n_groups;
+  const int nblk = ((j.n + pts_per_block - 1) / pts_per_block) * groups;
   if(lane < kNumAcc) {
     double s = 0.0;
     const float* __restrict__ pp = partials + lane;
@@ -198,6 +201,7 @@ __device__ __forceinline__ void gn_sum_partials(const PairJob& j, int pts_per_bl
     };
     if(nblk <= 8) chunked(std::integral_constant<int, 8>());      // (coarse levels: no point in 32 loads for 6 tiles)
     else chunked(std::integral_constant<int, 32>());
+    if(lane == 28 && groups > 1) s = s / (double) groups;      // every group counted the valid points
     s_sum[lane] = (float) s;
   }
 }

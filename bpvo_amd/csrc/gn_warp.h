@@ -159,10 +159,12 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
     return valid;
   }
 
+  // generic layout: records of `pitch` floats (= C, or the whole channel count when this job is one channel group of a wide descriptor)
+  const int PT = (C == 8 || C == 1) ? C : j.pitch;
   if(valid) {
     const double wx = 1.0 - xf, wy = 1.0 - yf;
-    const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * C;
-    const float* __restrict__ d1 = d0 + (size_t) W * C;
+    const float* __restrict__ d0 = j.desc + ((size_t) yi * W + xi) * PT;
+    const float* __restrict__ d1 = d0 + (size_t) W * PT;
     float I00[C], I01[C], I10[C], I11[C], I0[C];
     if constexpr(C == 8) {
       // Tap cache: the integer footprint (xi, yi) of a point rarely changes between consecutive GN iterations of a level
@@ -217,8 +219,8 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
     } else {
 #pragma unroll
       for(int c = 0; c < C; ++c) {
-        I00[c] = d0[c]; I01[c] = d0[C + c]; I10[c] = d1[c]; I11[c] = d1[C + c];
-        I0[c] = j.pix[(size_t) i * C + c];
+        I00[c] = d0[c]; I01[c] = d0[PT + c]; I10[c] = d1[c]; I11[c] = d1[PT + c];
+        I0[c] = j.pix[(size_t) i * PT + c];
       }
     }
 #pragma unroll
@@ -243,7 +245,7 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
         res[4] = 0.0f - t1.x; res[5] = 0.0f - t1.y; res[6] = 0.0f - t1.z; res[7] = 0.0f - t1.w;
       } else {
 #pragma unroll
-        for(int c = 0; c < C; ++c) res[c] = 0.0f - j.pix[(size_t) i * C + c];
+        for(int c = 0; c < C; ++c) res[c] = 0.0f - j.pix[(size_t) i * PT + c];
       }
     }
   }
@@ -287,9 +289,9 @@ __device__ __forceinline__ void warp_chunk(const PairJob& j, int mode, unsigned 
       float4* o = reinterpret_cast<float4*>(j.r.get());
       store_stream(o + tile_index<2>(i, 0), make_float4(res[0], res[1], res[2], res[3]));
       store_stream(o + tile_index<2>(i, 1), make_float4(res[4], res[5], res[6], res[7]));
-    } else {      // generic C: point-major records [N][C]
+    } else {      // generic C: point-major records [N][pitch]
 #pragma unroll
-      for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
+      for(int c = 0; c < C; ++c) j.r[(size_t) i * j.pitch + c] = res[c];
     }
   }
   // bracket pass of the exact median (see bracket_chunk) while the residuals are in registers

@@ -151,6 +151,7 @@ struct bpvo_hip_ctx {
   GaussTaps latch_after;        // imsmooth(1.75) of every LATCH channel (bpvo/latch_descriptor.cc:1082)
   int latch_taps[2] = {0, 0};   // fixed-point {centre, side} taps of LATCH's cv::GaussianBlur(Size(3,3), 2, 2) (:147)
   signed char* d_latch_off = nullptr;   // [48 * latchNumBytes] triplet coordinates as CalcuateSums uses them (:170-236)
+  int scratch_planes = kDfPlanes;   // work planes of FrameSlot::scratch
   bool plane_scratch = false; // descriptor built from plane operations (descriptor fields, central difference, smoothed gradient)
   hipStream_t stream = nullptr;
   std::vector<FrameSlot> frames;
@@ -182,6 +183,8 @@ struct bpvo_hip_ctx {
   int fuse_frozen = 1;         // estimate loops: fused residual + reduction once a workspace's scale is frozen (bit-identical,
                                // +3 % GN iterations/s).  Option "fuse_frozen".  (C = 8: ONE irls_reduce launch serves the plain and
                                // the fused workspaces with a per-workspace branch; the two-launch form measured slower at every batch size, round 2)
+  int G = 1, Cg = 0;           // channel groups of a wide descriptor (C > 48: C = G x Cg, Cg one of the channel counts the per-point kernels are built for;
+                               // types.h PairJob::pitch); G = 1: none
   int reference_reduction = 0; // option "reference_reduction" (validation mode): H, G and the squared norm summed in the reference's index order in f32
                                // (kernels_gn_ref.hip) — the four-kernel chain only, no fused path, no step inside the reduction, no persistent / team kernel
   int step_in_reduce_max = 128; // groups of up to this many pairs run the four-kernel chain as three: the last tile of a workspace in irls_reduce takes
@@ -203,6 +206,7 @@ struct bpvo_hip_ctx {
   int merge_levels_max_frames = 8;   // option "levels_in_one_launch_max_frames": frame stages of at most this many frames run the levels of the
                                  // bit-planes, selection and template-build kernels in one launch each (frames.hip)
   int small_batch_fused = 1;     // option "small_batch_fused": contexts of a few pairs — job table + poses in one launch, states copied out by pack_records (estimate.hip)
+  int nrm_dpp_asm = 1;           // option "normalization_dpp_asm": the hand-scheduled DPP add chains of the Hartley sums (kernels_frame.hip) or the compiler's form
   int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
   int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
   int team_split_max_pairs = 4;  // option "team_split_max_pairs": team batches of up to this many pairs run the coarsest level in a launch of its own, the deferred
@@ -319,18 +323,19 @@ struct ScopedTimer {
   Lane* ln;
   EventPair ep;
   bool on;
-  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units, Lane* lane = nullptr, bool sampled = true)
-      : ln(lane ? lane : &c_->lanes[0]), on(c_->profiling && sampled)
+  hipStream_t st;      // the stream the timed launches go to: the lane's own, or another one that is joined into it before the lane is synchronised (the side stream)
+  ScopedTimer(bpvo_hip_ctx* c_, int kc, double units, Lane* lane = nullptr, bool sampled = true, hipStream_t stream = nullptr)
+      : ln(lane ? lane : &c_->lanes[0]), on(c_->profiling && sampled), st(stream ? stream : (lane ? lane : &c_->lanes[0])->stream)
   {
     if(!on) return;
     ep.kc = kc; ep.units = units;
     ep.a = take_event(ln); ep.b = take_event(ln);
-    (void) hipEventRecord(ep.a, ln->stream);
+    (void) hipEventRecord(ep.a, st);
   }
   ~ScopedTimer()
   {
     if(!on) return;
-    (void) hipEventRecord(ep.b, ln->stream);
+    (void) hipEventRecord(ep.b, st);
     ln->ev_pending.push_back(ep);
   }
 };
@@ -379,6 +384,24 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
 int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const FrameRun& fr);
 int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count);
 bool team_serves(const bpvo_hip_ctx* c, int n);
+PairJob group_pair_job(const bpvo_hip_ctx* c, const PairJob& whole, int k);
+inline int job_tables(const bpvo_hip_ctx* c) { return c->G > 1 ? 1 + c->G : 1; }      // job tables of a lane: the whole jobs, then one table per channel group
+// The per-point kernels of a linearisation (warp + residual, the reduction): once — or, for a wide descriptor, once per channel group, on the
+// group's job table (`stride` jobs behind the table before it) with the group's channel count.
+template <class F>
+inline void for_each_group(const bpvo_hip_ctx* c, const bpvo_hip::GNLaunch& g, size_t stride, F&& f)
+{
+  if(c->G <= 1) { f(g); return; }
+  for(int k = 0; k < c->G; ++k) {
+    bpvo_hip::GNLaunch gg = g;
+    gg.jobs = g.jobs + (size_t) (1 + k) * stride;
+    gg.C = c->Cg;
+    f(gg);
+  }
+}
+// the exact median of a wide descriptor: the WHOLE job (it walks the bracket segments of every group), instantiated for the group's channel count
+// (the size of a segment)
+inline bpvo_hip::GNLaunch median_launch(const bpvo_hip_ctx* c, bpvo_hip::GNLaunch g) { if(c->G > 1) g.C = c->Cg; return g; }
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
                    bpvo_hip_stats* stats, float* d_records_out, bool allow_persistent);
 int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses, bpvo_hip_stats* stats);

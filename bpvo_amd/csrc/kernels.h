@@ -25,6 +25,27 @@ static inline void dispatch_channels(int C, F&& f)
   }
 }
 
+// ... and the WIDE descriptors (more than 48 channels): LATCH with 8 / 16 / 32 / 64 bytes, CentralDifference radii 4 .. 9.  Only kernels whose
+// per-thread state does not grow with C are instantiated for these (the saliency forms: C is a stride and a loop bound there); the per-point
+// kernels run the channels in groups (types.h PairJob::pitch) or loop over them at run time.
+template <class F>
+static inline bool dispatch_wide_channels(int C, F&& f)
+{
+  switch(C) {
+    case 64: f(std::integral_constant<int, 64>()); return true;
+    case 80: f(std::integral_constant<int, 80>()); return true;
+    case 120: f(std::integral_constant<int, 120>()); return true;
+    case 128: f(std::integral_constant<int, 128>()); return true;
+    case 168: f(std::integral_constant<int, 168>()); return true;
+    case 224: f(std::integral_constant<int, 224>()); return true;
+    case 256: f(std::integral_constant<int, 256>()); return true;
+    case 288: f(std::integral_constant<int, 288>()); return true;
+    case 360: f(std::integral_constant<int, 360>()); return true;
+    case 512: f(std::integral_constant<int, 512>()); return true;
+    default: return false;
+  }
+}
+
 namespace bpvo_hip {
 
 // A Gaussian smoothing kernel of cv::GaussianBlur as the descriptors use it: n taps (odd; 0 = no smoothing), k the f32 taps
@@ -59,7 +80,7 @@ void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, siz
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level, int num_levels,
                           int* out /*[nframes][kMaxLevels]*/);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
-                          int num_levels, int with_normalization);
+                          int num_levels, int with_normalization, int dpp_asm = 1);   // dpp_asm: the hand-scheduled DPP add chains (kernels_frame.hip nrm_add_batch) or the compiler's form: same sums
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3], int nlevels = 1,
                            int job_pitch = 0);   // gauss_k: the bit-planes blur taps (lazy levels)
@@ -110,6 +131,7 @@ bool launch_stereo_sgbm(hipStream_t s, const SgbmLaunch& g);
 // dimension of the next round's grids with that count; entry k of the list names the k-th active workspace.  Without it
 // every launch dispatches the workgroups of the finished workspaces as well: ~0.9 ns each, ~150 µs per launch in the tail
 // of a level at 1024 pairs.  list == nullptr: every workspace of the launch, in order.
+constexpr int kChunkPoints = 256;      // points per chunk of the warp + residual kernels = per bracket segment of the exact median (gn_common.h K6_BLOCK)
 struct ActiveSet {
   const int* list = nullptr;   // device [npairs]
 };
@@ -179,6 +201,7 @@ hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iteratio
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);
 int  gn_pts_per_block(int C);
 int  gn_partials_entries(int cap, int C);   // kPartialStride-float entries of a workspace's (double-buffered) tile partials
+// (C > 48: run-time channel loops over the point-major records)
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states = nullptr, GNState* h_states = nullptr,

@@ -1067,9 +1067,16 @@ __global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob*
 // of them by `s_nop 1` — its hazard table asks for two wait states between a VALU write and a DPP instruction that reads the register,
 // whichever operand reads it; the hardware needs them for the operand that goes through the lane crossbar (src0: loaded from LDS here),
 // not for the accumulator on the ordinary port (the sums are compared bit for bit with the sequential sums of the CPU restatement at
-// every size the suite runs: tests/test_gpu_parity.py).  NRM_DPP_ASM=0 is the compiler's form.
+// every size the suite runs: tests/test_gpu_parity.py).  Both forms are built — the kernel takes the choice as a template parameter, the
+// context's option "normalization_dpp_asm" selects it, and tests/test_gpu_parity.py runs one against the other (a toolchain or hardware
+// change that breaks the assumption shows there).  The hand-scheduled form is the default ONLY for the architecture it was measured on:
+// NRM_DPP_ASM = 0 (any other target, or a build that says so) makes the compiler's form the only one.
 #ifndef NRM_DPP_ASM
+#if defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
 #define NRM_DPP_ASM 1
+#else
+#define NRM_DPP_ASM 0
+#endif
 #endif
 #define NRM_ROW_(I) \
   "v_add_f32_dpp %0, %1, %0 row_shl:" #I " row_mask:0xf bank_mask:0xf bound_ctrl:0\n" \
@@ -1093,18 +1100,22 @@ __device__ __forceinline__ void nrm_add_row_c(float& acc, const float (&v)[4])
   }
 }
 // acc (lane 0 of every row) += the 64 elements of the batch its row holds, in order
+template <bool ASM>
 __device__ __forceinline__ void nrm_add_batch(float& acc, const float (&v)[4])
 {
 #if NRM_DPP_ASM
+  if constexpr(ASM) {
   asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4\n"
                NRM_ROW_(1) NRM_ROW_(2) NRM_ROW_(3) NRM_ROW_(4) NRM_ROW_(5) NRM_ROW_(6) NRM_ROW_(7) NRM_ROW_(8)
                NRM_ROW_(9) NRM_ROW_(10) NRM_ROW_(11) NRM_ROW_(12) NRM_ROW_(13) NRM_ROW_(14) NRM_ROW_(15)
                : "+v"(acc) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-#else
-  nrm_add_row_c<0>(acc, v);
+  return;
+  }
 #endif
+  nrm_add_row_c<0>(acc, v);
 }
 constexpr int NRM_THREADS = 256, NRM_CHUNK = 512;   // 20 KB of LDS: seven workgroups per CU (1024-point chunks: three; 0.93 -> 0.59 ms per 1024-pair step)
+template <bool ASM>
 __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
                                                                     int with_normalization)
 {
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
 #pragma unroll
           for(int q = 0; q < 4; ++q) nx[q] = sp[4 * (b + 64 + q)];
         }
-        nrm_add_batch(c, v);
+        nrm_add_batch<ASM>(c, v);
 #pragma unroll
         for(int q = 0; q < 4; ++q) v[q] = nx[q];
       }
@@ -1195,7 +1206,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
       for(int b = 0; b < cnt; b += 64) {
         if(b + 64 < cnt) n4 = *reinterpret_cast<const float4*>(&s_dist[cur][b + 64 + 4 * li]);
         const float v[4] = {d4.x, d4.y, d4.z, d4.w};
-        nrm_add_batch(m, v);
+        nrm_add_batch<ASM>(m, v);
         d4 = n4;
       }
     }
@@ -1355,6 +1366,37 @@ __global__ __launch_bounds__(256) void template_build_kernel(const FrameJob* job
   }
 }
 
+// template_build for descriptors of more than 48 channels: the generic branch above with a run-time channel loop (no per-channel arrays); same
+// arithmetic per channel, point-major pix[N][C], grad[N][2][C]
+__global__ __launch_bounds__(256) void template_build_wide_kernel(const FrameJob* jobs, int C, int grad_cd5, int nframes, int job_pitch)
+{
+  const FrameJob& j = level_job(jobs, blockIdx.z, nframes, job_pitch);
+  const int N = *j.n_out;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= N) return;
+  const int W = j.cols;
+  const int ii = j.inds[i];
+  const float fx = j.dspace ? 1.0f : j.K[0], fy = j.dspace ? 1.0f : j.K[4];
+  const float* __restrict__ D = j.desc;
+  const float NN = 1.0f / 18.0f;
+  const ptrdiff_t sx = C, sy = (ptrdiff_t) W * C;
+#pragma unroll 4
+  for(int c = 0; c < C; ++c) {
+    const float* cc = D + (size_t) ii * C + c;
+    float gx, gy;
+    if(!grad_cd5) {
+      gx = 0.5f * (cc[sx] - cc[-sx]);
+      gy = 0.5f * (cc[sy] - cc[-sy]);
+    } else {
+      gx = NN * (1.0f * cc[-2 * sx] - 8.0f * cc[-sx] + 8.0f * cc[sx] - 1.0f * cc[2 * sx]);
+      gy = NN * (1.0f * cc[-2 * sy] - 8.0f * cc[-sy] + 8.0f * cc[sy] - 1.0f * cc[2 * sy]);
+    }
+    j.pix[(size_t) i * C + c] = cc[0];
+    j.grad[((size_t) i * 2 + 0) * C + c] = fx * gx;
+    j.grad[((size_t) i * 2 + 1) * C + c] = fy * gy;
+  }
+}
+
 // point counts of every (frame, level) of a batch into one contiguous array, so that the host reads them back with a
 // single copy instead of one per frame
 __global__ void gather_counts_kernel(const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels, int* out /*[nframes][kMaxLevels]*/)
@@ -1394,6 +1436,24 @@ __global__ __launch_bounds__(256) void export_jacobians_kernel(const FrameJob* j
 #pragma unroll
     for(int k = 0; k < 6; ++k) o[k] = J[k];
   }
+}
+
+// ... for descriptors of more than 48 channels: one thread per (point, channel)
+__global__ __launch_bounds__(256) void export_jacobians_wide_kernel(const FrameJob* job, int C, float* out)
+{
+  const FrameJob& j = *job;
+  const int N = *j.n_out;
+  const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if(k >= (size_t) N * C) return;
+  const int c = (int) (k / N), i = (int) (k - (size_t) c * N);
+  const float4 P = j.pts[i];
+  const float Ix = j.grad[((size_t) i * 2 + 0) * C + c], Iy = j.grad[((size_t) i * 2 + 1) * C + c];
+  float J[6];
+  if(j.dspace) dspace_jac_row(P.x, P.y, P.z, j.K[0], j.K[4], 1.0f / j.K[0], 1.0f / j.K[4], 1.0f / j.b, Ix, Iy, J);
+  else jac_row(jac_point(P.x, P.y, P.z, j.nrm), Ix, Iy, J);
+  float* o = out + k * 6;
+#pragma unroll
+  for(int q = 0; q < 6; ++q) o[q] = J[q];
 }
 
 // ---- host-callable launchers ------------------------------------------------------------------------------------
@@ -1440,17 +1500,19 @@ void launch_saliency_select(hipStream_t s, const FrameJob* jobs, int C, int W, i
   if(nms_radius <= 1) {
     // tiles: saliency + NMS + gate in one pass, candidate bits, word scan, lane-per-pixel compaction
     const int WPR = (W + 63) / 64, nw = R * WPR;
-    dispatch_channels(C, [&](auto c) {
+    auto tile = [&](auto c) {
       hipLaunchKernelGGL(saliency_select_tile_kernel<decltype(c)::value>, dim3(WPR, (R + ST_H - 1) / ST_H, nframes * nlevels), dim3(256), 0, s, jobs,
                          min_saliency, min_disp, max_disp, border, nframes, job_pitch);
-    });
+    };
+    if(C <= 48 || !dispatch_wide_channels(C, tile)) dispatch_channels(C, tile);
     hipLaunchKernelGGL(select_words_scan_kernel, dim3(nframes * nlevels), dim3(1024), 0, s, jobs, nframes, job_pitch);
     hipLaunchKernelGGL(select_words_write_kernel, dim3((nw + 4 * SW_WORDS - 1) / (4 * SW_WORDS), 1, nframes * nlevels), dim3(256), 0, s, jobs, nframes,
                        job_pitch);
     return;
   }
   // larger NMS windows: the saliency map first, then flag bytes / chunk scan / compaction straight from it
-  dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(saliency_kernel<decltype(c)::value>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs); });
+  auto plain = [&](auto c) { hipLaunchKernelGGL(saliency_kernel<decltype(c)::value>, grid2d_rows(W, R, nframes), dim3(256), 0, s, jobs); };
+  if(C <= 48 || !dispatch_wide_channels(C, plain)) dispatch_channels(C, plain);
   const int nblk = (W * R + SEL_BLOCK_PX - 1) / SEL_BLOCK_PX;
   hipLaunchKernelGGL(select_flag_kernel, dim3(nblk, 1, nframes), dim3(256), 0, s, jobs, min_saliency, min_disp, max_disp, border);
   hipLaunchKernelGGL(select_scan_kernel, dim3(nframes), dim3(1024), 0, s, jobs);
@@ -1475,10 +1537,14 @@ void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, siz
                      (const unsigned long long*) src_host_pinned, pitch_bytes / 8, width_bytes / 8, rows);
 }
 void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels,
-                          int with_normalization)
+                          int with_normalization, int dpp_asm)
 {
-  hipLaunchKernelGGL(normalization_kernel, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
-                     with_normalization);
+  if(dpp_asm)
+    hipLaunchKernelGGL(normalization_kernel<true>, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
+                       with_normalization);
+  else
+    hipLaunchKernelGGL(normalization_kernel<false>, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
+                       with_normalization);
 }
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels, int* out)
 {
@@ -1490,6 +1556,7 @@ void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_p
 {
   if(max_points <= 0) return;
   const dim3 g((max_points + 255) / 256, 1, nframes * nlevels);
+  if(C > 48) { hipLaunchKernelGGL(template_build_wide_kernel, g, dim3(256), 0, s, jobs, C, grad_cd5, nframes, job_pitch); return; }
   dispatch_channels(C, [&](auto c) {
     hipLaunchKernelGGL(template_build_kernel<decltype(c)::value>, g, dim3(256), 0, s, jobs, grad_cd5, gauss_k[0], gauss_k[1], gauss_k[2], nframes, job_pitch);
   });
@@ -1499,6 +1566,7 @@ void launch_export_jacobians(hipStream_t s, const FrameJob* job, int C, int n, f
 {
   if(n <= 0) return;
   const dim3 g((n + 255) / 256);
+  if(C > 48) { hipLaunchKernelGGL(export_jacobians_wide_kernel, dim3((unsigned) (((size_t) n * C + 255) / 256)), dim3(256), 0, s, job, C, out); return; }
   dispatch_channels(C, [&](auto c) { hipLaunchKernelGGL(export_jacobians_kernel<decltype(c)::value>, g, dim3(256), 0, s, job, out); });
 }
 

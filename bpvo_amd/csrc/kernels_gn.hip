@@ -144,6 +144,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
   if(in_block) j.valid[i] = valid ? 1 : 0;
 
   constexpr int G = InterpGroup<C>::G;
+  const size_t PT = (C == 8 || C == 1) ? (size_t) C : (size_t) j.pitch;      // record pitch (a channel group of a wide descriptor: the whole channel count)
   float res[C];
 #pragma unroll
   for(int c = 0; c < C; ++c) res[c] = 0.0f;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
     }
     size_t row_off[4];      // float offset of (row, xi) for the 4 x 4 forms: rows yi-1 .. yi+2, the last clamped (Q21)
 #pragma unroll
-    for(int k = 0; k < 4; ++k) row_off[k] = ((size_t) min(yi - 1 + k, R - 1) * W + xi) * C;
-    const size_t off00 = ((size_t) yi * W + xi) * C;
+    for(int k = 0; k < 4; ++k) row_off[k] = ((size_t) min(yi - 1 + k, R - 1) * W + xi) * PT;
+    const size_t off00 = ((size_t) yi * W + xi) * PT;
 #pragma unroll
     for(int g = 0; g < C / G; ++g) {
       const int c0 = g * G;
@@ -172,13 +173,13 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
         I0[0] = ta.x; I0[1] = ta.y; I0[2] = ta.z; I0[3] = ta.w; I0[4] = tb.x; I0[5] = tb.y; I0[6] = tb.z; I0[7] = tb.w;
       } else {
 #pragma unroll
-        for(int q = 0; q < G; ++q) I0[q] = j.pix[(size_t) i * C + c0 + q];
+        for(int q = 0; q < G; ++q) I0[q] = j.pix[(size_t) i * PT + c0 + q];
       }
       if constexpr(two_tap) {
         float a[G], b[G], c[G], d[G];      // (yi, xi), (yi, xi+1), (yi+1, xi), (yi+1, xi+1)
         const float* __restrict__ d0 = j.desc + off00 + c0;
-        load_group<G>(d0, a); load_group<G>(d0 + C, b);
-        load_group<G>(d0 + (size_t) W * C, c); load_group<G>(d0 + (size_t) W * C + C, d);
+        load_group<G>(d0, a); load_group<G>(d0 + PT, b);
+        load_group<G>(d0 + (size_t) W * PT, c); load_group<G>(d0 + (size_t) W * PT + PT, d);
 #pragma unroll
         for(int q = 0; q < G; ++q) {
           const float e1 = a[q] * Cx[0] + b[q] * Cx[1];
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 #pragma unroll
           for(int k = 0; k < 2; ++k)
 #pragma unroll
-            for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * C + c0, t[k][m]);
+            for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * PT + c0, t[k][m]);
 #pragma unroll
           for(int k = 0; k < 2; ++k)
 #pragma unroll
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       o[tile_index<2>(i, 1)] = make_float4(res[4], res[5], res[6], res[7]);
     } else {
 #pragma unroll
-      for(int c = 0; c < C; ++c) j.r[(size_t) i * C + c] = res[c];
+      for(int c = 0; c < C; ++c) j.r[(size_t) i * PT + c] = res[c];
     }
   }
   if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, false, res);
@@ -444,6 +445,26 @@ __global__ __launch_bounds__(256) void weights_kernel(const PairJob* job, float*
   }
 }
 
+// ... and for descriptors of more than 48 channels (point-major records of C floats, run-time channel loop)
+__device__ __forceinline__ float mest_weight_rt(int loss, float r, float sigma_inv)
+{
+  return loss == BPVO_LOSS_HUBER ? mest_weight<BPVO_LOSS_HUBER>(r, sigma_inv) : loss == BPVO_LOSS_TUKEY ? mest_weight<BPVO_LOSS_TUKEY>(r, sigma_inv) : 1.0f;
+}
+__global__ __launch_bounds__(256) void weights_wide_kernel(const PairJob* job, int C, int loss, float* w_out /*[n][C] point-major*/)
+{
+  const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+  if(k >= (size_t) job->n * C) return;
+  w_out[k] = mest_weight_rt(loss, job->r[k], 1.0f / job->st->scale);
+}
+__global__ __launch_bounds__(256) void count_good_wide_kernel(const PairJob* job, int C, int loss, float thr, unsigned int* count)
+{
+  const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+  unsigned good = (k < (size_t) job->n * C && mest_weight_rt(loss, job->r[k], 1.0f / job->st->scale) > thr) ? 1u : 0u;
+#pragma unroll
+  for(int o = 32; o >= 1; o >>= 1) good += __shfl_down(good, o);
+  if((threadIdx.x & 63) == 0 && good) atomicAdd(count, good);
+}
+
 template <int C, int LOSS>
 __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, float thr, unsigned int* count)
 {
@@ -652,6 +673,7 @@ static void launch_weights_c(hipStream_t s, const PairJob* job, int n, int loss,
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out)
 {
   if(n <= 0) return;
+  if(C > 48) { hipLaunchKernelGGL(weights_wide_kernel, dim3((unsigned) (((size_t) n * C + 255) / 256)), dim3(256), 0, s, job, C, loss, w_out); return; }
   dispatch_channels(C, [&](auto c) { launch_weights_c<decltype(c)::value>(s, job, n, loss, w_out); });
 }
 template <int C>
@@ -667,6 +689,7 @@ static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int lo
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
 {
   if(n <= 0) return;
+  if(C > 48) { hipLaunchKernelGGL(count_good_wide_kernel, dim3((unsigned) (((size_t) n * C + 255) / 256)), dim3(256), 0, s, job, C, loss, thr, count); return; }
   dispatch_channels(C, [&](auto c) { launch_count_good_c<decltype(c)::value>(s, job, n, loss, thr, count); });
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,

@@ -176,8 +176,9 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
 // ---- LatchDescriptor, evaluated densely (reference: bpvo/latch_descriptor.cc:124-167 compute, :170-262 CalcuateSums, :264-493 pixelTests,
 // :1041-1086 LatchDescriptor::compute).  Key points are the pixels border <= y < R - border - 1, border <= x < W - border - 1 (row-major),
 // border = 24 + K, K = latchHalfSsdSize.  Work planes of FrameJob::scratch: the smoothed u8 image, the [key points][bytes] descriptor
-// bytes, one extracted channel, one smoothing temporary.
-enum { LATCH_P_GRAY = 0, LATCH_P_BYTES = 1, LATCH_P_CH = 2, LATCH_P_TMP = 3 };
+// bytes, one extracted channel, one smoothing temporary.  The descriptor bytes come LAST: they take latchNumBytes bytes per key point — one float
+// plane up to 4 bytes, 16 planes for 64 (the context sizes FrameJob::scratch for them: 3 + ceil(bytes / 4) planes).
+enum { LATCH_P_GRAY = 0, LATCH_P_CH = 1, LATCH_P_TMP = 2, LATCH_P_BYTES = 3 };
 __device__ __forceinline__ uint8_t* latch_u8_plane(const FrameJob& j, int plane)
 {
   return reinterpret_cast<uint8_t*>(j.scratch.get() + (size_t) plane * j.rows * j.cols);
@@ -407,7 +408,11 @@ void launch_latch(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes
     switch(bytes) {
       case 1: hipLaunchKernelGGL(latch_bits_kernel<1>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
       case 2: hipLaunchKernelGGL(latch_bits_kernel<2>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
-      default: hipLaunchKernelGGL(latch_bits_kernel<4>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
+      case 4: hipLaunchKernelGGL(latch_bits_kernel<4>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
+      case 8: hipLaunchKernelGGL(latch_bits_kernel<8>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
+      case 16: hipLaunchKernelGGL(latch_bits_kernel<16>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
+      case 32: hipLaunchKernelGGL(latch_bits_kernel<32>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
+      default: hipLaunchKernelGGL(latch_bits_kernel<64>, tiles, dim3(256), lds, s, jobs, offsets, K); break;
     }
   }
   auto op5 = [&](int o, int src, int dst, const float* k, const GaussTaps* g) {

@@ -15,6 +15,7 @@ constexpr int kPartialStride = 32;
 constexpr int kWsCounters = 12;
 constexpr int kRecordFloats = 32;  // packed per-pair result record (see bpvo_hip_batch_result_records_device)
 constexpr int kTraceFloats = BPVO_HIP_TRACE_FLOATS;   // one record per linearisation (c_api.h)
+constexpr int kMaxGroups = 16;     // channel groups of a wide descriptor (more than 48 channels): LATCH with 64 bytes is 16 groups of 32
 
 // TILED per-point layout.  Template pixels, Jacobians and residuals are records of W floats per point
 // (W = C, 6*C, C).  A record is cut into V-float vector pieces (V = 4 for C = 8; 1 or 2 for C = 1) and points are grouped
@@ -195,6 +196,14 @@ struct PairJob {
   // kIteration verbosity (bpvo/pose_estimator_base.h:231-247), with the pose, H, G and dp added
   GPtr<float> trace;
   int           trace_cap;
+  // Descriptors of more than 48 channels run their per-point kernels (warp + residual, reduction) once per channel GROUP: a group's job is the
+  // whole job with desc / pix / grad / r advanced to the group's first channel and cand / med_blk / partials to the group's segments, and
+  // `pitch` — floats between the records of consecutive pixels / points (2 x pitch between gradient records) — still the descriptor's channel
+  // count.  The whole job (what the median, the step and every per-workspace kernel take) has n_groups = the number of groups: its median walks
+  // n_groups x chunks bracket segments, its step sums n_groups x tiles partials.  pitch = C, n_groups = 1 everywhere else.
+  int           pitch;
+  int           n_groups;
+  int           pad_[1];
 };
 
 // selection / template-build job for one (frame, level)

@@ -278,7 +278,7 @@ def test_unsupported_and_invalid_create(hip):
     p.descriptor = 0x38      # past the last DescriptorType (bpvo/types.h:142-152): DenseDescriptor::Create throws
     with pytest.raises(capi.BpvoError):
         hip.create(K, b, 120, 160, p)
-    for nbytes in (3, 8):    # kLatch: a size LATCHDescriptorExtractorImpl rejects (bpvo/latch_descriptor.cc:104); one the device path does not serve
+    for nbytes in (3, 128):    # kLatch: sizes LATCHDescriptorExtractorImpl rejects (bpvo/latch_descriptor.cc:104)
         p = make_params(hip, levels=3, descriptor="latch", latchNumBytes=nbytes)
         with pytest.raises(capi.BpvoError):
             hip.create(K, b, 120, 160, p)
@@ -940,11 +940,15 @@ def test_descriptor_fields_sigma_variants(hip, orc, descriptor):
 @pytest.mark.parametrize("radius,rows,cols,levels,loss", [pytest.param(1, 120, 160, 3, "tukey", id="r1-8ch-160x120"),
                                                           pytest.param(2, 121, 163, 2, "huber", id="r2-24ch-163x121"),
                                                           pytest.param(3, 120, 160, 3, "huber", id="r3-48ch-160x120"),
-                                                          pytest.param(1, 480, 640, 4, "huber", id="r1-8ch-640x480")])
+                                                          pytest.param(1, 480, 640, 4, "huber", id="r1-8ch-640x480"),
+                                                          pytest.param(4, 120, 160, 3, "huber", id="r4-80ch-160x120-5-groups-of-16"),
+                                                          pytest.param(5, 121, 163, 2, "tukey", id="r5-120ch-163x121-5-groups-of-24"),
+                                                          pytest.param(9, 96, 128, 2, "huber", id="r9-360ch-128x96-15-groups-of-24")])
 def test_central_difference_descriptor_parity(hip, orc, radius, rows, cols, levels, loss):
     """kCentralDifference (bpvo/central_difference_descriptor.cc:36-131): the smoothed u8 image minus its shifts over a
     (2r+1)^2 window, each channel smoothed — 8 / 24 / 48 channels.  Radius 1 runs through the tuned 8-channel kernels (tiled
-    records, tap cache), radius 2 / 3 through the generic-C forms.  Every stage bit-exact, poses within the bar."""
+    records, tap cache), radius 2 / 3 through the generic-C forms, radii 4 .. 9 (80 .. 360 channels) through the same forms one channel
+    GROUP at a time (types.h PairJob::pitch).  Every stage bit-exact, poses within the bar — and, in reference order, equal."""
     C = (2 * radius + 1) ** 2 - 1
     ch, co, d = both(hip, orc, rows, cols, levels, descriptor="centraldiff", loss=loss, centralDifferenceRadius=radius)
     assert ch.Cn == co.Cn == C
@@ -962,9 +966,15 @@ def test_central_difference_descriptor_parity(hip, orc, radius, rows, cols, leve
             H64, G64, f64 = normal_equations_f64(co.get_jacobians(0, l), co.get_residuals(0), co.get_weights(0), vo, C)
             assert np.abs(a["H"] - H64).max() <= 1e-5 * np.abs(H64).max()
     Th, _ = ch.estimate_pose(0, 0, 1)
-    To, _ = co.estimate_pose(0, 0, 1)
+    To, so = co.estimate_pose(0, 0, 1)
     rot, trans = pose_error(Th, To)
     assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+    if C > 48:      # the groups change nothing but the summation order: in the reference's own order the run is the oracle's, bit for bit
+        ch.set_option("reference_reduction", 1)
+        Tr, sr = ch.estimate_pose(0, 0, 1)
+        assert bits_equal(Tr, To) and [s["numIterations"] for s in sr] == [s["numIterations"] for s in so] and [s["status"] for s in sr] == [s["status"] for s in so]
+        a, b = ch.linearize(0, 0, 1, 0, _perturbed_pose(1.0)), co.linearize(0, 0, 1, 0, _perturbed_pose(1.0))
+        assert bits_equal(a["H"], b["H"]) and bits_equal(a["G"], b["G"]) and a["f_norm"] == b["f_norm"] and a["num_valid"] == b["num_valid"]
 
 
 def test_central_difference_variants(hip, orc):
@@ -991,7 +1001,7 @@ def test_central_difference_variants(hip, orc):
     for k in range(3):
         rot, trans = pose_error(outs[0][k], outs[1][k])
         assert rot <= ROT_TOL and trans <= trans_tol(b3["K"]), (k, rot, trans)
-    for kw in (dict(centralDifferenceRadius=4), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=16.0)):
+    for kw in (dict(centralDifferenceRadius=10), dict(centralDifferenceRadius=0), dict(centralDifferenceSigmaAfter=16.0)):
         with pytest.raises(capi.BpvoError):
             hip.create(b3["K"], b3["b"], rows, cols, make_params(hip, descriptor="centraldiff", levels=2, **kw))
 
@@ -1103,7 +1113,9 @@ def test_selection_on_odd_shapes(hip, orc, rows, cols, radius, nms_from):
 @pytest.mark.parametrize("rows,cols,levels,nbytes,K,rotation", [
     pytest.param(120, 160, 3, 1, 1, 0, id="160x120-1byte"), pytest.param(120, 160, 3, 4, 1, 0, id="160x120-4bytes"),
     pytest.param(480, 640, 4, 1, 1, 0, id="640x480-1byte"), pytest.param(480, 640, 4, 4, 1, 0, id="640x480-4bytes"),
-    pytest.param(121, 163, 2, 2, 3, 1, id="163x121-2bytes-K3-rotation"), pytest.param(120, 160, 2, 1, 0, 1, id="160x120-1byte-K0-rotation")])
+    pytest.param(121, 163, 2, 2, 3, 1, id="163x121-2bytes-K3-rotation"), pytest.param(120, 160, 2, 1, 0, 1, id="160x120-1byte-K0-rotation"),
+    pytest.param(120, 160, 2, 8, 1, 0, id="160x120-8bytes-2-groups-of-32"), pytest.param(121, 163, 2, 16, 2, 1, id="163x121-16bytes-K2-rotation-4-groups-of-32"),
+    pytest.param(120, 160, 2, 64, 1, 0, id="160x120-64bytes-16-groups-of-32")])
 def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotation):
     """kLatch (LatchDescriptor, bpvo/latch_descriptor.cc:83-165,1041-1086; factory bpvo/dense_descriptor.cc:69-72; parameters of
     conf/tsukuba_eval.cfg:49-52 in the first cases): 8 * latchNumBytes channels of +-128-valued bit planes of the densely evaluated LATCH
@@ -1146,6 +1158,28 @@ def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotati
     if hip_err is None:
         rot, trans = pose_error(Th, To)
         assert rot <= ROT_TOL and trans <= trans_tol(d["K"]), (rot, trans)
+        if C > 48:      # channel groups: in the reference's summation order the run is the oracle's, bit for bit
+            ch.set_option("reference_reduction", 1)
+            assert bits_equal(ch.estimate_pose(0, 0, 1)[0], To)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4"),
+                                              pytest.param(243, 651, 3, id="651x243-L3-ragged")])
+def test_normalisation_sums_hand_scheduled_against_the_compilers_form(hip, rows, cols, levels):
+    """The Hartley sums (bpvo/warps.cc:27-48) are sequential f32 additions; the default kernel issues them as back-to-back DPP adds without the
+    wait states the compiler's hazard table inserts (kernels_frame.hip nrm_add_batch).  Option "normalization_dpp_asm" = 0 runs the compiler's
+    form of the same chains: T_n / T_n^-1 of every level, and every pose built on them, must be the same bits — a toolchain or hardware
+    change that invalidates the hand-scheduled form fails here (and against the oracle in test_template_bit_exact)."""
+    outs = []
+    for asm in (1, 0):
+        ch, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss="tukey")
+        ch.set_option("normalization_dpp_asm", asm)
+        ch.frame_set_template(0)
+        outs.append(([np.stack(ch.get_normalization(0, l)) for l in range(levels)], ch.estimate_pose(0, 0, 1)[0]))
+        ch.close()
+    for l in range(levels):
+        assert bits_equal(outs[0][0][l], outs[1][0][l]), l
+    assert bits_equal(outs[0][1], outs[1][1])
 
 
 def test_current_frames_of_a_pair_batch_keep_no_disparity_unless_asked(hip):
