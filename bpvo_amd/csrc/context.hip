@@ -575,9 +575,11 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     // (channel groups: a group's candidate segments and bracket counters follow those of the group before it, whole 256-point chunks each)
     CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * nblk_max * kChunkPoints * (size_t) cp->C));
     CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max * (size_t) cp->G));
-    if(cp->C == 8 || cp->C == 1) {      // tap cache of warp_residual: 4 taps x C floats per point
+    if(cp->C == 8 || cp->C == 1) {      // tap cache of warp_residual: the footprint's taps x C floats per point (2 x 2; kCubic / kCubicHermite: 4 x 4), whole tiles
+      const bool wide_taps = cp->params.interp == BPVO_INTERP_CUBIC || cp->params.interp == BPVO_INTERP_CUBIC_HERMITE;
+      const size_t cap_tiles = ((size_t) cp->cap_max + kTile - 1) / kTile * kTile;
       CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
-      CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * 4 * cp->C * (size_t) cp->cap_max));
+      CREATE_CK(hipMalloc((void**) &w.tapcache, sizeof(float) * (wide_taps ? 16 : 4) * cp->C * cap_tiles));
     }
     // two buffers of tile partials (the persistent kernels double-buffer them by iteration parity, kernels_gn.hip pk_partials)
     CREATE_CK(hipMalloc((void**) &w.partials, sizeof(float) * (size_t) gn_partials_entries(cp->cap_max, cp->G > 1 ? cp->Cg : cp->C) * std::max(1, (cp->G + 1) / 2) * kPartialStride));

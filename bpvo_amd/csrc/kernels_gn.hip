@@ -145,6 +145,22 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 
   constexpr int G = InterpGroup<C>::G;
   const size_t PT = (C == 8 || C == 1) ? (size_t) C : (size_t) j.pitch;      // record pitch (a channel group of a wide descriptor: the whole channel count)
+  // Tap cache (C = 8 and 1, as for kLinear: gn_warp.h): the point's whole footprint — 2 x 2 or 4 x 4 taps of C channels — kept per point in a
+  // tiled, coalesced buffer keyed by the footprint's origin (yi << 16 | xi).  A template point moves by less than a pixel between iterations, so
+  // at the sparse levels most lookups hit, and a hit replaces the gather — for 4 x 4 taps of eight channels four 128-byte row segments that
+  // straddle ~7 HBM lines (914 B of traffic per point measured, profiles/r06_interp_kernel.txt) — by one coalesced read of 512 B.  Dense levels of
+  // a batch run without it (tapcache_on = 0: neighbours share their lines there).
+  constexpr bool kCache = (C == 8 || C == 1);
+  constexpr int TAPS = two_tap ? 4 : 16;                 // taps per channel
+  constexpr int PIECES = kCache ? (TAPS * C) / 4 : 1;    // 16-byte pieces of the cached footprint: C = 8: 8 / 32, C = 1: 1 / 4
+  bool cached = false, hit = false;
+  unsigned key = 0;
+  float4* const tc = kCache ? reinterpret_cast<float4*>(j.tapcache.get()) : nullptr;
+  if constexpr(kCache) {
+    cached = j.tapcache_on != 0 && j.tapkey;             // (uniform over the workspace)
+    key = ((unsigned) yi << 16) | (unsigned) xi;
+    hit = cached && valid && j.tapkey[i] == key;
+  }
   float res[C];
 #pragma unroll
   for(int c = 0; c < C; ++c) res[c] = 0.0f;
@@ -178,8 +194,31 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       if constexpr(two_tap) {
         float a[G], b[G], c[G], d[G];      // (yi, xi), (yi, xi+1), (yi+1, xi), (yi+1, xi+1)
         const float* __restrict__ d0 = j.desc + off00 + c0;
-        load_group<G>(d0, a); load_group<G>(d0 + PT, b);
-        load_group<G>(d0 + (size_t) W * PT, c); load_group<G>(d0 + (size_t) W * PT + PT, d);
+        if(kCache && hit) {
+          if constexpr(C == 8) {      // pieces 0, 1: tap a; 2, 3: b; 4, 5: c; 6, 7: d (the layout of kLinear's cache)
+            float4 q[8];
+#pragma unroll
+            for(int p = 0; p < 8; ++p) q[p] = tc[tile_index<8>(i, p)];
+            const float4* qq = q;
+            auto put = [&](float (&v)[G], int t) { v[0] = qq[2 * t].x; v[1] = qq[2 * t].y; v[2] = qq[2 * t].z; v[3] = qq[2 * t].w; v[4] = qq[2 * t + 1].x; v[5] = qq[2 * t + 1].y; v[6] = qq[2 * t + 1].z; v[7] = qq[2 * t + 1].w; };
+            if constexpr(G == 8) { put(a, 0); put(b, 1); put(c, 2); put(d, 3); }
+          } else if constexpr(C == 1) {
+            const float4 q = tc[i];
+            a[0] = q.x; b[0] = q.y; c[0] = q.z; d[0] = q.w;
+          }
+        } else {
+          load_group<G>(d0, a); load_group<G>(d0 + PT, b);
+          load_group<G>(d0 + (size_t) W * PT, c); load_group<G>(d0 + (size_t) W * PT + PT, d);
+          if(kCache && cached && in_block) {
+            if constexpr(C == 8 && G == 8) {
+              auto get = [&](const float (&v)[G], int h) { return make_float4(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]); };
+              tc[tile_index<8>(i, 0)] = get(a, 0); tc[tile_index<8>(i, 1)] = get(a, 1); tc[tile_index<8>(i, 2)] = get(b, 0); tc[tile_index<8>(i, 3)] = get(b, 1);
+              tc[tile_index<8>(i, 4)] = get(c, 0); tc[tile_index<8>(i, 5)] = get(c, 1); tc[tile_index<8>(i, 6)] = get(d, 0); tc[tile_index<8>(i, 7)] = get(d, 1);
+            } else if constexpr(C == 1) {
+              tc[i] = make_float4(a[0], b[0], c[0], d[0]);
+            }
+          }
+        }
 #pragma unroll
         for(int q = 0; q < G; ++q) {
           const float e1 = a[q] * Cx[0] + b[q] * Cx[1];
@@ -191,10 +230,48 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 #pragma unroll
         for(int rp = 0; rp < 2; ++rp) {
           float t[2][4][G];      // [row of the pair][tap][channel of the group]
+          // ONE load path for a hit and a miss — the address is the cached piece or the descriptor's tap — so that the two cases do not hold two
+          // sets of tap registers; cached footprint: piece (row * 4 + tap) * 2 + half for C = 8 (32 pieces), piece = row for C = 1 (its four taps)
+          if constexpr(C == 8 && G == 8) {
+            const float4* const cb = tc + tile_index<PIECES>(i, 0);      // piece p of point i: cb + p * kTile
 #pragma unroll
-          for(int k = 0; k < 2; ++k)
+            for(int k = 0; k < 2; ++k)
 #pragma unroll
-            for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * PT + c0, t[k][m]);
+              for(int m = 0; m < 4; ++m) {
+                const int pc = ((2 * rp + k) * 4 + m) * 2;
+                const float4* g4 = reinterpret_cast<const float4*>(j.desc + row_off[2 * rp + k] + (size_t) m * PT);
+                const float4 lo = *(hit ? cb + (size_t) pc * kTile : g4), hi = *(hit ? cb + (size_t) (pc + 1) * kTile : g4 + 1);
+                t[k][m][0] = lo.x; t[k][m][1] = lo.y; t[k][m][2] = lo.z; t[k][m][3] = lo.w; t[k][m][4] = hi.x; t[k][m][5] = hi.y; t[k][m][6] = hi.z; t[k][m][7] = hi.w;
+              }
+            if(cached && !hit && in_block) {
+              float4* const cw = tc + tile_index<PIECES>(i, 0);
+#pragma unroll
+              for(int k = 0; k < 2; ++k)
+#pragma unroll
+                for(int m = 0; m < 4; ++m) {
+                  const int pc = ((2 * rp + k) * 4 + m) * 2;
+                  cw[(size_t) pc * kTile] = make_float4(t[k][m][0], t[k][m][1], t[k][m][2], t[k][m][3]);
+                  cw[(size_t) (pc + 1) * kTile] = make_float4(t[k][m][4], t[k][m][5], t[k][m][6], t[k][m][7]);
+                }
+            }
+          } else if constexpr(C == 1) {
+            const float* const cb = reinterpret_cast<const float*>(tc + tile_index<PIECES>(i, 0));      // row r of point i: cb + r * kTile * 4
+#pragma unroll
+            for(int k = 0; k < 2; ++k)
+#pragma unroll
+              for(int m = 0; m < 4; ++m)
+                t[k][m][0] = *(hit ? cb + (size_t) (2 * rp + k) * kTile * 4 + m : j.desc + row_off[2 * rp + k] + m);
+            if(cached && !hit && in_block) {
+              float4* const cw = tc + tile_index<PIECES>(i, 0);
+#pragma unroll
+              for(int k = 0; k < 2; ++k) cw[(size_t) (2 * rp + k) * kTile] = make_float4(t[k][0][0], t[k][1][0], t[k][2][0], t[k][3][0]);
+            }
+          } else {
+#pragma unroll
+            for(int k = 0; k < 2; ++k)
+#pragma unroll
+              for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * PT + c0, t[k][m]);
+          }
 #pragma unroll
           for(int k = 0; k < 2; ++k)
 #pragma unroll
@@ -217,6 +294,9 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       if(g + 1 < C / G) __builtin_amdgcn_sched_barrier(0);      // the next group's loads stay behind this group's arithmetic
     }
   }
+  if constexpr(kCache) {
+    if(cached && valid && !hit && in_block) j.tapkey[i] = key;
+  }
   if(in_block) {
     if constexpr(C == 8) {
       float4* o = reinterpret_cast<float4*>(j.r.get());
@@ -227,7 +307,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       for(int c = 0; c < C; ++c) j.r[(size_t) i * PT + c] = res[c];
     }
   }
-  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, false, res);
+  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, hit && in_block, res);
 }
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.

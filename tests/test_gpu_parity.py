@@ -362,6 +362,42 @@ def test_dense_levels_without_tap_cache_leave_no_stale_entries(hip, monkeypatch,
     ref.close()
 
 
+@pytest.mark.parametrize("interp", ["cosine", "cubic", "cubic_hermite"])
+@pytest.mark.parametrize("descriptor,loss,rows,cols,levels", [("bitplanes", "tukey", 376, 1241, 3), ("intensity", "huber", 240, 320, 3)])
+def test_tap_cache_of_the_other_interpolations_changes_nothing(hip, orc, monkeypatch, interp, descriptor, loss, rows, cols, levels):
+    """kCosine / kCubic / kCubicHermite (bpvo/photo_error.cc:391-444) keep a point's 2 x 2 / 4 x 4 footprint in the per-point tap cache (C = 8 and 1):
+    a batch with the cache at every level, a batch with the cache at no level (every tap gathered from the descriptor at every iteration) and the
+    same pairs one at a time give the same poses and statistics bit for bit — and the oracle's within the bar.  NMS on at the finest level
+    (1241 x 376: sparse points, where the cache hits) and off at the coarser ones."""
+    n = 3
+    b = synth.make_batch(rows, cols, n, first_index=70)
+    kw = dict(descriptor=descriptor, loss=loss, levels=levels, interp={"cosine": 1, "cubic": 2, "cubic_hermite": 3}[interp])
+    outs = []
+    for density in ("1e9", "0"):      # tapcache_max_density: levels denser than this gather straight from the descriptor
+        set_options(monkeypatch, tapcache_max_density=density, lanes="1")
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)
+        outs.append(ctx.batch_run(b["images"], b["disparities"]))
+        if density == "1e9":
+            hits, lookups, _, _ = ctx.tap_cache_counts()
+            assert lookups > 0 and hits > 0.5 * lookups, (hits, lookups)      # the cache is in use, and most lookups of a run hit
+        ctx.close()
+    assert bits_equal(outs[0][0], outs[1][0]) and outs[0][1].tobytes() == outs[1][1].tobytes()
+    monkeypatch.delenv("BPVO_HIP_OPTIONS", raising=False)
+    for k in range(n):
+        one = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2, n_pairs=1)
+        one.frame_set_data(0, b["images"][2 * k], b["disparities"][2 * k]); one.frame_set_template(0)
+        one.frame_set_data(1, b["images"][2 * k + 1], b["disparities"][2 * k + 1])
+        T, st = one.estimate_pose(0, 0, 1)
+        assert bits_equal(T, outs[0][0][k]) and [s_["numIterations"] for s_ in st] == [int(v) for v in outs[0][1]["numIterations"][k]], k
+        one.close()
+    co = orc.create(b["K"], b["b"], rows, cols, make_params(orc, **kw), n_frames=2, n_pairs=1)
+    co.frame_set_data(0, b["images"][0], b["disparities"][0]); co.frame_set_template(0)
+    co.frame_set_data(1, b["images"][1], b["disparities"][1])
+    To, _ = co.estimate_pose(0, 0, 1)
+    rot, trans = pose_error(outs[0][0][0], To)
+    assert rot <= ROT_TOL and trans <= trans_tol(b["K"]), (rot, trans)
+
+
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
