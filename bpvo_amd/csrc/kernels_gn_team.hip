@@ -471,7 +471,7 @@ __shared__ unsigned pk_team_xccs;      // XCDs the team's workgroups run on (bit
 // `target`: the value the team's arrival counter reaches when every member of the team has arrived at THIS barrier — the running sum of the
 // team sizes over its barriers so far (pk_arrivals: a team grows when idle workgroups join it, see pk_join_team).
 __shared__ unsigned pk_arrivals;
-__shared__ int pk_size_seen;      // the team size published by the leader, as read with the count that completed the last barrier
+__shared__ int pk_size_seen;      // the team's size word — size | (iteration it applies to) << 16, published by the leader — as read with the count that completed the last barrier
 // What the team kernel needs now and then (barrier budget, solver tolerances, the shape of the launch) lives in LDS, not in scalar registers
 // held across the reduction phase: that phase is inlined and takes every register there is — with the join logic's operands alive across
 // it the kernel spilled 55 vector registers (324 B of scratch per lane) and lost 2 % (profiles/r05_team_join.txt).
@@ -725,7 +725,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
       const int t = (own_team + k) % n_teams;
       unsigned* line = ctl + (size_t) (1 + t) * kTeamCtlWords;
       if(__hip_atomic_load(line + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) continue;       // dissolved
-      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;      // (the upper half: the iteration tag, pk_publish_admission)
       if(size == 0u) { unstarted = true; continue; }      // (its leader has not said hello yet: a spare workgroup at the start of the launch)
       const unsigned tickets = __hip_atomic_load(line + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned crowd = (unsigned) own_team_size + tickets;      // (every team starts with own_team_size members)
@@ -752,7 +752,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
     // wait for the leader's word: admitted (size > my index) or dissolved
     unsigned spins = 0;
     for(;;) {
-      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned size = __hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
       if(size > my_index) {
         seat->team = best; seat->member = (int) my_index; seat->nwg = (int) size;
         seat->arrivals = __hip_atomic_load(line + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -763,7 +763,7 @@ __device__ __attribute__((noinline)) bool pk_join_team(unsigned* ctl, int own_te
       }
       if(__hip_atomic_load(line + 5, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
         // dissolved; an admission that included this ticket would have been published before that
-        if(__hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) > my_index) continue;
+        if((__hip_atomic_load(line + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu) > my_index) continue;
         break;      // look for another team
       }
       __builtin_amdgcn_s_sleep(8);
@@ -835,15 +835,23 @@ __device__ __attribute__((noinline)) void pk_publish_admission(unsigned* team_ct
   __hip_atomic_store(team_ctl + 7, (unsigned) pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(team_ctl + 8, (unsigned) level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store(team_ctl + 9, epoch_it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(team_ctl + 1, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // The size is TAGGED with the iteration it applies to.  In iterations with a single team barrier (frozen scale, fused path) a fast leader can be
+  // a whole iteration ahead of a member that has arrived at barrier k but not yet made the poll that completes it; that member would read the
+  // count of barrier k together with the size published for k + 1, enter the admission barrier one iteration early — counted as its arrival at
+  // barrier k + 1 — and skip that iteration's partials.  With the tag it ignores a size meant for a later iteration (pk_admit) and meets it at
+  // that iteration's barrier.  (Sizes are at most kTeamMaxSize; the tag is the iteration modulo 2^16.)
+  __hip_atomic_store(team_ctl + 1, want | ((epoch_it & 0xffffu) << 16), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Every member, behind the step of such an iteration: has the team grown?  Then old members and newcomers meet once, with the full fences;
 // the leader's state goes ahead through HBM.  false: the barrier gave up.
-__device__ __attribute__((noinline)) bool pk_admit(unsigned* team_ctl, GNState* g_state, bool leader)
+__device__ __attribute__((noinline)) bool pk_admit(unsigned* team_ctl, GNState* g_state, bool leader, unsigned iteration)
 {
   const int tid = threadIdx.x;
-  const int new_nwg = pk_size_seen;      // (read with the count that completed the barrier between reduction and step: pk_team_barrier)
-  if(new_nwg == pk_nwg) return true;
+  // (read with the count that completed the barrier between reduction and step: pk_team_barrier; a size tagged for another iteration — the
+  // initial one, one already adopted, one a leader that runs ahead has published for the NEXT iteration — changes nothing now)
+  const unsigned word = (unsigned) pk_size_seen;
+  const int new_nwg = ((word >> 16) == (iteration & 0xffffu) && (word & 0xffffu) != 0u) ? (int) (word & 0xffffu) : pk_nwg;
+  if(new_nwg <= pk_nwg) return true;
   if(leader) {
     uint32_t* g = reinterpret_cast<uint32_t*>(g_state);
     for(int i = tid; i < kStateWords; i += PK_THREADS) __hip_atomic_store(g + i, pk_state[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -945,7 +953,7 @@ __device__ __forceinline__ bool team_run_pair_body(const TeamPairArgs a)
       ++epoch_it;
       if(admission_turn) {
         if(tid == 0) pk_arrivals = arrivals;
-        if(!pk_admit(team_ctl, jobs_all[(size_t) level_hi * job_pitch + pair].st.get(), stats_wg)) return false;
+        if(!pk_admit(team_ctl, jobs_all[(size_t) level_hi * job_pitch + pair].st.get(), stats_wg, epoch_it - 1u)) return false;
         arrivals = (unsigned) uni((int) pk_arrivals); nwg = uni(pk_nwg);
         team_mode = (pk_cfg.local_ok && __popc(pk_team_xccs) == 1) ? 2 : 0;
       }
