@@ -121,7 +121,14 @@ def add_frame_latency(hip, dev_index, seq, which):
     p.numPyramidLevels = 3; p.parameterTolerance = 1e-6; p.functionTolerance = 1e-4; p.gradientTolerance = 1e-6
     p.maxIterations = 50; p.relaxTolerancesForCoarseLevels = 1; p.gradientEstimation = capi.GRAD_CD5
     p.minValidDisparity = 1.0; p.goodPointThreshold = 0.75; p.verbosity = capi.VERB_SILENT
-    if which == "perf_bitplanes":
+    if which == "tsukuba":
+        # conf/tsukuba.cfg as AlgorithmParameters(filename) reads it (`Descriptor = ...` is not the key that is read: Intensity): 3 levels,
+        # CubicHermite, 55 iterations, Huber, minSaliency 0.001, NMS radius 0 -> dense templates (~ 300 k points at 640x480), key frames every ~ 3 frames
+        p.maxIterations = 55; p.relaxTolerancesForCoarseLevels = 0; p.interp = capi.INTERP_CUBIC_HERMITE
+        p.descriptor = capi.DESC_INTENSITY; p.lossFunction = capi.LOSS_HUBER; p.minSaliency = 0.001; p.nonMaxSuppRadius = 0
+        p.sigmaPriorToCensusTransform = 0.75; p.sigmaBitPlanes = 1.75
+        p.minTranslationMagToKeyFrame = 0.05; p.minRotationMagToKeyFrame = 2.5; p.maxFractionOfGoodPointsToKeyFrame = 0.5
+    elif which == "perf_bitplanes":
         p.descriptor = capi.DESC_BITPLANES; p.lossFunction = capi.LOSS_L2
         p.minTranslationMagToKeyFrame = 0.1; p.minRotationMagToKeyFrame = 5.0
         p.sigmaPriorToCensusTransform = 0.75; p.sigmaBitPlanes = 1.6
@@ -267,6 +274,7 @@ def other_configs(hip, torch, dev, dev_index, args, batch, other_batch, seq640=N
     if seq640 is not None:
         out["addFrame 640x480, parameters of conf/perf_intensity.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_intensity")
         out["addFrame 640x480, parameters of conf/perf_bitplanes.cfg"] = add_frame_latency(hip, dev_index, seq640, "perf_bitplanes")
+        out["addFrame 640x480, parameters of conf/tsukuba.cfg"] = add_frame_latency(hip, dev_index, seq640, "tsukuba")
     return out
 
 

@@ -277,6 +277,7 @@ const std::vector<OptionDef>& option_table()
               [](bpvo_hip_ctx* c, double v) { c->persistent = (int) v; if(c->persistent) c->persistent_failed.store(false); return BPVO_OK; }},
     OPT_INT("persist_max_ws", persist_max_ws, 1, kPersistMaxWs),
     OPT_INT("persist_grid", persist_grid, 1, 128),
+    OPT_INT("persist_max_points", persist_max_points, 0, 1 << 30),
     OPT_INT("persist_timeout_ticks", persist_timeout, 1, 1e15),
     OPT_INT("team", team_mode, 0, 1),
     OPT_INT("team_max_pairs", team_max_pairs, 0, 1 << 20),
@@ -614,6 +615,7 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     if(hipGetDeviceProperties(&prop, device) == hipSuccess) cp->num_cus = cp->device_cus = prop.multiProcessorCount;
   }
   cp->max_lanes_now = cp->C == 8 ? kDefaultLanes : kDefaultLanesNarrow;
+  cp->persist_max_points = cp->C == 8 ? 32768 : 65536;
   // BPVO_HIP_OPTIONS="key=value,key=value": bpvo_hip_set_option applied to every context the process creates (measurement scripts and
   // tests; a drop-in caller uses the function) — the library's one environment variable
   if(const char* e = std::getenv("BPVO_HIP_OPTIONS")) {
@@ -654,7 +656,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   if(c->stream) (void) hipStreamSynchronize(c->stream);
   for(auto& f : c->frames) { (void) hipFree(f.data_slab); (void) hipFree(f.tmpl_slab); }
   for(auto& w : c->ws) { (void) hipFree(w.r); (void) hipFree(w.valid); (void) hipFree(w.cand); (void) hipFree(w.med_blk); (void) hipFree(w.tapkey); (void) hipFree(w.tapcache); (void) hipFree(w.partials); }
-  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1); (void) hipFree(c->d_latch_off);
+  (void) hipFree(c->d_states); (void) hipFree(c->d_fjobs); (void) hipFree(c->d_job1); (void) hipFree(c->d_latch_off); (void) hipFree(c->d_cloud);
   (void) hipFree(c->d_records); (void) hipFree(c->d_wtmp);
   (void) hipFree(c->d_count); (void) hipFree(c->d_counters); (void) hipFree(c->d_tickets); (void) hipFree(c->d_trace);
   (void) hipFree(c->st_left); (void) hipFree(c->st_right); (void) hipFree(c->st_left_pre); (void) hipFree(c->st_right_pre); (void) hipFree(c->st_disp);

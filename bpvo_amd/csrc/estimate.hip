@@ -189,9 +189,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     begun = false;
     if(!was_begun) launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
     if(g.max_points <= 0) continue;
-    if(persistent && gn_persistent_serves(g)) {
+    if(persistent && gn_persistent_serves(g) && g.max_points <= c->persist_max_points) {
       // the whole level in one launch — and the start of the next level with it, when that one takes the kernel too
-      const bool next_too = l - 1 >= p.maxTestLevel && max_pts[l - 1] > 0 && gn_persistent_serves(level_launch(l - 1));
+      const bool next_too = l - 1 >= p.maxTestLevel && max_pts[l - 1] > 0 && gn_persistent_serves(level_launch(l - 1)) && max_pts[l - 1] <= c->persist_max_points;
       g.begin_level = was_begun ? l : -1;
       g.begin_moot = l2_moot ? 1 : 0;
       g.next_jobs = next_too ? ln->d_pjobs + (size_t) (l - 1) * NP : nullptr;

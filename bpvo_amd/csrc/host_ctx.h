@@ -174,7 +174,9 @@ struct bpvo_hip_ctx {
   int vo_ref = 0, vo_cur = 1, vo_prev = 2;
   M44 T_kf;
   std::vector<M44> trajectory;
-  std::vector<bpvo_hip_point_with_info> cloud;
+  bpvo_hip_point_with_info* d_cloud = nullptr;   // the last key frame's point cloud: built on the device (vo.hip build_point_cloud), copied out when asked for
+  size_t d_cloud_cap = 0;
+  size_t cloud_n = 0;
   M44 cloud_pose;
   // measurement
   double points_fused = 0;     // points linearised through the fused path since the last counter reset
@@ -196,6 +198,11 @@ struct bpvo_hip_ctx {
   // Options "persistent" (0 turns it off), "persist_max_ws", "persist_grid" size it.  persistent_failed: a launch gave up at a barrier
   // (workgroups not co-resident) — the context stays on the four-kernel chain from then on.
   int persistent = 1, persist_max_ws = 1, persist_grid = 64;
+  int persist_max_points = 32768;     // option "persist_max_points": a level with more template points than this — and the finer levels behind it — takes the
+                               // four-kernel chain even for a single pair: the persistent kernel's grid (64 workgroups) wins on the 6 - 26 k points of a
+                               // template with non-maximum suppression and loses on dense ones (8 channels: 30.7 against 32.1 us per linearisation at 16 k
+                               // points, 59.8 against 49.0 at 38 k, 220 against 134 at 280 k; one channel: equal at 40 k; scripts/persist_crossover.py).
+                               // Default 32768 for eight channels, 65536 for one (set at creation).
   long long persist_timeout = 50000000ll;   // ticks of the 100 MHz wall clock a grid barrier waits before it gives up (0.5 s)
   // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.

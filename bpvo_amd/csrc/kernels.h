@@ -204,6 +204,9 @@ int  gn_partials_entries(int cap, int C);   // kPartialStride-float entries of a
 // (C > 48: run-time channel loops over the point-major records)
 void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, float* w_out /*[n][C]*/);
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count);
+// the key frame's point cloud (bpvo/vo.cc:250-281) as 32-byte records on the device; K: the level's intrinsics, img: the key frame's level-0 image
+void launch_point_cloud(hipStream_t s, const PairJob* job, int n, int C, int loss, const uint8_t* img, int rows, int cols, const float K[9], int dspace,
+                        bpvo_hip_point_with_info* out);
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states = nullptr, GNState* h_states = nullptr,
                          const unsigned* d_ctl = nullptr, unsigned* h_ctl = nullptr, int ctl_words = 0, unsigned* zero = nullptr);   // h_states / h_ctl (pinned host): copied out by the same launch; zero: a word cleared by it
 // a few pairs: job table upload (from the pinned host rows) + initial poses + cleared control words in one launch

@@ -545,6 +545,40 @@ __global__ __launch_bounds__(256) void count_good_wide_kernel(const PairJob* job
   if((threadIdx.x & 63) == 0 && good) atomicAdd(count, good);
 }
 
+// getPointCloudFromRefFrame + GetColor (reference: bpvo/vo.cc:250-281) on the device: one 32-byte PointWithInfo per template point of the level the
+// estimate ended on — the point, the key frame's grey value at its projection (getImagePoint, bpvo/rigid_body_warp.h:123-128: x = K X in f32, index
+// order; DisparitySpaceWarp: disparity_space_warp.h:73-76), and weights[i] of the last linearisation, i.e. the weight of CHANNEL 0's residual
+// (the reference indexes the channel-major weight array with the point index).  The records stay on the device until somebody asks for them.
+struct CloudArgs { float K[9]; int rows, cols, dspace, C, loss; };
+__global__ __launch_bounds__(256) void point_cloud_kernel(const PairJob* job, const uint8_t* __restrict__ img, CloudArgs a, bpvo_hip_point_with_info* __restrict__ out)
+{
+  const PairJob& j = *job;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if(i >= j.n) return;
+  const float4 X = j.pts[i];
+  float x[3];
+#pragma unroll
+  for(int r = 0; r < 3; ++r) {
+    float s = a.K[r * 3 + 0] * X.x;
+    s += a.K[r * 3 + 1] * X.y;
+    s += a.K[r * 3 + 2] * X.z;
+    x[r] = s;
+  }
+  const float z_i = 1.0f / x[2];
+  float u = z_i * x[0], v = z_i * x[1];
+  if(a.dspace) { u = X.x + a.K[2]; v = X.y + a.K[5]; }
+  uint8_t col = 0;
+  if(v >= 0 && v < a.rows && u >= 0 && u < a.cols) col = img[(size_t) ((int) v) * a.cols + (int) u];
+  const float r0 = a.C == 8 ? j.r[tile_index<2>(i, 0) * 4] : j.r[(size_t) i * (a.C == 1 ? 1 : j.pitch)];
+  bpvo_hip_point_with_info pw;
+  pw.xyzw[0] = X.x; pw.xyzw[1] = X.y; pw.xyzw[2] = X.z; pw.xyzw[3] = X.w;
+  pw.rgba[0] = col; pw.rgba[1] = col; pw.rgba[2] = col; pw.rgba[3] = 255;
+  pw.weight = mest_weight_rt(a.loss, r0, 1.0f / j.st->scale);
+#pragma unroll
+  for(int k = 0; k < 8; ++k) pw.pad[k] = 0;
+  out[i] = pw;
+}
+
 template <int C, int LOSS>
 __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, float thr, unsigned int* count)
 {
@@ -765,6 +799,15 @@ static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int lo
     case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(256), 0, s, job, thr, count); break;
     default: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_L2>), grid, dim3(256), 0, s, job, thr, count); break;
   }
+}
+void launch_point_cloud(hipStream_t s, const PairJob* job, int n, int C, int loss, const uint8_t* img, int rows, int cols, const float K[9], int dspace,
+                        bpvo_hip_point_with_info* out)
+{
+  if(n <= 0) return;
+  CloudArgs a;
+  for(int k = 0; k < 9; ++k) a.K[k] = K[k];
+  a.rows = rows; a.cols = cols; a.dspace = dspace; a.C = C; a.loss = loss;
+  hipLaunchKernelGGL(point_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, s, job, img, a, out);
 }
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
 {

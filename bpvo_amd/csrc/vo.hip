@@ -29,41 +29,31 @@ static int should_keyframe(bpvo_hip_ctx* c, const M44& pose, int* reason)   // r
 // getPointCloudFromRefFrame + GetColor (reference: bpvo/vo.cc:250-281)
 static int build_point_cloud(bpvo_hip_ctx* c)
 {
+  // One kernel over the template points of the level the estimate ended on; nothing crosses the bus here: the 32-byte records wait in HBM for
+  // bpvo_hip_get_point_cloud (the reference's Result owns its cloud; here the caller fetches it — vo.hpp does, into the Result's vector).
+  // (Before: every channel's weights + the points + the image copied out and a host loop over the points — 5 - 9 ms per key frame of a dense
+  // 640 x 480 template, more than the estimate itself.)
   const int lvl = c->params.maxTestLevel;
   FrameSlot& ref = c->frames[c->vo_ref];
   const int n = ref.n_host[lvl];
-  std::vector<float> w_cm;
-  int nw = 0;
-  int rc = get_weights_host(c, 0, w_cm, &nw);
+  Workspace& w = c->ws[0];
+  if(w.last_ref < 0) return fail(c, BPVO_ERR_NO_DATA, "no linearisation has run on this workspace");
+  if(n > c->frames[w.last_ref].n_host[w.last_level]) return fail(c, BPVO_ERR_INVALID_ARG, "size mismatch");
+  int rc = ensure_residuals(c, 0);      // (fused path: the residual buffer may lag behind the last linearisation)
   if(rc) return rc;
-  if((size_t) n > w_cm.size()) return fail(c, BPVO_ERR_INVALID_ARG, "size mismatch");
-  std::vector<float> pts((size_t) n * 4);
-  std::vector<uint8_t> img(c->geom[0].npix);
-  if(n) HIP_CK(c, hipMemcpyAsync(pts.data(), ref.pts[lvl], pts.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIP_CK(c, hipMemcpyAsync(img.data(), ref.img[0], img.size(), hipMemcpyDeviceToHost, c->stream));
-  HIP_CK(c, hipStreamSynchronize(c->stream));
-  c->cloud.resize(n);
-  const float* Kl = c->geom[lvl].K;
-  for(int i = 0; i < n; ++i) {
-    const float* X = pts.data() + 4 * (size_t) i;
-    float x[3];
-    for(int r = 0; r < 3; ++r) {   // getImagePoint (bpvo/rigid_body_warp.h:123-128)
-      float s = Kl[r * 3 + 0] * X[0];
-      s += Kl[r * 3 + 1] * X[1];
-      s += Kl[r * 3 + 2] * X[2];
-      x[r] = s;
-    }
-    const float z_i = 1.0f / x[2];
-    float u = z_i * x[0], v = z_i * x[1];
-    if(c->dspace) { u = X[0] + Kl[2]; v = X[1] + Kl[5]; }   // DisparitySpaceWarp::getImagePoint (disparity_space_warp.h:73-76)
-    uint8_t col = 0;
-    if(v >= 0 && v < c->rows && u >= 0 && u < c->cols) col = img[(size_t) ((int) v) * c->cols + (int) u];
-    bpvo_hip_point_with_info& pw = c->cloud[i];
-    std::memset(&pw, 0, sizeof(pw));
-    std::memcpy(pw.xyzw, X, 4 * sizeof(float));
-    pw.rgba[0] = col; pw.rgba[1] = col; pw.rgba[2] = col; pw.rgba[3] = 255;
-    pw.weight = w_cm[i];
+  rc = upload_single_job(c, 0, w.last_ref, w.last_cur, w.last_level);
+  if(rc) return rc;
+  if((size_t) n > c->d_cloud_cap) {
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+    (void) hipFree(c->d_cloud);
+    c->d_cloud = nullptr; c->d_cloud_cap = 0;
+    const size_t cap = std::max<size_t>((size_t) c->geom[lvl].cap, (size_t) n);
+    HIP_CK(c, hipMalloc((void**) &c->d_cloud, cap * sizeof(bpvo_hip_point_with_info)));
+    c->d_cloud_cap = cap;
   }
+  launch_point_cloud(c->stream, c->d_job1, n, c->C, c->params.lossFunction, ref.img[0], c->rows, c->cols, c->geom[lvl].K, c->dspace, c->d_cloud);
+  HIP_CK(c, hipGetLastError());
+  c->cloud_n = (size_t) n;
   return BPVO_OK;
 }
 
@@ -267,7 +257,7 @@ static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* di
   ret->isKeyFrame = 0;
   ret->keyFramingReason = BPVO_KF_NO_KEYFRAMING;
   ret->hasPointCloud = 0;
-  c->cloud.clear();                 // the point cloud belongs to one Result (bpvo/types.h:549-563)
+  c->cloud_n = 0;                   // the point cloud belongs to one Result (bpvo/types.h:549-563)
   c->cloud_pose = I;
 
   int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, on_device);   // _cur_frame->setData (vo.cc:131)
@@ -348,8 +338,12 @@ int bpvo_hip_vo_points_at_level(bpvo_hip_ctx* c, int level, float* xyzw)
 int bpvo_hip_get_point_cloud(bpvo_hip_ctx* c, bpvo_hip_point_with_info* pts, size_t* n, float pose[16])
 {
   CHECK_CTX(c);
-  if(n) *n = c->cloud.size();
-  if(pts) std::memcpy(pts, c->cloud.data(), c->cloud.size() * sizeof(bpvo_hip_point_with_info));
+  if(n) *n = c->cloud_n;
+  if(pts && c->cloud_n) {
+    (void) hipSetDevice(c->device);
+    HIP_CK(c, hipMemcpyAsync(pts, c->d_cloud, c->cloud_n * sizeof(bpvo_hip_point_with_info), hipMemcpyDeviceToHost, c->stream));
+    HIP_CK(c, hipStreamSynchronize(c->stream));
+  }
   if(pose) std::memcpy(pose, c->cloud_pose.m, 64);
   return BPVO_OK;
 }

@@ -366,6 +366,9 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *                                      four-kernel chain.  Also the master switch of "team".
  *   "persist_max_ws"         1         groups of up to this many pairs take the persistent kernel (1 .. 8; more than 1 measured slower)
  *   "persist_grid"           64        workgroups of the persistent kernel (one per CU)
+ *   "persist_max_points"     32768 / 65536  (8 channels / 1) a pyramid level with more template points than this, and the finer levels behind it, take the
+ *                                      four-kernel chain even for a single pair: dense templates (no non-maximum suppression: conf/tsukuba.cfg) are
+ *                                      bandwidth work for the whole chip, not latency work for 64 workgroups (same bits either way)
  *   "persist_timeout_ticks"  5e7       100 MHz ticks a device-side barrier waits before the launch gives up and the call falls back to
  *                                      the chain (0.5 s; the tests of that path set 1)
  *   "team"                   1         batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in one team-persistent launch
