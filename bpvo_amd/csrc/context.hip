@@ -570,13 +570,24 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
       if(ensure_template_storage(cp, f) != BPVO_OK) return dev_fail(hipErrorOutOfMemory, "template storage");
   cp->ws.resize(n_pairs);
   const size_t nblk_max = (size_t) gn_num_blocks(cp->cap_max);
+  // the 4 x 4 tap cache of kCubic / kCubicHermite (512 B per point for eight channels) is an optimisation, not a requirement: a context whose
+  // workspaces would spend more than a third of the free memory on it runs without (the kernel gathers every footprint from the descriptor)
+  bool tap_cache = cp->C == 8 || cp->C == 1;
+  {
+    const bool wide_taps = cp->params.interp == BPVO_INTERP_CUBIC || cp->params.interp == BPVO_INTERP_CUBIC_HERMITE;
+    size_t free_b = 0, total_b = 0;
+    if(tap_cache && wide_taps && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t need = (size_t) n_pairs * sizeof(float) * 16 * cp->C * (((size_t) cp->cap_max + kTile - 1) / kTile * kTile);
+      if(need > free_b / 3) tap_cache = false;
+    }
+  }
   for(auto& w : cp->ws) {
     CREATE_CK(hipMalloc((void**) &w.r, sizeof(float) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
     // (channel groups: a group's candidate segments and bracket counters follow those of the group before it, whole 256-point chunks each)
     CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * nblk_max * kChunkPoints * (size_t) cp->C));
     CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max * (size_t) cp->G));
-    if(cp->C == 8 || cp->C == 1) {      // tap cache of warp_residual: the footprint's taps x C floats per point (2 x 2; kCubic / kCubicHermite: 4 x 4), whole tiles
+    if(tap_cache) {      // tap cache of warp_residual: the footprint's taps x C floats per point (2 x 2; kCubic / kCubicHermite: 4 x 4), whole tiles
       const bool wide_taps = cp->params.interp == BPVO_INTERP_CUBIC || cp->params.interp == BPVO_INTERP_CUBIC_HERMITE;
       const size_t cap_tiles = ((size_t) cp->cap_max + kTile - 1) / kTile * kTile;
       CREATE_CK(hipMalloc((void**) &w.tapkey, sizeof(uint32_t) * (size_t) cp->cap_max));
