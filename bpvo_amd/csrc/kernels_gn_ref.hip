@@ -9,7 +9,7 @@
 // hence every iterate, numIterations and status of PoseEstimatorBase::run, have the bits of the reference's index-order f32 sums.
 //
 // Shape: one 256-thread workgroup per workspace.  All threads form the entries of a chunk (weight, Jacobian row, residual) in LDS, then
-// lane s < 28 of the first wave owns accumulator slot s and walks the chunk in index order.  ~100 x slower than irls_reduce (one wave does the
+// lane s < 28 of the first wave owns accumulator slot s and walks the chunk in index order.  the reduction itself ~100 x slower than irls_reduce, an estimate 30 - 50 x (scripts/reference_mode_cost.py) (one wave does the
 // adds of a whole pair, one dependent f32 add per entry): a checker, chain path only — the host (estimate.hip) keeps the persistent / team /
 // fused / step-in-reduce forms away from a context in this mode.
 #include "kernels.h"

@@ -414,7 +414,7 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *                                      linearisation are accumulated exactly as the reference's default (serial, WITH_TBB OFF) build does —
  *                                      f32, in index order over the channel-major arrays, w' = w * float(valid), (w' J_a) J_b, (w' r) J, (w' r) r,
  *                                      one multiply and one add per slot (bpvo/linear_system_builder.cc:140-205,239-266) — by one wavefront per
- *                                      pair (kernels_gn_ref.hip), ~100 x slower than the default reduction.  Every iterate, the final pose,
+ *                                      pair (kernels_gn_ref.hip): an estimate takes 30 - 50 x as long (scripts/reference_mode_cost.py).  Every iterate, the final pose,
  *                                      numIterations and status of every level then equal the reference path's BIT FOR BIT
  *                                      (tests/test_gpu_reference_order.py, the conf/ sequences, the goldens, a 330-case randomised run).  The
  *                                      default (0) regroups the same sums (rank-2 form, FMA, wave tree, f64 block combine): H, G, f within
