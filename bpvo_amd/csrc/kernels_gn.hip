@@ -100,6 +100,9 @@ __device__ __forceinline__ void load_group(const float* __restrict__ p, float (&
   else v[0] = p[0];
 }
 
+#ifndef ROW_BARRIER_AT
+#define ROW_BARRIER_AT 1
+#endif
 template <int C, int INTERP>
 __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
 {
@@ -228,58 +231,46 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       } else {
         float d[4][G];      // the x pass of row k: kCubic dot4(taps, Cx), kCubicHermite interp_hermite(taps, xf)
 #pragma unroll
-        for(int rp = 0; rp < 2; ++rp) {
-          float t[2][4][G];      // [row of the pair][tap][channel of the group]
+        for(int row = 0; row < 4; ++row) {
+          float t[4][G];      // [tap][channel of the group] of this row
           // ONE load path for a hit and a miss — the address is the cached piece or the descriptor's tap — so that the two cases do not hold two
           // sets of tap registers; cached footprint: piece (row * 4 + tap) * 2 + half for C = 8 (32 pieces), piece = row for C = 1 (its four taps)
           if constexpr(C == 8 && G == 8) {
-            const float4* const cb = tc + tile_index<PIECES>(i, 0);      // piece p of point i: cb + p * kTile
+            // the row's eight 16-byte loads from ONE per-lane base and two per-lane strides — cached: piece (row * 4 + tap) * 2 + half at
+            // cb + piece * kTile; gathered: tap m at the row's record + 32 m bytes — formed row by row (the asm keeps the compiler from
+            // materialising all 32 piece addresses of the footprint ahead of the first load: 64 registers)
+            const char* rb = hit ? reinterpret_cast<const char*>(tc + tile_index<PIECES>(i, 0)) + (size_t) row * 8 * kTile * 16
+                                 : reinterpret_cast<const char*>(j.desc + row_off[row]);
+            asm volatile("" : "+v"(rb));
+            const unsigned tap_stride = hit ? 2u * kTile * 16u : 32u, half_off = hit ? kTile * 16u : 16u;
 #pragma unroll
-            for(int k = 0; k < 2; ++k)
+            for(int m = 0; m < 4; ++m) {
+              const float4 lo = *reinterpret_cast<const float4*>(rb + m * tap_stride), hi = *reinterpret_cast<const float4*>(rb + m * tap_stride + half_off);
+              t[m][0] = lo.x; t[m][1] = lo.y; t[m][2] = lo.z; t[m][3] = lo.w; t[m][4] = hi.x; t[m][5] = hi.y; t[m][6] = hi.z; t[m][7] = hi.w;
+            }
+            if(cached && !hit && in_block) {
+              char* wb = reinterpret_cast<char*>(tc + tile_index<PIECES>(i, 0)) + (size_t) row * 8 * kTile * 16;
 #pragma unroll
               for(int m = 0; m < 4; ++m) {
-                const int pc = ((2 * rp + k) * 4 + m) * 2;
-                const float4* g4 = reinterpret_cast<const float4*>(j.desc + row_off[2 * rp + k] + (size_t) m * PT);
-                const float4 lo = *(hit ? cb + (size_t) pc * kTile : g4), hi = *(hit ? cb + (size_t) (pc + 1) * kTile : g4 + 1);
-                t[k][m][0] = lo.x; t[k][m][1] = lo.y; t[k][m][2] = lo.z; t[k][m][3] = lo.w; t[k][m][4] = hi.x; t[k][m][5] = hi.y; t[k][m][6] = hi.z; t[k][m][7] = hi.w;
+                *reinterpret_cast<float4*>(wb + (size_t) (2 * m) * kTile * 16) = make_float4(t[m][0], t[m][1], t[m][2], t[m][3]);
+                *reinterpret_cast<float4*>(wb + (size_t) (2 * m + 1) * kTile * 16) = make_float4(t[m][4], t[m][5], t[m][6], t[m][7]);
               }
-            if(cached && !hit && in_block) {
-              float4* const cw = tc + tile_index<PIECES>(i, 0);
-#pragma unroll
-              for(int k = 0; k < 2; ++k)
-#pragma unroll
-                for(int m = 0; m < 4; ++m) {
-                  const int pc = ((2 * rp + k) * 4 + m) * 2;
-                  cw[(size_t) pc * kTile] = make_float4(t[k][m][0], t[k][m][1], t[k][m][2], t[k][m][3]);
-                  cw[(size_t) (pc + 1) * kTile] = make_float4(t[k][m][4], t[k][m][5], t[k][m][6], t[k][m][7]);
-                }
             }
           } else if constexpr(C == 1) {
             const float* const cb = reinterpret_cast<const float*>(tc + tile_index<PIECES>(i, 0));      // row r of point i: cb + r * kTile * 4
 #pragma unroll
-            for(int k = 0; k < 2; ++k)
-#pragma unroll
-              for(int m = 0; m < 4; ++m)
-                t[k][m][0] = *(hit ? cb + (size_t) (2 * rp + k) * kTile * 4 + m : j.desc + row_off[2 * rp + k] + m);
-            if(cached && !hit && in_block) {
-              float4* const cw = tc + tile_index<PIECES>(i, 0);
-#pragma unroll
-              for(int k = 0; k < 2; ++k) cw[(size_t) (2 * rp + k) * kTile] = make_float4(t[k][0][0], t[k][1][0], t[k][2][0], t[k][3][0]);
-            }
+            for(int m = 0; m < 4; ++m) t[m][0] = *(hit ? cb + (size_t) row * kTile * 4 + m : j.desc + row_off[row] + m);
+            if(cached && !hit && in_block) (tc + tile_index<PIECES>(i, 0))[(size_t) row * kTile] = make_float4(t[0][0], t[1][0], t[2][0], t[3][0]);
           } else {
 #pragma unroll
-            for(int k = 0; k < 2; ++k)
-#pragma unroll
-              for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[2 * rp + k] + (size_t) m * PT + c0, t[k][m]);
+            for(int m = 0; m < 4; ++m) load_group<G>(j.desc + row_off[row] + (size_t) m * PT + c0, t[m]);
           }
 #pragma unroll
-          for(int k = 0; k < 2; ++k)
-#pragma unroll
-            for(int q = 0; q < G; ++q) {
-              if constexpr(interp == BPVO_INTERP_CUBIC) d[2 * rp + k][q] = dot4(t[k][0][q], t[k][1][q], t[k][2][q], t[k][3][q], Cx);
-              else d[2 * rp + k][q] = interp_hermite(t[k][0][q], t[k][1][q], t[k][2][q], t[k][3][q], xf);
-            }
-          if(rp == 0) __builtin_amdgcn_sched_barrier(0);      // rows 2, 3 are requested behind the x pass of rows 0, 1
+          for(int q = 0; q < G; ++q) {
+            if constexpr(interp == BPVO_INTERP_CUBIC) d[row][q] = dot4(t[0][q], t[1][q], t[2][q], t[3][q], Cx);
+            else d[row][q] = interp_hermite(t[0][q], t[1][q], t[2][q], t[3][q], xf);
+          }
+          if(ROW_BARRIER_AT < 0 ? row < 3 : row == ROW_BARRIER_AT) __builtin_amdgcn_sched_barrier(0);      // the next rows are requested behind the x pass of these
         }
 #pragma unroll
         for(int q = 0; q < G; ++q) {
