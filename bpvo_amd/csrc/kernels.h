@@ -80,7 +80,7 @@ void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, siz
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level, int num_levels,
                           int* out /*[nframes][kMaxLevels]*/);
 void launch_normalization(hipStream_t s, const FrameJob* jobs /*[L][job_pitch]*/, int job_pitch, int nframes, int first_level,
-                          int num_levels, int with_normalization, int dpp_asm = 1);   // dpp_asm: the hand-scheduled DPP add chains (kernels_frame.hip nrm_add_batch) or the compiler's form: same sums
+                          int num_levels, int with_normalization, int form = 1);   // form of the sequential sums (same sums): 1 hand-scheduled DPP add chains, 0 the compiler's DPP form, 2 broadcast LDS reads + plain adds
 void launch_export_jacobians(hipStream_t s, const FrameJob* job /*device, one job*/, int C, int n, float* out /*[C*n][6]*/);
 void launch_template_build(hipStream_t s, const FrameJob* jobs, int C, int max_points, int nframes, int grad_cd5, const float gauss_k[3], int nlevels = 1,
                            int job_pitch = 0);   // gauss_k: the bit-planes blur taps (lazy levels)

@@ -1115,7 +1115,30 @@ __device__ __forceinline__ void nrm_add_batch(float& acc, const float (&v)[4])
   nrm_add_row_c<0>(acc, v);
 }
 constexpr int NRM_THREADS = 256, NRM_CHUNK = 512;   // 20 KB of LDS: seven workgroups per CU (1024-point chunks: three; 0.93 -> 0.59 ms per 1024-pair step)
-template <bool ASM>
+// FORM 2: no cross-lane traffic at all — the chunk is staged in LDS component by component, every lane of a row reads the SAME four consecutive
+// elements of its row's component with one ds_read_b128 (a broadcast), and the chain is four plain dependent v_add_f32 per read.  Plain C++: no
+// hazard assumption, nothing a toolchain can break — the portable form, and the third voice of the bit-identity test — but measured SLOWER than the
+// DPP chains (310 against 170 us for a 1241x376 template, 4.0 against 2.2 ms for a dense 640x480 one: scripts/nrm_forms.py), so FORM 1 (asm DPP
+// chains, gfx950) stays the default and FORM 0 (the compiler's DPP form) the fallback for other targets.
+template <int FORM>
+__device__ __forceinline__ void nrm_chain_b128(float& acc, const float4* __restrict__ sp, int n4)
+{
+  // n4 float4 (a multiple of 4: chunks hold multiples of 16 points) added in element order; the next four reads are in flight under these adds
+  float4 a[4], b[4];
+#pragma unroll
+  for(int q = 0; q < 4; ++q) { a[q] = sp[q]; b[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+  for(int k = 0; k < n4; k += 4) {
+    if(k + 4 < n4) {
+#pragma unroll
+      for(int q = 0; q < 4; ++q) b[q] = sp[k + 4 + q];
+    }
+#pragma unroll
+    for(int q = 0; q < 4; ++q) { acc += a[q].x; acc += a[q].y; acc += a[q].z; acc += a[q].w; }
+#pragma unroll
+    for(int q = 0; q < 4; ++q) a[q] = b[q];
+  }
+}
+template <int FORM>
 __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
                                                                     int with_normalization)
 {
@@ -1130,8 +1153,14 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
   // wave 0 then adds them strictly in point order, in batches of 64.  (a) Row r of wave 0 keeps the chain of component r, (b) the
   // global loads of chunk i + 1 are in flight while chunk i is being added (registers -> the other LDS buffer afterwards), and (c) in
   // the second pass every thread forms the distances of chunk i + 1 while wave 0 accumulates those of chunk i.  Same order, same roundings.
-  __shared__ float4 s_pts[2][NRM_CHUNK];
+  constexpr bool ASM = FORM == 1;
+  __shared__ float4 s_pts[2][NRM_CHUNK];      // FORM 2: the same 16 KB as s_comp[2][4][NRM_CHUNK], component by component
   __shared__ __align__(16) float s_dist[2][NRM_CHUNK];
+  float (*s_comp)[4][NRM_CHUNK] = reinterpret_cast<float (*)[4][NRM_CHUNK]>(&s_pts[0][0]);
+  auto stage = [&](int buf, int k, const float4& p) {
+    if constexpr(FORM == 2) { s_comp[buf][0][k] = p.x; s_comp[buf][1][k] = p.y; s_comp[buf][2][k] = p.z; s_comp[buf][3][k] = p.w; }
+    else s_pts[buf][k] = p;
+  };
   __shared__ float s_c[4];
   constexpr int PER = NRM_CHUNK / NRM_THREADS;     // points per thread and chunk
   const int nchunks = (N + NRM_CHUNK - 1) / NRM_CHUNK;
@@ -1147,14 +1176,16 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
   };
   fetch(0);
 #pragma unroll
-  for(int q = 0; q < PER; ++q) s_pts[0][q * NRM_THREADS + tid] = pre[q];
+  for(int q = 0; q < PER; ++q) stage(0, q * NRM_THREADS + tid, pre[q]);
   __syncthreads();
   float c = 0.0f;
   for(int ch = 0; ch < nchunks; ++ch) {
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) fetch(ch + 1);
-    if(tid < 64) {
+    if constexpr(FORM == 2) {
+      if(tid < 64) nrm_chain_b128<FORM>(c, reinterpret_cast<const float4*>(s_comp[cur][row]), cnt / 4);
+    } else if(tid < 64) {
       const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + row + 16 * li;      // component `row` of point 4 li of a batch
       float v[4], nx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -1172,7 +1203,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     }
     if(ch + 1 < nchunks) {
 #pragma unroll
-      for(int q = 0; q < PER; ++q) s_pts[cur ^ 1][q * NRM_THREADS + tid] = pre[q];
+      for(int q = 0; q < PER; ++q) stage(cur ^ 1, q * NRM_THREADS + tid, pre[q]);
     }
     __syncthreads();
   }
@@ -1200,7 +1231,9 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) dists(ch + 1);
-    if(tid < 64) {
+    if constexpr(FORM == 2) {
+      if(tid < 64) nrm_chain_b128<FORM>(m, reinterpret_cast<const float4*>(s_dist[cur]), cnt / 4);
+    } else if(tid < 64) {
       float4 d4 = *reinterpret_cast<const float4*>(&s_dist[cur][4 * li]), n4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       __builtin_amdgcn_s_waitcnt(0xc07f);
       for(int b = 0; b < cnt; b += 64) {
@@ -1537,14 +1570,12 @@ void launch_copy_rows(hipStream_t s, void* dst, const void* src_host_pinned, siz
                      (const unsigned long long*) src_host_pinned, pitch_bytes / 8, width_bytes / 8, rows);
 }
 void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels,
-                          int with_normalization, int dpp_asm)
+                          int with_normalization, int form)
 {
-  if(dpp_asm)
-    hipLaunchKernelGGL(normalization_kernel<true>, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
-                       with_normalization);
-  else
-    hipLaunchKernelGGL(normalization_kernel<false>, dim3(nframes, num_levels - first_level), dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level,
-                       with_normalization);
+  const dim3 grid(nframes, num_levels - first_level);
+  if(form == 2) hipLaunchKernelGGL(normalization_kernel<2>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
+  else if(form == 1) hipLaunchKernelGGL(normalization_kernel<1>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
+  else hipLaunchKernelGGL(normalization_kernel<0>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
 }
 void launch_gather_counts(hipStream_t s, const FrameJob* jobs, int job_pitch, int nframes, int first_level, int num_levels, int* out)
 {

@@ -386,8 +386,10 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
  *   "normalization_side_stream" 1      a frame stage that runs alone on the context's stream (single frames, batches on one lane) queues the
  *                                      Hartley normalisation sums on a stream of its own, next to template_build, and joins them before it returns
- *   "normalization_dpp_asm"  1         the sequential (reference-order) Hartley sums as hand-scheduled DPP add chains; 0: the compiler's form of the same adds
- *                                      (same sums bit for bit — tests/test_gpu_parity.py runs one against the other; ~2 x slower)
+ *   "normalization_form"     1         the sequential (reference-order) Hartley sums: 1 = hand-scheduled DPP add chains (170 us for a 1241x376 template); 0 = the
+ *                                      compiler's DPP form (274 us); 2 = every lane of a row reads the same four consecutive elements from LDS and adds them
+ *                                      with plain adds — no cross-lane traffic, no asm (310 us).  Same sums bit for bit: tests/test_gpu_parity.py runs the
+ *                                      three against each other
  *   "normalization_deferred" 1         ... and inside bpvo_hip_batch_run on one lane (not the team kernel) only the coarsest level's sums are joined:
  *                                      the others run on under that level's Gauss-Newton iterations, the estimation waits for them before its second level
  *   "team_split_max_pairs"   4         ... and team batches of up to this many pairs run the coarsest level of every pair in a launch of its own, the

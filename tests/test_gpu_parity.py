@@ -1202,20 +1202,21 @@ def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotati
 @pytest.mark.parametrize("rows,cols,levels", [pytest.param(120, 160, 3, id="160x120-L3"), pytest.param(376, 1241, 4, id="kitti-1241x376-L4"),
                                               pytest.param(243, 651, 3, id="651x243-L3-ragged")])
 def test_normalisation_sums_hand_scheduled_against_the_compilers_form(hip, rows, cols, levels):
-    """The Hartley sums (bpvo/warps.cc:27-48) are sequential f32 additions; the default kernel issues them as back-to-back DPP adds without the
-    wait states the compiler's hazard table inserts (kernels_frame.hip nrm_add_batch).  Option "normalization_dpp_asm" = 0 runs the compiler's
-    form of the same chains: T_n / T_n^-1 of every level, and every pose built on them, must be the same bits — a toolchain or hardware
-    change that invalidates the hand-scheduled form fails here (and against the oracle in test_template_bit_exact)."""
+    """The Hartley sums (bpvo/warps.cc:27-48) are sequential f32 additions.  Option "normalization_form": 1 (the default) back-to-back DPP adds without
+    the wait states the compiler's hazard table inserts (kernels_frame.hip nrm_add_batch), 0 the compiler's form of those chains, 2 broadcast LDS
+    reads + plain adds (no cross-lane traffic, no asm): T_n / T_n^-1 of every level, and every pose built on them, must be the same bits in all three — a toolchain
+    or hardware change that invalidates the hand-scheduled form fails here (and the default against the oracle in test_template_bit_exact)."""
     outs = []
-    for asm in (1, 0):
+    for asm in (2, 1, 0):
         ch, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss="tukey")
-        ch.set_option("normalization_dpp_asm", asm)
+        ch.set_option("normalization_form", asm)
         ch.frame_set_template(0)
         outs.append(([np.stack(ch.get_normalization(0, l)) for l in range(levels)], ch.estimate_pose(0, 0, 1)[0]))
         ch.close()
-    for l in range(levels):
-        assert bits_equal(outs[0][0][l], outs[1][0][l]), l
-    assert bits_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:
+        for l in range(levels):
+            assert bits_equal(outs[0][0][l], o[0][l]), l
+        assert bits_equal(outs[0][1], o[1])
 
 
 def test_current_frames_of_a_pair_batch_keep_no_disparity_unless_asked(hip):
