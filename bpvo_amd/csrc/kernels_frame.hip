@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void select_words_write_kernel(const FrameJob*
 // whichever operand reads it; the hardware needs them for the operand that goes through the lane crossbar (src0: loaded from LDS here),
 // not for the accumulator on the ordinary port (the sums are compared bit for bit with the sequential sums of the CPU restatement at
 // every size the suite runs: tests/test_gpu_parity.py).  Both forms are built — the kernel takes the choice as a template parameter, the
-// context's option "normalization_dpp_asm" selects it, and tests/test_gpu_parity.py runs one against the other (a toolchain or hardware
+// context's option "normalization_form" selects it, and tests/test_gpu_parity.py runs one against the other (a toolchain or hardware
 // change that breaks the assumption shows there).  The hand-scheduled form is the default ONLY for the architecture it was measured on:
 // NRM_DPP_ASM = 0 (any other target, or a build that says so) makes the compiler's form the only one.
 #ifndef NRM_DPP_ASM
