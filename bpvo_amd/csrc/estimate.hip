@@ -146,7 +146,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
       if(te == hipSuccess) {
         // (the first launch's control words: its abort word and join count are looked at with the second's)
         LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl + 32, ln->d_team_ctl, sizeof(unsigned) * 32, hipMemcpyDeviceToHost, ln->stream));
-        LANE_CK(ln, hipMemsetAsync(ln->d_team_ctl, 0, sizeof(unsigned) * (size_t) gn_team_ctl_words(t.n_teams), ln->stream));
+        launch_team_ctl_reset_keep_abort(ln->stream, ln->d_team_ctl, t.n_teams);      // (a first launch that gave up: the second leaves at once)
       }
       if(int rcj = join_normalization()) return rcj;
       t.level_hi = c->L - 2; t.level_lo = p.maxTestLevel;

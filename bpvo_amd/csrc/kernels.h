@@ -196,6 +196,7 @@ struct GNTeamLaunch {
   int join_mode = 2;         // workgroups whose team has run out of pairs join the teams still at work: 0 never, 1 teams on their own XCD, 2 any team
 };
 int  gn_team_ctl_words(int n_teams);
+void launch_team_ctl_reset_keep_abort(hipStream_t s, unsigned* ctl, int n_teams);   // between the launches of a split run: every control word to 0 but the abort word
 int  gn_team_max_size();       // teams stop admitting newcomers at this size
 hipError_t launch_gn_team(hipStream_t s, const GNTeamLaunch& t, int max_iterations, int max_fun_evals, float p_tol, float f_tol, float g_tol);
 void launch_prepare_linearize(hipStream_t s, const PairJob* job, const float* T /*device [16]*/, int reset_scale, int level, float given_scale = 0.0f);

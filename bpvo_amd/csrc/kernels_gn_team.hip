@@ -590,6 +590,8 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_fixed_kernel(const PairJob
       member = b % team_size;
     }
   }
+  // (the second launch of a split run — estimate.hip — behind a first one that gave up: its abort word was carried over, nothing to do here)
+  if(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if(tid == 0) { pk_member = member; pk_nwg = team_size; }
   const bool stats_wg = member == 0;
   const bool fuse = kCanFuse && fuse_frozen;
@@ -1005,6 +1007,8 @@ __global__ __launch_bounds__(PK_THREADS) void gn_team_kernel(const PairJob* __re
       member = b % team_size;
     }
   }
+  // (the second launch of a split run behind a first one that gave up: its abort word was carried over, nothing to do here)
+  if(__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if(tid == 0) {
     pk_member = member; pk_nwg = team_size; pk_arrivals = 0u;
     pk_cfg.timeout = timeout; pk_cfg.abort_word = ctl + 1; pk_cfg.prm = prm; pk_cfg.n_pairs = n_pairs; pk_cfg.n_teams = n_teams; pk_cfg.team_size = team_size;
@@ -1125,6 +1129,18 @@ hipError_t launch_gn_persistent(hipStream_t s, const GNLaunch& g, int max_iterat
 }
 // ---- team-persistent kernel for small batches
 int gn_team_ctl_words(int n_teams) { return (1 + n_teams) * kTeamCtlWords; }
+// between the two launches of a split run: the control words back to zero — EXCEPT the abort word, so that a second launch behind a first one
+// that gave up at a barrier leaves at once instead of running every remaining level on states that were never written back
+__global__ void team_ctl_reset_keep_abort_kernel(unsigned* ctl, int words)
+{
+  for(int i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x)
+    if(i != 1) ctl[i] = 0u;
+}
+void launch_team_ctl_reset_keep_abort(hipStream_t s, unsigned* ctl, int n_teams)
+{
+  const int words = gn_team_ctl_words(n_teams);
+  hipLaunchKernelGGL(team_ctl_reset_keep_abort_kernel, dim3(std::max(1, std::min(64, (words + 255) / 256))), dim3(256), 0, s, ctl, words);
+}
 int gn_team_max_size() { return kTeamMaxSize; }
 template <int C>
 static hipError_t launch_gn_team_c(hipStream_t s, const GNTeamLaunch& t, const GNParams& prm)

@@ -230,6 +230,20 @@ def test_team_kernel_gives_up_cleanly(hip, monkeypatch):
     assert bits_equal(ref["poses2"], got["poses2"]) and bits_equal(ref["r"], got["r"]) and bits_equal(ref["w"], got["w"])
 
 
+def test_split_team_launch_gives_up_cleanly(hip, monkeypatch):
+    """Batches of up to team_split_max_pairs pairs run the team kernel in TWO launches (the coarsest level, then the others behind the deferred
+    normalisation).  A first launch that gives up at a barrier (budget 10 ns) hands its abort word on: the second launch leaves in its prologue
+    instead of running every remaining level on states that were never written back; the library reruns the batch on the chain.  Same results."""
+    rows, cols, levels, n = 120, 160, 3, 3
+    set_options(monkeypatch, team="0")
+    ref = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    set_options(monkeypatch, team="1", team_split_max_pairs="4", persist_timeout_ticks="1")
+    got = run_batch(hip, rows, cols, levels, n, "bitplanes", "tukey", first_index=31)
+    assert got["pk"][1] == 1 and got["team"] == 1          # launched once (two launches of one run), gave up, never tried again
+    assert bits_equal(ref["poses"], got["poses"]) and ref["stats"].tobytes() == got["stats"].tobytes()
+    assert bits_equal(ref["poses2"], got["poses2"]) and bits_equal(ref["r"], got["r"]) and bits_equal(ref["w"], got["w"])
+
+
 @pytest.mark.parametrize("n", [16, 40])
 @pytest.mark.parametrize("descriptor,loss", [("bitplanes", "tukey"), ("intensity", "huber")])
 def test_team_kernel_with_a_team_per_xcd(hip, n, descriptor, loss, monkeypatch):
