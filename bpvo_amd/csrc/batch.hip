@@ -299,10 +299,9 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   fr.defer_finest_nrm = !team_serves(c, n_pairs) || n_pairs <= c->team_split_max_pairs;      // (the team kernel: in two launches then, estimate.hip)
   rc = frames_set_template(c, 0, 2, n_pairs, fr);
   if(rc == BPVO_OK) rc = bpvo_hip_batch_estimate(c, n_pairs, nullptr, poses, stats);
-  if(c->nrm_pending) {      // (an error on the way: nothing of this call stays in flight)
-    (void) hipEventSynchronize(c->nrm_pending);
-    c->nrm_pending = nullptr;
-  }
+  // (an error on the way: nothing of this call stays in flight)
+  if(c->nrm_pending) { (void) hipEventSynchronize(c->nrm_pending); c->nrm_pending = nullptr; }
+  if(c->nrm_pending_finest) { (void) hipEventSynchronize(c->nrm_pending_finest); c->nrm_pending_finest = nullptr; }
   return rc;
 }
 int bpvo_hip_batch_result_records_device(bpvo_hip_ctx* c, const float** d_records, int* floats_per_pair)

@@ -163,6 +163,7 @@ PairJob make_pair_job(bpvo_hip_ctx* c, int ws, int ref, int cur, int l)
   if(ws == c->trace_ws) { j.trace = c->d_trace; j.trace_cap = c->trace_cap; }
   j.pitch = c->C;
   j.n_groups = c->G;
+  j.med_tot = (int) med_totals_at(c);
   return j;
 }
 
@@ -278,6 +279,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("persist_max_ws", persist_max_ws, 1, kPersistMaxWs),
     OPT_INT("persist_grid", persist_grid, 1, 128),
     OPT_INT("persist_max_points", persist_max_points, 0, 1 << 30),
+    OPT_INT("dense_candidates_from", dense_candidates_from, 0, 1 << 30),
     OPT_INT("persist_timeout_ticks", persist_timeout, 1, 1e15),
     OPT_INT("team", team_mode, 0, 1),
     OPT_INT("team_max_pairs", team_max_pairs, 0, 1 << 20),
@@ -585,8 +587,10 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
     CREATE_CK(hipMalloc((void**) &w.r, sizeof(float) * (size_t) cp->cap_max * cp->C));
     CREATE_CK(hipMalloc((void**) &w.valid, (size_t) cp->cap_max));
     // (channel groups: a group's candidate segments and bracket counters follow those of the group before it, whole 256-point chunks each)
-    CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * nblk_max * kChunkPoints * (size_t) cp->C));
-    CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * nblk_max * (size_t) cp->G));
+    // (+ kDenseRuns chunks: the dense form's runs are whole multiples of a chunk; + kDenseRuns lines of totals behind the chunks' counters)
+    CREATE_CK(hipMalloc((void**) &w.cand, sizeof(uint32_t) * (nblk_max + bpvo_hip::kDenseRuns) * kChunkPoints * (size_t) cp->C));
+    CREATE_CK(hipMalloc((void**) &w.med_blk, sizeof(uint32_t) * 4 * (med_totals_at(cp) + 8 * (size_t) bpvo_hip::kDenseRuns)));
+    CREATE_CK(hipMemset(w.med_blk + 4 * med_totals_at(cp), 0, sizeof(uint32_t) * 4 * 8 * bpvo_hip::kDenseRuns));      // (every finish leaves the totals at zero again)
     if(tap_cache) {      // tap cache of warp_residual: the footprint's taps x C floats per point (2 x 2; kCubic / kCubicHermite: 4 x 4), whole tiles
       const bool wide_taps = cp->params.interp == BPVO_INTERP_CUBIC || cp->params.interp == BPVO_INTERP_CUBIC_HERMITE;
       const size_t cap_tiles = ((size_t) cp->cap_max + kTile - 1) / kTile * kTile;
@@ -692,6 +696,7 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
     if(ln.owns_stream && ln.stream) (void) hipStreamDestroy(ln.stream);
   }
   if(c->side_stream) { (void) hipStreamSynchronize(c->side_stream); (void) hipStreamDestroy(c->side_stream); }
+  if(c->side_stream2) { (void) hipStreamSynchronize(c->side_stream2); (void) hipStreamDestroy(c->side_stream2); }
   for(auto e : c->side_ev) if(e) (void) hipEventDestroy(e);
   if(c->stream) (void) hipStreamDestroy(c->stream);
   delete c;

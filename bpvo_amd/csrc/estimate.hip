@@ -110,10 +110,16 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   bool team_ran = false;
   // the normalisation of the levels below the coarsest, of the template stage queued just before (frames.hip, ctx->nrm_pending), may still be
   // running on the context's side stream: this lane waits for it where the second level starts — the team kernel, every level in one launch, at once
-  auto join_normalization = [&]() -> int {
-    if(!c->nrm_pending) return BPVO_OK;
-    LANE_CK(ln, hipStreamWaitEvent(ln->stream, c->nrm_pending, 0));
-    c->nrm_pending = nullptr;
+  // (level: the pyramid level about to start — the finest level's own event is joined only there; < 0: everything)
+  auto join_normalization = [&](int level) -> int {
+    if(c->nrm_pending) {
+      LANE_CK(ln, hipStreamWaitEvent(ln->stream, c->nrm_pending, 0));
+      c->nrm_pending = nullptr;
+    }
+    if(c->nrm_pending_finest && (level < 0 || level <= p.maxTestLevel)) {
+      LANE_CK(ln, hipStreamWaitEvent(ln->stream, c->nrm_pending_finest, 0));
+      c->nrm_pending_finest = nullptr;
+    }
     return BPVO_OK;
   };
   bool team_split = false;
@@ -123,9 +129,9 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     // for a 1241x376 frame, whatever the batch) then run under the coarsest level's iterations instead of in front of the first one;
     // larger batches join them here, at once: a launch boundary makes every pair wait for the slowest (measured: 2 / 4 pairs + 1.2 / + 1.5 %,
     // 8 / 16 / 32 / 64 pairs - 5 / - 7 / - 4 / - 6 %: option "team_split_max_pairs", 4).
-    team_split = c->nrm_pending != nullptr && n <= c->team_split_max_pairs && c->L - 1 > p.maxTestLevel;
+    team_split = (c->nrm_pending != nullptr || c->nrm_pending_finest != nullptr) && n <= c->team_split_max_pairs && c->L - 1 > p.maxTestLevel;
     if(!team_split)
-      if(int rcj = join_normalization()) return rcj;
+      if(int rcj = join_normalization(-1)) return rcj;
     GNTeamLaunch t;
     t.jobs_all = ln->d_pjobs; t.job_pitch = NP; t.n_pairs = n; t.level_hi = c->L - 1; t.level_lo = p.maxTestLevel;
     t.C = c->C; t.loss = p.lossFunction; t.fuse_frozen = c->fuse_frozen;
@@ -148,7 +154,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
         LANE_CK(ln, hipMemcpyAsync(ln->h_team_ctl + 32, ln->d_team_ctl, sizeof(unsigned) * 32, hipMemcpyDeviceToHost, ln->stream));
         launch_team_ctl_reset_keep_abort(ln->stream, ln->d_team_ctl, t.n_teams);      // (a first launch that gave up: the second leaves at once)
       }
-      if(int rcj = join_normalization()) return rcj;
+      if(int rcj = join_normalization(-1)) return rcj;
       t.level_hi = c->L - 2; t.level_lo = p.maxTestLevel;
       if(te == hipSuccess) te = launch_gn_team(ln->stream, t, p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance);
     } else {
@@ -175,6 +181,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     g.fuse_frozen = fuse_frozen;
     g.step_in_reduce = (n <= c->step_in_reduce_max && !ref_mode && c->G == 1) ? 1 : 0;
     g.reference_reduction = ref_mode ? 1 : 0;
+    g.dense_candidates = dense_candidates(c, g.max_points);
     g.step_prm = GNParams{p.maxIterations, max_fun_evals, p.parameterTolerance, p.functionTolerance, p.gradientTolerance};
     return g;
   };
@@ -184,7 +191,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
   for(int l = c->L - 1; l >= p.maxTestLevel && !team_ran; --l) {
     GNLaunch g = level_launch(l);
     if(l < c->L - 1)
-      if(int rcj = join_normalization()) return rcj;
+      if(int rcj = join_normalization(l)) return rcj;
     const bool was_begun = begun;
     begun = false;
     if(!was_begun) launch_level_begin(ln->stream, g.jobs, n, g.max_points, l, l2_moot ? 1 : 0);    // (and the tap-cache keys of the level)
@@ -365,7 +372,7 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
   // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
   if(nl > 1) {
-    if(c->nrm_pending) { HIP_CK(c, hipStreamWaitEvent(c->stream, c->nrm_pending, 0)); c->nrm_pending = nullptr; }
+    HIP_CK(c, join_pending_normalization(c, c->stream));
     HIP_CK(c, hipStreamSynchronize(c->stream));
   }
   std::vector<int> rcs(nl, BPVO_OK);
@@ -555,6 +562,7 @@ static int linearize_impl(bpvo_hip_ctx* c, int ws, int ref_slot, int cur_slot, i
   g.fast_warp = c->fast_warp;
   g.interp = c->params.interp;
   g.reference_reduction = c->reference_reduction ? 1 : 0;
+  g.dense_candidates = dense_candidates(c, g.max_points);
   launch_reset_tapkeys(c->stream, g);
   { ScopedTimer t(c, KC_WARP_RESIDUAL, 0.0); for_each_group(c, g, 1, [&](const GNLaunch& gg) { launch_warp_residual(c->stream, gg); }); }
   { ScopedTimer t(c, KC_MEDIAN, 0.0); launch_median(c->stream, median_launch(c, g)); }

@@ -180,6 +180,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   if(c->nrm_side_stream && !fr.own_thread && fr.ln == &c->lanes[0] && counts_ev) {
     if(!c->side_stream) {
       FR_CK(c, fr, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      FR_CK(c, fr, hipStreamCreateWithFlags(&c->side_stream2, hipStreamNonBlocking));
       for(auto& e : c->side_ev) FR_CK(c, fr, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     side = c->side_stream;
@@ -189,7 +190,7 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
   // 1241x376 frame, 0.17 ms — are needed when the Gauss-Newton iterations leave the coarsest level: ctx->nrm_pending, waited for by the
   // estimation just before its second level (estimate.hip).
   const int with_nrm = c->dspace ? 0 : p.withNormalization;      // DisparitySpaceWarp::setNormalization is a no-op (bpvo/disparity_space_warp.h:87-90)
-  const bool defer = side && fr.defer_finest_nrm && c->nrm_defer && c->L - p.maxTestLevel > 1 && !c->nrm_pending;
+  const bool defer = side && fr.defer_finest_nrm && c->nrm_defer && c->L - p.maxTestLevel > 1 && !c->nrm_pending && !c->nrm_pending_finest;
   if(one_launch) {
     double px = 0;
     for(int l = p.maxTestLevel; l < c->L; ++l) px += (double) c->geom[l].npix * count;
@@ -209,11 +210,19 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
     FR_CK(c, fr, hipStreamWaitEvent(side, c->side_ev[0], 0));
     // (timed like the in-line form, with events on the side stream: they are resolved once this stream — which the side stream joins — is synchronised)
     if(defer) {
+      // the finest level first, on its own stream (the longest chain of adds starts at once); the coarsest, then the levels between, on the other
+      hipStream_t side2 = c->side_stream2;
+      FR_CK(c, fr, hipStreamWaitEvent(side2, c->side_ev[0], 0));
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side2); launch_normalization(side2, tab, NF, count, p.maxTestLevel, p.maxTestLevel + 1, with_nrm, c->nrm_dpp_asm); }
+      FR_CK(c, fr, hipEventRecord(c->side_ev[3], side2));
+      c->nrm_pending_finest = c->side_ev[3];
       { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, c->L - 1, c->L, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
-      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L - 1, with_nrm, c->nrm_dpp_asm); }
-      FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
-      c->nrm_pending = c->side_ev[2];
+      if(c->L - 1 > p.maxTestLevel + 1) {
+        { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel + 1, c->L - 1, with_nrm, c->nrm_dpp_asm); }
+        FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
+        c->nrm_pending = c->side_ev[2];
+      }
     } else {
       { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));

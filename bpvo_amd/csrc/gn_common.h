@@ -106,8 +106,15 @@ __device__ __forceinline__ int active_workspace(const ActiveSet& a, int k) { ret
 // Generalised form: `blk` is the chunk (the blockIdx.x of warp_residual), `wave` the wavefront inside the 256-thread chunk, `s` the
 // chunk's LDS scratch; `write` = false for a chunk past the end that only keeps its threads in step (persistent kernel).  All
 // threads of the WORKGROUP must call it (it holds a __syncthreads).
-struct BracketLds { unsigned in[K6_WAVES], below[K6_WAVES], valid[K6_WAVES]; };
-template <int C>
+// DENSE (chain launches over templates of many points, GNLaunch::dense_candidates): chunk b belongs to run b mod 64 of the workspace; its
+// leader adds the chunk's four counts to the run's totals (two 64-bit adds: {inside | below << 32}, {valid points | tap-cache hits << 32};
+// every run's totals on a 128-byte line of their own, entry med_tot + 8 * run of med_blk) and the returning add gives the chunk its place
+// in the run's contiguous candidates, cand[run * dense_run_cap ...].  The finish then reads 64 totals and 64 arrays instead of a
+// thousand counters and segments.  (One run for all chunks: a thousand returning adds on one address, 50 us.)  The order inside a run
+// differs from launch to launch; the order statistics selected from the candidates do not.
+__device__ __forceinline__ unsigned dense_run_cap(int n, int C) { return (unsigned) ((((n + K6_BLOCK - 1) / K6_BLOCK) + kDenseRuns - 1) / kDenseRuns) * (unsigned) (K6_BLOCK * C); }
+struct BracketLds { unsigned in[K6_WAVES], below[K6_WAVES], valid[K6_WAVES], base; };
+template <int C, bool DENSE = false>
 __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C],
                                               unsigned blk, int wave, BracketLds& s, bool write)
 {
@@ -133,6 +140,7 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
   const unsigned sum_below = wave_sum_u32(below);
   const unsigned sum_valid = wave_sum_u32((v ? 1u : 0u) | (hit ? 0x10000u : 0u));      // valid points | tap-cache hits << 16 (wave-uniform results)
   unsigned woff = 0;
+  static_assert(!DENSE || K6_WAVES > 1, "the dense form hands the run's offset through the chunk's LDS scratch");
   if constexpr(K6_WAVES == 1) {     // one wavefront per workgroup: no LDS, no barrier
     const unsigned t_in = (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
     if(lane == 0 && write) reinterpret_cast<uint4*>(j.med_blk.get())[blk] = make_uint4(sum_below, t_in, sum_valid & 0xffffu, sum_valid >> 16);
@@ -144,11 +152,20 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
     if(wave == 0 && lane == 0 && write) {
       uint4 o = make_uint4(0u, 0u, 0u, 0u);
       for(int w = 0; w < K6_WAVES; ++w) { o.x += s.below[w]; o.y += s.in[w]; o.z += s.valid[w] & 0xffffu; o.w += s.valid[w] >> 16; }
-      reinterpret_cast<uint4*>(j.med_blk.get())[blk] = o;
+      if constexpr(DENSE) {
+        const unsigned run = blk & (unsigned) (kDenseRuns - 1);
+        unsigned long long* tot = reinterpret_cast<unsigned long long*>(j.med_blk.get() + 4 * ((size_t) j.med_tot + 8 * run));
+        const unsigned long long old = atomicAdd(tot, (unsigned long long) o.y | ((unsigned long long) o.x << 32));
+        atomicAdd(tot + 1, (unsigned long long) o.z | ((unsigned long long) o.w << 32));
+        s.base = run * dense_run_cap(j.n, C) + (unsigned) old;
+      } else {
+        reinterpret_cast<uint4*>(j.med_blk.get())[blk] = o;
+      }
     }
   }
+  if constexpr(DENSE) __syncthreads();      // (the leader's returning add)
   if(cnt) {
-    unsigned* seg = j.cand + (size_t) blk * K6_BLOCK * C;
+    unsigned* seg = DENSE ? j.cand + s.base : j.cand + (size_t) blk * K6_BLOCK * C;
     unsigned pos = woff + incl - cnt;
 #pragma unroll
     for(int c = 0; c < C; ++c)
@@ -158,10 +175,11 @@ __device__ __forceinline__ void bracket_chunk(const PairJob& j, unsigned lo, uns
 
 // the form warp_residual uses: one 256-thread workgroup = one chunk
 template <int C>
-__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C])
+__device__ __forceinline__ void bracket_block(const PairJob& j, unsigned lo, unsigned hi, bool v, bool hit, const float (&res)[C], bool dense)
 {
   __shared__ BracketLds s;
-  bracket_chunk<C>(j, lo, hi, v, hit, res, blockIdx.x, (int) (threadIdx.x >> 6), s, true);
+  if(dense) bracket_chunk<C, true>(j, lo, hi, v, hit, res, blockIdx.x, (int) (threadIdx.x >> 6), s, true);
+  else bracket_chunk<C, false>(j, lo, hi, v, hit, res, blockIdx.x, (int) (threadIdx.x >> 6), s, true);
 }
 
 }  // namespace bpvo_hip

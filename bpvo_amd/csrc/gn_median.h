@@ -100,13 +100,25 @@ __device__ __forceinline__ void for_each_valid_key(const PairJob& j, F f)
       }
     }
   } else {
-    for(int p4 = threadIdx.x * 4; p4 < n; p4 += NT * 4) {   // n is a multiple of 16
-      const uchar4 v = *reinterpret_cast<const uchar4*>(j.valid + p4);
-      const float4 a = *reinterpret_cast<const float4*>(j.r + p4);
-      if(v.x) f(__float_as_uint(a.x) & 0x7fffffffu, p4 + 0);
-      if(v.y) f(__float_as_uint(a.y) & 0x7fffffffu, p4 + 1);
-      if(v.z) f(__float_as_uint(a.z) & 0x7fffffffu, p4 + 2);
-      if(v.w) f(__float_as_uint(a.w) & 0x7fffffffu, p4 + 3);
+    constexpr int U = 4;      // 16 points in flight per thread: a dense level (NMS off: 300 k points) is 18 rounds of this, each one memory latency
+    for(int base = threadIdx.x * 4; base < n; base += NT * 4 * U) {   // n is a multiple of 16
+      uchar4 v[U];
+      float4 a[U];
+#pragma unroll
+      for(int u = 0; u < U; ++u) {
+        const int p4 = base + u * NT * 4;
+        const bool in = p4 < n;
+        v[u] = in ? *reinterpret_cast<const uchar4*>(j.valid + p4) : make_uchar4(0, 0, 0, 0);
+        a[u] = in ? *reinterpret_cast<const float4*>(j.r + p4) : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for(int u = 0; u < U; ++u) {
+        const int p4 = base + u * NT * 4;
+        if(v[u].x) f(__float_as_uint(a[u].x) & 0x7fffffffu, p4 + 0);
+        if(v[u].y) f(__float_as_uint(a[u].y) & 0x7fffffffu, p4 + 1);
+        if(v[u].z) f(__float_as_uint(a[u].z) & 0x7fffffffu, p4 + 2);
+        if(v[u].w) f(__float_as_uint(a[u].w) & 0x7fffffffu, p4 + 3);
+      }
     }
   }
 }
@@ -168,7 +180,7 @@ __device__ __forceinline__ void refine_pass(Src&& src, unsigned shift, unsigned 
 // COPIES privatised pass-1 histograms (a power of two >= 2: the second one doubles as the segment-offset table of the bracketed path),
 // CACHE words of key cache: the LDS footprint is ((COPIES + 1) * MED_BINS + CACHE + 24) words.
 template <int C, int NT, int COPIES = MED_COPIES, int CACHE = MED_CACHE>
-__device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsigned char* smem_raw, bool stats)
+__device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsigned char* smem_raw, bool stats, bool dense = false)
 {
   unsigned* hist_lo = reinterpret_cast<unsigned*>(smem_raw);              // [COPIES][MED_BINS]
   unsigned* hist_hi = hist_lo + COPIES * MED_BINS;                    // [MED_BINS]
@@ -181,6 +193,11 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
   float median = 0.0f;
   unsigned n_total = 0;
   bool done = false;
+#ifdef MED_DEBUG
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_t1 = dbg_t0, dbg_t2 = dbg_t0;
+  unsigned dbg_m = 0, dbg_lds = 0, dbg_nbits = 0, dbg_nlo = 0;
+#endif
   unsigned tap_hits = 0, tap_lookups = 0;      // tap-cache statistics of this linearisation's warp_residual pass (bracket counters)
 
   // ---- bracketed path
@@ -190,13 +207,23 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     // groups x valid points, and C x that is every valid entry, as below)
     const int nblk = ((j.n + K6_BLOCK - 1) / K6_BLOCK) * j.n_groups;
     unsigned c_below = 0, c_in = 0, c_valid = 0, c_hit = 0, cnt_first = 0;    // cnt_first: candidates of segment `tid`
-    for(int b = tid; b < nblk; b += NT) {
-      const uint4 o = reinterpret_cast<const uint4*>(j.med_blk.get())[b];
-      if(b == tid) cnt_first = o.y;
-      c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
+    if(!dense) {
+      for(int b = tid; b < nblk; b += NT) {
+        const uint4 o = reinterpret_cast<const uint4*>(j.med_blk.get())[b];
+        if(b == tid) cnt_first = o.y;
+        c_below += o.x; c_in += o.y; c_valid += o.z; c_hit += o.w;
+      }
     }
     unsigned t_below, t_in, t_valid;
-    {   // four block sums with one LDS round
+    unsigned run_incl = 0;      // dense form: inclusive scan of the runs' candidate counts (lane = run)
+    if(dense) {   // the totals the chunks' leaders added up, run by run (bracket_chunk<C, true>); wave 0 clears them at the end
+      static_assert(kDenseRuns == 64, "one run per lane");
+      const uint4 o = reinterpret_cast<const uint4*>(j.med_blk.get())[j.med_tot + 8 * (tid & 63)];      // {inside, below, valid points, tap-cache hits}
+      run_incl = wave_incl_scan_u32(o.x);
+      t_in = (unsigned) __builtin_amdgcn_readlane((int) run_incl, 63);
+      t_below = wave_sum_u32(o.y); t_valid = wave_sum_u32(o.z); tap_hits = wave_sum_u32(o.w);
+      tap_lookups = j.tapcache_on ? t_valid : 0u;
+    } else {   // four block sums with one LDS round
       c_below = wave_sum_u32(c_below); c_in = wave_sum_u32(c_in); c_valid = wave_sum_u32(c_valid); c_hit = wave_sum_u32(c_hit);
       __syncthreads();
       if((tid & 63) == 0) { unsigned* w4 = cache + (tid >> 6) * 4; w4[0] = c_below; w4[1] = c_in; w4[2] = c_valid; w4[3] = c_hit; }
@@ -221,9 +248,42 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
       // candidates or segments for the LDS areas: the segment walk from global memory (same keys, same result).
       unsigned* s_off = hist_lo + MED_BINS;                              // [nblk + 1] — refine_pass only uses the first MED_BINS words of hist_lo
       constexpr unsigned kListRoom = 2u * (unsigned) NT;                  // cache[0 .. 2 NT): lists of the ranking step
-      unsigned* dense = cache + kListRoom;
-      const bool in_lds = m <= (unsigned) CACHE - kListRoom && nblk < (COPIES - 1) * MED_BINS;
-      if(in_lds) {
+      unsigned* dense_keys = cache + kListRoom;
+      const bool in_lds = m <= (unsigned) CACHE - kListRoom && (dense || nblk < (COPIES - 1) * MED_BINS);
+      const unsigned run_cap = dense_run_cap(j.n, C);
+      if(dense) {      // s_off[run .. run + 1]: the run's place among all candidates
+        if(tid < kDenseRuns) { s_off[tid + 1] = run_incl; if(tid == 0) s_off[0] = 0; }
+        __syncthreads();
+      }
+      // the dense form's candidates: every wave walks its runs, each a contiguous array (four loads in flight per lane)
+      auto for_each_dense = [&](auto f) {
+        const int lane = tid & 63;
+        for(int r = tid >> 6; r < kDenseRuns; r += NT / 64) {
+          const unsigned o0 = s_off[r], cnt = s_off[r + 1] - o0;
+          const unsigned* run = j.cand + (size_t) r * run_cap;
+          const uint4* run4 = reinterpret_cast<const uint4*>(run);      // (a run starts on a multiple of 256 C words and is a multiple of four long)
+          for(unsigned i0 = 4u * lane; i0 < cnt; i0 += 1024u) {
+            uint4 v[4];
+#pragma unroll
+            for(int u = 0; u < 4; ++u) v[u] = (i0 + 256u * u < cnt) ? run4[(i0 + 256u * u) >> 2] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for(int u = 0; u < 4; ++u) {
+              const unsigned i = i0 + 256u * u;
+              if(i + 0 < cnt) f(v[u].x - lo_key, o0 + i + 0);
+              if(i + 1 < cnt) f(v[u].y - lo_key, o0 + i + 1);
+              if(i + 2 < cnt) f(v[u].z - lo_key, o0 + i + 2);
+              if(i + 3 < cnt) f(v[u].w - lo_key, o0 + i + 3);
+            }
+          }
+        }
+      };
+#ifdef MED_DEBUG
+      dbg_m = m; dbg_lds = in_lds; dbg_nbits = nbits;
+#endif
+      if(in_lds && dense) {
+        for_each_dense([&](unsigned d, unsigned at) { dense_keys[at] = d; });
+        __syncthreads();
+      } else if(in_lds) {
         unsigned run = 0;                                                  // running offset of the chunks of NT segments
         for(int b0 = 0; b0 < nblk; b0 += NT) {
           const int b = b0 + tid;
@@ -256,14 +316,18 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
 #pragma unroll
           for(int u = 0; u < U; ++u) {
             const unsigned f = f0 + (unsigned) u * NT;
-            if(f < m) dense[f] = v[u] - lo_key;
+            if(f < m) dense_keys[f] = v[u] - lo_key;
           }
         }
         __syncthreads();
       }
       auto src = [&](auto f) {
         if(in_lds) {
-          for(unsigned i = tid; i < m; i += NT) f(dense[i]);
+          for(unsigned i = tid; i < m; i += NT) f(dense_keys[i]);
+          return;
+        }
+        if(dense) {
+          for_each_dense([&](unsigned d, unsigned) { f(d); });
           return;
         }
         const int lane = tid & 63, wave = tid >> 6;
@@ -273,6 +337,9 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
           for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
         }
       };
+#ifdef MED_DEBUG
+      dbg_t1 = wall_clock64();
+#endif
       unsigned remaining = nbits;
       bool first = true;
       while(remaining > 0) {
@@ -287,6 +354,9 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
         const unsigned dmask = (1u << width) - 1u;
         const unsigned n_lo = hist_lo[lo.prefix & dmask];
         const unsigned n_hi = was_split ? hist_hi[hi.prefix & dmask] : hist_lo[hi.prefix & dmask];
+#ifdef MED_DEBUG
+        dbg_t2 = wall_clock64(); dbg_nlo = n_lo;
+#endif
         if(n_lo > (unsigned) NT || n_hi > (unsigned) NT) continue;
         unsigned* list_lo = cache;                    // [NT]
         unsigned* list_hi = cache + NT;               // [NT]
@@ -387,6 +457,12 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     }
   }
 
+  if(dense && tid < kDenseRuns) reinterpret_cast<uint4*>(j.med_blk.get())[j.med_tot + 8 * tid] = make_uint4(0u, 0u, 0u, 0u);     // (every wave's reads lie before a barrier behind this one)
+#ifdef MED_DEBUG
+  if(tid == 0 && j.n > 100000)
+    printf("K7 n=%d done=%d m=%u in_lds=%u nbits=%u n_lo=%u  gather %llu  pass1 %llu  rest %llu (x10 ns)\n", j.n, (int) done, dbg_m, dbg_lds, dbg_nbits, dbg_nlo,
+           dbg_t1 - dbg_t0, dbg_t2 - dbg_t1, wall_clock64() - dbg_t2);
+#endif
   if(tid == 0) {
     if(stats) {
       j.cnt[done ? 2 : 3] += 1ull;                                          // measurement: bracketed vs full selections

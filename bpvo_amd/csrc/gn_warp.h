@@ -257,8 +257,9 @@ __device__ __forceinline__ bool warp_point(const PairJob& j, const float (&P)[12
 // mode 0: every active workspace.  mode 1 (estimate loops with the fused path): skip workspaces whose scale is frozen
 // for the rest of the level — no median is needed and irls_reduce recomputes their residuals itself.  mode 2: refresh
 // the residual / valid buffers of workspaces marked r_stale from the pose of their last linearisation (T_lin).
+// dense: the bracket step's dense form (bracket_chunk; chain launches only).
 template <int C, bool FAST>
-__device__ __forceinline__ void warp_chunk(const PairJob& j, int mode, unsigned chunk, BracketLds& s)
+__device__ __forceinline__ void warp_chunk(const PairJob& j, int mode, unsigned chunk, BracketLds& s, bool dense = false)
 {
   const GNState* __restrict__ st = j.st;
   if(mode == 2) { if(!st->r_stale) return; }
@@ -295,8 +296,10 @@ __device__ __forceinline__ void warp_chunk(const PairJob& j, int mode, unsigned 
     }
   }
   // bracket pass of the exact median (see bracket_chunk) while the residuals are in registers
-  if(mode != 2 && (st->delta_scale > 1e-6f) && st->median_valid)
-    bracket_chunk<C>(j, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res, chunk, (int) (threadIdx.x >> 6), s, true);
+  if(mode != 2 && (st->delta_scale > 1e-6f) && st->median_valid) {
+    if(dense) bracket_chunk<C, true>(j, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res, chunk, (int) (threadIdx.x >> 6), s, true);
+    else bracket_chunk<C, false>(j, st->lo_key, st->hi_key, valid && in_block, hit && valid && in_block, res, chunk, (int) (threadIdx.x >> 6), s, true);
+  }
 }
 
 }  // namespace bpvo_hip

@@ -203,6 +203,10 @@ struct bpvo_hip_ctx {
                                // template with non-maximum suppression and loses on dense ones (8 channels: 30.7 against 32.1 us per linearisation at 16 k
                                // points, 59.8 against 49.0 at 38 k, 220 against 134 at 280 k; one channel: equal at 40 k; scripts/persist_crossover.py).
                                // Default 32768 for eight channels, 65536 for one (set at creation).
+  // option "dense_candidates_from": chain launches over a level of at least this many template points keep the exact median's candidates
+  // in ONE run per workspace (kernels.h, GNLaunch::dense_candidates) — the finish of a 300 k-point level walked 1172 segments, 120 us where the
+  // run takes 10.  Not for channel groups (their jobs hold their own counters).
+  int dense_candidates_from = 32768;
   long long persist_timeout = 50000000ll;   // ticks of the 100 MHz wall clock a grid barrier waits before it gives up (0.5 s)
   // Batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in ONE launch of the team-persistent kernel
   // (kernels_gn.hip, gn_team_kernel): teams of team_size workgroups, one workgroup per CU, a pair per team at a time.
@@ -220,10 +224,14 @@ struct bpvo_hip_ctx {
   int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
   int team_split_max_pairs = 4;  // option "team_split_max_pairs": team batches of up to this many pairs run the coarsest level in a launch of its own, the deferred
                                  // normalisation under it (estimate.hip)
-  hipStream_t side_stream = nullptr;  // the normalisation's stream (created at its first use) and its events: [0] fork, [1] coarsest level done (or all), [2] the levels below done
-  hipEvent_t side_ev[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels below the coarsest of the template stage just queued; whoever
-                                 // reads those levels' (scale, centroid) next makes its stream wait for it (estimate.hip) and clears it
+  // the normalisation's streams (created at their first use) and their events: [0] fork, [1] coarsest level done (or all), [2] the levels between the
+  // coarsest and the finest done, [3] the finest level done.  Deferred form: the finest level — the long one: 2.3 ms of dependent adds for a dense
+  // 640x480 template — has a stream of its own, so that the levels above it are ready, and their Gauss-Newton iterations run, while it is still adding.
+  hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels between the coarsest and the finest of the template stage just
+                                 // queued; whoever reads those levels' (scale, centroid) next makes its stream wait for it (estimate.hip) and clears it
+  hipEvent_t nrm_pending_finest = nullptr;   // ... and behind the finest level's
   int team_spares = 1;           // option "team_spares": the team kernel's grid fills the chip, the workgroups beyond the teams join them (growing form only)
   int team_join_from_pairs = 48; // option "team_join_from_pairs": smaller batches run the fixed-size team kernel (A/B: profiles/r05_team_join.txt)
   int team_local_barriers = 1;   // option "team_local_barriers": kernels_gn_team.hip pk_team_barrier mode 2 for teams on one XCD (0: agent-scope fences always)
@@ -361,7 +369,7 @@ struct FrameRun {
   hipEvent_t selected_ev;   // recorded once the selection of all levels has been queued (the next lane's frame stage starts behind it), or null
   std::function<void()> on_selected;   // ... and called right after that record (releases the next lane's host thread)
   // a template stage whose estimation follows on the same stream inside the same call (bpvo_hip_batch_run on one lane):
-  bool defer_finest_nrm = false;       // the normalisation of every level but the coarsest stays on the side stream: ctx->nrm_pending, joined by the estimation
+  bool defer_finest_nrm = false;       // the normalisation of every level but the coarsest stays on the side streams: ctx->nrm_pending / nrm_pending_finest, joined by the estimation
   bool no_final_sync = false;          // no host synchronisation at the end of the stage
 };
 #define FR_CK(c_, fr_, expr)                                                                \
@@ -410,6 +418,17 @@ inline void for_each_group(const bpvo_hip_ctx* c, const bpvo_hip::GNLaunch& g, s
 }
 // the exact median of a wide descriptor: the WHOLE job (it walks the bracket segments of every group), instantiated for the group's channel count
 // (the size of a segment)
+// entry of Workspace::med_blk (uint4 units, a multiple of 8 = one 128-byte line) where the dense form's totals begin
+inline size_t med_totals_at(const bpvo_hip_ctx* c) { return (((size_t) ((c->cap_max + bpvo_hip::kChunkPoints - 1) / bpvo_hip::kChunkPoints) * (size_t) c->G) + 7) / 8 * 8; }
+// every deferred normalisation joins `s` (errors aside, the estimation has done that level by level: estimate.hip)
+inline hipError_t join_pending_normalization(bpvo_hip_ctx* c, hipStream_t s)
+{
+  hipError_t e = hipSuccess;
+  if(c->nrm_pending) { e = hipStreamWaitEvent(s, c->nrm_pending, 0); c->nrm_pending = nullptr; }
+  if(c->nrm_pending_finest) { const hipError_t e2 = hipStreamWaitEvent(s, c->nrm_pending_finest, 0); c->nrm_pending_finest = nullptr; if(e == hipSuccess) e = e2; }
+  return e;
+}
+inline int dense_candidates(const bpvo_hip_ctx* c, int max_points) { return (c->G == 1 && max_points >= c->dense_candidates_from) ? 1 : 0; }
 inline bpvo_hip::GNLaunch median_launch(const bpvo_hip_ctx* c, bpvo_hip::GNLaunch g) { if(c->G > 1) g.C = c->Cg; return g; }
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
                    bpvo_hip_stats* stats, float* d_records_out, bool allow_persistent);

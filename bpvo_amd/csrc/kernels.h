@@ -131,6 +131,7 @@ bool launch_stereo_sgbm(hipStream_t s, const SgbmLaunch& g);
 // dimension of the next round's grids with that count; entry k of the list names the k-th active workspace.  Without it
 // every launch dispatches the workgroups of the finished workspaces as well: ~0.9 ns each, ~150 µs per launch in the tail
 // of a level at 1024 pairs.  list == nullptr: every workspace of the launch, in order.
+constexpr int kDenseRuns = 64;         // runs of candidates per workspace in the dense form of the exact median's bracket step (gn_common.h, bracket_chunk)
 constexpr int kChunkPoints = 256;      // points per chunk of the warp + residual kernels = per bracket segment of the exact median (gn_common.h K6_BLOCK)
 struct ActiveSet {
   const int* list = nullptr;   // device [npairs]
@@ -146,6 +147,9 @@ struct GNLaunch {
   int interp = 0;        // BPVO_INTERP_* (kLinear uses the tap-cached kernel, the others warp_residual_interp_kernel)
   int fuse_frozen = 0;   // estimate loops, C = 8, kLinear, f64 formulation: once a workspace's scale is frozen, irls_reduce
                          // recomputes the residuals itself and warp_residual skips the workspace
+  // 1: the bracket step of warp_residual and median_finish keep a workspace's candidates in one contiguous run with four totals
+  // (bracket_chunk<C, true>, gn_common.h) instead of per-chunk segments and counters; both launches of an iteration must agree
+  int dense_candidates = 0;
   int fast_warp = 0;     // 1: projectPoints / BilinearInterp all-f32 formulation (bpvo_hip_set_warp_formulation)
   // 1: the tile of a workspace that stores its partial LAST in an irls_reduce launch also takes the Gauss-Newton step (what
   // gn_step_kernel does, with step_prm) — the chain is then three kernels per iteration and launch_gn_step is not called

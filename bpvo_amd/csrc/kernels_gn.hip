@@ -27,10 +27,10 @@
 namespace bpvo_hip {
 
 template <int C, bool FAST>
-__global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode)
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int mode, int dense)
 {
   __shared__ BracketLds s;
-  warp_chunk<C, FAST>(jobs[active_workspace(act, blockIdx.y)], mode, blockIdx.x, s);
+  warp_chunk<C, FAST>(jobs[active_workspace(act, blockIdx.y)], mode, blockIdx.x, s, dense != 0);
 }
 
 // clears r_stale after a refresh launch (one thread per workspace)
@@ -104,7 +104,7 @@ __device__ __forceinline__ void load_group(const float* __restrict__ p, float (&
 #define ROW_BARRIER_AT 1
 #endif
 template <int C, int INTERP>
-__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+__global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int dense)
 {
   constexpr int interp = INTERP;
   const PairJob& j = jobs[active_workspace(act, blockIdx.y)];
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
       for(int c = 0; c < C; ++c) j.r[(size_t) i * PT + c] = res[c];
     }
   }
-  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, hit && in_block, res);
+  if((st->delta_scale > 1e-6f) && st->median_valid) bracket_block<C>(j, st->lo_key, st->hi_key, valid && in_block, hit && in_block, res, dense != 0);
 }
 
 // K7b: one workgroup per workspace — bracketed select among the candidates, or the full 3-pass select.
@@ -307,14 +307,14 @@ __global__ __launch_bounds__(K6_BLOCK) void warp_residual_interp_kernel(const Pa
 // than CUs, which with the first shape run in waves of 256 workgroups at ~10 us each (1024 pairs: 41 / 32 / 22 / 12 us per launch as
 // the pairs converge).  The selection is exact in either shape.
 template <int C, int NT, int COPIES, int CACHE>
-__global__ __launch_bounds__(NT) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act)
+__global__ __launch_bounds__(NT) void median_finish_kernel(const PairJob* __restrict__ jobs, ActiveSet act, int dense)
 {
   const PairJob& j = jobs[active_workspace(act, blockIdx.x)];
   GNState* st = j.st;
   if(!st->active) return;
   if(!(st->delta_scale > 1e-6f)) return;   // scale is stable: frozen for the rest of the level (mestimator.cc:472,485)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  median_block<C, NT, COPIES, CACHE>(j, st, smem_raw, true);
+  median_block<C, NT, COPIES, CACHE>(j, st, smem_raw, true, dense != 0);
 }
 
 // Two instantiations share the work of a launch slot: FUSED = false handles the workspaces whose scale still moves, FUSED =
@@ -467,7 +467,9 @@ __global__ __launch_bounds__(GN_BLOCK) void level_begin_kernel(const PairJob* jo
     const int i = blockIdx.x * GN_BLOCK + threadIdx.x;
     if(i < j.n && j.tapkey) j.tapkey[i] = 0xffffffffu;
   }
-  if(blockIdx.x != 0 || threadIdx.x != 0) return;
+  if(blockIdx.x != 0) return;
+  if(threadIdx.x < kDenseRuns && j.med_blk) reinterpret_cast<uint4*>(j.med_blk.get())[j.med_tot + 8 * threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);      // the totals of the dense bracket form start a level at zero
+  if(threadIdx.x != 0) return;
   gn_level_reset(j.st, level, scale_is_moot, j.n);
 }
 
@@ -529,11 +531,18 @@ __global__ __launch_bounds__(256) void weights_wide_kernel(const PairJob* job, i
 }
 __global__ __launch_bounds__(256) void count_good_wide_kernel(const PairJob* job, int C, int loss, float thr, unsigned int* count)
 {
-  const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
-  unsigned good = (k < (size_t) job->n * C && mest_weight_rt(loss, job->r[k], 1.0f / job->st->scale) > thr) ? 1u : 0u;
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) good += __shfl_down(good, o);
-  if((threadIdx.x & 63) == 0 && good) atomicAdd(count, good);
+  const size_t total = (size_t) job->n * C;
+  const float sigma_inv = 1.0f / job->st->scale;
+  unsigned good = 0;
+  for(size_t k = (size_t) blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t) gridDim.x * 256) good += mest_weight_rt(loss, job->r[k], sigma_inv) > thr ? 1u : 0u;
+  __shared__ unsigned s_good[4];
+  good = wave_sum_u32(good);
+  if((threadIdx.x & 63) == 0) s_good[threadIdx.x >> 6] = good;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    const unsigned t = s_good[0] + s_good[1] + s_good[2] + s_good[3];
+    if(t) atomicAdd(count, t);
+  }
 }
 
 // getPointCloudFromRefFrame + GetColor (reference: bpvo/vo.cc:250-281) on the device: one 32-byte PointWithInfo per template point of the level the
@@ -570,28 +579,35 @@ __global__ __launch_bounds__(256) void point_cloud_kernel(const PairJob* job, co
   out[i] = pw;
 }
 
+// (grid-stride over the points and ONE add per workgroup: a thousand workgroups of four waves adding to one word took 55 us on a
+// 300 k-point template — the adds serialise at the L2 — where the points take 5)
 template <int C, int LOSS>
 __global__ __launch_bounds__(256) void count_good_kernel(const PairJob* job, float thr, unsigned int* count)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
   unsigned good = 0;
-  if(i < job->n) {
-    const float sigma_inv = 1.0f / job->st->scale;
+  const int n = job->n;
+  const float sigma_inv = 1.0f / job->st->scale;
+  for(int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     if constexpr(C == 8) {
       const float4* q = reinterpret_cast<const float4*>(job->r.get());
       const float4 a = q[tile_index<2>(i, 0)], b = q[tile_index<2>(i, 1)];
-      good = (mest_weight<LOSS>(a.x, sigma_inv) > thr) + (mest_weight<LOSS>(a.y, sigma_inv) > thr) +
-             (mest_weight<LOSS>(a.z, sigma_inv) > thr) + (mest_weight<LOSS>(a.w, sigma_inv) > thr) +
-             (mest_weight<LOSS>(b.x, sigma_inv) > thr) + (mest_weight<LOSS>(b.y, sigma_inv) > thr) +
-             (mest_weight<LOSS>(b.z, sigma_inv) > thr) + (mest_weight<LOSS>(b.w, sigma_inv) > thr);
+      good += (mest_weight<LOSS>(a.x, sigma_inv) > thr) + (mest_weight<LOSS>(a.y, sigma_inv) > thr) +
+              (mest_weight<LOSS>(a.z, sigma_inv) > thr) + (mest_weight<LOSS>(a.w, sigma_inv) > thr) +
+              (mest_weight<LOSS>(b.x, sigma_inv) > thr) + (mest_weight<LOSS>(b.y, sigma_inv) > thr) +
+              (mest_weight<LOSS>(b.z, sigma_inv) > thr) + (mest_weight<LOSS>(b.w, sigma_inv) > thr);
     } else {
 #pragma unroll
       for(int c = 0; c < C; ++c) good += mest_weight<LOSS>(job->r[(size_t) i * C + c], sigma_inv) > thr;
     }
   }
-#pragma unroll
-  for(int o = 32; o >= 1; o >>= 1) good += __shfl_down(good, o);
-  if((threadIdx.x & 63) == 0 && good) atomicAdd(count, good);
+  __shared__ unsigned s_good[4];
+  good = wave_sum_u32(good);
+  if((threadIdx.x & 63) == 0) s_good[threadIdx.x >> 6] = good;
+  __syncthreads();
+  if(threadIdx.x == 0) {
+    const unsigned t = s_good[0] + s_good[1] + s_good[2] + s_good[3];
+    if(t) atomicAdd(count, t);
+  }
 }
 
 // 32-float result record per pair for the RCCL gather: pose 3x4 (12), numIterations per level (8), status per level (8),
@@ -666,21 +682,21 @@ void launch_warp_residual(hipStream_t s, const GNLaunch& g)
     dispatch_channels(g.C, [&](auto c) {
       constexpr int CC = decltype(c)::value;
       switch(g.interp) {
-        case BPVO_INTERP_COSINE: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_COSINE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
-        case BPVO_INTERP_CUBIC: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
-        default: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC_HERMITE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active); break;
+        case BPVO_INTERP_COSINE: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_COSINE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.dense_candidates); break;
+        case BPVO_INTERP_CUBIC: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.dense_candidates); break;
+        default: hipLaunchKernelGGL((warp_residual_interp_kernel<CC, BPVO_INTERP_CUBIC_HERMITE>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, g.dense_candidates); break;
       }
     });
     return;
   }
   if(g.fast_warp) {
     dispatch_channels(g.C, [&](auto c) {
-      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0);
+      hipLaunchKernelGGL((warp_residual_kernel<decltype(c)::value, true>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, 0, g.dense_candidates);
     });
   } else {
     dispatch_channels(g.C, [&](auto c) {
       constexpr int CC = decltype(c)::value;
-      hipLaunchKernelGGL((warp_residual_kernel<CC, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0);
+      hipLaunchKernelGGL((warp_residual_kernel<CC, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, g.active, (CC == 8 && g.fuse_frozen) ? 1 : 0, g.dense_candidates);
     });
   }
 }
@@ -689,7 +705,7 @@ void launch_refresh_residuals(hipStream_t s, const GNLaunch& g)
 {
   if(g.max_points <= 0 || g.C != 8) return;
   const dim3 grid((g.max_points + K6_BLOCK - 1) / K6_BLOCK, g.npairs);
-  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2);
+  hipLaunchKernelGGL((warp_residual_kernel<8, false>), grid, dim3(K6_BLOCK), 0, s, g.jobs, ActiveSet(), 2, 0);
   hipLaunchKernelGGL(clear_stale_kernel, dim3((g.npairs + 63) / 64), dim3(64), 0, s, g.jobs, g.npairs);
 }
 void launch_median(hipStream_t s, const GNLaunch& g)
@@ -711,9 +727,9 @@ void launch_median(hipStream_t s, const GNLaunch& g)
   dispatch_channels(g.C, [&](auto c) {
     constexpr int CC = decltype(c)::value;
     if(g.npairs >= wide_from)
-      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS_B, MED_COPIES_B, MED_CACHE_B>), dim3(g.npairs), dim3(MED_THREADS_B), kMedianLdsB, s, g.jobs, g.active);
+      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS_B, MED_COPIES_B, MED_CACHE_B>), dim3(g.npairs), dim3(MED_THREADS_B), kMedianLdsB, s, g.jobs, g.active, g.dense_candidates);
     else
-      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS, MED_COPIES, MED_CACHE>), dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active);
+      hipLaunchKernelGGL((median_finish_kernel<CC, MED_THREADS, MED_COPIES, MED_CACHE>), dim3(g.npairs), dim3(MED_THREADS), kMedianLds, s, g.jobs, g.active, g.dense_candidates);
   });
 }
 
@@ -784,7 +800,7 @@ void launch_weights(hipStream_t s, const PairJob* job, int n, int C, int loss, f
 template <int C>
 static void launch_count_good_c(hipStream_t s, const PairJob* job, int n, int loss, float thr, unsigned int* count)
 {
-  const dim3 grid((n + 255) / 256);
+  const dim3 grid(std::min((n + 255) / 256, 256));
   switch(loss) {
     case BPVO_LOSS_HUBER: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_HUBER>), grid, dim3(256), 0, s, job, thr, count); break;
     case BPVO_LOSS_TUKEY: hipLaunchKernelGGL((count_good_kernel<C, BPVO_LOSS_TUKEY>), grid, dim3(256), 0, s, job, thr, count); break;
@@ -803,7 +819,7 @@ void launch_point_cloud(hipStream_t s, const PairJob* job, int n, int C, int los
 void launch_count_good(hipStream_t s, const PairJob* job, int n, int C, int loss, float thr, unsigned int* count)
 {
   if(n <= 0) return;
-  if(C > 48) { hipLaunchKernelGGL(count_good_wide_kernel, dim3((unsigned) (((size_t) n * C + 255) / 256)), dim3(256), 0, s, job, C, loss, thr, count); return; }
+  if(C > 48) { hipLaunchKernelGGL(count_good_wide_kernel, dim3((unsigned) std::min<size_t>(((size_t) n * C + 255) / 256, 1024)), dim3(256), 0, s, job, C, loss, thr, count); return; }
   dispatch_channels(C, [&](auto c) { launch_count_good_c<decltype(c)::value>(s, job, n, loss, thr, count); });
 }
 void launch_pack_records(hipStream_t s, const PairJob* jobs, int n, int L, float* records, const GNState* d_states, GNState* h_states, const unsigned* d_ctl,

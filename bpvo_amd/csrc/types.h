@@ -203,7 +203,7 @@ struct PairJob {
   // n_groups x chunks bracket segments, its step sums n_groups x tiles partials.  pitch = C, n_groups = 1 everywhere else.
   int           pitch;
   int           n_groups;
-  int           pad_[1];
+  int           med_tot;   // entry of med_blk (uint4 units) that holds the four totals of the dense bracket form (bracket_chunk<C, true>): behind every chunk's counters
 };
 
 // selection / template-build job for one (frame, level)

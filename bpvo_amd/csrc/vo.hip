@@ -307,9 +307,17 @@ static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* di
       std::swap(c->vo_prev, c->vo_ref);
       c->frames[c->vo_prev].has_data = false;
       c->frames[c->vo_prev].has_template = false;
-      rc = frames_set_template(c, c->vo_ref, 1, 1);
-      if(rc) return rc;
-      rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, I.m, T_est.m, ret->optimizerStatistics);
+      // the estimate against the new key frame follows on the same stream: the template stage ends without a host round trip of its own and
+      // leaves the normalisation sums of the levels below the coarsest on the side streams, under the Gauss-Newton iterations of the levels
+      // above them (a dense 640x480 template, conf/tsukuba.cfg: 2.3 ms of dependent adds for the finest level)
+      FrameRun fr = ctx_run(c);
+      fr.no_final_sync = !c->profiling;
+      fr.defer_finest_nrm = true;
+      rc = frames_set_template(c, c->vo_ref, 1, 1, fr);
+      if(rc == BPVO_OK) rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, I.m, T_est.m, ret->optimizerStatistics);
+      // (an error on the way: nothing of this call stays in flight)
+      if(c->nrm_pending) { (void) hipEventSynchronize(c->nrm_pending); c->nrm_pending = nullptr; }
+      if(c->nrm_pending_finest) { (void) hipEventSynchronize(c->nrm_pending_finest); c->nrm_pending_finest = nullptr; }
       if(rc) return rc;
       pose = T_est;
       c->T_kf = T_est;

@@ -369,6 +369,9 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "persist_max_points"     32768 / 65536  (8 channels / 1) a pyramid level with more template points than this, and the finer levels behind it, take the
  *                                      four-kernel chain even for a single pair: dense templates (no non-maximum suppression: conf/tsukuba.cfg) are
  *                                      bandwidth work for the whole chip, not latency work for 64 workgroups (same bits either way)
+ *   "dense_candidates_from"  32768     chain launches over a pyramid level with at least this many template points keep the candidates of
+ *                                      the exact median in one contiguous run per workspace instead of one segment per 256-point chunk: the
+ *                                      selection reads four totals and one array (a 300 k-point level: 10 us instead of 120); same median
  *   "persist_timeout_ticks"  5e7       100 MHz ticks a device-side barrier waits before the launch gives up and the call falls back to
  *                                      the chain (0.5 s; the tests of that path set 1)
  *   "team"                   1         batches of 2 .. team_max_pairs pairs run their whole Gauss-Newton stage in one team-persistent launch

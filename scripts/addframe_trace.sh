@@ -19,6 +19,9 @@ p.interp = capi.INTERP_CUBIC_HERMITE
 ctx = hip.create(seq["K"], seq["b"], 480, 640, p, device=0, n_frames=3, n_pairs=1)
 for img, disp in seq["frames"]:
     ctx.add_frame(img, disp)
+print("exact median: bracketed / full selections", ctx.median_path_counts(), file=sys.stderr)
 PY
 rm -rf /tmp/traf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/traf -- python3 /tmp/aft.py > /tmp/traf.out 2>/tmp/traf.err
 python3 $R/profiles/dbstats.py /tmp/traf | head -16
+python3 $R/scripts/addframe_timeline.py /tmp/traf ${TIMELINE_N:-0} ${TIMELINE_SKIP:-0}
+grep 'exact median' /tmp/traf.err

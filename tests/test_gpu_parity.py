@@ -398,6 +398,48 @@ def test_tap_cache_of_the_other_interpolations_changes_nothing(hip, orc, monkeyp
     assert rot <= ROT_TOL and trans <= trans_tol(b["K"]), (rot, trans)
 
 
+@pytest.mark.parametrize("case", ["kitti-bitplanes", "vga-dense-intensity-hermite", "vga-dense-bitplanes"])
+def test_dense_candidate_run_of_the_median_changes_nothing(hip, orc, monkeypatch, case):
+    """The exact median's candidates (keys inside the bracket around the previous median: bpvo/mestimator.cc:452-490, utils.h:224-252) as ONE
+    contiguous run per workspace with four totals (option dense_candidates_from; the chunks' leaders take their place with a returning add, so
+    the run's order differs from launch to launch) against one segment and one counter record per 256-point chunk: the same poses, statistics
+    and per-linearisation records (pose, H, G, f, sigma, valid count, step) bit for bit, for a batch on the chain and for a single pair, with
+    the bracketed selection in use — and the oracle's trajectory bit for bit in reference order.  Dense templates (NMS off, conf/tsukuba.cfg)
+    are what the run is for: a 640 x 480 level has 1172 chunks."""
+    kw, rows, cols, n = {"kitti-bitplanes": (dict(descriptor="bitplanes", loss="tukey", levels=3), 376, 1241, 3),
+                         "vga-dense-intensity-hermite": (dict(descriptor="intensity", loss="huber", levels=3, interp=3, nonMaxSuppRadius=0, minSaliency=0.001), 480, 640, 2),
+                         "vga-dense-bitplanes": (dict(descriptor="bitplanes", loss="tukey", levels=2, nonMaxSuppRadius=0), 480, 640, 2)}[case]
+    b = synth.make_batch(rows, cols, n, first_index=90)
+    outs, traces = [], []
+    for dense_from in ("0", "1073741824"):
+        set_options(monkeypatch, dense_candidates_from=dense_from, lanes="1", team="0", persistent="0")      # the four-kernel chain
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)
+        outs.append(ctx.batch_run(b["images"], b["disparities"]))
+        bracketed, full = ctx.median_path_counts()
+        assert bracketed > full > 0, (bracketed, full)
+        ctx.close()
+        one = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2, n_pairs=1)
+        one.frame_set_data(0, b["images"][0], b["disparities"][0]); one.frame_set_template(0)
+        one.frame_set_data(1, b["images"][1], b["disparities"][1])
+        traces.append(one.estimate_pose_trace(0, 0, 1, max_records=4096))
+        one.close()
+    assert bits_equal(outs[0][0], outs[1][0]) and outs[0][1].tobytes() == outs[1][1].tobytes()
+    assert bits_equal(traces[0][0], traces[1][0]) and bits_equal(traces[0][2], traces[1][2])
+    assert bits_equal(traces[0][0], outs[0][0][0])
+    # reference order, dense run: the oracle's records
+    set_options(monkeypatch, dense_candidates_from="0", persistent="0")
+    ref = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2, n_pairs=1)
+    ref.set_option("reference_reduction", 1)
+    co = orc.create(b["K"], b["b"], rows, cols, make_params(orc, **kw), n_frames=2, n_pairs=1)
+    for c in (ref, co):
+        c.frame_set_data(0, b["images"][0], b["disparities"][0]); c.frame_set_template(0)
+        c.frame_set_data(1, b["images"][1], b["disparities"][1])
+    Th, sh, th = ref.estimate_pose_trace(0, 0, 1, max_records=4096)
+    To, so, to = co.estimate_pose_trace(0, 0, 1, max_records=4096)
+    assert bits_equal(Th, To) and bits_equal(th, to) and [s_["numIterations"] for s_ in sh] == [s_["numIterations"] for s_ in so]
+    ref.close(); co.close()
+
+
 def test_batch_matches_single_and_records(hip, orc):
     """Config 5 shape: a batch of independent pairs equals the pairs run one by one, and equals the oracle."""
     rows, cols, levels, n = 120, 160, 3, 6
