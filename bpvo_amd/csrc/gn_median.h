@@ -193,11 +193,6 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
   float median = 0.0f;
   unsigned n_total = 0;
   bool done = false;
-#ifdef MED_DEBUG
-  const unsigned long long dbg_t0 = wall_clock64();
-  unsigned long long dbg_t1 = dbg_t0, dbg_t2 = dbg_t0;
-  unsigned dbg_m = 0, dbg_lds = 0, dbg_nbits = 0, dbg_nlo = 0;
-#endif
   unsigned tap_hits = 0, tap_lookups = 0;      // tap-cache statistics of this linearisation's warp_residual pass (bracket counters)
 
   // ---- bracketed path
@@ -277,9 +272,6 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
           }
         }
       };
-#ifdef MED_DEBUG
-      dbg_m = m; dbg_lds = in_lds; dbg_nbits = nbits;
-#endif
       if(in_lds && dense) {
         for_each_dense([&](unsigned d, unsigned at) { dense_keys[at] = d; });
         __syncthreads();
@@ -337,9 +329,6 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
           for(unsigned i = lane; i < mb; i += 64) f(seg[i] - lo_key);
         }
       };
-#ifdef MED_DEBUG
-      dbg_t1 = wall_clock64();
-#endif
       unsigned remaining = nbits;
       bool first = true;
       while(remaining > 0) {
@@ -354,9 +343,6 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
         const unsigned dmask = (1u << width) - 1u;
         const unsigned n_lo = hist_lo[lo.prefix & dmask];
         const unsigned n_hi = was_split ? hist_hi[hi.prefix & dmask] : hist_lo[hi.prefix & dmask];
-#ifdef MED_DEBUG
-        dbg_t2 = wall_clock64(); dbg_nlo = n_lo;
-#endif
         if(n_lo > (unsigned) NT || n_hi > (unsigned) NT) continue;
         unsigned* list_lo = cache;                    // [NT]
         unsigned* list_hi = cache + NT;               // [NT]
@@ -458,11 +444,6 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
   }
 
   if(dense && tid < kDenseRuns) reinterpret_cast<uint4*>(j.med_blk.get())[j.med_tot + 8 * tid] = make_uint4(0u, 0u, 0u, 0u);     // (every wave's reads lie before a barrier behind this one)
-#ifdef MED_DEBUG
-  if(tid == 0 && j.n > 100000)
-    printf("K7 n=%d done=%d m=%u in_lds=%u nbits=%u n_lo=%u  gather %llu  pass1 %llu  rest %llu (x10 ns)\n", j.n, (int) done, dbg_m, dbg_lds, dbg_nbits, dbg_nlo,
-           dbg_t1 - dbg_t0, dbg_t2 - dbg_t1, wall_clock64() - dbg_t2);
-#endif
   if(tid == 0) {
     if(stats) {
       j.cnt[done ? 2 : 3] += 1ull;                                          // measurement: bracketed vs full selections

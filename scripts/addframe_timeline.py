@@ -1,40 +1,27 @@
-#!/usr/bin/env python3
-"""Per-dispatch view of scripts/addframe_trace.sh's kernel trace: for every Gauss-Newton kernel the launches grouped by grid size (= pyramid
-level of the single pair) with count / average / max duration, and the first N dispatches in order.  usage: addframe_timeline.py <dir> [N [skip]]"""
-import glob
-import sqlite3
-import sys
+"""Sequential addFrame with the parameters of conf/perf_bitplanes.cfg / perf_intensity.cfg on a 640x480 sequence (what bench.py's
+other_configs time); run under rocprofv3 --kernel-trace by scripts/addframe_timeline.sh to see the kernels of one call."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bpvo_amd
+from bpvo_amd import capi, synth
 
-f = sorted(glob.glob(sys.argv[1] + "/*/*_results.db"))[-1]
-n_first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-db = sqlite3.connect(f)
-try:
-    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-    gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else "grid_size")
-    rows = list(db.execute(f"select name, start, end, {gx} from kernels order by start"))
-except Exception as e:  # noqa: BLE001
-    print("schema:", [r for r in db.execute("select name, type from sqlite_master")], e)
-    sys.exit(1)
-agg = {}
-last_warp = 0
-for i, (name, s, e, g) in enumerate(rows):
-    if "warp_residual" in name:
-        last_warp = g
-    elif "median_finish" in name:          # one grid for every level: label it with the grid of the warp + residual launch before it
-        rows[i] = (name, s, e, last_warp)
-        g = last_warp
-    k = (name.split("(")[0].replace("void bpvo_hip::", "").replace("bpvo_hip::", "")[:60], g)
-    a = agg.setdefault(k, [0, 0.0, 0.0, []])
-    a[3].append((e - s) / 1e3)
-    a[0] += 1; a[1] += (e - s) / 1e3; a[2] = max(a[2], (e - s) / 1e3)
-print("%-62s %10s %7s %10s %9s %9s  %s" % ("kernel", "grid_x", "calls", "total_us", "avg_us", "max_us", "deciles of the duration (us)"))
-for (k, g), a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    d = sorted(a[3])
-    print("%-62s %10d %7d %10.1f %9.2f %9.2f  %s" % (k, g, a[0], a[1], a[1] / a[0], a[2], " ".join("%.0f" % d[min(len(d) - 1, len(d) * q // 10)] for q in range(1, 10))))
-skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-t0 = rows[skip][1] if len(rows) > skip else 0
-prev_end = t0
-for name, s, e, g in rows[skip:skip + n_first]:
-    print("gap %6.2f " % ((s - prev_end) / 1e3), end="")
-    prev_end = e
-    print("%10.1f us  +%8.2f  grid %8d  %s" % ((s - t0) / 1e3, (e - s) / 1e3, g, name.split("(")[0][-70:]))
+which = sys.argv[1] if len(sys.argv) > 1 else "perf_bitplanes"
+hip = bpvo_amd.load()
+seq = synth.make_sequence(480, 640, 14, index=3, step_rot=0.002, step_trans=0.01)
+p = hip.default_params()
+p.numPyramidLevels = 3; p.parameterTolerance = 1e-6; p.functionTolerance = 1e-4; p.gradientTolerance = 1e-6
+p.maxIterations = 50; p.relaxTolerancesForCoarseLevels = 1; p.gradientEstimation = capi.GRAD_CD5
+p.minValidDisparity = 1.0; p.goodPointThreshold = 0.75; p.verbosity = capi.VERB_SILENT
+if which == "perf_bitplanes":
+    p.descriptor = capi.DESC_BITPLANES; p.lossFunction = capi.LOSS_L2
+    p.minTranslationMagToKeyFrame = 0.1; p.minRotationMagToKeyFrame = 5.0
+    p.sigmaPriorToCensusTransform = 0.75; p.sigmaBitPlanes = 1.6
+else:
+    p.descriptor = capi.DESC_INTENSITY; p.lossFunction = capi.LOSS_HUBER; p.minSaliency = 2.5; p.nonMaxSuppRadius = 2
+    p.minTranslationMagToKeyFrame = 1000.0; p.minRotationMagToKeyFrame = 1000.0; p.maxFractionOfGoodPointsToKeyFrame = 0.75
+ctx = hip.create(seq["K"], seq["b"], 480, 640, p, device=0, n_frames=3, n_pairs=1)
+ts = []
+for img, disp in seq["frames"]:
+    t0 = time.perf_counter(); r = ctx.add_frame(img, disp); ts.append((1e3 * (time.perf_counter() - t0), r["isKeyFrame"]))
+    time.sleep(0.002)     # a visible gap between the calls in the trace
+print(which, "addFrame ms:", " ".join(f"{t:.2f}{'K' if k else ''}" for t, k in ts))

@@ -23,5 +23,5 @@ print("exact median: bracketed / full selections", ctx.median_path_counts(), fil
 PY
 rm -rf /tmp/traf; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/traf -- python3 /tmp/aft.py > /tmp/traf.out 2>/tmp/traf.err
 python3 $R/profiles/dbstats.py /tmp/traf | head -16
-python3 $R/scripts/addframe_timeline.py /tmp/traf ${TIMELINE_N:-0} ${TIMELINE_SKIP:-0}
+python3 $R/scripts/addframe_trace_levels.py /tmp/traf ${TIMELINE_N:-0} ${TIMELINE_SKIP:-0}
 grep 'exact median' /tmp/traf.err
