@@ -299,7 +299,7 @@ const std::vector<OptionDef>& option_table()
     OPT_INT("team_join_from_pairs", team_join_from_pairs, 0, 1 << 20),
     OPT_INT("team_spares", team_spares, 0, 1),
     OPT_INT("normalization_side_stream", nrm_side_stream, 0, 1),
-    OPT_INT("normalization_form", nrm_dpp_asm, 0, 2),
+    OPT_INT("normalization_form", nrm_dpp_asm, 0, 4),
     OPT_INT("small_batch_fused", small_batch_fused, 0, 1),
     OPT_INT("levels_in_one_launch_max_frames", merge_levels_max_frames, 0, 1 << 20),
     OPT_INT("normalization_deferred", nrm_defer, 0, 1),

@@ -217,9 +217,11 @@ struct bpvo_hip_ctx {
   int merge_levels_max_frames = 8;   // option "levels_in_one_launch_max_frames": frame stages of at most this many frames run the levels of the
                                  // bit-planes, selection and template-build kernels in one launch each (frames.hip)
   int small_batch_fused = 1;     // option "small_batch_fused": contexts of a few pairs — job table + poses in one launch, states copied out by pack_records (estimate.hip)
-  int nrm_dpp_asm = 1;           // option "normalization_form": the sequential Hartley sums (kernels_frame.hip) as 1: hand-scheduled DPP add chains (the default:
-                                 // 170 us for a 1241x376 template, 2.2 ms for a dense 640x480 one), 0: the compiler's DPP form (274 us / 3.5 ms), 2: broadcast LDS
-                                 // reads + plain adds, no cross-lane traffic and no asm (310 us / 4.0 ms: the compiler's loop does not keep the adds back to back)
+  int nrm_dpp_asm = 4;           // option "normalization_form": the sequential Hartley sums (kernels_frame.hip) as 1: hand-scheduled DPP add chains (170 us for a
+                                 // 1241x376 template, 2.28 ms for a dense 640x480 one), 0: the compiler's DPP form (281 us / 3.6 ms), 2: broadcast LDS reads +
+                                 // plain adds, no cross-lane traffic and no asm (311 us / 4.0 ms: the compiler's loop does not keep the adds back to back), 3: the
+                                 // same reads with the adds as asm blocks of plain v_add_f32 on a wave that does nothing else (170 us / 2.04 ms), 4 (the default):
+                                 // 3 for launches of at most 1024 workgroups, 1 for larger ones
   int nrm_side_stream = 1;       // option "normalization_side_stream": frames.hip frames_set_template
   int nrm_defer = 1;             // option "normalization_deferred": ... and the sums of the levels below the coarsest run on under the coarsest level's iterations
   int team_split_max_pairs = 4;  // option "team_split_max_pairs": team batches of up to this many pairs run the coarsest level in a launch of its own, the deferred

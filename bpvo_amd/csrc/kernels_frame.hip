@@ -1138,6 +1138,39 @@ __device__ __forceinline__ void nrm_chain_b128(float& acc, const float4* __restr
     for(int q = 0; q < 4; ++q) a[q] = b[q];
   }
 }
+// FORM 3: FORM 2's layout and reads, the adds as blocks of sixteen back-to-back plain `v_add_f32` (a dependent plain add issues every 6 cycles
+// on gfx950, one with a DPP operand every 7: scripts/micro/addchain.hip), 32 elements per buffer and two buffers, so that a buffer's eight
+// ds_read_b128 are in flight under the other's 192 cycles of adds; wave 0 does nothing else (the other three waves stage the chunks and form
+// the second pass's distances).  Elements beyond `cnt` up to the next multiple of 32 are the zeros the staging wrote (x + 0 = x).
+#define NRM_ADD16_(A, B, C, D) \
+  asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %2\n v_add_f32 %0, %0, %3\n v_add_f32 %0, %0, %4\n" \
+               "v_add_f32 %0, %0, %5\n v_add_f32 %0, %0, %6\n v_add_f32 %0, %0, %7\n v_add_f32 %0, %0, %8\n" \
+               "v_add_f32 %0, %0, %9\n v_add_f32 %0, %0, %10\n v_add_f32 %0, %0, %11\n v_add_f32 %0, %0, %12\n" \
+               "v_add_f32 %0, %0, %13\n v_add_f32 %0, %0, %14\n v_add_f32 %0, %0, %15\n v_add_f32 %0, %0, %16\n" \
+               : "+v"(acc) : "v"(A.x), "v"(A.y), "v"(A.z), "v"(A.w), "v"(B.x), "v"(B.y), "v"(B.z), "v"(B.w), \
+                             "v"(C.x), "v"(C.y), "v"(C.z), "v"(C.w), "v"(D.x), "v"(D.y), "v"(D.z), "v"(D.w))
+__device__ __forceinline__ void nrm_chain_asm(float& acc, const float4* __restrict__ sp, int cnt)
+{
+  const int blocks = (cnt + 31) / 32;
+  float4 x[8], y[8];
+#pragma unroll
+  for(int q = 0; q < 8; ++q) x[q] = sp[q];
+  // (the reads are unconditional — the block index clamped to the last one, whose values then go unused — so that the compiler can count
+  // them: it waits for the older buffer only, and the newer one's reads stay in flight under the adds)
+  for(int b = 0; b < blocks; b += 2) {
+    const int by = min(b + 1, blocks - 1), bx = min(b + 2, blocks - 1);
+#pragma unroll
+    for(int q = 0; q < 8; ++q) y[q] = sp[by * 8 + q];
+    NRM_ADD16_(x[0], x[1], x[2], x[3]);
+    NRM_ADD16_(x[4], x[5], x[6], x[7]);
+#pragma unroll
+    for(int q = 0; q < 8; ++q) x[q] = sp[bx * 8 + q];
+    if(b + 1 < blocks) {
+      NRM_ADD16_(y[0], y[1], y[2], y[3]);
+      NRM_ADD16_(y[4], y[5], y[6], y[7]);
+    }
+  }
+}
 template <int FORM>
 __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJob* jobs, int job_pitch, int first_level,
                                                                     int with_normalization)
@@ -1154,15 +1187,20 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
   // global loads of chunk i + 1 are in flight while chunk i is being added (registers -> the other LDS buffer afterwards), and (c) in
   // the second pass every thread forms the distances of chunk i + 1 while wave 0 accumulates those of chunk i.  Same order, same roundings.
   constexpr bool ASM = FORM == 1;
-  __shared__ float4 s_pts[2][NRM_CHUNK];      // FORM 2: the same 16 KB as s_comp[2][4][NRM_CHUNK], component by component
+  constexpr bool COMP = FORM >= 2;            // component-major staging (FORM 2, 3)
+  // FORM 3: wave 0 only adds; threads 64 .. 255 stage the chunks and form the distances (three points each per chunk)
+  constexpr int W0 = FORM == 3 ? 64 : 0, NW = NRM_THREADS - W0;
+  __shared__ float4 s_pts[2][NRM_CHUNK];      // FORM 2, 3: the same 16 KB as s_comp[2][4][NRM_CHUNK], component by component
   __shared__ __align__(16) float s_dist[2][NRM_CHUNK];
   float (*s_comp)[4][NRM_CHUNK] = reinterpret_cast<float (*)[4][NRM_CHUNK]>(&s_pts[0][0]);
   auto stage = [&](int buf, int k, const float4& p) {
-    if constexpr(FORM == 2) { s_comp[buf][0][k] = p.x; s_comp[buf][1][k] = p.y; s_comp[buf][2][k] = p.z; s_comp[buf][3][k] = p.w; }
+    if constexpr(COMP) { s_comp[buf][0][k] = p.x; s_comp[buf][1][k] = p.y; s_comp[buf][2][k] = p.z; s_comp[buf][3][k] = p.w; }
     else s_pts[buf][k] = p;
   };
   __shared__ float s_c[4];
-  constexpr int PER = NRM_CHUNK / NRM_THREADS;     // points per thread and chunk
+  constexpr int PER = (NRM_CHUNK + NW - 1) / NW;     // points per (staging) thread and chunk
+  const int wt = tid - W0;                            // index among the staging threads (< 0: wave 0 of FORM 3)
+  auto mine = [&](int q) { return wt >= 0 && q * NW + wt < NRM_CHUNK; };
   const int nchunks = (N + NRM_CHUNK - 1) / NRM_CHUNK;
   const int row = (tid >> 4) & 3, li = tid & 15;
   float4 pre[PER];
@@ -1170,20 +1208,52 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int base = chunk * NRM_CHUNK;
 #pragma unroll
     for(int q = 0; q < PER; ++q) {
-      const int k = base + q * NRM_THREADS + tid;
-      pre[q] = (k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const int k = base + q * NW + wt;
+      pre[q] = (mine(q) && k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   };
   fetch(0);
 #pragma unroll
-  for(int q = 0; q < PER; ++q) stage(0, q * NRM_THREADS + tid, pre[q]);
+  for(int q = 0; q < PER; ++q) if(mine(q)) stage(0, q * NW + wt, pre[q]);
   __syncthreads();
   float c = 0.0f;
-  for(int ch = 0; ch < nchunks; ++ch) {
+  // FORM 3: the points of chunk i + 2 are requested while chunk i is being added and chunk i + 1, requested an iteration earlier, is staged —
+  // a chunk's adds take 1.3 us, a trip to HBM up to two: with one chunk of lead the barrier waited for the loads (0.4 us per chunk)
+  float4 pa[PER], pb[PER];
+  auto fetch_to = [&](int chunk, float4 (&dst)[PER]) {
+    const int base = chunk * NRM_CHUNK;
+#pragma unroll
+    for(int q = 0; q < PER; ++q) {
+      const int k = base + q * NW + wt;
+      dst[q] = (mine(q) && k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  };
+  auto chunk_cnt = [&](int chunk) { return min(NRM_CHUNK, N - chunk * NRM_CHUNK); };
+  if constexpr(FORM == 3) {
+    auto stage_from = [&](int buf, const float4 (&src)[PER]) {
+#pragma unroll
+      for(int q = 0; q < PER; ++q) if(mine(q)) stage(buf, q * NW + wt, src[q]);
+    };
+    fetch_to(1, pa);
+    for(int ch = 0; ch < nchunks; ch += 2) {
+      fetch_to(ch + 2, pb);
+      if(tid < 64) nrm_chain_asm(c, reinterpret_cast<const float4*>(s_comp[0][row]), chunk_cnt(ch));
+      if(ch + 1 < nchunks) stage_from(1, pa);
+      __syncthreads();
+      if(ch + 1 >= nchunks) break;
+      fetch_to(ch + 3, pa);
+      if(tid < 64) nrm_chain_asm(c, reinterpret_cast<const float4*>(s_comp[1][row]), chunk_cnt(ch + 1));
+      if(ch + 2 < nchunks) stage_from(0, pb);
+      __syncthreads();
+    }
+  }
+  for(int ch = 0; ch < nchunks && FORM != 3; ++ch) {
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) fetch(ch + 1);
-    if constexpr(FORM == 2) {
+    if constexpr(FORM == 3) {
+      if(tid < 64) nrm_chain_asm(c, reinterpret_cast<const float4*>(s_comp[cur][row]), cnt);
+    } else if constexpr(FORM == 2) {
       if(tid < 64) nrm_chain_b128<FORM>(c, reinterpret_cast<const float4*>(s_comp[cur][row]), cnt / 4);
     } else if(tid < 64) {
       const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + row + 16 * li;      // component `row` of point 4 li of a batch
@@ -1203,7 +1273,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     }
     if(ch + 1 < nchunks) {
 #pragma unroll
-      for(int q = 0; q < PER; ++q) stage(cur ^ 1, q * NRM_THREADS + tid, pre[q]);
+      for(int q = 0; q < PER; ++q) if(mine(q)) stage(cur ^ 1, q * NW + wt, pre[q]);
     }
     __syncthreads();
   }
@@ -1216,22 +1286,49 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int base = chunk * NRM_CHUNK;
 #pragma unroll
     for(int q = 0; q < PER; ++q) {
-      const int k = base + q * NRM_THREADS + tid;
-      const float4 p = (k < N) ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const int k = base + q * NW + wt;
+      const bool in = mine(q) && k < N;
+      const float4 p = in ? j.pts[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
-      dpre[q] = (k < N) ? sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) : 0.0f;
+      dpre[q] = in ? sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) : 0.0f;
     }
   };
   dists(0);
 #pragma unroll
-  for(int q = 0; q < PER; ++q) s_dist[0][q * NRM_THREADS + tid] = dpre[q];
+  for(int q = 0; q < PER; ++q) if(mine(q)) s_dist[0][q * NW + wt] = dpre[q];
   __syncthreads();
   float m = 0.0f;
-  for(int ch = 0; ch < nchunks; ++ch) {
+  if constexpr(FORM == 3) {      // the same two chunks of lead: points requested two chunks ahead, their distances formed and stored one chunk ahead
+    auto dist_store = [&](int buf, const float4 (&src)[PER], int chunk) {
+      const int base = chunk * NRM_CHUNK;
+#pragma unroll
+      for(int q = 0; q < PER; ++q) {
+        if(!mine(q)) continue;
+        const float4 p = src[q];
+        const float d0 = p.x - c0, d1 = p.y - c1, d2 = p.z - c2, d3 = p.w - c3;
+        s_dist[buf][q * NW + wt] = (base + q * NW + wt < N) ? sqrtf((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) : 0.0f;
+      }
+    };
+    fetch_to(1, pa);
+    for(int ch = 0; ch < nchunks; ch += 2) {
+      fetch_to(ch + 2, pb);
+      if(tid < 64) nrm_chain_asm(m, reinterpret_cast<const float4*>(s_dist[0]), chunk_cnt(ch));
+      if(ch + 1 < nchunks) dist_store(1, pa, ch + 1);
+      __syncthreads();
+      if(ch + 1 >= nchunks) break;
+      fetch_to(ch + 3, pa);
+      if(tid < 64) nrm_chain_asm(m, reinterpret_cast<const float4*>(s_dist[1]), chunk_cnt(ch + 1));
+      if(ch + 2 < nchunks) dist_store(0, pb, ch + 2);
+      __syncthreads();
+    }
+  }
+  for(int ch = 0; ch < nchunks && FORM != 3; ++ch) {
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) dists(ch + 1);
-    if constexpr(FORM == 2) {
+    if constexpr(FORM == 3) {
+      if(tid < 64) nrm_chain_asm(m, reinterpret_cast<const float4*>(s_dist[cur]), cnt);
+    } else if constexpr(FORM == 2) {
       if(tid < 64) nrm_chain_b128<FORM>(m, reinterpret_cast<const float4*>(s_dist[cur]), cnt / 4);
     } else if(tid < 64) {
       float4 d4 = *reinterpret_cast<const float4*>(&s_dist[cur][4 * li]), n4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1245,7 +1342,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     }
     if(ch + 1 < nchunks) {
 #pragma unroll
-      for(int q = 0; q < PER; ++q) s_dist[cur ^ 1][q * NRM_THREADS + tid] = dpre[q];
+      for(int q = 0; q < PER; ++q) if(mine(q)) s_dist[cur ^ 1][q * NW + wt] = dpre[q];
     }
     __syncthreads();
   }
@@ -1573,7 +1670,11 @@ void launch_normalization(hipStream_t s, const FrameJob* jobs, int job_pitch, in
                           int with_normalization, int form)
 {
   const dim3 grid(nframes, num_levels - first_level);
-  if(form == 2) hipLaunchKernelGGL(normalization_kernel<2>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
+  // 4 (the default): FORM 3 — plain adds on a wave of its own, 10 % faster on a dense template, at 118 registers instead of 28 — where every
+  // workgroup of the launch is resident anyway; FORM 1 for the launches of a large batch, whose throughput is the number of resident chains
+  if(form == 4) form = (nframes * (num_levels - first_level) <= 1024) ? 3 : 1;
+  if(form == 3) hipLaunchKernelGGL(normalization_kernel<3>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
+  else if(form == 2) hipLaunchKernelGGL(normalization_kernel<2>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
   else if(form == 1) hipLaunchKernelGGL(normalization_kernel<1>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
   else hipLaunchKernelGGL(normalization_kernel<0>, grid, dim3(NRM_THREADS), 0, s, jobs, job_pitch, first_level, with_normalization);
 }

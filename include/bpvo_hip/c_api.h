@@ -389,12 +389,15 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
  *   "normalization_side_stream" 1      a frame stage that runs alone on the context's stream (single frames, batches on one lane) queues the
  *                                      Hartley normalisation sums on a stream of its own, next to template_build, and joins them before it returns
- *   "normalization_form"     1         the sequential (reference-order) Hartley sums: 1 = hand-scheduled DPP add chains (170 us for a 1241x376 template); 0 = the
- *                                      compiler's DPP form (274 us); 2 = every lane of a row reads the same four consecutive elements from LDS and adds them
- *                                      with plain adds — no cross-lane traffic, no asm (310 us).  Same sums bit for bit: tests/test_gpu_parity.py runs the
- *                                      three against each other
- *   "normalization_deferred" 1         ... and inside bpvo_hip_batch_run on one lane (not the team kernel) only the coarsest level's sums are joined:
- *                                      the others run on under that level's Gauss-Newton iterations, the estimation waits for them before its second level
+ *   "normalization_form"     4         the sequential (reference-order) Hartley sums: 1 = hand-scheduled DPP add chains (170 us for a 1241x376 template,
+ *                                      2.28 ms for a dense 640x480 one); 0 = the compiler's DPP form (281 us / 3.6 ms); 2 = every lane of a row reads the same
+ *                                      four consecutive elements from LDS and adds them with plain adds — no cross-lane traffic, no asm (311 us / 4.0 ms);
+ *                                      3 = those reads with the adds as asm blocks of back-to-back plain adds on a wave that does nothing else (170 us /
+ *                                      2.04 ms, 118 registers); 4 = 3 for launches of at most 1024 workgroups, 1 for larger ones.  Same sums bit for bit:
+ *                                      tests/test_gpu_parity.py runs the four against each other
+ *   "normalization_deferred" 1         ... and inside bpvo_hip_batch_run on one lane (not the team kernel), and where addFrame re-estimates against a new key
+ *                                      frame, only the coarsest level's sums are joined: the others run on under the Gauss-Newton iterations of the levels
+ *                                      above them (the finest level's on a stream of its own), the estimation waits for them level by level
  *   "team_split_max_pairs"   4         ... and team batches of up to this many pairs run the coarsest level of every pair in a launch of its own, the
  *                                      deferred sums under it, the other levels in a second launch behind them (2 / 4 pairs + 1.2 / + 1.5 %; from 8 pairs on the
  *                                      launch boundary — every pair waits for the slowest — costs 4 - 7 %: DESIGN.md 7; 0: one launch, sums joined first)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The three forms of the sequential Hartley sums (option "normalization_form"): time of the normalisation launch by HIP events (kernel class
+"""The four forms of the sequential Hartley sums (option "normalization_form"): time of the normalisation launch by HIP events (kernel class
 "normalization", profiling level 2) for a 1241x376 template with NMS (26 k points at most per level) and a dense 640x480 one (300 k), and the
 bits of (s, c) of every level compared.   python scripts/nrm_forms.py"""
 import os, sys, time
@@ -12,7 +12,7 @@ for name, rows, cols, levels, kw in (("1241x376 bit-planes, NMS (sparse template
                                      ("640x480 intensity, NMS off (dense template)", 480, 640, 3, dict(nonMaxSuppRadius=0, minSaliency=0.001, descriptor=capi.DESC_INTENSITY))):
     b = synth.make_batch(rows, cols, 1, first_index=0, workers=1)
     ref = None
-    for form in (2, 1, 0):
+    for form in (2, 1, 0, 3):
         p = hip.default_params(); p.numPyramidLevels = levels; p.descriptor = capi.DESC_BITPLANES; p.lossFunction = capi.LOSS_TUKEY; p.verbosity = capi.VERB_SILENT
         for k, v in kw.items(): setattr(p, k, v)
         ctx = hip.create(b["K"], b["b"], rows, cols, p, n_frames=2, n_pairs=1)

@@ -1246,10 +1246,11 @@ def test_latch_descriptor_parity(hip, orc, rows, cols, levels, nbytes, K, rotati
 def test_normalisation_sums_hand_scheduled_against_the_compilers_form(hip, rows, cols, levels):
     """The Hartley sums (bpvo/warps.cc:27-48) are sequential f32 additions.  Option "normalization_form": 1 (the default) back-to-back DPP adds without
     the wait states the compiler's hazard table inserts (kernels_frame.hip nrm_add_batch), 0 the compiler's form of those chains, 2 broadcast LDS
-    reads + plain adds (no cross-lane traffic, no asm): T_n / T_n^-1 of every level, and every pose built on them, must be the same bits in all three — a toolchain
+    reads + plain adds (no cross-lane traffic, no asm), 3 the same reads with the adds as blocks of back-to-back plain v_add_f32 on a wave that does nothing else:
+    T_n / T_n^-1 of every level, and every pose built on them, must be the same bits in all four — a toolchain
     or hardware change that invalidates the hand-scheduled form fails here (and the default against the oracle in test_template_bit_exact)."""
     outs = []
-    for asm in (2, 1, 0):
+    for asm in (2, 1, 0, 3):
         ch, d, _ = setup_pair(hip, rows, cols, levels=levels, descriptor="bitplanes", loss="tukey")
         ch.set_option("normalization_form", asm)
         ch.frame_set_template(0)
