@@ -1247,13 +1247,11 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
       __syncthreads();
     }
   }
-  for(int ch = 0; ch < nchunks && FORM != 3; ++ch) {
+  for(int ch = 0; ch < nchunks && FORM != 3; ++ch) {      // (forms 0 - 2: one chunk of lead)
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) fetch(ch + 1);
-    if constexpr(FORM == 3) {
-      if(tid < 64) nrm_chain_asm(c, reinterpret_cast<const float4*>(s_comp[cur][row]), cnt);
-    } else if constexpr(FORM == 2) {
+    if constexpr(FORM == 2) {
       if(tid < 64) nrm_chain_b128<FORM>(c, reinterpret_cast<const float4*>(s_comp[cur][row]), cnt / 4);
     } else if(tid < 64) {
       const float* sp = reinterpret_cast<const float*>(s_pts[cur]) + row + 16 * li;      // component `row` of point 4 li of a batch
@@ -1326,9 +1324,7 @@ __global__ __launch_bounds__(NRM_THREADS) void normalization_kernel(const FrameJ
     const int cur = ch & 1;
     const int cnt = min(NRM_CHUNK, N - ch * NRM_CHUNK);
     if(ch + 1 < nchunks) dists(ch + 1);
-    if constexpr(FORM == 3) {
-      if(tid < 64) nrm_chain_asm(m, reinterpret_cast<const float4*>(s_dist[cur]), cnt);
-    } else if constexpr(FORM == 2) {
+    if constexpr(FORM == 2) {
       if(tid < 64) nrm_chain_b128<FORM>(m, reinterpret_cast<const float4*>(s_dist[cur]), cnt / 4);
     } else if(tid < 64) {
       float4 d4 = *reinterpret_cast<const float4*>(&s_dist[cur][4 * li]), n4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
