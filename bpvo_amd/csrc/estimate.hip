@@ -50,6 +50,18 @@ bool team_serves(const bpvo_hip_ctx* c, int n)
          c->num_cus >= 2 && g_live_ctx[c->device & 63].load() <= 1;
 }
 
+// ... and only templates the team kernel is good at: a pyramid level of more points than the persistent kernels are given (persist_max_points: dense
+// templates, NMS off) is bandwidth work for the chain's chip-wide launches — the teams' per-pair median alone walks a thousand candidate segments
+// per iteration there (640x480 bit-planes, NMS off, 4 / 16 / 64 pairs: 11.4 / 15.2 / 30.1 ms per step on the team kernel, 6.0 / 10.1 / 20.8 on the
+// chain: scripts/dense_batch_ab.py)
+static bool templates_suit_teams(const bpvo_hip_ctx* c, int n, const int* refs)
+{
+  for(int i = 0; i < n; ++i)
+    for(int l = c->params.maxTestLevel; l < c->L; ++l)
+      if(c->frames[refs[i]].n_host[l] > c->persist_max_points) return false;
+  return true;
+}
+
 // allow_persistent: only a group that has the device to itself (a batch on ONE lane) may take the persistent kernel — two
 // hand-barrier grids of concurrent lanes must not be co-scheduled.
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init,
@@ -123,7 +135,7 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     return BPVO_OK;
   };
   bool team_split = false;
-  if(allow_persistent && ln == &c->lanes[0] && team_serves(c, n)) {
+  if(allow_persistent && ln == &c->lanes[0] && team_serves(c, n) && templates_suit_teams(c, n, refs)) {
     // Small batches whose template stage left the normalisation of the levels below the coarsest on the side stream (frames.hip): the
     // team kernel in TWO launches — the coarsest level of every pair, then (behind that normalisation) the others.  The sums (0.17 - 0.19 ms
     // for a 1241x376 frame, whatever the batch) then run under the coarsest level's iterations instead of in front of the first one;
@@ -368,7 +380,7 @@ int estimate_batch(bpvo_hip_ctx* c, int n, const int* wss, const int* refs, cons
   }
   int nl = lanes_for(c, n, 8);
   if(nl < 0) return nl;
-  if(team_serves(c, n)) nl = 1;      // the team-persistent kernel takes the whole chip
+  if(team_serves(c, n) && templates_suit_teams(c, n, refs)) nl = 1;      // the team-persistent kernel takes the whole chip
   // frame stages run on the ctx stream: the other lanes' streams start from a quiet device.  A single lane IS the ctx stream — its
   // launches simply queue behind the frame stage (sequential addFrame: ~30 us of idle device per frame otherwise).
   if(nl > 1) {
