@@ -296,7 +296,10 @@ int bpvo_hip_batch_run(bpvo_hip_ctx* c, int n_pairs, const uint8_t* images, cons
   // coarsest (a single pair per call: 0.15 of 3.2 ms)
   FrameRun fr = ctx_run(c);
   fr.no_final_sync = !c->profiling;
-  fr.defer_finest_nrm = !team_serves(c, n_pairs) || n_pairs <= c->team_split_max_pairs;      // (the team kernel: in two launches then, estimate.hip)
+  // (the team kernel: in two launches then, estimate.hip.  Whether it serves the batch is only known once the templates are — dense ones take the
+  // chain — so parameters that allow a dense level defer as the chain does: 8 dense pairs lost 11 - 43 % to the sums in front of their first
+  // iteration; sparse team batches of 8 - 16 pairs lose 2 - 4 % to the deferral's three launches: scripts/path_sweep.py)
+  fr.defer_finest_nrm = !team_serves(c, n_pairs) || n_pairs <= c->team_split_max_pairs || templates_may_be_dense(c);
   rc = frames_set_template(c, 0, 2, n_pairs, fr);
   if(rc == BPVO_OK) rc = bpvo_hip_batch_estimate(c, n_pairs, nullptr, poses, stats);
   // (an error on the way: nothing of this call stays in flight)

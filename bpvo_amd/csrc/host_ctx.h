@@ -430,6 +430,14 @@ inline hipError_t join_pending_normalization(bpvo_hip_ctx* c, hipStream_t s)
   if(c->nrm_pending_finest) { const hipError_t e2 = hipStreamWaitEvent(s, c->nrm_pending_finest, 0); c->nrm_pending_finest = nullptr; if(e == hipSuccess) e = e2; }
   return e;
 }
+// can a template of this context have a level of more points than the persistent kernels are given (persist_max_points)?  Only a level without
+// non-maximum suppression selects (nearly) every pixel; known from the parameters alone, before any template exists
+inline bool templates_may_be_dense(const bpvo_hip_ctx* c)
+{
+  for(int l = c->params.maxTestLevel; l < c->L; ++l)
+    if(c->geom[l].nms_radius <= 0 && c->geom[l].npix > (size_t) std::max(0, c->persist_max_points)) return true;
+  return false;
+}
 inline int dense_candidates(const bpvo_hip_ctx* c, int max_points) { return (c->G == 1 && max_points >= c->dense_candidates_from) ? 1 : 0; }
 inline bpvo_hip::GNLaunch median_launch(const bpvo_hip_ctx* c, bpvo_hip::GNLaunch g) { if(c->G > 1) g.C = c->Cg; return g; }
 int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* refs, const int* curs, const float* T_init, float* poses,
