@@ -493,7 +493,9 @@ int bpvo_hip_create(bpvo_hip_ctx** out, const float K[9], float baseline, int ro
   }
   const bool grad_smoothed = c->params.descriptor == BPVO_DESC_INTENSITY_AND_GRADIENT && c->params.sigmaPriorToCensusTransform > 0.0f;
   // (LATCH keeps its [key points][bytes] buffer behind three work planes: kernels_planes.hip)
-  c->scratch_planes = c->params.descriptor == BPVO_DESC_LATCH ? std::max(kDfPlanes, 3 + (c->params.latchNumBytes + 3) / 4) : kDfPlanes;
+  // (... and both wide descriptors eight more: the row passes of a group of eight channels, kernels_planes.hip df_col8_kernel)
+  c->scratch_planes = c->params.descriptor == BPVO_DESC_LATCH ? std::max(kDfPlanes, 3 + (c->params.latchNumBytes + 3) / 4 + 8)
+                      : c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE ? std::max(kDfPlanes, 3 + 8) : (c->C == 5 || c->C == 10) ? kDfPlanes + 8 : kDfPlanes;
   c->plane_scratch = c->C == 5 || c->C == 10 || c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE || c->params.descriptor == BPVO_DESC_LATCH || grad_smoothed;
   if(c->params.descriptor == BPVO_DESC_CENTRAL_DIFFERENCE) {
     gaussian_taps(imsmooth_taps(c->params.centralDifferenceSigmaBefore), c->params.centralDifferenceSigmaBefore, &c->cd_before);

@@ -173,6 +173,92 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
   D.p[q * D.stride] = v;
 }
 
+// ---- wide descriptors built channel by channel (CentralDifference: 48 ... 360 channels, LATCH: 8 ... 512): a column pass that wrote ONE channel of the
+// pixel-interleaved records stored 4 bytes every 4 C — a partial sector per pixel and channel, 0.88 ms per 640x480 frame for 48 channels against 0.44 ms
+// for 128 frames of bit-planes.  So the row passes of up to eight consecutive channels go to eight work planes (coalesced), and ONE column pass forms the
+// eight channels of a pixel and stores them as one contiguous 32-byte piece of its record.  Same operations per channel, same order: same bits.
+// (a) the row pass of the smoothing of (image - its clamped shift by (ox, oy)) without the difference plane in between: DF_SHIFT_DIFF + DF_GAUSS_ROW(_N)
+__global__ __launch_bounds__(256) void cd_diff_row_kernel(const FrameJob* jobs, int src_code, int dst_code, int ox, int oy, float k0, float k1, float k2, GaussTaps gt)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const float* __restrict__ S = j.scratch + (size_t) src_code * R * W;
+  const float* __restrict__ r0 = S + (size_t) y * W;
+  const float* __restrict__ r1 = S + (size_t) min(max(y + oy, 0), R - 1) * W;
+  auto d = [&](int xx) { return r0[xx] - r1[min(max(xx + ox, 0), W - 1)]; };
+  float v;
+  if(gt.n == 5) {
+    v = d(x) * k0 + (d(reflect101(x - 1, W)) + d(reflect101(x + 1, W))) * k1 + (d(reflect101(x - 2, W)) + d(reflect101(x + 2, W))) * k2;
+  } else {
+    const int r = gt.n >> 1;
+    v = gt.k[0] * d(reflect101_wide(x - r, W));
+    for(int t = 1; t < gt.n; ++t) v += gt.k[t] * d(reflect101_wide(x - r + t, W));
+  }
+  (j.scratch + (size_t) dst_code * R * W)[(size_t) y * W + x] = v;
+}
+// (b) the column pass (DF_GAUSS_COL / DF_GAUSS_COL_N) of work planes src_code .. src_code + nch - 1 into channels c0 .. c0 + nch - 1
+__global__ __launch_bounds__(256) void df_col8_kernel(const FrameJob* jobs, int src_code, int nch, int c0, int C, float k0, float k1, float k2, GaussTaps gt)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const size_t plane = (size_t) R * W;
+  const float* __restrict__ S = j.scratch + (size_t) src_code * plane;
+  float v[8];
+  if(gt.n == 5) {
+    const size_t q0 = (size_t) y * W + x, qp1 = (size_t) reflect101(y + 1, R) * W + x, qm1 = (size_t) reflect101(y - 1, R) * W + x,
+                 qp2 = (size_t) reflect101(y + 2, R) * W + x, qm2 = (size_t) reflect101(y - 2, R) * W + x;
+#pragma unroll
+    for(int k = 0; k < 8; ++k) {
+      if(k >= nch) { v[k] = 0.0f; continue; }
+      const float* __restrict__ P = S + (size_t) k * plane;
+      float a = k0 * P[q0];
+      a += k1 * (P[qp1] + P[qm1]);
+      a += k2 * (P[qp2] + P[qm2]);
+      v[k] = a;
+    }
+  } else {
+    const int r = gt.n >> 1;
+#pragma unroll
+    for(int k = 0; k < 8; ++k) v[k] = k < nch ? gt.k[r] * S[(size_t) k * plane + (size_t) y * W + x] : 0.0f;
+    for(int t = 1; t <= r; ++t) {
+      const size_t qa = (size_t) reflect101_wide(y + t, R) * W + x, qb = (size_t) reflect101_wide(y - t, R) * W + x;
+#pragma unroll
+      for(int k = 0; k < 8; ++k)
+        if(k < nch) v[k] += gt.k[r + t] * (S[(size_t) k * plane + qa] + S[(size_t) k * plane + qb]);
+    }
+  }
+  float* __restrict__ dst = j.desc + ((size_t) y * W + x) * C + c0;
+  if(nch == 8 && (C & 3) == 0 && (c0 & 3) == 0) {
+    reinterpret_cast<float4*>(dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for(int k = 0; k < 8; ++k) if(k < nch) dst[k] = v[k];
+  }
+}
+// (c) CentralDifference without smoothing afterwards: the differences of up to eight offsets straight into their channels
+struct CdOffsets { signed char ox[8], oy[8]; };
+__global__ __launch_bounds__(256) void cd_diff8_kernel(const FrameJob* jobs, int src_code, int nch, int c0, int C, CdOffsets o)
+{
+  const FrameJob& j = jobs[blockIdx.z];
+  const int W = j.cols, R = j.rows;
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if(x >= W || y >= R) return;
+  const float* __restrict__ S = j.scratch + (size_t) src_code * R * W;
+  const float ctr = S[(size_t) y * W + x];
+  float* __restrict__ dst = j.desc + ((size_t) y * W + x) * C + c0;
+#pragma unroll
+  for(int k = 0; k < 8; ++k)
+    if(k < nch) dst[k] = ctr - S[(size_t) min(max(y + (int) o.oy[k], 0), R - 1) * W + min(max(x + (int) o.ox[k], 0), W - 1)];
+}
+
 // ---- LatchDescriptor, evaluated densely (reference: bpvo/latch_descriptor.cc:124-167 compute, :170-262 CalcuateSums, :264-493 pixelTests,
 // :1041-1086 LatchDescriptor::compute).  Key points are the pixels border <= y < R - border - 1, border <= x < W - border - 1 (row-major),
 // border = 24 + K, K = latchHalfSsdSize.  Work planes of FrameJob::scratch: the smoothed u8 image, the [key points][bytes] descriptor
@@ -330,13 +416,28 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
   };
   auto op = [&](int o, int src, int dst, int dst2 = 0) { op5(o, src, dst, nullptr, nullptr, dst2); };
   auto ch = [](int c) { return -1 - c; };
-  enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6 };
+  enum { P_I0 = 0, P_I = 1, P_B1 = 2, P_B2 = 3, P_POS = 4, P_NEG = 5, P_TMP = 6, P_ROW = 7 };
   auto smooth = [&](int src, int dst, const GaussTaps& g) { df_smooth(op5, src, P_TMP, dst, g); };
+  // the smoothed channels come in ascending order, two per split: their row passes go to the work planes P_ROW .. P_ROW + 7 and one column pass
+  // writes up to eight of them into the records at once (df_col8_kernel: contiguous stores instead of one strided float per pixel and channel)
+  const float k5[3] = {g2.k[2], g2.k[3], g2.k[4]};
+  int batch_c0 = -1, batch_n = 0;
+  auto flush = [&]() {
+    if(batch_n) hipLaunchKernelGGL(df_col8_kernel, grid, dim3(256), 0, s, jobs, (int) P_ROW, batch_n, batch_c0, C, k5[0], k5[1], k5[2], g2);
+    batch_n = 0;
+  };
+  auto smooth_to_channel = [&](int src, int c) {
+    if(batch_n && (c != batch_c0 + batch_n || batch_n == 8)) flush();
+    if(batch_n == 0) batch_c0 = c;
+    if(g2.n == 5) op5(DF_GAUSS_ROW, src, P_ROW + batch_n, k5, nullptr);
+    else op5(DF_GAUSS_ROW_N, src, P_ROW + batch_n, nullptr, &g2);
+    ++batch_n;
+  };
   auto split = [&](int src, int cpos, int cneg) {
     if(g2.n > 0) {
       op(DF_SPLIT, src, P_POS, P_NEG);
-      smooth(P_POS, ch(cpos), g2);
-      smooth(P_NEG, ch(cneg), g2);
+      smooth_to_channel(P_POS, cpos);
+      smooth_to_channel(P_NEG, cneg);
     } else {
       op(DF_SPLIT, src, ch(cpos), ch(cneg));
     }
@@ -355,6 +456,7 @@ void launch_descriptor_fields(hipStream_t s, const FrameJob* jobs, int W, int R,
     op(DF_GRAD_Y, I, P_B1);    split(P_B1, 6, 7);   // Iy
     op(DF_GRAD_Y, P_B1, P_B2); split(P_B2, 8, 9);   // Iyy
   }
+  flush();
 }
 // one level of CentralDifferenceDescriptor: C = (2r+1)^2 - 1 channels; before = the u8 blur of sigma_before (fixed-point taps),
 // after = the f32 kernel of sigma_after (n = 0: not applied)
@@ -378,18 +480,27 @@ void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R
   } else {
     opi(DF_CONVERT, 0, P_IMG, nullptr, nullptr);
   }
-  int c = 0;
+  // channels in groups of eight: their row passes into the work planes P_ROW .. P_ROW + 7, one column pass for the group (see cd_diff_row_kernel)
+  enum { P_ROW = 3 };
+  const float k5[3] = {after.k[2], after.k[3], after.k[4]};
+  int c = 0, in_group = 0;
+  CdOffsets offs;
+  auto flush = [&]() {
+    if(in_group == 0) return;
+    if(after.n > 0) hipLaunchKernelGGL(df_col8_kernel, grid, dim3(256), 0, s, jobs, (int) P_ROW, in_group, c - in_group, C, k5[0], k5[1], k5[2], after);
+    else hipLaunchKernelGGL(cd_diff8_kernel, grid, dim3(256), 0, s, jobs, (int) P_IMG, in_group, c - in_group, C, offs);
+    in_group = 0;
+  };
   for(int oy = -radius; oy <= radius; ++oy)
     for(int ox = -radius; ox <= radius; ++ox) {
       if(ox == 0 && oy == 0) continue;
-      if(after.n > 0) {
-        opi(DF_SHIFT_DIFF, P_IMG, P_DIFF, nullptr, nullptr, ox, oy);
-        df_smooth(op5, P_DIFF, P_TMP, -1 - c, after);
-      } else {
-        opi(DF_SHIFT_DIFF, P_IMG, -1 - c, nullptr, nullptr, ox, oy);
-      }
+      if(after.n > 0) hipLaunchKernelGGL(cd_diff_row_kernel, grid, dim3(256), 0, s, jobs, (int) P_IMG, P_ROW + in_group, ox, oy, k5[0], k5[1], k5[2], after);
+      else { offs.ox[in_group] = (signed char) ox; offs.oy[in_group] = (signed char) oy; }
       ++c;
+      if(++in_group == 8) flush();
     }
+  flush();
+  (void) op5;
   if(C == 8) opi(DF_TO_CH0, -1, 0, nullptr, nullptr);
 }
 
@@ -419,11 +530,18 @@ void launch_latch(hipStream_t s, const FrameJob* jobs, int W, int R, int nframes
     hipLaunchKernelGGL(df_plane_kernel, grid, dim3(256), 0, s, jobs, o, src, dst, 0, C, k ? k[0] : 0.0f, k ? k[1] : 0.0f, k ? k[2] : 0.0f, 0, 0, 0,
                        g ? *g : GaussTaps());
   };
-  for(int c = 0; c < bytes; ++c)
+  // the eight channels of a descriptor byte: their row passes into eight work planes behind the descriptor bytes, one column pass for the byte
+  // (df_col8_kernel: one contiguous 32-byte store per pixel instead of eight strided ones)
+  const int p_row = LATCH_P_BYTES + (bytes + 3) / 4;
+  const float k5[3] = {after.k[2], after.k[3], after.k[4]};
+  for(int c = 0; c < bytes; ++c) {
     for(int bit = 0; bit < 8; ++bit) {
       hipLaunchKernelGGL(latch_extract_kernel, grid, dim3(256), 0, s, jobs, c, bit, K);
-      df_smooth(op5, LATCH_P_CH, LATCH_P_TMP, -1 - (8 * c + bit), after);
+      if(after.n == 5) op5(DF_GAUSS_ROW, LATCH_P_CH, p_row + bit, k5, nullptr);
+      else op5(DF_GAUSS_ROW_N, LATCH_P_CH, p_row + bit, nullptr, &after);
     }
+    hipLaunchKernelGGL(df_col8_kernel, grid, dim3(256), 0, s, jobs, p_row, 8, 8 * c, C, k5[0], k5[1], k5[2], after);
+  }
   if(C == 8) op5(DF_TO_CH0, -1, 0, nullptr, nullptr);
 }
 
