@@ -209,8 +209,9 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
     FR_CK(c, fr, hipEventRecord(c->side_ev[0], s));
     FR_CK(c, fr, hipStreamWaitEvent(side, c->side_ev[0], 0));
     // (timed like the in-line form, with events on the side stream: they are resolved once this stream — which the side stream joins — is synchronised)
-    if(defer) {
-      // the finest level first, on its own stream (the longest chain of adds starts at once); the coarsest, then the levels between, on the other
+    if(defer && templates_may_be_dense(c)) {
+      // parameters that allow a dense level (NMS off on a large one): the finest level first, on its own stream (the longest chain of adds — 2 ms for
+      // 300 k points — starts at once and runs on under the iterations of ALL the levels above it); the coarsest, then the levels between, on the other
       hipStream_t side2 = c->side_stream2;
       FR_CK(c, fr, hipStreamWaitEvent(side2, c->side_ev[0], 0));
       { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side2); launch_normalization(side2, tab, NF, count, p.maxTestLevel, p.maxTestLevel + 1, with_nrm, c->nrm_dpp_asm); }
@@ -223,6 +224,13 @@ int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const
         FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
         c->nrm_pending = c->side_ev[2];
       }
+    } else if(defer) {
+      // (sparse templates: two launches on one stream — the third launch, the second stream and their events cost a single pair 1 % of its step)
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, c->L - 1, c->L, with_nrm, c->nrm_dpp_asm); }
+      FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
+      { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L - 1, with_nrm, c->nrm_dpp_asm); }
+      FR_CK(c, fr, hipEventRecord(c->side_ev[2], side));
+      c->nrm_pending = c->side_ev[2];
     } else {
       { ScopedTimer t(c, KC_NORMALIZATION, 0.0, fr.ln, true, side); launch_normalization(side, tab, NF, count, p.maxTestLevel, c->L, with_nrm, c->nrm_dpp_asm); }
       FR_CK(c, fr, hipEventRecord(c->side_ev[1], side));
