@@ -457,11 +457,18 @@ __device__ __forceinline__ void median_block(const PairJob& j, GNState* st, unsi
     if((double) s < 1e-6) s = 1.0f;
     st->delta_scale = fabsf(s - st->scale);
     st->scale = s;
-    // bracket for the next linearisation of this level: centred on this median, as wide as 2.5x the last relative
-    // change + 2 % (first use: 25 %), at most 50 %
+    // bracket for the next linearisation of this level: centred on this median, as wide as 2x the last relative
+    // change + 1 % (first use: 25 %), at most 50 %
     if(n_total >= 3 && median > 0.0f) {
       float rel = 0.25f;
-      if(st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(0.02f, 2.5f * fabsf(median - st->last_median) / st->last_median + 0.02f));
+      // (gain 2.5 + 2 % until round 6: on the benched batch the bracket then held 5 - 15 % of the keys where the median moved by 0.02 - 1 % — 2 + 1 %
+// holds half as many, misses 0.4 % of the selections instead of none, and is worth 0.5 % of the 1024-pair step and 2 % of a single pair's;
+// 2 + 0.5 % misses more than it saves on a single pair: scripts/shard_ab.py with builds of -DMED_REL_FLOOR / -DMED_REL_GAIN)
+#ifndef MED_REL_FLOOR
+#define MED_REL_FLOOR 0.01f
+#define MED_REL_GAIN 2.0f
+#endif
+      if(st->last_median > 0.0f) rel = fminf(0.5f, fmaxf(MED_REL_FLOOR, MED_REL_GAIN * fabsf(median - st->last_median) / st->last_median + MED_REL_FLOOR));
       st->last_median = median;
       st->lo_key = __float_as_uint(median * (1.0f - rel));
       st->hi_key = __float_as_uint(median * (1.0f + rel)) + 1u;

@@ -54,7 +54,8 @@ def child(a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gn = ctx.total_linearizations()
-    print(json.dumps(dict(pairs=n, value=gn / dt, ms_per_step=1e3 * dt / a.steps, gn_per_step=gn / a.steps,
+    bracketed, full = ctx.median_path_counts()      # exact-median selections from the bracket's candidates / over all keys (level starts + bracket misses)
+    print(json.dumps(dict(pairs=n, value=gn / dt, ms_per_step=1e3 * dt / a.steps, gn_per_step=gn / a.steps, median_bracketed=bracketed, median_full=full,
                           checksum=float(np.abs(poses.astype(np.float64)).sum()))))
     ctx.close()
 
@@ -107,7 +108,7 @@ def main():
                 r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 out.append(json.loads(line[-1]) if line else dict(error=(r.stdout + r.stderr)[-400:]))
-            msg = " | ".join(f"{o.get('pairs')}: {o.get('value', 0) / 1e3:8.1f} k GN it/s {o.get('ms_per_step', 0):7.2f} ms" if "value" in o else str(o) for o in out)
+            msg = " | ".join(f"{o.get('pairs')}: {o.get('value', 0) / 1e3:8.1f} k GN it/s {o.get('ms_per_step', 0):7.2f} ms, full selections {o.get('median_full', 0)} of {o.get('median_full', 0) + o.get('median_bracketed', 0)}, checksum {o.get('checksum', 0):.9g}" if "value" in o else str(o) for o in out)
             if len(out) == 2 and "value" in out[0] and "value" in out[1]:
                 msg += f" | ratio {out[0]['value'] / out[1]['value']:.3f}"
             print(f"[{rep}] {v or 'default':60s} {msg}", flush=True)
