@@ -178,13 +178,18 @@ __global__ __launch_bounds__(256) void df_plane_kernel(const FrameJob* jobs, int
 // for 128 frames of bit-planes.  So the row passes of up to eight consecutive channels go to eight work planes (coalesced), and ONE column pass forms the
 // eight channels of a pixel and stores them as one contiguous 32-byte piece of its record.  Same operations per channel, same order: same bits.
 // (a) the row pass of the smoothing of (image - its clamped shift by (ox, oy)) without the difference plane in between: DF_SHIFT_DIFF + DF_GAUSS_ROW(_N)
-__global__ __launch_bounds__(256) void cd_diff_row_kernel(const FrameJob* jobs, int src_code, int dst_code, int ox, int oy, float k0, float k1, float k2, GaussTaps gt)
+// (blockIdx.z = frame * 8 + channel of the group: the row passes of a group's eight offsets are ONE launch)
+struct CdOffsets { signed char ox[8], oy[8]; };
+__global__ __launch_bounds__(256) void cd_diff_row_kernel(const FrameJob* jobs, int src_code, int dst_code0, int nch, CdOffsets o, float k0, float k1, float k2, GaussTaps gt)
 {
-  const FrameJob& j = jobs[blockIdx.z];
+  const int kch = blockIdx.z & 7;
+  if(kch >= nch) return;
+  const FrameJob& j = jobs[blockIdx.z >> 3];
   const int W = j.cols, R = j.rows;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if(x >= W || y >= R) return;
+  const int ox = o.ox[kch], oy = o.oy[kch];
   const float* __restrict__ S = j.scratch + (size_t) src_code * R * W;
   const float* __restrict__ r0 = S + (size_t) y * W;
   const float* __restrict__ r1 = S + (size_t) min(max(y + oy, 0), R - 1) * W;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void cd_diff_row_kernel(const FrameJob* jobs, 
     v = gt.k[0] * d(reflect101_wide(x - r, W));
     for(int t = 1; t < gt.n; ++t) v += gt.k[t] * d(reflect101_wide(x - r + t, W));
   }
-  (j.scratch + (size_t) dst_code * R * W)[(size_t) y * W + x] = v;
+  (j.scratch + (size_t) (dst_code0 + kch) * R * W)[(size_t) y * W + x] = v;
 }
 // (b) the column pass (DF_GAUSS_COL / DF_GAUSS_COL_N) of work planes src_code .. src_code + nch - 1 into channels c0 .. c0 + nch - 1
 __global__ __launch_bounds__(256) void df_col8_kernel(const FrameJob* jobs, int src_code, int nch, int c0, int C, float k0, float k1, float k2, GaussTaps gt)
@@ -243,7 +248,6 @@ __global__ __launch_bounds__(256) void df_col8_kernel(const FrameJob* jobs, int 
   }
 }
 // (c) CentralDifference without smoothing afterwards: the differences of up to eight offsets straight into their channels
-struct CdOffsets { signed char ox[8], oy[8]; };
 __global__ __launch_bounds__(256) void cd_diff8_kernel(const FrameJob* jobs, int src_code, int nch, int c0, int C, CdOffsets o)
 {
   const FrameJob& j = jobs[blockIdx.z];
@@ -484,18 +488,24 @@ void launch_central_difference(hipStream_t s, const FrameJob* jobs, int W, int R
   enum { P_ROW = 3 };
   const float k5[3] = {after.k[2], after.k[3], after.k[4]};
   int c = 0, in_group = 0;
-  CdOffsets offs;
+  CdOffsets offs = {};
   auto flush = [&]() {
     if(in_group == 0) return;
-    if(after.n > 0) hipLaunchKernelGGL(df_col8_kernel, grid, dim3(256), 0, s, jobs, (int) P_ROW, in_group, c - in_group, C, k5[0], k5[1], k5[2], after);
-    else hipLaunchKernelGGL(cd_diff8_kernel, grid, dim3(256), 0, s, jobs, (int) P_IMG, in_group, c - in_group, C, offs);
+    if(after.n > 0) {
+      for(int f0 = 0; f0 < nframes; f0 += 8000) {      // (grid.z <= 65535)
+        const dim3 grid8(grid.x, grid.y, (unsigned) std::min(8000, nframes - f0) * 8u);
+        hipLaunchKernelGGL(cd_diff_row_kernel, grid8, dim3(256), 0, s, jobs + f0, (int) P_IMG, (int) P_ROW, in_group, offs, k5[0], k5[1], k5[2], after);
+      }
+      hipLaunchKernelGGL(df_col8_kernel, grid, dim3(256), 0, s, jobs, (int) P_ROW, in_group, c - in_group, C, k5[0], k5[1], k5[2], after);
+    } else {
+      hipLaunchKernelGGL(cd_diff8_kernel, grid, dim3(256), 0, s, jobs, (int) P_IMG, in_group, c - in_group, C, offs);
+    }
     in_group = 0;
   };
   for(int oy = -radius; oy <= radius; ++oy)
     for(int ox = -radius; ox <= radius; ++ox) {
       if(ox == 0 && oy == 0) continue;
-      if(after.n > 0) hipLaunchKernelGGL(cd_diff_row_kernel, grid, dim3(256), 0, s, jobs, (int) P_IMG, P_ROW + in_group, ox, oy, k5[0], k5[1], k5[2], after);
-      else { offs.ox[in_group] = (signed char) ox; offs.oy[in_group] = (signed char) oy; }
+      offs.ox[in_group] = (signed char) ox; offs.oy[in_group] = (signed char) oy;
       ++c;
       if(++in_group == 8) flush();
     }
