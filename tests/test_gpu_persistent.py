@@ -287,6 +287,31 @@ def test_which_batches_take_the_team_kernel(hip):
             ctx.close()
 
 
+def test_dense_templates_take_the_chain_not_the_team_kernel(hip, monkeypatch):
+    """A small batch whose templates have a pyramid level of more points than the persistent kernels are given (option persist_max_points: NMS
+    off on a large level, conf/tsukuba.cfg) is bandwidth work for the chain's chip-wide launches: the team kernel's per-pair median walks a
+    thousand candidate segments per iteration there (4 dense 640 x 480 pairs: 11.5 ms per step on the team kernel, 6.0 on the chain:
+    scripts/dense_batch_ab.py).  Same bits either way; with the threshold raised the team kernel takes the batch again."""
+    rows, cols, levels, n = 480, 640, 3, 4
+    b = synth.make_batch(rows, cols, n, first_index=40)
+    kw = dict(levels=levels, descriptor="bitplanes", loss="tukey", nonMaxSuppRadius=0)
+    outs = []
+    for raise_threshold in (False, True):
+        ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, **kw), n_frames=2 * n, n_pairs=n)
+        if raise_threshold:
+            ctx.set_option("persist_max_points", 1 << 22)
+        outs.append(ctx.batch_run(b["images"], b["disparities"]))
+        assert max(ctx.num_points(0, l) for l in range(levels)) > 32768
+        assert ctx.team_counts() == (1 if raise_threshold else 0), (raise_threshold, ctx.team_counts())
+        ctx.close()
+    assert bits_equal(outs[0][0], outs[1][0]) and outs[0][1].tobytes() == outs[1][1].tobytes()
+    # templates with non-maximum suppression: the team kernel, as before
+    ctx = hip.create(b["K"], b["b"], rows, cols, make_params(hip, levels=levels, descriptor="bitplanes", loss="tukey"), n_frames=2 * n, n_pairs=n)
+    ctx.batch_run(b["images"], b["disparities"])
+    assert ctx.team_counts() == 1
+    ctx.close()
+
+
 @pytest.mark.parametrize("rows,cols,levels,descriptor,loss", [pytest.param(376, 1241, 4, "bitplanes", "tukey", id="kitti-bitplanes"),
                                                               pytest.param(480, 640, 5, "bitplanes", "huber", id="vga-L5"),
                                                               pytest.param(120, 160, 3, "intensity", "huber", id="160x120-intensity"),
