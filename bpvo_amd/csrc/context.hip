@@ -298,6 +298,7 @@ const std::vector<OptionDef>& option_table()
               [](bpvo_hip_ctx* c, double) { c->team_joins.store(0); return BPVO_OK; }},
     OPT_INT("team_join_from_pairs", team_join_from_pairs, 0, 1 << 20),
     OPT_INT("team_spares", team_spares, 0, 1),
+    OPT_INT("vo_disparity_late", vo_disparity_late, 0, 1),
     OPT_INT("normalization_side_stream", nrm_side_stream, 0, 1),
     OPT_INT("normalization_form", nrm_dpp_asm, 0, 4),
     OPT_INT("small_batch_fused", small_batch_fused, 0, 1),
@@ -699,6 +700,8 @@ void bpvo_hip_destroy(bpvo_hip_ctx* c)
   }
   if(c->side_stream) { (void) hipStreamSynchronize(c->side_stream); (void) hipStreamDestroy(c->side_stream); }
   if(c->side_stream2) { (void) hipStreamSynchronize(c->side_stream2); (void) hipStreamDestroy(c->side_stream2); }
+  if(c->copy_stream) { (void) hipStreamSynchronize(c->copy_stream); (void) hipStreamDestroy(c->copy_stream); }
+  if(c->copy_ev) (void) hipEventDestroy(c->copy_ev);
   for(auto e : c->side_ev) if(e) (void) hipEventDestroy(e);
   if(c->stream) (void) hipStreamDestroy(c->stream);
   delete c;

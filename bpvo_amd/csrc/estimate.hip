@@ -313,6 +313,11 @@ int estimate_group(bpvo_hip_ctx* c, Lane* ln, int n, const int* wss, const int* 
     if(pk_group)
       LANE_CK(ln, hipMemcpyAsync(ln->h_pk_ctl, ln->d_pk_ctl, sizeof(unsigned) * kPkCtlWords * kMaxLevels, hipMemcpyDeviceToHost, ln->stream));
   }
+  if(c->before_final_sync && ln == &c->lanes[0]) {      // (every kernel of the estimate is queued: the host is free for a moment)
+    const std::function<int()> f = std::move(c->before_final_sync);
+    c->before_final_sync = nullptr;
+    if(const int rcf = f()) return rcf;
+  }
   LANE_CK(ln, hipStreamSynchronize(ln->stream));
   LANE_CK(ln, hipGetLastError());
   if(frac_queued) { c->frac_valid = true; c->frac_ws = wss[0]; c->frac_thr = c->prefetch_frac_thr; c->frac_cnt = (unsigned) c->h_ints[0]; }

@@ -48,7 +48,7 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     for(int i = 0; i < count; ++i) {
       FrameSlot& f = c->frames[first + i * stride];
       FR_CK(c, fr, hipMemcpyAsync(f.img[0], images + (size_t) i * npix, npix, hipMemcpyHostToDevice, s));
-      if(!(skip_odd_disp && (i & 1)))
+      if(!(skip_odd_disp && (i & 1)) && !fr.skip_disparity_upload)
         FR_CK(c, fr, hipMemcpyAsync(f.disp, disps + (size_t) i * npix, npix * sizeof(float), hipMemcpyHostToDevice, s));
     }
   }
@@ -133,6 +133,20 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
     f.has_data = true;
     f.has_disp = !(skip_odd_disp && (i & 1));
   }
+  return BPVO_OK;
+}
+// the disparity of a slot whose data stage ran with FrameRun::skip_disparity_upload, from the caller's host buffer, on the context's copy stream; the
+// context's stream waits for it (whatever is queued there later sees the disparity).  A copy from pageable memory holds the host until it is done
+// (1.2 MB of a 640x480 disparity: 90 us): addFrame calls this with the estimate queued, so that the GPU works meanwhile.
+int upload_disparity(bpvo_hip_ctx* c, int slot, const float* disparity)
+{
+  if(!c->copy_stream) {
+    HIP_CK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_CK(c, hipEventCreateWithFlags(&c->copy_ev, hipEventDisableTiming));
+  }
+  HIP_CK(c, hipMemcpyAsync(c->frames[slot].disp, disparity, c->geom[0].npix * sizeof(float), hipMemcpyHostToDevice, c->copy_stream));
+  HIP_CK(c, hipEventRecord(c->copy_ev, c->copy_stream));
+  HIP_CK(c, hipStreamWaitEvent(c->stream, c->copy_ev, 0));
   return BPVO_OK;
 }
 int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device, int skip_odd_disp)

@@ -230,6 +230,12 @@ struct bpvo_hip_ctx {
   // coarsest and the finest done, [3] the finest level done.  Deferred form: the finest level — the long one: 2.3 ms of dependent adds for a dense
   // 640x480 template — has a stream of its own, so that the levels above it are ready, and their Gauss-Newton iterations run, while it is still adding.
   hipStream_t side_stream = nullptr, side_stream2 = nullptr;
+  hipStream_t copy_stream = nullptr;      // addFrame's disparity upload (frames.hip upload_disparity); created at its first use, with its event
+  hipEvent_t copy_ev = nullptr;
+  // run once by the estimation of a group on the context's stream right before its final synchronisation, i.e. with every kernel of the estimate
+  // queued (estimate.hip): addFrame's disparity upload
+  std::function<int()> before_final_sync;
+  int vo_disparity_late = 1;      // option "vo_disparity_late": addFrame uploads a host frame's disparity under the queued estimate (1) or in its data stage (0)
   hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t nrm_pending = nullptr;   // non-null: recorded behind the normalisation of the levels between the coarsest and the finest of the template stage just
                                  // queued; whoever reads those levels' (scale, centroid) next makes its stream wait for it (estimate.hip) and clears it
@@ -373,6 +379,9 @@ struct FrameRun {
   // a template stage whose estimation follows on the same stream inside the same call (bpvo_hip_batch_run on one lane):
   bool defer_finest_nrm = false;       // the normalisation of every level but the coarsest stays on the side streams: ctx->nrm_pending / nrm_pending_finest, joined by the estimation
   bool no_final_sync = false;          // no host synchronisation at the end of the stage
+  // frames_set_data from host buffers (addFrame): the disparity — which nothing of the data stage or of the estimate reads — is not copied by the stage;
+  // the caller uploads it (upload_disparity, frames.hip) once the estimate is queued, so that the copy's hold on the host lies under the GPU's work
+  bool skip_disparity_upload = false;
 };
 #define FR_CK(c_, fr_, expr)                                                                \
   do {                                                                                      \
@@ -401,6 +410,7 @@ int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uin
                     int skip_odd_disp = 0);
 int frames_set_data(bpvo_hip_ctx* c, int first, int stride, int count, const uint8_t* images, const float* disps, bool on_device, int skip_odd_disp = 0);
 int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count, const FrameRun& fr);
+int upload_disparity(bpvo_hip_ctx* c, int slot, const float* disparity);
 int frames_set_template(bpvo_hip_ctx* c, int first, int stride, int count);
 bool team_serves(const bpvo_hip_ctx* c, int n);
 PairJob group_pair_job(const bpvo_hip_ctx* c, const PairJob& whole, int k);
@@ -437,6 +447,14 @@ inline bool templates_may_be_dense(const bpvo_hip_ctx* c)
   for(int l = c->params.maxTestLevel; l < c->L; ++l)
     if(c->geom[l].nms_radius <= 0 && c->geom[l].npix > (size_t) std::max(0, c->persist_max_points)) return true;
   return false;
+}
+// will the estimate of ONE pair be a handful of launches — the persistent kernel, a launch per pyramid level — queued in one go?  (Then the host is free
+// while the GPU works, and addFrame uploads its frame's disparity in that time: vo.hip.  On the chain the host paces the rounds, and the upload's hold on
+// it costs more behind the last round than in front of the first: conf/tsukuba.cfg's parameters 2.9 -> 3.2 ms per frame.)
+inline bool single_pair_is_queued_at_once(const bpvo_hip_ctx* c)
+{
+  return c->persistent && !c->persistent_failed.load() && !c->profile_all && !c->reference_reduction && (c->C == 8 || c->C == 1) &&
+         c->params.interp == BPVO_INTERP_LINEAR && !c->fast_warp && !templates_may_be_dense(c);
 }
 inline int dense_candidates(const bpvo_hip_ctx* c, int max_points) { return (c->G == 1 && max_points >= c->dense_candidates_from) ? 1 : 0; }
 inline bpvo_hip::GNLaunch median_launch(const bpvo_hip_ctx* c, bpvo_hip::GNLaunch g) { if(c->G > 1) g.C = c->Cg; return g; }

@@ -260,14 +260,29 @@ static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* di
   c->cloud_n = 0;                   // the point cloud belongs to one Result (bpvo/types.h:549-563)
   c->cloud_pose = I;
 
-  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, on_device);   // _cur_frame->setData (vo.cc:131)
-  if(rc) return rc;
-  HIP_CK(c, hipStreamSynchronize(c->stream));
+  // _cur_frame->setData (vo.cc:131).  No host synchronisation behind it: the estimate queues behind the data stage on the same stream and ends
+  // with one (every copy from the caller's buffers is complete when this function returns — its early returns synchronise themselves).  The
+  // disparity of a host frame, which only a later template stage reads, is uploaded once the estimate is queued (upload_disparity): the copy
+  // from pageable memory holds the host for 90 us, which then lie under the Gauss-Newton kernels instead of in front of them.
+  if(c->vo_cur < 0 || c->vo_cur >= c->n_frames) return fail(c, BPVO_ERR_INVALID_ARG, "bad frame slot range");
+  FrameRun data_run = ctx_run(c);
+  data_run.skip_disparity_upload = !on_device && c->vo_disparity_late && single_pair_is_queued_at_once(c);
+  int rc = frames_set_data(c, c->vo_cur, 1, 1, image, disparity, on_device, data_run, 0);
+  if(rc) { (void) hipStreamSynchronize(c->stream); return rc; }
+  const int data_slot = c->vo_cur;
+  bool disparity_pending = data_run.skip_disparity_upload;
+  auto upload_now = [&]() -> int {
+    c->before_final_sync = nullptr;
+    if(!disparity_pending) return BPVO_OK;
+    disparity_pending = false;
+    return upload_disparity(c, data_slot, disparity);
+  };
 
   if(!c->frames[c->vo_ref].has_template) {            // first frame (vo.cc:133-139)
     std::swap(c->vo_ref, c->vo_cur);
-    rc = frames_set_template(c, c->vo_ref, 1, 1);
-    if(rc) return rc;
+    rc = upload_now();                                 // (its template stage reads the disparity)
+    if(rc == BPVO_OK) rc = frames_set_template(c, c->vo_ref, 1, 1);
+    if(rc) { (void) hipStreamSynchronize(c->stream); return rc; }
     trajectory_push(c, c->T_kf);
     ret->isKeyFrame = 1;
     ret->keyFramingReason = BPVO_KF_FIRST_FRAME;
@@ -277,11 +292,16 @@ static int add_frame_impl(bpvo_hip_ctx* c, const uint8_t* image, const float* di
   M44 T_est;
   const int ws0 = 0;
   rc = check_template_not_empty(c, c->vo_ref);
-  if(rc) return rc;
+  if(rc) { (void) upload_now(); (void) hipStreamSynchronize(c->stream); return rc; }
   c->prefetch_frac_thr = c->params.goodPointThreshold;      // should_keyframe's fraction of good points rides behind the estimate
+  if(disparity_pending) c->before_final_sync = [&]() { return upload_now(); };
   rc = estimate_batch(c, 1, &ws0, &c->vo_ref, &c->vo_cur, c->T_kf.m, T_est.m, ret->optimizerStatistics);
   c->prefetch_frac_thr = -1.0f;
-  if(rc) return rc;
+  {      // (an estimate that did not come by its final synchronisation — an error on the way, another path — : now)
+    const int rcu = upload_now();
+    if(rc == BPVO_OK) rc = rcu;
+  }
+  if(rc) { (void) hipStreamSynchronize(c->stream); return rc; }
   int reason = BPVO_KF_NO_KEYFRAMING;
   rc = should_keyframe(c, T_est, &reason);
   if(rc) return rc;

@@ -389,6 +389,10 @@ int bpvo_hip_tap_cache_counts(bpvo_hip_ctx* ctx, uint64_t out[4]);
  *   "team_joins_seen"        (counter) workgroups that joined another team so far (set: resets it)
  *   "normalization_side_stream" 1      a frame stage that runs alone on the context's stream (single frames, batches on one lane) queues the
  *                                      Hartley normalisation sums on a stream of its own, next to template_build, and joins them before it returns
+ *   "vo_disparity_late"      1         bpvo_hip_add_frame uploads the disparity of a host frame — which only a later template stage reads — once the
+ *                                      estimate is queued: the copy from pageable memory holds the host for 90 us (640x480), which then lie under the
+ *                                      Gauss-Newton kernels — where the estimate is the persistent kernel's launch per level, queued in one go (0, and on
+ *                                      the chain, whose rounds the host paces: in the data stage)
  *   "normalization_form"     4         the sequential (reference-order) Hartley sums: 1 = hand-scheduled DPP add chains (170 us for a 1241x376 template,
  *                                      2.28 ms for a dense 640x480 one); 0 = the compiler's DPP form (281 us / 3.6 ms); 2 = every lane of a row reads the same
  *                                      four consecutive elements from LDS and adds them with plain adds — no cross-lane traffic, no asm (311 us / 4.0 ms);
